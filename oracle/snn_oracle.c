@@ -1,0 +1,519 @@
+/*
+ * snn_oracle.c -- CPU restatement of the BindsNET Network.run() hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product path (bindsnet_amd + libsnnhip)
+ * never links, imports or falls back to it.
+ *
+ * Every function restates one reference function in plain scalar C (IEEE f32, no FMA:
+ * build with -ffp-contract=off, no -ffast-math) and cites the reference file:line it
+ * follows (paths relative to /root/reference).  The floating-point *order* of every
+ * reduction follows ATen's CPU sum kernel (aten/src/ATen/native/cpu/SumKernel.cpp,
+ * torch 2.10: multi_row_sum / row_sum / vectorized_outer_sum), restated in
+ * SURVEY.md Appendix A, because that is what the reference executes.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
+ * fixtures produced by running the unmodified reference (tests/golden/make_golden.py).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * ATen float-sum order (SumKernel.cpp: multi_row_sum<acc_t, nrows>, row_sum, and the column
+ * split of vectorized_outer_sum).  Loader callback keeps the order code independent of where
+ * the summands come from.
+ * ---------------------------------------------------------------------------------------- */
+typedef float (*orc_term_fn)(const void *ctx, long i);
+
+static int ceil_log2_l(long x)
+{
+    if (x <= 2) return 1;
+    int l = 0; long v = x - 1;
+    while (v > 0) { v >>= 1; ++l; }
+    return l;
+}
+
+/* multi_row_sum for one column: 4-level cascade, block 2^p, p = max(4, ceil_log2(n)/4). */
+static float cascade_sum(orc_term_fn f, const void *ctx, long start, long stride, long n)
+{
+    int p = ceil_log2_l(n) / 4; if (p < 4) p = 4;
+    const long step = 1L << p, mask = step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    long i = 0;
+    while (i + step <= n) {
+        for (long j = 0; j < step; ++j, ++i) acc[0] += f(ctx, start + i * stride);
+        for (int l = 1; l < 4; ++l) {
+            acc[l] += acc[l - 1];
+            acc[l - 1] = 0.f;
+            const long m = mask << (l * p);
+            if ((i & m) != 0) break;
+        }
+    }
+    for (; i < n; ++i) acc[0] += f(ctx, start + i * stride);
+    for (int l = 1; l < 4; ++l) acc[0] += acc[l];
+    return acc[0];
+}
+
+/* row_sum: 4 interleaved lanes, each a cascade over n/4 terms, leftovers into lane 0. */
+static float row_sum4(orc_term_fn f, const void *ctx, long n)
+{
+    const long n4 = n / 4;
+    float lane[4];
+    for (int k = 0; k < 4; ++k) lane[k] = cascade_sum(f, ctx, k, 4, n4);
+    for (long i = n4 * 4; i < n; ++i) lane[0] += f(ctx, i);
+    for (int k = 1; k < 4; ++k) lane[0] += lane[k];
+    return lane[0];
+}
+
+/* Reduce n terms that feed output column `col` of `ncols` contiguous columns
+ * (vectorized_outer_sum: columns below 32*floor(ncols/32) take the 4-vector multi_row_sum
+ * path, the rest take row_sum -- vector or scalar row_sum give the same per-column order). */
+static float outer_sum(orc_term_fn f, const void *ctx, long n, long col, long ncols)
+{
+    if (col < (ncols / 32) * 32) return cascade_sum(f, ctx, 0, 1, n);
+    return row_sum4(f, ctx, n);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a5: MulticompartmentConnection.compute + Weight.compute
+ *     bindsnet/network/topology.py:437-479, bindsnet/network/topology_features.py:633-645
+ *     out[b,j] = sum_i value[i,j] * s[b,i], as broadcast multiply then torch.sum(dim=1).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { const float *W; const uint8_t *s; long N; long j; } prop_ctx;
+static float prop_term(const void *c, long i)
+{
+    const prop_ctx *p = (const prop_ctx *)c;
+    return p->W[i * p->N + p->j] * (float)p->s[i];
+}
+
+ORC_API void orc_prop_mcc(const float *W, const uint8_t *s, float *out,
+                          int B, int Nin, int N, int accumulate)
+{
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < N; ++j) {
+            prop_ctx c = { W, s + (long)b * Nin, N, j };
+            float r = outer_sum(prop_term, &c, Nin, j, N);
+            /* network.py:240-248: inputs = zeros; inputs += compute(...) per connection */
+            out[(long)b * N + j] = (accumulate ? out[(long)b * N + j] : 0.0f) + r;
+        }
+}
+
+/* a6: Connection.compute, bindsnet/network/topology.py:332-346.  The reference calls MKL
+ * sgemm whose order is not reproducible (SURVEY.md finding 5); this is the ORDER-PINNED
+ * canonical form the HIP path is held to: ascending-k sequential f32 (spikes are 0/1 so
+ * fma(s,w,acc) == acc + s*w exactly). */
+ORC_API void orc_prop_dense(const float *W, const float *bias, const uint8_t *s, float *out,
+                            int B, int Nin, int N, int accumulate)
+{
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.f;
+            for (int i = 0; i < Nin; ++i) acc += (float)s[(long)b * Nin + i] * W[(long)i * N + j];
+            if (bias) acc += bias[j];
+            out[(long)b * N + j] = (accumulate ? out[(long)b * N + j] : 0.0f) + acc;
+        }
+}
+
+/* a7: Conv2dConnection.compute, bindsnet/network/topology.py:799-815 (F.conv2d, oneDNN).
+ * Order per SURVEY.md finding 5 / probe P8: bias-free sequential accumulation over
+ * (c_in, kh, kw) row-major, then + bias. */
+ORC_API void orc_prop_conv2d(const float *W, const float *bias, const uint8_t *s, float *out,
+                             int B, int Cin, int H, int Wd, int Cout, int KH, int KW,
+                             int stride, int pad, int accumulate)
+{
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int oy = 0; oy < OH; ++oy)
+                for (int ox = 0; ox < OW; ++ox) {
+                    float acc = 0.f;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int ky = 0; ky < KH; ++ky)
+                            for (int kx = 0; kx < KW; ++kx) {
+                                const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                                if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
+                                acc += (float)s[(((long)b * Cin + ci) * H + iy) * Wd + ix] *
+                                       W[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+                            }
+                    if (bias) acc += bias[co];
+                    const long o = (((long)b * Cout + co) * OH + oy) * OW + ox;
+                    out[o] = (accumulate ? out[o] : 0.0f) + acc;
+                }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a2: Nodes.forward trace update, bindsnet/network/nodes.py:96-107 (Input.forward :211-221
+ *     just aliases s = x first).
+ * ---------------------------------------------------------------------------------------- */
+static void trace_update(float *x, const uint8_t *s, long n, float trace_decay,
+                         float trace_scale, int additive)
+{
+    for (long k = 0; k < n; ++k) {
+        float t = x[k] * trace_decay;
+        if (additive) t = t + trace_scale * (float)s[k];
+        else if (s[k]) t = trace_scale;
+        x[k] = t;
+    }
+}
+
+ORC_API void orc_input_step(const uint8_t *s, float *x, long n_total, int traces,
+                            float trace_decay, float trace_scale, int additive)
+{
+    if (traces) trace_update(x, s, n_total, trace_decay, trace_scale, additive);
+}
+
+/* a3: LIFNodes.forward, bindsnet/network/nodes.py:500-529. `I` is masked in place like the
+ * reference does to its input (nodes.py:511). */
+ORC_API void orc_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I,
+                          int B, int N, float decay, float rest, float reset, float thresh,
+                          float refrac0, float dt, int has_lbound, float lbound,
+                          int traces, float trace_decay, float trace_scale, int additive)
+{
+    const long n = (long)B * N;
+    for (long k = 0; k < n; ++k) {
+        float vv = v[k] - rest;          /* nodes.py:508 three separately rounded ops */
+        vv = decay * vv;
+        vv = vv + rest;
+        if (refrac[k] > 0.f) I[k] = 0.f;  /* :511 */
+        refrac[k] = refrac[k] - dt;       /* :514 */
+        vv = vv + I[k];                   /* :516 */
+        const uint8_t sp = vv >= thresh;  /* :519 */
+        if (sp) { refrac[k] = refrac0; vv = reset; } /* :522-523 */
+        if (has_lbound && vv < lbound) vv = lbound;  /* :526-527 */
+        v[k] = vv; s[k] = sp;
+    }
+    if (traces) trace_update(x, s, n, trace_decay, trace_scale, additive);
+}
+
+/* a4: DiehlAndCookNodes.forward, bindsnet/network/nodes.py:1069-1111.
+ * Q / cursor: pre-drawn torch.empty(K).exponential_(1) stream standing in for the
+ * torch.multinomial call at :1100-1102 (multinomial(p,1) ==
+ * argmax(p / q) with one draw per element of the [rows_with_spike, N] operand).
+ * Returns number of rows that consumed noise, or -1 if Q is too short. */
+ORC_API int orc_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta,
+                        const float *I, int B, int N,
+                        float decay, float rest, float reset, float thresh, float refrac0,
+                        float dt, float theta_decay, float theta_plus, int learning,
+                        int one_spike, int has_lbound, float lbound,
+                        int traces, float trace_decay, float trace_scale, int additive,
+                        const float *Q, long Qlen, long *cursor)
+{
+    if (learning)                                  /* :1078-1079 */
+        for (int j = 0; j < N; ++j) theta[j] = theta[j] * theta_decay;
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < N; ++j) {
+            const long k = (long)b * N + j;
+            float vv = v[k] - rest;                /* :1077 */
+            vv = decay * vv;
+            vv = vv + rest;
+            const float gate = (refrac[k] <= 0.f) ? 1.0f : 0.0f;   /* :1082 */
+            const float gx = gate * I[k];
+            vv = vv + gx;
+            refrac[k] = refrac[k] - dt;            /* :1085 */
+            const float th = thresh + theta[j];    /* :1088 */
+            const uint8_t sp = vv >= th;
+            if (sp) { refrac[k] = refrac0; vv = reset; }   /* :1091-1092 */
+            v[k] = vv; s[k] = sp;
+        }
+    if (learning)                                  /* :1093-1094: sum over batch, pre-winner */
+        for (int j = 0; j < N; ++j) {
+            float cnt = 0.f;
+            for (int b = 0; b < B; ++b) cnt += (float)s[(long)b * N + j];
+            theta[j] = theta[j] + theta_plus * cnt;
+        }
+    int rows = 0;
+    if (one_spike) {                               /* :1097-1105 */
+        for (int b = 0; b < B; ++b) {
+            uint8_t *row = s + (long)b * N;
+            int any = 0;
+            for (int j = 0; j < N; ++j) any |= row[j];
+            if (!any) continue;
+            const long off = *cursor + (long)rows * N;
+            if (off + N > Qlen) return -1;
+            int best = 0; float bestv = -INFINITY;
+            for (int j = 0; j < N; ++j) {
+                const float val = (float)row[j] / Q[off + j];
+                if (val > bestv) { bestv = val; best = j; }   /* argmax: first maximal index */
+            }
+            memset(row, 0, (size_t)N);
+            row[best] = 1;
+            ++rows;
+        }
+        *cursor += (long)rows * N;
+    }
+    if (has_lbound)                                /* :1108-1109 */
+        for (long k = 0; k < (long)B * N; ++k) if (v[k] < lbound) v[k] = lbound;
+    if (traces) trace_update(x, s, (long)B * N, trace_decay, trace_scale, additive);  /* :1111 */
+    return rows;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a8/a9: PostPre.  MCC: bindsnet/learning/MCC_learning.py:224-302 + base update :86-110.
+ *        dense: bindsnet/learning/learning.py:390-420 + LearningRule.update :87-104.
+ * Batch reduction = torch.sum(dim=0) of the [B, Nin, N] outer products: element e = i*N+j of
+ * Nin*N contiguous columns, reduced over b in outer_sum order.
+ *   dt_scale: MCC multiplies each reduced update by connection.dt (use_dt=1); dense does not.
+ *   decay:    the multiplicative weight decay actually applied (1.0 by default).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { const uint8_t *sp; const float *tr; long ns, nt, is, it; float nu; int spike_is_tgt; } pp_ctx;
+static float pp_term(const void *c, long b)
+{
+    const pp_ctx *p = (const pp_ctx *)c;
+    if (!p->spike_is_tgt)   /* pre: source_s[b,i] * (target_x[b,j] * nu0) */
+        return (float)p->sp[b * p->ns + p->is] * (p->tr[b * p->nt + p->it] * p->nu);
+    /* post: source_x[b,i] * (target_s[b,j] * nu1) */
+    return p->tr[b * p->nt + p->it] * ((float)p->sp[b * p->ns + p->is] * p->nu);
+}
+
+ORC_API void orc_postpre(float *W, const uint8_t *s_src, const float *x_src,
+                         const uint8_t *s_tgt, const float *x_tgt,
+                         int B, int Nin, int N, float nu0, float nu1,
+                         int use_dt, float dt, float decay,
+                         int has_min, float wmin, int has_max, float wmax)
+{
+    const long E = (long)Nin * N;
+    for (int i = 0; i < Nin; ++i)
+        for (int j = 0; j < N; ++j) {
+            const long e = (long)i * N + j;
+            float w = W[e];
+            if (nu0 != 0.f) {
+                pp_ctx c = { s_src, x_tgt, Nin, N, i, j, nu0, 0 };
+                float u = outer_sum(pp_term, &c, B, e, E);
+                if (use_dt) u = u * dt;
+                w = w - u;
+            }
+            if (nu1 != 0.f) {
+                pp_ctx c = { s_tgt, x_src, N, Nin, j, i, nu1, 1 };
+                float u = outer_sum(pp_term, &c, B, e, E);
+                if (use_dt) u = u * dt;
+                w = w + u;
+            }
+            w = w * decay;
+            if (has_min && w < wmin) w = wmin;
+            if (has_max && w > wmax) w = wmax;
+            W[e] = w;
+        }
+}
+
+/* a10: MSTDP._connection_update, bindsnet/learning/learning.py:1504-1574.
+ * elig is the dense [B,Nin,N] eligibility of the reference (kept dense here on purpose). */
+typedef struct { const float *elig; long E; long e; float reward; const float *reward_vec; } ms_ctx;
+static float ms_term(const void *c, long b)
+{
+    const ms_ctx *p = (const ms_ctx *)c;
+    const float r = p->reward_vec ? p->reward_vec[b] : p->reward;
+    return r * p->elig[b * p->E + p->e];
+}
+
+ORC_API void orc_mstdp(float *W, float *elig, float *p_plus, float *p_minus,
+                       const uint8_t *s_src, const uint8_t *s_tgt,
+                       int B, int Nin, int N, float reward, const float *reward_vec,
+                       float nu0, float a_plus, float a_minus, float decay_plus,
+                       float decay_minus, float wdecay,
+                       int has_min, float wmin, int has_max, float wmax)
+{
+    const long E = (long)Nin * N;
+    for (long e = 0; e < E; ++e) {                 /* :1558-1561 */
+        ms_ctx c = { elig, E, e, reward, reward_vec };
+        const float u = outer_sum(ms_term, &c, B, e, E);
+        W[e] = W[e] + nu0 * u;
+    }
+    for (long k = 0; k < (long)B * Nin; ++k) {     /* :1564-1565 */
+        float p = p_plus[k] * decay_plus;
+        p_plus[k] = p + a_plus * (float)s_src[k];
+    }
+    for (long k = 0; k < (long)B * N; ++k) {       /* :1566-1567 */
+        float p = p_minus[k] * decay_minus;
+        p_minus[k] = p + a_minus * (float)s_tgt[k];
+    }
+    for (int b = 0; b < B; ++b)                    /* :1570-1572 */
+        for (int i = 0; i < Nin; ++i)
+            for (int j = 0; j < N; ++j) {
+                const float a = p_plus[(long)b * Nin + i] * (float)s_tgt[(long)b * N + j];
+                const float c2 = (float)s_src[(long)b * Nin + i] * p_minus[(long)b * N + j];
+                elig[(long)b * E + (long)i * N + j] = a + c2;
+            }
+    for (long e = 0; e < E; ++e) {                 /* learning.py:92-104 */
+        float w = W[e] * wdecay;
+        if (has_min && w < wmin) w = wmin;
+        if (has_max && w > wmax) w = wmax;
+        W[e] = w;
+    }
+}
+
+/* a11: AbstractFeature.normalize (signed column sum), topology_features.py:250-266, and
+ * Connection.normalize (abs column sum), topology.py:383-392.  `norm / colsum` is evaluated
+ * by torch as reciprocal(colsum) * norm (python scalar / tensor). */
+typedef struct { const float *W; long N; long j; int use_abs; } nm_ctx;
+static float nm_term(const void *c, long i)
+{
+    const nm_ctx *p = (const nm_ctx *)c;
+    const float w = p->W[i * p->N + p->j];
+    return p->use_abs ? fabsf(w) : w;
+}
+
+ORC_API void orc_normalize(float *W, int Nin, int N, float norm, int use_abs)
+{
+    float *scale = (float *)malloc(sizeof(float) * (size_t)N);
+    for (int j = 0; j < N; ++j) {
+        nm_ctx c = { W, N, j, use_abs };
+        float cs = outer_sum(nm_term, &c, Nin, j, N);
+        if (cs == 0.f) cs = 1.0f;
+        const float rc = 1.0f / cs;
+        scale[j] = rc * norm;
+    }
+    for (int i = 0; i < Nin; ++i)
+        for (int j = 0; j < N; ++j) W[(long)i * N + j] = W[(long)i * N + j] * scale[j];
+    free(scale);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a1: Network.run for the DiehlAndCook2015 graph, bindsnet/network/network.py:380-465 with
+ * the wiring of bindsnet/models/models.py:156-244 (layers X, Ae, Ai in that order;
+ * connections X->Ae (PostPre), Ae->Ai, Ai->Ae in that order).
+ * State in/out: everything the reference keeps between run() calls.
+ * rasters (optional): [T,B,N] u8 for Ae and Ai.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, Nin, N, T;
+    float dt;
+    /* X (Input, traces) */
+    float x_trace_decay, x_trace_scale;
+    /* Ae (DiehlAndCookNodes) */
+    float e_decay, e_rest, e_reset, e_thresh, e_refrac, e_theta_decay, e_theta_plus,
+          e_trace_decay, e_trace_scale;
+    int e_one_spike;
+    /* Ai (LIFNodes, no traces) */
+    float i_decay, i_rest, i_reset, i_thresh, i_refrac;
+    /* X->Ae PostPre (MCC) */
+    float nu0, nu1, wmin, wmax, norm;
+    int learning;
+} orc_dc_params;
+
+ORC_API int orc_run_dc2015(const orc_dc_params *P,
+                           float *W_xe, const float *W_ei, const float *W_ie,
+                           const uint8_t *inputs,        /* [T,B,Nin] */
+                           uint8_t *sX_prev,             /* [B,Nin] X.s at entry / exit */
+                           float *xX,                    /* [B,Nin] X trace */
+                           float *vE, float *rE, uint8_t *sE, float *xE, float *theta,
+                           float *vI, float *rI, uint8_t *sI,
+                           const float *Q, long Qlen, long *cursor,
+                           uint8_t *rasterE, uint8_t *rasterI)
+{
+    const int B = P->B, Nin = P->Nin, N = P->N;
+    float *IE = (float *)malloc(sizeof(float) * (size_t)B * N);
+    float *II = (float *)malloc(sizeof(float) * (size_t)B * N);
+    const uint8_t *sX = sX_prev;
+    int rc = 0;
+    for (int t = 0; t < P->T; ++t) {
+        /* network.py:384 _get_inputs(): connection insertion order, previous-step spikes */
+        orc_prop_mcc(W_xe, sX, IE, B, Nin, N, 0);
+        orc_prop_mcc(W_ei, sE, II, B, N, N, 0);
+        orc_prop_mcc(W_ie, sI, IE, B, N, N, 1);
+        /* network.py:386-413 layers in insertion order */
+        sX = inputs + (long)t * B * Nin;
+        orc_input_step(sX, xX, (long)B * Nin, 1, P->x_trace_decay, P->x_trace_scale, 0);
+        const int r = orc_dc_step(vE, rE, sE, xE, theta, IE, B, N, P->e_decay, P->e_rest,
+                                  P->e_reset, P->e_thresh, P->e_refrac, P->dt,
+                                  P->e_theta_decay, P->e_theta_plus, P->learning,
+                                  P->e_one_spike, 0, 0.f, 1, P->e_trace_decay,
+                                  P->e_trace_scale, 0, Q, Qlen, cursor);
+        if (r < 0) { rc = -1; break; }
+        orc_lif_step(vI, rI, sI, NULL, II, B, N, P->i_decay, P->i_rest, P->i_reset,
+                     P->i_thresh, P->i_refrac, P->dt, 0, 0.f, 0, 0.f, 0.f, 0);
+        /* network.py:431-454 connection updates (only X->Ae has a rule) */
+        if (P->learning)
+            orc_postpre(W_xe, sX, xX, sE, xE, B, Nin, N, P->nu0, P->nu1, 1, P->dt, 1.0f,
+                        1, P->wmin, 1, P->wmax);
+        if (rasterE) memcpy(rasterE + (long)t * B * N, sE, (size_t)B * N);
+        if (rasterI) memcpy(rasterI + (long)t * B * N, sI, (size_t)B * N);
+    }
+    if (rc == 0) {
+        /* network.py:464-465: normalize every connection (only X->Ae has a norm) */
+        orc_normalize(W_xe, Nin, N, P->norm, 0);
+        if (P->T > 0) memcpy(sX_prev, inputs + (long)(P->T - 1) * B * Nin, (size_t)B * Nin);
+    }
+    free(IE); free(II);
+    return rc;
+}
+
+/* a1 (dense family): Input -> Connection -> LIFNodes with PostPre or MSTDP, the graph of
+ * TwoLayerNetwork (bindsnet/models/models.py:21-91) and of cfg5.
+ * rule: 0 none, 1 PostPre (learning.py:390-420), 2 MSTDP (learning.py:1504-1574). */
+typedef struct {
+    int B, Nin, N, T, rule;
+    float dt;
+    float x_trace_decay, x_trace_scale; int x_traces;
+    float decay, rest, reset, thresh, refrac; int y_traces; float y_trace_decay, y_trace_scale;
+    float nu0, nu1; int has_min, has_max; float wmin, wmax; int has_norm; float norm;
+    float reward, a_plus, a_minus, decay_plus, decay_minus;
+    int learning;
+} orc_two_params;
+
+ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *bias,
+                               const uint8_t *inputs, uint8_t *sX_prev, float *xX,
+                               float *vY, float *rY, uint8_t *sY, float *xY,
+                               float *elig, float *p_plus, float *p_minus,
+                               const float *I_forced,   /* optional [T,B,N] teacher-forced currents */
+                               uint8_t *rasterY)
+{
+    const int B = P->B, Nin = P->Nin, N = P->N;
+    float *I = (float *)malloc(sizeof(float) * (size_t)B * N);
+    const uint8_t *sX = sX_prev;
+    for (int t = 0; t < P->T; ++t) {
+        if (I_forced) memcpy(I, I_forced + (long)t * B * N, sizeof(float) * (size_t)B * N);
+        else orc_prop_dense(W, bias, sX, I, B, Nin, N, 0);
+        sX = inputs + (long)t * B * Nin;
+        orc_input_step(sX, xX, (long)B * Nin, P->x_traces, P->x_trace_decay, P->x_trace_scale, 0);
+        orc_lif_step(vY, rY, sY, xY, I, B, N, P->decay, P->rest, P->reset, P->thresh,
+                     P->refrac, P->dt, 0, 0.f, P->y_traces, P->y_trace_decay,
+                     P->y_trace_scale, 0);
+        if (P->learning && P->rule == 1)
+            orc_postpre(W, sX, xX, sY, xY, B, Nin, N, P->nu0, P->nu1, 0, P->dt, 1.0f,
+                        P->has_min, P->wmin, P->has_max, P->wmax);
+        else if (P->learning && P->rule == 2)
+            orc_mstdp(W, elig, p_plus, p_minus, sX, sY, B, Nin, N, P->reward, NULL, P->nu0,
+                      P->a_plus, P->a_minus, P->decay_plus, P->decay_minus, 1.0f,
+                      P->has_min, P->wmin, P->has_max, P->wmax);
+        if (rasterY) memcpy(rasterY + (long)t * B * N, sY, (size_t)B * N);
+    }
+    if (P->has_norm) orc_normalize(W, Nin, N, P->norm, 1);
+    if (P->T > 0) memcpy(sX_prev, inputs + (long)(P->T - 1) * B * Nin, (size_t)B * Nin);
+    free(I);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Host RNG stream used by one_spike: torch CPU generator = mt19937; exponential_(1) on a
+ * float tensor draws random64() per element, u = (r & (2^53-1)) * 2^-53 and returns
+ * (float)(-log1p(-u))  (ATen core/TransformationHelper.h, DistributionTemplates.h; verified
+ * against torch 2.10 in tests/test_oracle_golden.py).  state[624], *pos in [0,624] (624 =>
+ * twist before next output), exactly at::mt19937's (state_, next_) with left_ = 624 - pos...
+ * expressed as a plain index.
+ * ---------------------------------------------------------------------------------------- */
+static void mt_twist(uint32_t *mt)
+{
+    for (int i = 0; i < 624; ++i) {
+        const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+}
+static uint32_t mt_next(uint32_t *mt, int *pos)
+{
+    if (*pos >= 624) { mt_twist(mt); *pos = 0; }
+    uint32_t y = mt[(*pos)++];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+ORC_API void orc_mt_exponential(uint32_t *mt, int *pos, float *out, long n)
+{
+    for (long k = 0; k < n; ++k) {
+        const uint64_t hi = mt_next(mt, pos), lo = mt_next(mt, pos);
+        const uint64_t r = (hi << 32) | lo;
+        const double u = (double)(r & ((1ULL << 53) - 1)) * 0x1.0p-53;
+        out[k] = (float)(-1.0 * log1p(-u));
+    }
+}
