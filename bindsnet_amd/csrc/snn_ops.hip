@@ -1,0 +1,572 @@
+// snn_ops.hip -- per-operator gfx950 kernels + their C-ABI entry points (include/snnhip.h).
+// One entry point per reference function of SURVEY.md 8(a); the fused multi-step drivers live in
+// snn_run.hip and reuse the device code here.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).  -ffp-contract=off
+// is load-bearing: the reference rounds after every multiply and every add.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/snnhip.h"
+#include "snn_order.hpp"
+#include "snn_common.hpp"
+
+using namespace snn;
+
+// =============================================================================================
+// a5 / a6: spike propagation, event-driven.
+// grid (ceil(N/256), B), 256 threads: thread <-> target column j, block <-> sample b.
+// Per 1024-source chunk each of the 4 waves compacts its 256 sources into an ascending list in
+// LDS (wave ballot + popcount), then every thread walks the 4 lists in order and accumulates
+// W[i,j] (coalesced 1 KiB row segments) through the ordered-sum state machine.
+// =============================================================================================
+template <class SUM>
+__global__ __launch_bounds__(256) void k_prop(const float *__restrict__ W, const float *__restrict__ bias,
+                                              const uint8_t *__restrict__ s, float *__restrict__ out,
+                                              int B, int Nin, int N, int accumulate) {
+    __shared__ uint32_t list[4][256];
+    __shared__ int cnt[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y, j = blockIdx.x * 256 + tid;
+    const bool valid = j < N;
+    const int jc = valid ? j : N - 1;
+    const uint8_t *srow = s + (size_t)b * Nin;
+    SUM acc;
+    acc.init(j >= (N / 32) * 32);
+    const uint64_t lt = (1ull << lane) - 1ull;
+
+    for (int base = 0; base < Nin; base += 1024) {
+        int n_w = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int i = base + wave * 256 + p * 64 + lane;
+            const uint32_t sv = (i < Nin) ? srow[i] : 0u;
+            const uint64_t m = __ballot(sv != 0);
+            if (sv) list[wave][n_w + __popcll(m & lt)] = ((uint32_t)i << 8) | sv;
+            n_w += __popcll(m);
+        }
+        if (lane == 0) cnt[wave] = n_w;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) {
+            const int n = cnt[w];
+            for (int k = 0; k < n; k += 4) {
+                uint32_t e[4]; float wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    e[u] = list[w][(k + u < n) ? k + u : k];
+                    wv[u] = W[(size_t)(e[u] >> 8) * N + jc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u < n) acc.add((int)(e[u] >> 8), wv[u] * (float)(e[u] & 255u), Nin);
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        float r = acc.finish(Nin);
+        if (bias) r = r + bias[j];
+        const size_t o = (size_t)b * N + j;
+        out[o] = (accumulate ? out[o] : 0.0f) + r;
+    }
+}
+
+extern "C" int snn_prop_cascade_f32(const float *W, const uint8_t *s, float *out, int B, int Nin, int N,
+                                    int accumulate, snn_stream_t stream) {
+    if (!W || !s || !out || B <= 0 || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (Nin > kMaxTerms || B > 65535) return SNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_prop<OuterSum>, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, W,
+                       (const float *)nullptr, s, out, B, Nin, N, accumulate);
+    return snn_check_launch();
+}
+
+extern "C" int snn_prop_dense_f32(const float *W, const float *bias, const uint8_t *s, float *out, int B,
+                                  int Nin, int N, int accumulate, snn_stream_t stream) {
+    if (!W || !s || !out || B <= 0 || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (Nin >= (1 << 24) || B > 65535) return SNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_prop<SeqSum>, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, W, bias, s,
+                       out, B, Nin, N, accumulate);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a7: conv2d propagation.  thread <-> (b, oy, ox); all Cout channels accumulated in registers in
+// chunks of 8 so the u8 input window is read once per chunk; weights broadcast from LDS.
+// Tap order (cin, kh, kw) row-major, sequential, then + bias.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_conv2d(const float *__restrict__ W, const float *__restrict__ bias,
+                                                const uint8_t *__restrict__ s, float *__restrict__ out, int B,
+                                                int Cin, int H, int Wd, int Cout, int KH, int KW, int stride,
+                                                int pad, int OH, int OW, int accumulate) {
+    extern __shared__ float wsm[];  // [Cout][Cin*KH*KW]
+    const int taps = Cin * KH * KW;
+    for (int k = threadIdx.x; k < Cout * taps; k += blockDim.x) wsm[k] = W[k];
+    __syncthreads();
+    const long npix = (long)B * OH * OW;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((long)OW * OH));
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        int tap = 0;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx, ++tap) {
+                    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
+                    const uint8_t sv = s[(((size_t)b * Cin + ci) * H + iy) * Wd + ix];
+                    if (!sv) continue;
+                    const float fs = (float)sv;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u < Cout) acc[u] += fs * wsm[(c0 + u) * taps + tap];
+                }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < Cout) {
+                float r = acc[u];
+                if (bias) r = r + bias[c0 + u];
+                const size_t o = (((size_t)b * Cout + c0 + u) * OH + oy) * OW + ox;
+                out[o] = (accumulate ? out[o] : 0.0f) + r;
+            }
+    }
+}
+
+extern "C" int snn_prop_conv2d_f32(const float *W, const float *bias, const uint8_t *s, float *out, int B,
+                                   int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad,
+                                   int accumulate, snn_stream_t stream) {
+    if (!W || !s || !out || B <= 0 || Cin <= 0 || H <= 0 || Wd <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
+        stride <= 0 || pad < 0)
+        return SNN_ERR_INVALID;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
+    const size_t lds = sizeof(float) * (size_t)Cout * Cin * KH * KW;
+    if (lds > 64 * 1024) return SNN_ERR_UNSUPPORTED;
+    const long npix = (long)B * OH * OW;
+    hipLaunchKernelGGL(k_conv2d, dim3((unsigned)((npix + 255) / 256)), dim3(256), lds, (hipStream_t)stream, W,
+                       bias, s, out, B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW, accumulate);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a2: input layer: trace + raster.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_input(const uint8_t *__restrict__ s, float *__restrict__ x, long n,
+                                               float trace_decay, float trace_scale, int additive,
+                                               uint8_t *__restrict__ raster) {
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        const uint8_t sv = s[k];
+        if (x) x[k] = trace_next(x[k], sv, trace_decay, trace_scale, additive);
+        if (raster) raster[k] = sv;
+    }
+}
+
+extern "C" int snn_input_step(const uint8_t *s, float *x, long n_total, float trace_decay, float trace_scale,
+                              int additive, uint8_t *raster_out, snn_stream_t stream) {
+    if (!s || n_total <= 0) return SNN_ERR_INVALID;
+    if (!x && !raster_out) return SNN_OK;
+    const unsigned grid = (unsigned)((n_total + 255) / 256 < 2048 ? (n_total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_input, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, x, n_total, trace_decay,
+                       trace_scale, additive, raster_out);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a3: LIF step, fully elementwise (state streaming: v, refrac r/w, I r/w, s w, x r/w).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_lif(float *__restrict__ v, float *__restrict__ refrac,
+                                             uint8_t *__restrict__ s, float *__restrict__ x,
+                                             float *__restrict__ I, long n, snn_lif_params p,
+                                             uint8_t *__restrict__ raster_s, float *__restrict__ raster_v) {
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        float vv = v[k], rc = refrac[k], cur = I[k];
+        if (rc > 0.f) { cur = 0.f; I[k] = 0.f; }   // nodes.py:511 masks the caller's tensor in place
+        const uint8_t sp = lif_update(vv, rc, cur, p);
+        v[k] = vv; refrac[k] = rc; s[k] = sp;
+        if (p.traces) x[k] = trace_next(x[k], sp, p.trace_decay, p.trace_scale, p.traces_additive);
+        if (raster_s) raster_s[k] = sp;
+        if (raster_v) raster_v[k] = vv;
+    }
+}
+
+extern "C" int snn_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
+                            const snn_lif_params *h_p, uint8_t *raster_s, float *raster_v, snn_stream_t stream) {
+    if (!v || !refrac || !s || !I || !h_p || B <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (h_p->traces && !x) return SNN_ERR_INVALID;
+    const long n = (long)B * N;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_lif, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, refrac, s, x, I, n, *h_p,
+                       raster_s, raster_v);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a4: Diehl&Cook step = two kernels.
+//  k_dc_membrane: thread <-> neuron j, loops the batch (theta is shared by the batch and needs the
+//                 per-neuron spike count over b) -> crossings written to s; snapshots the cursor.
+//  k_dc_arbitrate: block <-> sample b: rank of b among rows with a crossing (noise offset),
+//                 argmax of 1/q over the candidates (first maximal index), winner written back,
+//                 trace + raster for the row.  The block of the last row publishes the new cursor.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dc_membrane(float *__restrict__ v, float *__restrict__ refrac,
+                                                     uint8_t *__restrict__ s, float *__restrict__ theta,
+                                                     const float *__restrict__ I, int B, int N,
+                                                     snn_dc_params p, long long *__restrict__ cursor,
+                                                     float *__restrict__ raster_v) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && cursor) cursor[1] = cursor[0];   // snapshot read by k_dc_arbitrate
+    if (j >= N) return;
+    float th = theta[j];
+    if (p.learning) th = th * p.theta_decay;            // nodes.py:1079
+    const float thr = p.lif.thresh + th;                // nodes.py:1088
+    int cnt = 0;
+    for (int b = 0; b < B; ++b) {
+        const size_t k = (size_t)b * N + j;
+        float vv = v[k], rc = refrac[k];
+        const uint8_t sp = dc_update(vv, rc, I[k], thr, p.lif);
+        v[k] = vv; refrac[k] = rc; s[k] = sp;
+        cnt += sp;
+        if (raster_v) raster_v[k] = vv;
+    }
+    if (p.learning) th = th + p.theta_plus * (float)cnt;   // nodes.py:1094 (count is exact in f32)
+    theta[j] = th;
+}
+
+__global__ __launch_bounds__(256) void k_dc_arbitrate(uint8_t *__restrict__ s, float *__restrict__ x, int B,
+                                                      int N, snn_dc_params p, const float *__restrict__ Q,
+                                                      long long q_len, long long *__restrict__ cursor,
+                                                      int *__restrict__ status, uint8_t *__restrict__ raster_s) {
+    __shared__ int any_row[1024];
+    __shared__ float red_v[4];
+    __shared__ int red_j[4];
+    __shared__ int s_win;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    int win = -2;  // -2: keep crossings as they are (one_spike off / no crossing / noise exhausted)
+    if (p.one_spike) {
+        // which rows 0..b have a crossing: one wave per row, strided
+        for (int r = wave; r <= b; r += 4) {
+            bool a = false;
+            for (int j = lane; j < N; j += 64) a |= s[(size_t)r * N + j] != 0;
+            const uint64_t m = __ballot(a);
+            if (lane == 0) any_row[r] = m != 0;
+        }
+        __syncthreads();
+        int rank = 0;
+        for (int r = 0; r < b; ++r) rank += any_row[r];
+        const int mine = any_row[b];
+        const long long cur = cursor[1];
+        const long long off = cur + (long long)rank * N;
+        if (b == B - 1) {
+            const long long nxt = cur + (long long)(rank + mine) * N;
+            if (tid == 0) { cursor[0] = nxt <= q_len ? nxt : cur; if (nxt > q_len) atomicExch(status, SNN_ERR_NOISE); }
+        }
+        if (mine && off + N <= q_len) {
+            float bv = -1.f; int bj = 0x7fffffff;
+            for (int j = tid; j < N; j += 256)
+                if (s[(size_t)b * N + j]) {
+                    const float val = 1.0f / Q[off + j];        // p / q with p = 1 (nodes.py:1100-1102)
+                    if (val > bv) { bv = val; bj = j; }         // ascending j: strict > keeps the first max
+                }
+            // wave reduce: max value, ties -> lowest index
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(bv, d); const int oj = __shfl_xor(bj, d);
+                if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            if (lane == 0) { red_v[wave] = bv; red_j[wave] = bj; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w)
+                    if (red_v[w] > bv || (red_v[w] == bv && red_j[w] < bj)) { bv = red_v[w]; bj = red_j[w]; }
+                s_win = bj;
+            }
+            __syncthreads();
+            win = s_win;
+        } else if (mine) {
+            if (tid == 0) atomicExch(status, SNN_ERR_NOISE);
+        }
+    }
+    for (int j = tid; j < N; j += 256) {
+        const size_t k = (size_t)b * N + j;
+        uint8_t sp = s[k];
+        if (win >= 0) { sp = (j == win); s[k] = sp; }
+        if (p.lif.traces) x[k] = trace_next(x[k], sp, p.lif.trace_decay, p.lif.trace_scale, p.lif.traces_additive);
+        if (raster_s) raster_s[k] = sp;
+    }
+}
+
+extern "C" int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta, const float *I, int B,
+                           int N, const snn_dc_params *h_p, const float *noise_q, long long q_len,
+                           long long *cursor, int *status, uint8_t *raster_s, float *raster_v,
+                           snn_stream_t stream) {
+    if (!v || !refrac || !s || !theta || !I || !h_p || B <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (h_p->lif.traces && !x) return SNN_ERR_INVALID;
+    if (h_p->one_spike && (!noise_q || !cursor || !status)) return SNN_ERR_INVALID;
+    if (B > 1024) return SNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_dc_membrane, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, refrac, s,
+                       theta, I, B, N, *h_p, cursor, raster_v);
+    int rc = snn_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dc_arbitrate, dim3(B), dim3(256), 0, (hipStream_t)stream, s, x, B, N, *h_p, noise_q,
+                       q_len, cursor, status, raster_s);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a8 / a9 / a10: outer-product plasticity.  grid (ceil(N/TJ), ceil(Nin/16)), 256 threads.
+// A block owns a 16 x TJ tile of W.  The batch-side factors of the tile's rows and columns are
+// staged in LDS once; per element the batch reduction walks only the samples in which the row's
+// source or the column's target spiked (bit masks over b), through the ATen-ordered accumulator.
+// =============================================================================================
+struct StdpArgs {
+    float *W;
+    const uint8_t *s_src; const float *x_src; const uint8_t *s_tgt; const float *x_tgt;
+    int B, Nin, N;
+    float nu0, nu1; int use_dt; float dt, decay;
+    int has_min; float wmin; int has_max; float wmax;
+    int assume_clamped;
+    // MSTDP (mode 1): x_src = p_plus, x_tgt = p_minus, s_* = previous-step spikes
+    int mode; float reward; const float *reward_vec;
+};
+
+constexpr int kTI = 16;
+
+template <int TJ>
+__global__ __launch_bounds__(256) void k_plasticity(StdpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = a.B, Nin = a.Nin, N = a.N;
+    const int MW = (B + 31) / 32;                       // mask words per row / column
+    float *xt = (float *)smem;                          // [B][TJ]  target-side float factor
+    float *xs = xt + (size_t)B * TJ;                    // [B][kTI] source-side float factor
+    uint32_t *mT = (uint32_t *)(xs + (size_t)B * kTI);  // [TJ][MW] target spike masks
+    uint32_t *mS = mT + (size_t)TJ * MW;                // [kTI][MW]
+    uint8_t *vT = (uint8_t *)(mS + (size_t)kTI * MW);   // [B][TJ] target spike values
+    uint8_t *vS = vT + (size_t)B * TJ;                  // [B][kTI]
+    __shared__ int any_flag;
+
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * TJ, i0 = blockIdx.y * kTI;
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    int local_any = 0;
+    for (int k = tid; k < B * TJ; k += 256) {
+        const int b = k / TJ, jj = k - b * TJ, j = j0 + jj;
+        float f = 0.f; uint8_t sv = 0;
+        if (j < N) {
+            sv = a.s_tgt[(size_t)b * N + j];
+            f = a.x_tgt[(size_t)b * N + j];
+            if (a.mode == 0) f = f * a.nu0;             // target_x * nu[0]  (MCC_learning.py:235)
+        }
+        xt[k] = f; vT[k] = sv; local_any |= sv;
+    }
+    for (int k = tid; k < B * kTI; k += 256) {
+        const int b = k / kTI, ii = k - b * kTI, i = i0 + ii;
+        float f = 0.f; uint8_t sv = 0;
+        if (i < Nin) { sv = a.s_src[(size_t)b * Nin + i]; f = a.x_src[(size_t)b * Nin + i]; }
+        xs[k] = f; vS[k] = sv; local_any |= sv;
+    }
+    if (local_any) any_flag = 1;
+    __syncthreads();
+    if (a.assume_clamped && !any_flag) return;          // nothing in this tile can change
+    for (int k = tid; k < (TJ + kTI) * MW; k += 256) {
+        const bool tgt = k < TJ * MW;
+        const int kk = tgt ? k : k - TJ * MW;
+        const int col = kk / MW, w = kk - col * MW;
+        uint32_t m = 0;
+        for (int bit = 0; bit < 32; ++bit) {
+            const int b = w * 32 + bit;
+            if (b < B && (tgt ? vT[(size_t)b * TJ + col] : vS[(size_t)b * kTI + col])) m |= 1u << bit;
+        }
+        (tgt ? mT : mS)[kk] = m;
+    }
+    __syncthreads();
+
+    const long E = (long)Nin * N, Emain = (E / 32) * 32;
+    constexpr int RG = 256 / TJ;                        // row groups handled concurrently
+    const int jj = tid % TJ, rg = tid / TJ, j = j0 + jj;
+    if (j >= N) return;
+    for (int ii = rg; ii < kTI; ii += RG) {
+        const int i = i0 + ii;
+        if (i >= Nin) break;
+        uint32_t anyS = 0, anyT = 0;
+        for (int w = 0; w < MW; ++w) { anyS |= mS[ii * MW + w]; anyT |= mT[jj * MW + w]; }
+        if (a.assume_clamped && !anyS && !anyT) continue;
+        const long e = (long)i * N + j;
+        const bool tail = e >= Emain;
+        float w_ = a.W[e];
+        if (a.mode == 0) {
+            if (a.nu0 != 0.f) {                         // pre: sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+                OuterSum acc; acc.init(tail);
+                for (int w = 0; w < MW; ++w) {
+                    uint32_t m = mS[ii * MW + w];
+                    while (m) {
+                        const int b = w * 32 + __ffs(m) - 1; m &= m - 1;
+                        acc.add(b, (float)vS[(size_t)b * kTI + ii] * xt[(size_t)b * TJ + jj], B);
+                    }
+                }
+                float u = acc.finish(B);
+                if (a.use_dt) u = u * a.dt;
+                w_ = w_ - u;
+            }
+            if (a.nu1 != 0.f) {                         // post: sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+                OuterSum acc; acc.init(tail);
+                for (int w = 0; w < MW; ++w) {
+                    uint32_t m = mT[jj * MW + w];
+                    while (m) {
+                        const int b = w * 32 + __ffs(m) - 1; m &= m - 1;
+                        const float st = (float)vT[(size_t)b * TJ + jj] * a.nu1;
+                        acc.add(b, xs[(size_t)b * kTI + ii] * st, B);
+                    }
+                }
+                float u = acc.finish(B);
+                if (a.use_dt) u = u * a.dt;
+                w_ = w_ + u;
+            }
+        } else {                                        // MSTDP: sum_b reward * elig[b][i,j]
+            OuterSum acc; acc.init(tail);
+            for (int w = 0; w < MW; ++w) {
+                uint32_t m = mS[ii * MW + w] | mT[jj * MW + w];
+                while (m) {
+                    const int b = w * 32 + __ffs(m) - 1; m &= m - 1;
+                    const float e1 = xs[(size_t)b * kTI + ii] * (float)vT[(size_t)b * TJ + jj];   // p_plus (x) s_tgt
+                    const float e2 = (float)vS[(size_t)b * kTI + ii] * xt[(size_t)b * TJ + jj];   // s_src (x) p_minus
+                    const float el = e1 + e2;
+                    const float r = a.reward_vec ? a.reward_vec[b] : a.reward;
+                    acc.add(b, r * el, B);
+                }
+            }
+            const float u = acc.finish(B);
+            w_ = w_ + a.nu0 * u;                        // learning.py:1561
+        }
+        w_ = w_ * a.decay;
+        if (a.has_min && w_ < a.wmin) w_ = a.wmin;
+        if (a.has_max && w_ > a.wmax) w_ = a.wmax;
+        a.W[e] = w_;
+    }
+}
+
+static int launch_plasticity(const StdpArgs &a, hipStream_t st) {
+    const int B = a.B, MW = (B + 31) / 32;
+    auto lds = [&](int TJ) {
+        return (size_t)B * TJ * 4 + (size_t)B * kTI * 4 + (size_t)(TJ + kTI) * MW * 4 + (size_t)B * TJ + (size_t)B * kTI;
+    };
+    const dim3 blk(256);
+    const unsigned gy = (a.Nin + kTI - 1) / kTI;
+    constexpr size_t kSmall = 64 * 1024, kBig = 144 * 1024;   // 160 KiB LDS per CU on gfx950
+    static bool attr_set = false;
+    if (!attr_set) {   // allow > 64 KiB dynamic LDS for the narrow-tile instantiation
+        if (snn_check(hipFuncSetAttribute((const void *)k_plasticity<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kBig)))
+            return SNN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (lds(256) <= kSmall) {
+        hipLaunchKernelGGL(k_plasticity<256>, dim3((a.N + 255) / 256, gy), blk, lds(256), st, a);
+    } else if (lds(128) <= kSmall) {
+        hipLaunchKernelGGL(k_plasticity<128>, dim3((a.N + 127) / 128, gy), blk, lds(128), st, a);
+    } else if (lds(64) <= kSmall) {
+        hipLaunchKernelGGL(k_plasticity<64>, dim3((a.N + 63) / 64, gy), blk, lds(64), st, a);
+    } else if (lds(32) <= kBig) {
+        hipLaunchKernelGGL(k_plasticity<32>, dim3((a.N + 31) / 32, gy), blk, lds(32), st, a);
+    } else {
+        return SNN_ERR_UNSUPPORTED;
+    }
+    return snn_check_launch();
+}
+
+extern "C" int snn_stdp_postpre(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt,
+                                const float *x_tgt, int B, int Nin, int N, float nu0, float nu1, int use_dt,
+                                float dt, float decay, int has_min, float wmin, int has_max, float wmax,
+                                int assume_clamped, snn_stream_t stream) {
+    if (!W || !s_src || !x_src || !s_tgt || !x_tgt || B <= 0 || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (B > 256) return SNN_ERR_UNSUPPORTED;
+    StdpArgs a{W, s_src, x_src, s_tgt, x_tgt, B, Nin, N, nu0, nu1, use_dt, dt, decay, has_min, wmin, has_max,
+               wmax, (assume_clamped && decay == 1.0f) ? 1 : 0, 0, 0.f, nullptr};
+    return launch_plasticity(a, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void k_mstdp_traces(float *__restrict__ p_plus, float *__restrict__ p_minus,
+                                                      uint8_t *__restrict__ s_src_prev,
+                                                      uint8_t *__restrict__ s_tgt_prev,
+                                                      const uint8_t *__restrict__ s_src,
+                                                      const uint8_t *__restrict__ s_tgt, long n_src, long n_tgt,
+                                                      float a_plus, float a_minus, float d_plus, float d_minus) {
+    const long n = n_src + n_tgt;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        if (k < n_src) {
+            const uint8_t sv = s_src[k];
+            const float p = p_plus[k] * d_plus;                  // learning.py:1564
+            p_plus[k] = p + a_plus * (float)sv;                  // :1565
+            s_src_prev[k] = sv;
+        } else {
+            const long q = k - n_src;
+            const uint8_t sv = s_tgt[q];
+            const float p = p_minus[q] * d_minus;                // :1566
+            p_minus[q] = p + a_minus * (float)sv;                // :1567
+            s_tgt_prev[q] = sv;
+        }
+    }
+}
+
+extern "C" int snn_mstdp_step(float *W, float *p_plus, float *p_minus, uint8_t *s_src_prev, uint8_t *s_tgt_prev,
+                              const uint8_t *s_src, const uint8_t *s_tgt, int B, int Nin, int N, float reward,
+                              const float *reward_vec, float nu0, float a_plus, float a_minus, float decay_plus,
+                              float decay_minus, float wdecay, int has_min, float wmin, int has_max, float wmax,
+                              snn_stream_t stream) {
+    if (!W || !p_plus || !p_minus || !s_src_prev || !s_tgt_prev || !s_src || !s_tgt || B <= 0 || Nin <= 0 || N <= 0)
+        return SNN_ERR_INVALID;
+    if (B > 256) return SNN_ERR_UNSUPPORTED;
+    // (1) W += nu0 * sum_b reward * elig_prev[b]; decay; clamp -- uses the OLD p_plus/p_minus.
+    StdpArgs a{W, s_src_prev, p_plus, s_tgt_prev, p_minus, B, Nin, N, nu0, 0.f, 0, 1.f, wdecay, has_min, wmin,
+               has_max, wmax, 0, 1, reward, reward_vec};
+    int rc = launch_plasticity(a, (hipStream_t)stream);
+    if (rc) return rc;
+    // (2) trace updates + remember this step's spikes as the factors of the next eligibility.
+    const long n = (long)B * (Nin + N);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_mstdp_traces, dim3(grid), dim3(256), 0, (hipStream_t)stream, p_plus, p_minus, s_src_prev,
+                       s_tgt_prev, s_src, s_tgt, (long)B * Nin, (long)B * N, a_plus, a_minus, decay_plus,
+                       decay_minus);
+    return snn_check_launch();
+}
+
+// =============================================================================================
+// a11: normalize.  k_colsum: thread <-> column, rows walked in order through the ATen-ordered
+// accumulator (dense: every row is a term).  k_scale: elementwise W *= norm * (1/colsum).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ W, int Nin, int N, float norm,
+                                                int use_abs, float *__restrict__ scale) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    OuterSum acc;
+    acc.init(j >= (N / 32) * 32);
+    for (int i = 0; i < Nin; ++i) {
+        float w = W[(size_t)i * N + j];
+        if (use_abs) w = fabsf(w);
+        acc.add(i, w, Nin);
+    }
+    float cs = acc.finish(Nin);
+    if (cs == 0.f) cs = 1.0f;                           // topology_features.py:265
+    const float rc = 1.0f / cs;                         // torch: python_scalar / tensor == reciprocal * scalar
+    scale[j] = rc * norm;
+}
+
+__global__ __launch_bounds__(256) void k_scale_cols(float *__restrict__ W, long E, int N,
+                                                    const float *__restrict__ scale) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x)
+        W[e] = W[e] * scale[e % N];
+}
+
+extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *colsum_ws,
+                             snn_stream_t stream) {
+    if (!W || !colsum_ws || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (Nin > kMaxTerms) return SNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_colsum, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Nin, N, norm,
+                       use_abs, colsum_ws);
+    int rc = snn_check_launch();
+    if (rc) return rc;
+    const long E = (long)Nin * N;
+    const unsigned grid = (unsigned)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, E, N, colsum_ws);
+    return snn_check_launch();
+}

@@ -1,0 +1,155 @@
+/*
+ * snnhip.h -- C ABI of libsnnhip.so: the MI355X (gfx950) implementation of BindsNET's
+ * per-timestep Network.run() hot path.
+ *
+ * BindsNET has no FFI / operator-plugin interface of its own (it is pure Python on PyTorch),
+ * so the entry points below are what a binding of that path needs: one per reference function
+ * of SURVEY.md section 8(a), plus fused multi-step drivers.  Each declaration cites the
+ * reference function it replaces (paths relative to the BindsNET repository root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer unless the
+ *     parameter name starts with `h_`.  The caller owns every buffer; nothing is allocated
+ *     behind the caller's back except inside an snn_ctx (workspace, created explicitly).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls are
+ *     asynchronous and stream-ordered; none synchronises the device.
+ *   - return value: 0 = SNN_OK, negative = error (snn_error_string()).  No C++ exception ever
+ *     crosses the boundary.
+ *   - arithmetic: IEEE binary32, round-to-nearest-even, no FMA contraction; every reduction
+ *     follows the order the reference executes on CPU (ATen cascade sum: SURVEY.md Appendix A;
+ *     serial order, see DESIGN.md "Summation order").  Spikes are uint8 (0/1), row-major
+ *     [B, n]; weights are float32 row-major [Nin, N] (source-major, like BindsNET's `w`).
+ */
+#ifndef SNNHIP_H
+#define SNNHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNN_ABI_VERSION 1
+
+typedef void *snn_stream_t;
+
+enum {
+    SNN_OK = 0,
+    SNN_ERR_INVALID = -1,      /* bad argument (null pointer, non-positive size, ...) */
+    SNN_ERR_UNSUPPORTED = -2,  /* size outside what the kernels were built for */
+    SNN_ERR_LAUNCH = -3,       /* hip launch / runtime error (see snn_last_hip_error) */
+    SNN_ERR_NOISE = -4,        /* one_spike noise stream exhausted (device status word) */
+    SNN_ERR_NO_DEVICE = -5
+};
+
+int snn_abi_version(void);
+const char *snn_error_string(int code);
+/* hipGetErrorString() of the last failing HIP call made by this library on this thread. */
+const char *snn_last_hip_error(void);
+/* Number of visible HIP devices, or SNN_ERR_NO_DEVICE. */
+int snn_device_count(void);
+
+/* ---- a5: MulticompartmentConnection.compute + Weight.compute -------------------------------
+ * bindsnet/network/topology.py:437-479, bindsnet/network/topology_features.py:633-645
+ * out[b,j] (+)= sum_i W[i,j] * s[b,i] in ATen sum(dim=1) order (cascade over i for columns
+ * j < 32*floor(N/32), 4-lane row_sum for the rest).  accumulate=0: out = 0 + r;
+ * accumulate=1: out = out + r (network.py:240-248, connection insertion order).
+ * Limits: Nin <= 2^19.                                                                     */
+int snn_prop_cascade_f32(const float *W, const uint8_t *s, float *out,
+                         int B, int Nin, int N, int accumulate, snn_stream_t stream);
+
+/* ---- a6: Connection.compute ---------------------------------------------------------------
+ * bindsnet/network/topology.py:332-346.  out[b,j] (+)= sum_i s[b,i]*W[i,j] (+ bias[j]),
+ * canonical ascending-i sequential f32 (the reference's MKL order is not reproducible,
+ * SURVEY.md finding 5).  bias may be NULL.                                                  */
+int snn_prop_dense_f32(const float *W, const float *bias, const uint8_t *s, float *out,
+                       int B, int Nin, int N, int accumulate, snn_stream_t stream);
+
+/* ---- a7: Conv2dConnection.compute ---------------------------------------------------------
+ * bindsnet/network/topology.py:799-815 (F.conv2d).  s [B,Cin,H,W] u8, W [Cout,Cin,KH,KW],
+ * out [B,Cout,OH,OW]; taps accumulated sequentially in (cin,kh,kw) row-major order, then bias.*/
+int snn_prop_conv2d_f32(const float *W, const float *bias, const uint8_t *s, float *out,
+                        int B, int Cin, int H, int Wd, int Cout, int KH, int KW,
+                        int stride, int pad, int accumulate, snn_stream_t stream);
+
+/* ---- a2: Input.forward + Nodes.forward trace ------------------------------------------------
+ * bindsnet/network/nodes.py:211-221, :96-107.  s is the caller's input slice (aliased, never
+ * copied); x (nullable) is the trace, updated in place; raster_out (nullable) receives s.   */
+int snn_input_step(const uint8_t *s, float *x, long n_total, float trace_decay,
+                   float trace_scale, int additive, uint8_t *raster_out, snn_stream_t stream);
+
+typedef struct {
+    float decay, rest, reset, thresh, refrac, dt;
+    int has_lbound; float lbound;
+    int traces; float trace_decay, trace_scale; int traces_additive;
+} snn_lif_params;
+
+/* ---- a3: LIFNodes.forward -------------------------------------------------------------------
+ * bindsnet/network/nodes.py:500-529.  v, refrac [B,N] f32 in/out; s [B,N] u8 out; x nullable
+ * trace; I [B,N] input current, masked in place where refractory (nodes.py:511);
+ * raster_s / raster_v nullable per-step monitor slices.                                      */
+int snn_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
+                 const snn_lif_params *h_p, uint8_t *raster_s, float *raster_v,
+                 snn_stream_t stream);
+
+typedef struct {
+    snn_lif_params lif;
+    float theta_decay, theta_plus;
+    int learning;      /* nodes.py:1078,1093: theta decays / grows only while learning */
+    int one_spike;     /* nodes.py:1097 */
+} snn_dc_params;
+
+/* ---- a4: DiehlAndCookNodes.forward ----------------------------------------------------------
+ * bindsnet/network/nodes.py:1069-1111.  theta [N] shared by the batch.  one_spike winner
+ * selection reproduces torch.multinomial on the CPU generator: noise_q is the pre-drawn
+ * Exp(1) stream (torch.empty(K).exponential_(1)), *cursor (device int64) the number of
+ * draws consumed so far; a step with r rows that crossed threshold consumes r*N draws
+ * (SURVEY.md Appendix B).  *status (device int32) is set to SNN_ERR_NOISE, and the step
+ * leaves s as the un-arbitrated crossings, if fewer than r*N draws remain.                   */
+int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta, const float *I,
+                int B, int N, const snn_dc_params *h_p,
+                const float *noise_q, long long q_len, long long *cursor, int *status,
+                uint8_t *raster_s, float *raster_v, snn_stream_t stream);
+
+/* ---- a8 / a9: PostPre -----------------------------------------------------------------------
+ * MCC: bindsnet/learning/MCC_learning.py:224-302 + :86-110 (use_dt = 1: each reduced update
+ * is multiplied by connection.dt).  Dense: bindsnet/learning/learning.py:390-420 + :87-104
+ * (use_dt = 0).  W -= sum_b s_src (x) (x_tgt*nu0); W += sum_b x_src (x) (s_tgt*nu1);
+ * W *= decay; clamp.  Batch sums in ATen sum(dim=0) order.  nu0 == 0 / nu1 == 0 skip that
+ * half like the reference.  assume_clamped = 1: the caller guarantees decay == 1 and W already
+ * inside [wmin, wmax], so elements with no pre- and no post-synaptic spike are skipped.
+ * Limits: B <= 256.                                                                          */
+int snn_stdp_postpre(float *W, const uint8_t *s_src, const float *x_src,
+                     const uint8_t *s_tgt, const float *x_tgt, int B, int Nin, int N,
+                     float nu0, float nu1, int use_dt, float dt, float decay,
+                     int has_min, float wmin, int has_max, float wmax, int assume_clamped,
+                     snn_stream_t stream);
+
+/* ---- a10: MSTDP -----------------------------------------------------------------------------
+ * bindsnet/learning/learning.py:1504-1574.  The reference's dense eligibility [B,Nin,N] is kept
+ * FACTORED: elig[b] = p_plus[b] (x) s_tgt_prev[b] + s_src_prev[b] (x) p_minus[b], where p_plus /
+ * p_minus are the values left by the previous call and *_prev the spikes of the previous call
+ * (in/out, zero before the first call == the reference's zero-initialised eligibility).
+ * Order: W += nu0 * sum_b reward*elig[b]  (batch sum in ATen sum(dim=0) order);
+ *        p_plus = p_plus*decay_plus + a_plus*s_src;  p_minus = p_minus*decay_minus + a_minus*s_tgt;
+ *        *_prev = current spikes;  W *= wdecay;  clamp.
+ * reward_vec (nullable, device [B]) overrides the scalar reward.  Limits: B <= 256.          */
+int snn_mstdp_step(float *W, float *p_plus, float *p_minus,
+                   uint8_t *s_src_prev, uint8_t *s_tgt_prev,
+                   const uint8_t *s_src, const uint8_t *s_tgt, int B, int Nin, int N,
+                   float reward, const float *reward_vec, float nu0, float a_plus, float a_minus,
+                   float decay_plus, float decay_minus, float wdecay,
+                   int has_min, float wmin, int has_max, float wmax, snn_stream_t stream);
+
+/* ---- a11: normalize -------------------------------------------------------------------------
+ * AbstractFeature.normalize, bindsnet/network/topology_features.py:250-266 (use_abs = 0) and
+ * Connection.normalize, bindsnet/network/topology.py:383-392 (use_abs = 1).
+ * colsum in ATen sum(dim=0) order, zero -> 1, W *= norm * (1/colsum).
+ * colsum_ws: device scratch of N floats.                                                      */
+int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *colsum_ws,
+                  snn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNNHIP_H */
