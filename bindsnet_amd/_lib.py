@@ -29,6 +29,36 @@ class DcParams(C.Structure):
                 ("learning", C.c_int), ("one_spike", C.c_int)]
 
 
+class LayerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_int), ("p", DcParams),
+                ("v", C.c_void_p), ("refrac", C.c_void_p), ("x", C.c_void_p), ("theta", C.c_void_p),
+                ("s", C.c_void_p), ("ext_spikes", C.c_void_p), ("raster_s", C.c_void_p),
+                ("raster_v", C.c_void_p), ("current", C.c_void_p)]
+
+
+class ConnDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("src", C.c_int), ("dst", C.c_int), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("cin", C.c_int), ("h", C.c_int), ("wd", C.c_int), ("cout", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("rule", C.c_int), ("nu0", C.c_float), ("nu1", C.c_float), ("use_dt", C.c_int),
+                ("wdecay", C.c_float), ("has_min", C.c_int), ("wmin", C.c_float), ("has_max", C.c_int),
+                ("wmax", C.c_float),
+                ("p_plus", C.c_void_p), ("p_minus", C.c_void_p), ("s_src_prev", C.c_void_p),
+                ("s_tgt_prev", C.c_void_p), ("reward", C.c_float), ("reward_vec", C.c_void_p),
+                ("a_plus", C.c_float), ("a_minus", C.c_float), ("decay_plus", C.c_float),
+                ("decay_minus", C.c_float),
+                ("has_norm", C.c_int), ("norm", C.c_float), ("norm_abs", C.c_int), ("norm_ws", C.c_void_p)]
+
+
+class RunDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
+                ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("cursor", C.c_void_p), ("status", C.c_void_p)]
+
+
+LAYER_INPUT, LAYER_LIF, LAYER_DC = 0, 1, 2
+CONN_MCC, CONN_DENSE, CONN_CONV2D = 0, 1, 2
+RULE_NONE, RULE_POSTPRE, RULE_MSTDP = 0, 1, 2
+
 _lib = None
 
 _vp, _i, _f, _l, _ll = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_longlong
@@ -46,6 +76,9 @@ _SIGS = {
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
+    "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
+    "snn_plan_name": ([], C.c_char_p),
+    "snn_set_plan_mode": ([_i], None),
 }
 
 

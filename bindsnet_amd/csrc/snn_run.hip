@@ -1,0 +1,142 @@
+// snn_run.hip -- Network.run() in C++: the per-timestep scheduler of
+// bindsnet/network/network.py:380-465 driving the gfx950 kernels.
+//
+// Plan "generic": per-operator launches in exactly the reference's order (connections in
+// insertion order feed `zeros + c1 + c2`, layers step in insertion order, then learning rules,
+// monitors are written by the node kernels themselves, normalisation after the loop).
+// Fused plans (below) replace the whole step by one launch for graphs they recognise.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/snnhip.h"
+#include "snn_common.hpp"
+
+static thread_local const char *g_plan = "none";
+static int g_plan_mode = 0;
+
+extern "C" const char *snn_plan_name(void) { return g_plan; }
+extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
+
+int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                         hipStream_t st, int *handled);
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
+    if (!L || nL <= 0 || (nC > 0 && !C) || !R || R->B <= 0 || R->T < 0) return SNN_ERR_INVALID;
+    for (int l = 0; l < nL; ++l) {
+        const snn_layer_desc &d = L[l];
+        if (d.n <= 0) return SNN_ERR_INVALID;
+        switch (d.kind) {
+            case SNN_LAYER_INPUT:
+                if (!d.ext_spikes || !d.s) return SNN_ERR_INVALID;
+                if (d.p.lif.traces && !d.x) return SNN_ERR_INVALID;
+                break;
+            case SNN_LAYER_DC:
+                if (!d.theta) return SNN_ERR_INVALID;
+                if (d.p.one_spike && (!R->noise_q || !R->cursor || !R->status)) return SNN_ERR_INVALID;
+                /* fallthrough */
+            case SNN_LAYER_LIF:
+                if (!d.v || !d.refrac || !d.s || !d.current) return SNN_ERR_INVALID;
+                if (d.p.lif.traces && !d.x) return SNN_ERR_INVALID;
+                break;
+            default: return SNN_ERR_INVALID;
+        }
+    }
+    for (int c = 0; c < nC; ++c) {
+        const snn_conn_desc &d = C[c];
+        if (d.src < 0 || d.src >= nL || d.dst < 0 || d.dst >= nL || !d.w) return SNN_ERR_INVALID;
+        if (L[d.dst].kind == SNN_LAYER_INPUT) return SNN_ERR_UNSUPPORTED;
+        if (d.rule != SNN_RULE_NONE && d.kind == SNN_CONN_CONV2D) return SNN_ERR_UNSUPPORTED;
+        if (d.rule == SNN_RULE_POSTPRE && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
+        if (d.rule == SNN_RULE_MSTDP && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
+        if (d.has_norm && (!d.norm_ws || d.kind == SNN_CONN_CONV2D)) return SNN_ERR_INVALID;
+    }
+    return SNN_OK;
+}
+
+// spikes of layer l as seen by connections BEFORE (after=false) / AFTER (after=true) its forward() at step t
+static const uint8_t *layer_spikes(const snn_layer_desc &d, int B, int t, bool after) {
+    if (d.kind != SNN_LAYER_INPUT) return d.s;
+    const size_t stride = (size_t)B * d.n;
+    if (after) return d.ext_spikes + (size_t)t * stride;
+    return t == 0 ? d.s : d.ext_spikes + (size_t)(t - 1) * stride;
+}
+
+static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                       hipStream_t st) {
+    const int B = R->B;
+    bool fed[64];
+    if (nL > 64) return SNN_ERR_UNSUPPORTED;
+    for (int t = 0; t < R->T; ++t) {
+        // (1) network.py:384 _get_inputs(): previous-step spikes through every connection, in order
+        for (int l = 0; l < nL; ++l) fed[l] = false;
+        for (int c = 0; c < nC; ++c) {
+            const snn_conn_desc &d = C[c];
+            const snn_layer_desc &S = L[d.src], &D = L[d.dst];
+            const uint8_t *sp = layer_spikes(S, B, t, false);
+            const int acc = fed[d.dst] ? 1 : 0;
+            if (d.kind == SNN_CONN_MCC) TRY(snn_prop_cascade_f32(d.w, sp, D.current, B, S.n, D.n, acc, st));
+            else if (d.kind == SNN_CONN_DENSE) TRY(snn_prop_dense_f32(d.w, d.bias, sp, D.current, B, S.n, D.n, acc, st));
+            else TRY(snn_prop_conv2d_f32(d.w, d.bias, sp, D.current, B, d.cin, d.h, d.wd, d.cout, d.kh, d.kw,
+                                         d.stride, d.pad, acc, st));
+            fed[d.dst] = true;
+        }
+        // (2) network.py:386-413 layers in insertion order
+        for (int l = 0; l < nL; ++l) {
+            const snn_layer_desc &d = L[l];
+            const size_t off = (size_t)t * B * d.n;
+            uint8_t *rs = d.raster_s ? d.raster_s + off : nullptr;
+            float *rv = d.raster_v ? d.raster_v + off : nullptr;
+            if (d.kind == SNN_LAYER_INPUT) {
+                TRY(snn_input_step(d.ext_spikes + off, d.p.lif.traces ? d.x : nullptr, (long)B * d.n,
+                                   d.p.lif.trace_decay, d.p.lif.trace_scale, d.p.lif.traces_additive, rs, st));
+                continue;
+            }
+            if (!fed[l]) TRY(snn_check(hipMemsetAsync(d.current, 0, sizeof(float) * (size_t)B * d.n, st)));  // :409-413
+            if (d.kind == SNN_LAYER_LIF) TRY(snn_lif_step(d.v, d.refrac, d.s, d.x, d.current, B, d.n, &d.p.lif, rs, rv, st));
+            else TRY(snn_dc_step(d.v, d.refrac, d.s, d.x, d.theta, d.current, B, d.n, &d.p, R->noise_q, R->q_len,
+                                 R->cursor, R->status, rs, rv, st));
+        }
+        // (3) network.py:431-454 learning rules, connection order
+        if (R->learning)
+            for (int c = 0; c < nC; ++c) {
+                const snn_conn_desc &d = C[c];
+                if (d.rule == SNN_RULE_NONE) continue;
+                const snn_layer_desc &S = L[d.src], &D = L[d.dst];
+                const uint8_t *ss = layer_spikes(S, B, t, true);
+                if (d.rule == SNN_RULE_POSTPRE)
+                    TRY(snn_stdp_postpre(d.w, ss, S.x, D.s, D.x, B, S.n, D.n, d.nu0, d.nu1, d.use_dt, R->dt, d.wdecay,
+                                         d.has_min, d.wmin, d.has_max, d.wmax, /*assume_clamped=*/t > 0, st));
+                else
+                    TRY(snn_mstdp_step(d.w, d.p_plus, d.p_minus, d.s_src_prev, d.s_tgt_prev, ss, D.s, B, S.n, D.n,
+                                       d.reward, d.reward_vec, d.nu0, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus,
+                                       d.wdecay, d.has_min, d.wmin, d.has_max, d.wmax, st));
+            }
+    }
+    return SNN_OK;
+}
+
+extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                           snn_stream_t stream) {
+    TRY(validate(L, nL, C, nC, R));
+    hipStream_t st = (hipStream_t)stream;
+    int handled = 0;
+    if (g_plan_mode == 0) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, &handled));
+    if (!handled) {
+        g_plan = "generic";
+        TRY(run_generic(L, nL, C, nC, R, st));
+    }
+    // network.py:464-465: normalise every connection after the loop (learning or not)
+    for (int c = 0; c < nC; ++c)
+        if (C[c].has_norm)
+            TRY(snn_normalize(C[c].w, L[C[c].src].n, L[C[c].dst].n, C[c].norm, C[c].norm_abs, C[c].norm_ws, st));
+    return SNN_OK;
+}
+
+// --- fused plans: filled in below -------------------------------------------------------------
+int snn_try_fused_dc2015(const snn_layer_desc *, int, const snn_conn_desc *, int, const snn_run_desc *, hipStream_t,
+                         int *handled) {
+    *handled = 0;
+    return SNN_OK;
+}

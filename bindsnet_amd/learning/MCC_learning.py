@@ -1,0 +1,109 @@
+"""Learning rules for MulticompartmentConnection features: API mirror of
+bindsnet/learning/MCC_learning.py for `MCC_LearningRule`, `NoOp`, `PostPre`.
+The update itself is snn_stdp_postpre (use_dt = 1)."""
+import warnings
+from typing import Optional, Sequence, Union
+
+import torch
+
+
+class MCC_LearningRule:
+    """Reference: MCC_learning.py:16-118 (nu parsing, reduction default, decay, clamp range)."""
+
+    def __init__(self, connection, feature_value, range: Optional[Union[list, tuple]] = None,
+                 nu: Optional[Union[float, Sequence[float]]] = None, reduction: Optional[callable] = None,
+                 decay: float = 0.0, enforce_polarity: bool = False, **kwargs) -> None:
+        self.connection = connection
+        self.source, self.target = connection.source, connection.target
+        self.feature_value = feature_value
+        self.enforce_polarity = enforce_polarity
+        if enforce_polarity:
+            raise NotImplementedError("bindsnet_amd: enforce_polarity is outside the accelerated path")
+        self.min, self.max = range
+        if nu is None:
+            nu = [0.2, 0.1]
+        elif isinstance(nu, (float, int)):
+            nu = [nu, nu]
+        self.nu = torch.zeros(2, dtype=torch.float)
+        self.nu[0], self.nu[1] = nu[0], nu[1]
+        if (self.nu == torch.zeros(2)).all() and not isinstance(self, NoOp):
+            warnings.warn(f"nu is set to [0., 0.] for {type(self).__name__} learning rule. "
+                          "It will disable the learning process.")
+        # MCC_learning.py:75-81: batch reduction defaults to sum unless the source already has batch 1
+        if reduction is None:
+            reduction = torch.squeeze if self.source.batch_size == 1 else torch.sum
+        self.reduction = reduction
+        self.decay = 1.0 - decay if decay else 1.0
+
+    def _bounds(self):
+        def one(v):
+            if v is None:
+                return None
+            if isinstance(v, torch.Tensor):
+                if v.numel() != 1:
+                    raise NotImplementedError("bindsnet_amd: per-synapse clamp ranges are not supported")
+                v = v.item()
+            v = float(v)
+            return None if v in (float("inf"), float("-inf")) else v
+        return one(self.min), one(self.max)
+
+    def update(self, **kwargs) -> None:
+        raise NotImplementedError
+
+    def reset_state_variables(self) -> None:
+        pass
+
+
+class NoOp(MCC_LearningRule):
+    def __init__(self, **args) -> None:
+        pass
+
+    def update(self, **kwargs) -> None:
+        pass
+
+    def reset_state_variables(self) -> None:
+        pass
+
+
+class PostPre(MCC_LearningRule):
+    """STDP with pre- (depressing) and post-synaptic (potentiating) terms.
+    Reference: MCC_learning.py:149-305."""
+
+    def __init__(self, connection, feature_value, range=None, nu=None, reduction=None, decay: float = 0.0,
+                 enforce_polarity: bool = False, **kwargs) -> None:
+        super().__init__(connection=connection, feature_value=feature_value,
+                         range=[-1, +1] if range is None else range, nu=nu, reduction=reduction, decay=decay,
+                         enforce_polarity=enforce_polarity, **kwargs)
+        assert self.source.traces and self.target.traces, (
+            "Both pre- and post-synaptic nodes must record spike traces "
+            "(use traces='True' on source/target layers)")
+        from ..network.topology import MulticompartmentConnection
+        if not isinstance(connection, MulticompartmentConnection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        if kwargs.get("average_update", 0):
+            raise NotImplementedError("bindsnet_amd: average_update buffers are outside the accelerated path")
+        if self.reduction not in (torch.sum, torch.squeeze):
+            raise NotImplementedError("bindsnet_amd: only reduction=torch.sum (or squeeze at batch 1) is supported")
+
+    def update(self, **kwargs) -> None:
+        """One step of MCC_learning.py:224-302 through the C ABI (used when a connection is
+        updated by hand; Network.run drives the same kernel from C++)."""
+        from .. import ops
+        B = self.source.batch_size
+        if self.reduction is torch.squeeze and B != 1:
+            raise RuntimeError("reduction=torch.squeeze requires batch size 1 (as in the reference)")
+        lo, hi = self._bounds()
+        ops.stdp_postpre(self.feature_value.data, self.source.s.reshape(B, -1).contiguous(),
+                         self.source.x.reshape(B, -1), self.target.s.reshape(B, -1), self.target.x.reshape(B, -1),
+                         float(self.nu[0]), float(self.nu[1]), use_dt=True, dt=float(self.connection.dt),
+                         decay=float(self.decay), wmin=lo, wmax=hi)
+
+
+class MSTDP(MCC_LearningRule):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("bindsnet_amd: MCC MSTDP is not on the accelerated path yet (SURVEY.md 8(f)-3)")
+
+
+class MSTDPET(MCC_LearningRule):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("bindsnet_amd: MCC MSTDPET is outside the accelerated path")

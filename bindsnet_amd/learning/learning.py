@@ -1,0 +1,133 @@
+"""Learning rules for dense `Connection`s: API mirror of bindsnet/learning/learning.py for
+`LearningRule`, `NoOp`, `PostPre`, `MSTDP`.  Updates run in snn_stdp_postpre / snn_mstdp_step."""
+import warnings
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+
+class LearningRule:
+    """Reference: learning.py:25-104."""
+
+    def __init__(self, connection, nu: Optional[Union[float, Sequence[float], Sequence[torch.Tensor]]] = None,
+                 reduction: Optional[callable] = None, weight_decay: float = 0.0, **kwargs) -> None:
+        self.connection = connection
+        self.source, self.target = connection.source, connection.target
+        self.wmin, self.wmax = connection.wmin, connection.wmax
+        if nu is None:
+            self.nu = torch.tensor([0.0, 0.0], dtype=torch.float)
+        elif isinstance(nu, (float, int)):
+            self.nu = torch.tensor([nu, nu], dtype=torch.float)
+        elif all(isinstance(e, (float, int)) for e in nu):
+            self.nu = torch.tensor(nu, dtype=torch.float)
+        else:
+            raise NotImplementedError("bindsnet_amd: per-synapse tensor learning rates are not supported")
+        if not self.nu.any() and not isinstance(self, NoOp):
+            warnings.warn(f"nu is set to zeros for {type(self).__name__} learning rule. "
+                          "It will disable the learning process.")
+        if reduction is None:  # learning.py:76-82
+            reduction = torch.squeeze if self.source.batch_size == 1 else torch.sum
+        self.reduction = reduction
+        self.weight_decay = 1.0 - weight_decay if weight_decay else 1.0
+
+    def _bounds(self):
+        c = self.connection
+        if c.wmin.numel() != 1 or c.wmax.numel() != 1:
+            raise NotImplementedError("bindsnet_amd: per-synapse wmin/wmax tensors are not supported")
+        lo, hi = float(c.wmin), float(c.wmax)
+        clamp = (lo != -np.inf or hi != np.inf) and not isinstance(self, NoOp)   # learning.py:97-104
+        if not clamp:
+            return None, None
+        return (None if lo == -np.inf else lo), (None if hi == np.inf else hi)
+
+    def _check_reduction(self):
+        B = self.source.batch_size
+        if self.reduction is torch.squeeze:
+            if B != 1:
+                raise RuntimeError("reduction=torch.squeeze with batch size > 1: pass reduction=torch.sum "
+                                   "(the reference fails with a broadcast error here)")
+        elif self.reduction is not torch.sum:
+            raise NotImplementedError("bindsnet_amd: only reduction=torch.sum (or squeeze at batch 1) is supported")
+
+    def update(self, **kwargs) -> None:
+        raise NotImplementedError
+
+    def reset_state_variables(self) -> None:
+        pass
+
+
+class NoOp(LearningRule):
+    def update(self, **kwargs) -> None:
+        if self.weight_decay != 1.0:
+            raise NotImplementedError("bindsnet_amd: weight_decay without a learning rule is not supported")
+
+
+class PostPre(LearningRule):
+    """Reference: learning.py:149-206, _connection_update :390-420."""
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        assert self.source.traces and self.target.traces, "Both pre- and post-synaptic nodes must record spike traces."
+        from ..network.topology import Connection
+        if not isinstance(connection, Connection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        self._check_reduction()
+        B = self.source.batch_size
+        lo, hi = self._bounds()
+        ops.stdp_postpre(self.connection.w.data, self.source.s.reshape(B, -1).contiguous(),
+                         self.source.x.reshape(B, -1), self.target.s.reshape(B, -1), self.target.x.reshape(B, -1),
+                         float(self.nu[0]), float(self.nu[1]), use_dt=False, decay=float(self.weight_decay),
+                         wmin=lo, wmax=hi)
+
+
+class MSTDP(LearningRule):
+    """Reward-modulated STDP (reference: learning.py:1441-1574).  The dense eligibility tensor of the
+    reference is kept factored on the device (see snn_mstdp_step); `p_plus`, `p_minus` keep their
+    reference meaning."""
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        from ..network.topology import Connection
+        if not isinstance(connection, Connection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
+        self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
+
+    def _ensure_state(self):
+        B, dev = self.source.batch_size, self.connection.w.device
+        if not hasattr(self, "p_plus") or self.p_plus.shape[0] != B or self.p_plus.device != dev:
+            self.p_plus = torch.zeros(B, self.source.n, device=dev)
+            self.p_minus = torch.zeros(B, self.target.n, device=dev)
+            self._s_src_prev = torch.zeros(B, self.source.n, dtype=torch.uint8, device=dev)
+            self._s_tgt_prev = torch.zeros(B, self.target.n, dtype=torch.uint8, device=dev)
+
+    def _decays(self):
+        dt = torch.tensor(self.connection.dt)
+        return float(torch.exp(-dt / self.tc_plus)), float(torch.exp(-dt / self.tc_minus))   # learning.py:1564,1566
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        self._check_reduction()
+        self._ensure_state()
+        B = self.source.batch_size
+        reward = kwargs["reward"]
+        rvec = None
+        if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+            rvec, reward = reward.to(self.connection.w.device, torch.float32).reshape(-1).contiguous(), 0.0
+        dp, dm = self._decays()
+        lo, hi = self._bounds()
+        ops.mstdp_step(self.connection.w.data, self.p_plus, self.p_minus, self._s_src_prev, self._s_tgt_prev,
+                       self.source.s.reshape(B, -1).contiguous(), self.target.s.reshape(B, -1), float(reward),
+                       float(self.nu[0]), float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0)), dp, dm,
+                       wdecay=float(self.weight_decay), wmin=lo, wmax=hi, reward_vec=rvec)
+
+    @property
+    def eligibility(self) -> torch.Tensor:
+        """Dense view of the factored eligibility (for inspection only)."""
+        self._ensure_state()
+        return (self.p_plus.unsqueeze(2) * self._s_tgt_prev.float().unsqueeze(1)
+                + self._s_src_prev.float().unsqueeze(2) * self.p_minus.unsqueeze(1))

@@ -1,0 +1,317 @@
+"""`Network`: API mirror of bindsnet/network/network.py.
+
+`run()` does not loop over timesteps in Python.  It translates the network (layers and
+connections in insertion order, monitors, keyword arguments) into the descriptor arrays of
+include/snnhip.h and makes ONE call to snn_net_run, which executes all T timesteps on the
+device (bindsnet/network/network.py:380-465 restated in bindsnet_amd/csrc/snn_run.hip).
+Anything the kernels do not implement raises NotImplementedError -- there is no fallback.
+"""
+import ctypes as C
+import tempfile
+from typing import Dict, Optional, Type
+
+import torch
+
+from .. import _lib
+from ..rng import NoiseStream
+from .monitors import AbstractMonitor, Monitor
+from .nodes import DiehlAndCookNodes, Input, LIFNodes, Nodes, _f
+from .topology import AbstractConnection, Connection, Conv2dConnection, MulticompartmentConnection
+
+
+def load(file_name: str, map_location: str = "cpu", learning: bool = None) -> "Network":
+    """Reference: network.py:12-28 (whole-object pickle)."""
+    network = torch.load(open(file_name, "rb"), map_location=map_location, weights_only=False)
+    if learning is not None and "learning" in vars(network):
+        network.learning = learning
+    return network
+
+
+def _dptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Network(torch.nn.Module):
+    def __init__(self, dt: float = 1.0, batch_size: int = 1, learning: bool = True,
+                 reward_fn: Optional[Type] = None) -> None:
+        super().__init__()
+        self.dt, self.batch_size = dt, batch_size
+        self.layers, self.connections, self.monitors = {}, {}, {}
+        self.train(learning)
+        self.reward_fn = reward_fn() if reward_fn is not None else None
+        self.last_plan = None          # name of the device plan the last run() used
+
+    # ------------------------------------------------------------------ construction (network.py:119-161)
+    def add_layer(self, layer: Nodes, name: str) -> None:
+        self.layers[name] = layer
+        self.add_module(name, layer)
+        layer.train(self.learning)
+        layer.compute_decays(self.dt)
+        layer.set_batch_size(self.batch_size)
+
+    def add_connection(self, connection, source: str, target: str) -> None:
+        self.connections[(source, target)] = connection
+        self.add_module(source + "_to_" + target, connection)
+        connection.dt = self.dt
+        connection.train(self.learning)
+
+    def add_monitor(self, monitor: AbstractMonitor, name: str) -> None:
+        self.monitors[name] = monitor
+        monitor.network = self
+        monitor.dt = self.dt
+
+    def save(self, file_name: str) -> None:
+        torch.save(self, open(file_name, "wb"))
+
+    def clone(self) -> "Network":
+        f = tempfile.SpooledTemporaryFile()
+        torch.save(self, f)
+        f.seek(0)
+        return torch.load(f, weights_only=False)
+
+    def reset_state_variables(self) -> None:
+        for l in self.layers.values():
+            l.reset_state_variables()
+        for c in self.connections.values():
+            c.reset_state_variables()
+        for m in self.monitors.values():
+            m.reset_state_variables()
+
+    def train(self, mode: bool = True) -> "torch.nn.Module":
+        self.learning = mode
+        return super().train(mode)
+
+    # ------------------------------------------------------------------ run
+    def run(self, inputs: Dict[str, torch.Tensor], time: int, one_step=False, **kwargs) -> None:
+        assert type(inputs) == dict, (
+            "'inputs' must be a dict of names of layers (str) and relevant input tensors. "
+            f"Got {type(inputs).__name__} instead.")
+        for k in ("clamp", "unclamp", "masks", "injects_v"):
+            if kwargs.get(k):
+                raise NotImplementedError(f"bindsnet_amd: run(..., {k}=...) is outside the accelerated path")
+        if one_step:
+            raise NotImplementedError("bindsnet_amd: one_step mode is outside the accelerated path")
+        if self.reward_fn is not None:
+            kwargs["reward"] = self.reward_fn.compute(**kwargs)
+
+        # shape normalisation + dynamic batch size (network.py:329-353)
+        for key in inputs:
+            if inputs[key].dim() == 1:
+                inputs[key] = inputs[key].unsqueeze(0).unsqueeze(0)
+            elif inputs[key].dim() == 2:
+                inputs[key] = inputs[key].unsqueeze(1)
+        for key in inputs:
+            if inputs[key].size(1) != self.batch_size:
+                self.batch_size = inputs[key].size(1)
+                for l in self.layers.values():
+                    l.set_batch_size(self.batch_size)
+                for m in self.monitors.values():
+                    m.reset_state_variables()
+            break
+
+        T, B = int(time / self.dt), self.batch_size
+        if T <= 0:
+            self._normalize_all()
+            return
+        dev = self._device()
+        if dev.type != "cuda":
+            raise _lib.SnnError("bindsnet_amd executes on an MI355X only: move the network with network.to('cuda') "
+                                "(there is no CPU fallback)")
+        keep = []                                 # tensors that must outlive the asynchronous launch
+        names = list(self.layers)
+        index = {n: i for i, n in enumerate(names)}
+        L = (_lib.LayerDesc * len(names))()
+        rasters = []                              # (monitor, var, tensor)
+        max_draws = 0
+        for i, name in enumerate(names):
+            layer, d = self.layers[name], L[i]
+            d.n = layer.n
+            if isinstance(layer, Input):
+                if name not in inputs:
+                    raise NotImplementedError(f"bindsnet_amd: Input layer '{name}' needs an entry in `inputs`")
+                x = inputs[name]
+                if x.shape[0] < T:
+                    raise ValueError(f"inputs['{name}'] has {x.shape[0]} timesteps, run() needs {T}")
+                if x.dtype not in (torch.uint8, torch.bool):
+                    raise NotImplementedError("bindsnet_amd: input spike trains must be uint8 or bool "
+                                              f"(got {x.dtype}); encoders produce uint8")
+                x = x.to(dev).contiguous()
+                if x.numel() != x.shape[0] * B * layer.n:
+                    raise ValueError(f"inputs['{name}'] has shape {tuple(x.shape)}, expected [T, {B}, {layer.n}]")
+                entry = layer.s
+                if entry.dtype not in (torch.uint8, torch.bool) or entry.numel() != B * layer.n or entry.device != dev:
+                    entry = torch.zeros(B, layer.n, dtype=torch.uint8, device=dev)
+                entry = entry.contiguous()
+                keep += [x, entry]
+                d.kind, d.ext_spikes, d.s = _lib.LAYER_INPUT, _dptr(x), _dptr(entry)
+                layer._trace_fields(d.p.lif)
+                d.x = _dptr(layer.x) if layer.traces else None
+                for m in self.monitors.values():   # the raster of an input layer IS its input (no copy)
+                    if isinstance(m, Monitor) and m.obj is layer:
+                        if list(m.state_vars) != ["s"]:
+                            raise NotImplementedError("bindsnet_amd: Input layers can only be monitored for 's'")
+                        rasters.append((m, "s", x[:T].view(T, B, *layer.shape)))
+                inputs[name] = x
+                continue
+            if name in inputs:
+                raise NotImplementedError("bindsnet_amd: external input currents into non-Input layers are "
+                                          "outside the accelerated path")
+            self._check_state(layer, B, dev)
+            mon_s, mon_v = self._monitor_buffers(layer, T, B, dev, rasters)
+            cur = torch.empty(B, layer.n, device=dev)
+            keep.append(cur)
+            d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
+            d.x = _dptr(layer.x) if layer.traces else None
+            d.raster_s, d.raster_v = _dptr(mon_s), _dptr(mon_v)
+            if isinstance(layer, DiehlAndCookNodes):
+                d.kind, d.p, d.theta = _lib.LAYER_DC, layer._dc_params(), _dptr(layer.theta)
+                if layer.one_spike:
+                    max_draws += B * layer.n * T
+            elif isinstance(layer, LIFNodes):
+                d.kind = _lib.LAYER_LIF
+                d.p.lif = layer._lif_params()
+            else:
+                raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
+                                          "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
+
+        Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
+        for k, ((src, dst), conn) in enumerate(self.connections.items()):
+            self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+
+        R = _lib.RunDesc()
+        R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
+        with NoiseStream(dev, max_draws) as ns:
+            R.noise_q, R.q_len = _dptr(ns.q), (0 if ns.q is None else ns.q.numel())
+            R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
+            rc = _lib.lib().snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "snn_net_run")
+            self.last_plan = _lib.lib().snn_plan_name().decode()
+        # Input.s aliases the last input slice, as in the reference (nodes.py:219)
+        for name in names:
+            if isinstance(self.layers[name], Input):
+                self.layers[name].s = inputs[name][T - 1]
+        for mon, var, buf in rasters:
+            mon._append(var, buf)
+        self._keep = keep
+
+    # ------------------------------------------------------------------ helpers
+    def _normalize_all(self):
+        for c in self.connections.values():
+            c.normalize()
+
+    def _device(self) -> torch.device:
+        for l in self.layers.values():
+            if hasattr(l, "v"):
+                return l.v.device
+        for l in self.layers.values():
+            return l.s.device
+        return torch.device("cpu")
+
+    @staticmethod
+    def _check_state(layer, B, dev):
+        for nm in ("v", "refrac_count") + (("x",) if layer.traces else ()):
+            t = getattr(layer, nm)
+            if t.device != dev or t.dtype != torch.float32 or t.numel() != B * layer.n or not t.is_contiguous():
+                raise ValueError(f"layer state '{nm}' must be a contiguous float32 [{B}, {layer.n}] tensor on {dev}")
+        if layer.s.dtype not in (torch.bool, torch.uint8) or layer.s.numel() != B * layer.n or layer.s.device != dev \
+                or not layer.s.is_contiguous():
+            layer.s = torch.zeros(B, *layer.shape, dtype=torch.bool, device=dev)
+
+    def _monitor_buffers(self, layer, T, B, dev, rasters):
+        mon_s = mon_v = None
+        for m in self.monitors.values():
+            if not isinstance(m, Monitor) or m.obj is not layer:
+                if isinstance(m, Monitor) and not isinstance(m.obj, Nodes):
+                    raise NotImplementedError("bindsnet_amd: monitors on connections/features are not supported")
+                continue
+            for var in m.state_vars:
+                if var == "s":
+                    if mon_s is None:          # bool like layer.s; the kernels store 0/1 bytes
+                        mon_s = torch.zeros(T, B, *layer.shape, dtype=torch.bool, device=dev)
+                    rasters.append((m, "s", mon_s))
+                elif var == "v" and hasattr(layer, "v"):
+                    if mon_v is None:
+                        mon_v = torch.zeros(T, B, *layer.shape, device=dev)
+                    rasters.append((m, "v", mon_v))
+                else:
+                    raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "
+                                              "outside the accelerated path (supported: 's', 'v')")
+        return mon_s, mon_v
+
+    def _fill_conn(self, d, conn, src, dst, B, dev, keep, kwargs):
+        from ..learning import learning as dense_rules
+        from ..learning import MCC_learning as mcc_rules
+        d.src, d.dst, d.rule, d.wdecay = src, dst, _lib.RULE_NONE, 1.0
+        if isinstance(conn, MulticompartmentConnection):
+            feat = conn._weight()
+            if feat.value.device != dev:
+                feat.to(dev)
+            d.kind, d.w = _lib.CONN_MCC, _dptr(feat.value.data)
+            rule = feat.learning_rule
+            if isinstance(rule, mcc_rules.PostPre) and not conn.manual_update:
+                if rule.reduction is torch.squeeze and B != 1:
+                    raise RuntimeError("reduction=torch.squeeze requires batch size 1")
+                lo, hi = rule._bounds()
+                d.rule, d.use_dt, d.wdecay = _lib.RULE_POSTPRE, 1, float(rule.decay)
+                d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+                d.has_min, d.wmin = int(lo is not None), lo or 0.0
+                d.has_max, d.wmax = int(hi is not None), hi or 0.0
+            elif not isinstance(rule, mcc_rules.NoOp):
+                raise NotImplementedError(f"bindsnet_amd: MCC rule {type(rule).__name__} is not supported")
+            if feat.norm is not None:
+                if isinstance(feat.norm, torch.Tensor):
+                    raise NotImplementedError("bindsnet_amd: tensor norms are not supported")
+                ws = torch.empty(conn.target.n, device=dev)
+                keep.append(ws)
+                d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(feat.norm), 0, _dptr(ws)
+            return
+        if not isinstance(conn, AbstractConnection):
+            raise NotImplementedError(f"bindsnet_amd: connection type {type(conn).__name__} is not supported")
+        if conn.w.device != dev:
+            raise ValueError("connection weights are not on the network's device; call network.to('cuda')")
+        d.w = _dptr(conn.w.data)
+        d.bias = _dptr(conn.b.data) if getattr(conn, "b", None) is not None else None
+        if isinstance(conn, Conv2dConnection):
+            d.kind = _lib.CONN_CONV2D
+            d.cin, d.h, d.wd = conn.in_channels, conn.source.shape[1], conn.source.shape[2]
+            d.cout, d.kh, d.kw = conn.out_channels, conn.kernel_size[0], conn.kernel_size[1]
+            d.stride, d.pad = conn.stride[0], conn.padding[0]
+        elif isinstance(conn, Connection):
+            d.kind = _lib.CONN_DENSE
+        else:
+            raise NotImplementedError(f"bindsnet_amd: connection type {type(conn).__name__} is not supported")
+        rule = conn.update_rule
+        if isinstance(rule, (dense_rules.PostPre, dense_rules.MSTDP)):
+            rule._check_reduction()
+            lo, hi = rule._bounds()
+            d.wdecay = float(rule.weight_decay)
+            d.has_min, d.wmin = int(lo is not None), lo or 0.0
+            d.has_max, d.wmax = int(hi is not None), hi or 0.0
+            d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+            if isinstance(rule, dense_rules.PostPre):
+                d.rule, d.use_dt = _lib.RULE_POSTPRE, 0
+            else:
+                if "reward" not in kwargs:
+                    raise KeyError("reward")
+                rule._ensure_state()
+                reward = kwargs["reward"]
+                if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+                    rv = reward.to(dev, torch.float32).reshape(-1).contiguous()
+                    keep.append(rv)
+                    d.reward_vec, reward = _dptr(rv), 0.0
+                a_plus, a_minus = kwargs.get("a_plus", 1.0), kwargs.get("a_minus", -1.0)
+                if isinstance(a_plus, dict) or isinstance(a_minus, dict):
+                    raise NotImplementedError("bindsnet_amd: per-connection a_plus/a_minus dicts are not supported")
+                d.rule, d.reward, d.a_plus, d.a_minus = _lib.RULE_MSTDP, float(reward), float(a_plus), float(a_minus)
+                d.decay_plus, d.decay_minus = rule._decays()
+                d.p_plus, d.p_minus = _dptr(rule.p_plus), _dptr(rule.p_minus)
+                d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
+        elif not isinstance(rule, dense_rules.NoOp):
+            raise NotImplementedError(f"bindsnet_amd: rule {type(rule).__name__} is not supported")
+        if conn.norm is not None:
+            if isinstance(conn, Conv2dConnection):
+                raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not supported")
+            ws = torch.empty(conn.target.n, device=dev)
+            keep.append(ws)
+            d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(conn.norm), 1, _dptr(ws)

@@ -1,0 +1,217 @@
+"""Neuron groups: API mirror of bindsnet/network/nodes.py for the layer types on the hot path
+(`Nodes`, `Input`, `LIFNodes`, `DiehlAndCookNodes`); the arithmetic lives in libsnnhip
+(snn_input_step / snn_lif_step / snn_dc_step).
+
+State is held in the same attributes as the reference (`s`, `x`, `v`, `refrac_count`, `theta`,
+`decay`, `trace_decay`, ...), so monitors, pickling and user code that pokes at them keep working.
+"""
+from functools import reduce
+from operator import mul
+from typing import Iterable, Optional, Union
+
+import torch
+
+from .. import _lib, ops
+
+Scalar = Union[float, torch.Tensor]
+
+
+def _f(t) -> float:
+    """Python float of a 0-dim parameter.  Per-neuron (tensor-valued) parameters are outside
+    the accelerated path (SURVEY.md 8(b) fallback rule) and are rejected loudly."""
+    if isinstance(t, torch.Tensor):
+        if t.numel() != 1:
+            raise NotImplementedError("bindsnet_amd: tensor-valued per-neuron parameters are not supported")
+        return float(t.reshape(()).item())
+    return float(t)
+
+
+class Nodes(torch.nn.Module):
+    """Base class (reference: nodes.py:9-162): spikes `s`, optional trace `x`."""
+
+    def __init__(self, n: Optional[int] = None, shape: Optional[Iterable[int]] = None, traces: bool = False,
+                 traces_additive: bool = False, tc_trace: Scalar = 20.0, trace_scale: Scalar = 1.0,
+                 sum_input: bool = False, learning: bool = True, **kwargs) -> None:
+        super().__init__()
+        if n is None and shape is None:
+            raise AssertionError("Must provide either no. of neurons or shape of layer")
+        self.n = reduce(mul, shape) if n is None else n
+        self.shape = [self.n] if shape is None else shape
+        assert self.n == reduce(mul, self.shape), "No. of neurons and shape do not match"
+        if sum_input:
+            raise NotImplementedError("bindsnet_amd: sum_input=True is outside the accelerated path")
+        self.traces, self.traces_additive, self.sum_input = traces, traces_additive, sum_input
+        self.register_buffer("s", torch.ByteTensor())
+        if traces:
+            self.register_buffer("x", torch.Tensor())
+            self.register_buffer("tc_trace", torch.tensor(tc_trace))
+            self.register_buffer("trace_scale", torch.tensor(trace_scale))
+            self.register_buffer("trace_decay", torch.empty_like(self.tc_trace))
+        self.dt = None
+        self.batch_size = None
+        self.learning = learning
+
+    # -- lifecycle hooks called by Network.add_layer (network.py:130-132) ----------------------
+    def compute_decays(self, dt) -> None:
+        self.dt = torch.tensor(dt)
+        if self.traces:  # same torch op as the reference so the constant is the same float
+            self.trace_decay = torch.exp(-self.dt / self.tc_trace.cpu()).to(self.tc_trace.device)
+
+    def set_batch_size(self, batch_size) -> None:
+        self.batch_size = batch_size
+        dev = self.s.device
+        self.s = torch.zeros(batch_size, *self.shape, device=dev, dtype=torch.bool)
+        if self.traces:
+            self.x = torch.zeros(batch_size, *self.shape, device=dev)
+
+    def reset_state_variables(self) -> None:
+        self.s.zero_()
+        if self.traces:
+            self.x.zero_()
+
+    def train(self, mode: bool = True) -> "Nodes":
+        self.learning = mode
+        return super().train(mode)
+
+    # -- descriptor pieces for the run driver ---------------------------------------------------
+    def _trace_fields(self, p: _lib.LifParams) -> None:
+        p.traces = int(self.traces)
+        if self.traces:
+            p.trace_decay, p.trace_scale = _f(self.trace_decay), _f(self.trace_scale)
+            p.traces_additive = int(self.traces_additive)
+
+    def forward(self, x: torch.Tensor) -> None:
+        raise NotImplementedError
+
+
+class AbstractInput:
+    pass
+
+
+class Input(Nodes, AbstractInput):
+    """User-driven spikes (reference: nodes.py:172-228): `s` aliases the input, trace optional."""
+
+    def __init__(self, n=None, shape=None, traces=False, traces_additive=False, tc_trace=20.0, trace_scale=1.0,
+                 sum_input=False, **kwargs) -> None:
+        super().__init__(n=n, shape=shape, traces=traces, traces_additive=traces_additive, tc_trace=tc_trace,
+                         trace_scale=trace_scale, sum_input=sum_input)
+
+    def forward(self, x: torch.Tensor) -> None:
+        self.s = x
+        if self.traces:
+            ops.input_step(x.contiguous(), self.x, _f(self.trace_decay), _f(self.trace_scale), self.traces_additive)
+
+
+class LIFNodes(Nodes):
+    """Leaky integrate-and-fire layer (reference: nodes.py:418-559)."""
+
+    def __init__(self, n=None, shape=None, traces=False, traces_additive=False, tc_trace=20.0, trace_scale=1.0,
+                 sum_input=False, thresh: Scalar = -52.0, rest: Scalar = -65.0, reset: Scalar = -65.0,
+                 refrac: Union[int, torch.Tensor] = 5, tc_decay: Scalar = 100.0, lbound: float = None,
+                 **kwargs) -> None:
+        super().__init__(n=n, shape=shape, traces=traces, traces_additive=traces_additive, tc_trace=tc_trace,
+                         trace_scale=trace_scale, sum_input=sum_input)
+        self.register_buffer("rest", torch.tensor(rest, dtype=torch.float))
+        self.register_buffer("reset", torch.tensor(reset, dtype=torch.float))
+        self.register_buffer("thresh", torch.tensor(thresh, dtype=torch.float))
+        self.register_buffer("refrac", torch.tensor(refrac))
+        self.register_buffer("tc_decay", torch.tensor(tc_decay, dtype=torch.float))
+        self.register_buffer("decay", torch.zeros(*self.shape))
+        self.register_buffer("v", torch.FloatTensor())
+        self.register_buffer("refrac_count", torch.FloatTensor())
+        self.lbound = None if lbound is None else torch.tensor(lbound, dtype=torch.float)
+
+    def compute_decays(self, dt) -> None:
+        super().compute_decays(dt=dt)
+        self.decay = torch.exp(-self.dt / self.tc_decay.cpu()).to(self.tc_decay.device)
+
+    def set_batch_size(self, batch_size) -> None:
+        super().set_batch_size(batch_size=batch_size)
+        dev = self.v.device
+        self.v = self.rest.to(dev) * torch.ones(batch_size, *self.shape, device=dev)
+        self.refrac_count = torch.zeros_like(self.v)
+
+    def reset_state_variables(self) -> None:
+        super().reset_state_variables()
+        self.v.fill_(_f(self.rest))
+        self.refrac_count.zero_()
+
+    def _lif_params(self) -> _lib.LifParams:
+        p = _lib.LifParams()
+        p.decay, p.rest, p.reset, p.thresh = _f(self.decay), _f(self.rest), _f(self.reset), _f(self.thresh)
+        p.refrac, p.dt = _f(self.refrac), _f(self.dt)
+        p.has_lbound = int(self.lbound is not None)
+        p.lbound = _f(self.lbound) if self.lbound is not None else 0.0
+        self._trace_fields(p)
+        return p
+
+    def forward(self, x: torch.Tensor) -> None:
+        """One step (nodes.py:500-529); `x` is masked in place where refractory, as in the reference."""
+        if self.s.dtype != torch.bool or self.s.shape != self.v.shape:
+            self.s = torch.zeros_like(self.v, dtype=torch.bool)
+        ops.lif_step(self.v, self.refrac_count, self.s, self.x if self.traces else None, x, self._lif_params())
+
+
+class DiehlAndCookNodes(Nodes):
+    """LIF with adaptive threshold and one-spike arbitration (reference: nodes.py:981-1144)."""
+
+    def __init__(self, n=None, shape=None, traces=False, traces_additive=False, tc_trace=20.0, trace_scale=1.0,
+                 sum_input=False, thresh: Scalar = -52.0, rest: Scalar = -65.0, reset: Scalar = -65.0,
+                 refrac: Union[int, torch.Tensor] = 5, tc_decay: Scalar = 100.0, theta_plus: Scalar = 0.05,
+                 tc_theta_decay: Scalar = 1e7, lbound: float = None, one_spike: bool = True, **kwargs) -> None:
+        super().__init__(n=n, shape=shape, traces=traces, traces_additive=traces_additive, tc_trace=tc_trace,
+                         trace_scale=trace_scale, sum_input=sum_input)
+        self.register_buffer("rest", torch.tensor(rest))
+        self.register_buffer("reset", torch.tensor(reset))
+        self.register_buffer("thresh", torch.tensor(thresh))
+        self.register_buffer("refrac", torch.tensor(refrac))
+        self.register_buffer("tc_decay", torch.tensor(tc_decay))
+        self.register_buffer("decay", torch.empty_like(self.tc_decay))
+        self.register_buffer("theta_plus", torch.tensor(theta_plus))
+        self.register_buffer("tc_theta_decay", torch.tensor(tc_theta_decay))
+        self.register_buffer("theta_decay", torch.empty_like(self.tc_theta_decay))
+        self.register_buffer("v", torch.FloatTensor())
+        self.register_buffer("theta", torch.zeros(*self.shape))
+        self.register_buffer("refrac_count", torch.FloatTensor())
+        self.lbound = lbound
+        self.one_spike = one_spike
+
+    def compute_decays(self, dt) -> None:
+        super().compute_decays(dt=dt)
+        dev = self.tc_decay.device
+        self.decay = torch.exp(-self.dt / self.tc_decay.cpu()).to(dev)
+        self.theta_decay = torch.exp(-self.dt / self.tc_theta_decay.cpu()).to(dev)
+
+    def set_batch_size(self, batch_size) -> None:
+        super().set_batch_size(batch_size=batch_size)
+        dev = self.v.device
+        self.v = self.rest.to(dev) * torch.ones(batch_size, *self.shape, device=dev)
+        self.refrac_count = torch.zeros_like(self.v)
+
+    def reset_state_variables(self) -> None:  # theta is NOT reset (nodes.py:1113-1120)
+        super().reset_state_variables()
+        self.v.fill_(_f(self.rest))
+        self.refrac_count.zero_()
+
+    def _dc_params(self) -> _lib.DcParams:
+        p = _lib.DcParams()
+        l = p.lif
+        l.decay, l.rest, l.reset, l.thresh = _f(self.decay), _f(self.rest), _f(self.reset), _f(self.thresh)
+        l.refrac, l.dt = _f(self.refrac), _f(self.dt)
+        l.has_lbound = int(self.lbound is not None)
+        l.lbound = float(self.lbound) if self.lbound is not None else 0.0
+        self._trace_fields(l)
+        p.theta_decay, p.theta_plus = _f(self.theta_decay), _f(self.theta_plus)
+        p.learning, p.one_spike = int(self.learning), int(self.one_spike)
+        return p
+
+    def forward(self, x: torch.Tensor) -> None:
+        """One step (nodes.py:1069-1111).  The winner draw consumes the global CPU generator
+        exactly like torch.multinomial does in the reference (see bindsnet_amd/rng.py)."""
+        from ..rng import NoiseStream
+        if self.s.dtype != torch.bool or self.s.shape != self.v.shape:
+            self.s = torch.zeros_like(self.v, dtype=torch.bool)
+        B = self.v.shape[0]
+        with NoiseStream(self.v.device, max_draws=B * self.n if self.one_spike else 0) as ns:
+            ops.dc_step(self.v, self.refrac_count, self.s, self.x if self.traces else None, self.theta, x,
+                        self._dc_params(), ns.q, ns.cursor, ns.status)

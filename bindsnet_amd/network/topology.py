@@ -1,0 +1,213 @@
+"""Connections: API mirror of bindsnet/network/topology.py for the connection types on the hot
+path (`Connection`, `MulticompartmentConnection`, `Conv2dConnection`).  `compute()` launches the
+matching propagation kernel of libsnnhip; inside Network.run the same kernels are driven from C++.
+"""
+import warnings
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch.nn import Module, Parameter
+from torch.nn.modules.utils import _pair
+
+from .. import ops
+from .nodes import Nodes
+
+
+class AbstractConnection(Module):
+    """Reference: topology.py:17-156 (wmin/wmax/norm/update_rule plumbing)."""
+
+    def __init__(self, source: Nodes, target: Nodes, nu=None, reduction: Optional[callable] = None,
+                 weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__()
+        assert isinstance(source, Nodes), "Source is not a Nodes object"
+        assert isinstance(target, Nodes), "Target is not a Nodes object"
+        self.source, self.target = source, target
+        self.weight_decay, self.reduction = weight_decay, reduction
+        from ..learning import NoOp
+        self.wmin = Parameter(torch.as_tensor(kwargs.get("wmin", -np.inf), dtype=torch.float32), requires_grad=False)
+        self.wmax = Parameter(torch.as_tensor(kwargs.get("wmax", np.inf), dtype=torch.float32), requires_grad=False)
+        self.norm = kwargs.get("norm", None)
+        self.decay = kwargs.get("decay", None)
+        if kwargs.get("Dales_rule", None) is not None:
+            raise NotImplementedError("bindsnet_amd: Dales_rule is outside the accelerated path")
+        self.Dales_rule = None
+        rule = kwargs.get("update_rule", None) or NoOp
+        self.update_rule = rule(connection=self, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+
+    def update(self, **kwargs) -> None:
+        """Reference: topology.py:112-139."""
+        if kwargs.get("learning", True):
+            self.update_rule.update(**kwargs)
+        if kwargs.get("mask", None) is not None:
+            raise NotImplementedError("bindsnet_amd: weight masks are outside the accelerated path")
+
+    def reset_state_variables(self) -> None:
+        pass
+
+    @staticmethod
+    def cast_dtype_if_needed(w, w_dtype):
+        if w.dtype != w_dtype:
+            warnings.warn(f"Provided w has data type {w.dtype} but parameter w_dtype is {w_dtype}")
+            return w.to(dtype=w_dtype)
+        return w
+
+
+class Connection(AbstractConnection):
+    """Dense all-to-all synapses (reference: topology.py:265-399)."""
+
+    def __init__(self, source: Nodes, target: Nodes, nu=None, reduction=None, weight_decay: float = 0.0,
+                 w_dtype: torch.dtype = torch.float32, **kwargs) -> None:
+        super().__init__(source, target, nu, reduction, weight_decay, **kwargs)
+        if w_dtype != torch.float32:
+            raise NotImplementedError("bindsnet_amd computes in float32 only")
+        w = kwargs.get("w", None)
+        unbounded = bool((self.wmin == -np.inf).any() or (self.wmax == np.inf).any())
+        if w is None:  # consumes the global generator exactly like the reference (topology.py:309-315)
+            if unbounded:
+                w = torch.clamp(torch.rand(source.n, target.n), self.wmin, self.wmax)
+            else:
+                w = self.wmin + torch.rand(source.n, target.n) * (self.wmax - self.wmin)
+            w = w.to(dtype=w_dtype)
+        else:
+            if bool((self.wmin != -np.inf).any() or (self.wmax != np.inf).any()):
+                w = torch.clamp(torch.as_tensor(w), self.wmin, self.wmax)
+            w = self.cast_dtype_if_needed(w, w_dtype)
+        self.w = Parameter(w, requires_grad=False)
+        b = kwargs.get("b", None)
+        self.b = Parameter(b, requires_grad=False) if b is not None else None
+
+    def compute(self, s: torch.Tensor) -> torch.Tensor:
+        """s.view(B,-1) @ w (+ b) in canonical ascending-source order (topology.py:332-346)."""
+        B = s.size(0)
+        out = torch.empty(B, self.target.n, device=self.w.device)
+        ops.prop_dense(self.w.data, s.reshape(B, -1).contiguous(), out, bias=None if self.b is None else self.b.data)
+        return out.view(B, *self.target.shape)
+
+    def normalize(self) -> None:
+        """Reference: topology.py:383-392 (abs column sums)."""
+        if self.norm is not None:
+            ops.normalize(self.w.data, float(self.norm), use_abs=True)
+
+
+class Conv2dConnection(AbstractConnection):
+    """2-D convolutional synapses (reference: topology.py:686-844); propagation only."""
+
+    def __init__(self, source: Nodes, target: Nodes, kernel_size: Union[int, Tuple[int, int]],
+                 stride: Union[int, Tuple[int, int]] = 1, padding: Union[int, Tuple[int, int]] = 0,
+                 dilation: Union[int, Tuple[int, int]] = 1, nu=None, reduction=None, weight_decay: float = 0.0,
+                 w_dtype: torch.dtype = torch.float32, **kwargs) -> None:
+        super().__init__(source, target, nu, reduction, weight_decay, **kwargs)
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        if self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("bindsnet_amd: conv2d supports dilation 1 and symmetric stride/padding only")
+        if kwargs.get("update_rule", None) is not None:
+            raise NotImplementedError("bindsnet_amd: learning on Conv2dConnection is not on the accelerated path "
+                                      "(SURVEY.md 8(f)-4)")
+        self.in_channels, ih, iw = source.shape[0], source.shape[1], source.shape[2]
+        self.out_channels = target.shape[0]
+        oh = int((ih - self.kernel_size[0] + 2 * self.padding[0]) / self.stride[0] + 1)
+        ow = int((iw - self.kernel_size[1] + 2 * self.padding[1]) / self.stride[1] + 1)
+        assert target.shape[1] == oh and target.shape[2] == ow, (
+            "Target dimensionality must be (out_channels, ?,"
+            "(input_height - filter_height + 2 * padding_height) / stride_height + 1,"
+            "(input_width - filter_width + 2 * padding_width) / stride_width + 1")
+        w = kwargs.get("w", None)
+        inf = torch.tensor(np.inf)
+        unbounded = bool((self.wmin == -inf).any() or (self.wmax == inf).any())
+        if w is None:
+            r = torch.rand(self.out_channels, self.in_channels, *self.kernel_size)
+            w = torch.clamp(r, self.wmin, self.wmax) if unbounded else (self.wmax - self.wmin) * r + self.wmin
+            w = w.to(dtype=w_dtype)
+        else:
+            if unbounded:
+                w = torch.clamp(w, self.wmin, self.wmax)
+            w = self.cast_dtype_if_needed(w, w_dtype)
+        self.w = Parameter(w, requires_grad=False)
+        self.b = Parameter(kwargs.get("b", torch.zeros(self.out_channels)), requires_grad=False)
+
+    def compute(self, s: torch.Tensor) -> torch.Tensor:
+        B = s.size(0)
+        out = torch.empty(B, *self.target.shape, device=self.w.device)
+        ops.prop_conv2d(self.w.data, s.contiguous(), out, bias=self.b.data, stride=self.stride[0], pad=self.padding[0])
+        return out
+
+    def normalize(self) -> None:
+        if self.norm is not None:
+            raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not on the accelerated path")
+
+
+class AbstractMulticompartmentConnection(Module):
+    """Reference: topology.py:159-262 (feature pipeline bookkeeping)."""
+
+    def __init__(self, source: Nodes, target: Nodes, device, pipeline: list = None, **kwargs) -> None:
+        super().__init__()
+        assert isinstance(source, Nodes), "Source is not a Nodes object"
+        assert isinstance(target, Nodes), "Target is not a Nodes object"
+        self.source, self.target, self.device = source, target, device
+        self.pipeline = [] if pipeline is None else pipeline
+        self.feature_index = {}
+        for feature in self.pipeline:
+            self.feature_index[feature.name] = feature
+            feature.prime_feature(connection=self, device=self.device, **kwargs)
+
+    def append_pipeline(self, feature) -> None:
+        self.pipeline.append(feature)
+        feature.prime_feature(connection=self, device=self.device)
+        self.feature_index[feature.name] = feature
+
+    def remove_pipeline(self, feature) -> None:
+        self.pipeline.remove(feature)
+        del self.feature_index[feature.name]
+
+    def _apply(self, fn, *a, **k):
+        """nn.Module.to()/cuda() hook: also move feature values, which live in a plain python list
+        and which the reference leaves behind on the CPU (SURVEY.md finding 8)."""
+        out = super()._apply(fn, *a, **k)
+        probe = fn(torch.empty(0))
+        for f in self.pipeline:
+            f.to(probe.device)
+        self.device = probe.device
+        return out
+
+
+class MulticompartmentConnection(AbstractMulticompartmentConnection):
+    """Feature-pipeline connection (reference: topology.py:402-537).  The accelerated path is a
+    pipeline of exactly one `Weight`."""
+
+    def __init__(self, source: Nodes, target: Nodes, device, pipeline: list = [], manual_update: bool = False,
+                 traces: bool = False, **kwargs) -> None:
+        super().__init__(source, target, device, pipeline, **kwargs)
+        if traces:
+            raise NotImplementedError("bindsnet_amd: connection activity traces are outside the accelerated path")
+        self.traces, self.manual_update = traces, manual_update
+
+    def _weight(self):
+        from .topology_features import Weight
+        if len(self.pipeline) != 1 or not isinstance(self.pipeline[0], Weight):
+            raise NotImplementedError("bindsnet_amd accelerates MulticompartmentConnection with a single Weight "
+                                      f"feature; got {[type(f).__name__ for f in self.pipeline]}")
+        return self.pipeline[0]
+
+    def compute(self, s: torch.Tensor) -> torch.Tensor:
+        """out[b,j] = sum_i value[i,j]*s[b,i] in the reference's ATen sum order (topology.py:437-479)."""
+        w = self._weight().value
+        B = s.size(0)
+        out = torch.empty(B, self.target.n, device=w.device)
+        ops.prop_cascade(w.data, s.reshape(B, -1).contiguous(), out)
+        return out.view(B, *self.target.shape)
+
+    def update(self, **kwargs) -> None:
+        """Reference: topology.py:509-518 (note the default learning=False)."""
+        if kwargs.get("learning", False) and not self.manual_update:
+            for f in self.pipeline:
+                f.update(**kwargs)
+
+    def normalize(self) -> None:
+        for f in self.pipeline:
+            f.normalize()
+
+    def reset_state_variables(self) -> None:
+        for f in self.pipeline:
+            f.reset_state_variables()

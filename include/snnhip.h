@@ -149,6 +149,66 @@ int snn_mstdp_step(float *W, float *p_plus, float *p_minus,
 int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *colsum_ws,
                   snn_stream_t stream);
 
+
+/* ---- a1: Network.run ------------------------------------------------------------------------
+ * bindsnet/network/network.py:380-465 (the per-timestep loop and the post-loop normalisation),
+ * for graphs built from {Input, LIFNodes, DiehlAndCookNodes} x {MulticompartmentConnection+
+ * Weight, Connection, Conv2dConnection} x {no rule, PostPre, MSTDP}.  The descriptors are HOST
+ * structs holding DEVICE pointers; layers and connections are listed in network insertion
+ * order, which fixes the evaluation order exactly as the reference's dict iteration does.   */
+enum { SNN_LAYER_INPUT = 0, SNN_LAYER_LIF = 1, SNN_LAYER_DC = 2 };
+enum { SNN_CONN_MCC = 0, SNN_CONN_DENSE = 1, SNN_CONN_CONV2D = 2 };
+enum { SNN_RULE_NONE = 0, SNN_RULE_POSTPRE = 1, SNN_RULE_MSTDP = 2 };
+
+typedef struct {
+    int kind;                   /* SNN_LAYER_* */
+    int n;                      /* neurons per sample */
+    snn_dc_params p;            /* LIF uses p.lif only; INPUT uses p.lif.traces/trace_* only */
+    float *v, *refrac, *x, *theta;   /* state [B,n] ([n] for theta); NULL where the layer has none */
+    uint8_t *s;                 /* [B,n] spikes at entry, updated in place (INPUT: entry value, read only) */
+    const uint8_t *ext_spikes;  /* INPUT: the [T,B,n] input tensor (aliased per step, never copied) */
+    uint8_t *raster_s;          /* nullable [T,B,n] spike monitor */
+    float *raster_v;            /* nullable [T,B,n] voltage monitor */
+    float *current;             /* [B,n] scratch for the summed input current (non-INPUT layers) */
+} snn_layer_desc;
+
+typedef struct {
+    int kind;                   /* SNN_CONN_* */
+    int src, dst;               /* indices into the layer array */
+    float *w;                   /* [Nin,N] (CONV2D: [Cout,Cin,KH,KW]) */
+    const float *bias;          /* nullable */
+    int cin, h, wd, cout, kh, kw, stride, pad;   /* CONV2D geometry */
+    int rule;                   /* SNN_RULE_* */
+    float nu0, nu1;
+    int use_dt;                 /* 1: MCC PostPre multiplies updates by dt */
+    float wdecay;               /* multiplicative decay actually applied (1.0 = none) */
+    int has_min; float wmin; int has_max; float wmax;
+    float *p_plus, *p_minus;    /* MSTDP state [B,Nin] / [B,N] */
+    uint8_t *s_src_prev, *s_tgt_prev;
+    float reward; const float *reward_vec; float a_plus, a_minus, decay_plus, decay_minus;
+    int has_norm; float norm; int norm_abs;   /* post-run normalisation (norm_abs: Connection) */
+    float *norm_ws;             /* [N] scratch when has_norm */
+} snn_conn_desc;
+
+typedef struct {
+    int B, T;
+    float dt;
+    int learning;               /* Network.learning */
+    const float *noise_q;       /* Exp(1) stream for one_spike (see snn_dc_step); nullable */
+    long long q_len;
+    long long *cursor;          /* device int64[2] */
+    int *status;                /* device int32[1]: 0 or SNN_ERR_NOISE after the run */
+} snn_run_desc;
+
+/* Runs T timesteps.  Asynchronous; the caller synchronises the stream before reading *status /
+ * cursor[0].  Picks a fused plan when the graph matches one (snn_plan_name reports which).  */
+int snn_net_run(const snn_layer_desc *h_layers, int n_layers, const snn_conn_desc *h_conns, int n_conns,
+                const snn_run_desc *h_run, snn_stream_t stream);
+/* Name of the plan the last snn_net_run on this thread used ("generic", "dc2015-fused", ...). */
+const char *snn_plan_name(void);
+/* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only. */
+void snn_set_plan_mode(int mode);
+
 #ifdef __cplusplus
 }
 #endif
