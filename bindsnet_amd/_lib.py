@@ -52,7 +52,8 @@ class ConnDesc(C.Structure):
 
 class RunDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
-                ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("cursor", C.c_void_p), ("status", C.c_void_p)]
+                ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
+                ("cursor", C.c_void_p), ("status", C.c_void_p)]
 
 
 LAYER_INPUT, LAYER_LIF, LAYER_DC = 0, 1, 2
@@ -76,6 +77,7 @@ _SIGS = {
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
+    "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
     "snn_plan_name": ([], C.c_char_p),
     "snn_set_plan_mode": ([_i], None),

@@ -9,6 +9,7 @@
 #include "../../include/snnhip.h"
 #include "snn_order.hpp"
 #include "snn_common.hpp"
+#include "snn_rng.hpp"
 
 using namespace snn;
 
@@ -295,6 +296,19 @@ __global__ __launch_bounds__(256) void k_dc_arbitrate(uint8_t *__restrict__ s, f
     }
 }
 
+int snn_launch_dc_membrane(float *v, float *refrac, uint8_t *s, float *theta, const float *I, int B, int N,
+                           const snn_dc_params &p, long long *cursor, float *raster_v, hipStream_t st) {
+    hipLaunchKernelGGL(k_dc_membrane, dim3((N + 255) / 256), dim3(256), 0, st, v, refrac, s, theta, I, B, N, p, cursor,
+                       raster_v);
+    return snn_check_launch();
+}
+
+int snn_launch_dc_arbitrate(uint8_t *s, float *x, int B, int N, const snn_dc_params &p, const float *Q, long long q_len,
+                            long long *cursor, int *status, uint8_t *raster_s, hipStream_t st) {
+    hipLaunchKernelGGL(k_dc_arbitrate, dim3(B), dim3(256), 0, st, s, x, B, N, p, Q, q_len, cursor, status, raster_s);
+    return snn_check_launch();
+}
+
 extern "C" int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta, const float *I, int B,
                            int N, const snn_dc_params *h_p, const float *noise_q, long long q_len,
                            long long *cursor, int *status, uint8_t *raster_s, float *raster_v,
@@ -303,13 +317,83 @@ extern "C" int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float 
     if (h_p->lif.traces && !x) return SNN_ERR_INVALID;
     if (h_p->one_spike && (!noise_q || !cursor || !status)) return SNN_ERR_INVALID;
     if (B > 1024) return SNN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_dc_membrane, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, refrac, s,
-                       theta, I, B, N, *h_p, cursor, raster_v);
-    int rc = snn_check_launch();
+    int rc = snn_launch_dc_membrane(v, refrac, s, theta, I, B, N, *h_p, cursor, raster_v, (hipStream_t)stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dc_arbitrate, dim3(B), dim3(256), 0, (hipStream_t)stream, s, x, B, N, *h_p, noise_q,
-                       q_len, cursor, status, raster_s);
+    return snn_launch_dc_arbitrate(s, x, B, N, *h_p, noise_q, q_len, cursor, status, raster_s, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side noise for one_spike: materialise, for the rows that crossed threshold this step,
+// exactly the Exp(1) draws torch.multinomial would consume (row-major over [rows_with_crossing, N]),
+// but only at the candidate positions (the others are never read by the arbitration).
+// One workgroup: the mt19937 state is staged in LDS and advanced block by block.
+// qbuf[rank*N + j] receives the draw of candidate (b, j); cursor[1] is zeroed so that
+// k_dc_arbitrate indexes qbuf from 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rng_fill(snn_rng_state *__restrict__ rng, const uint8_t *__restrict__ s,
+                                                   int B, int N, float *__restrict__ qbuf,
+                                                   long long *__restrict__ cursor) {
+    __shared__ uint32_t mt[2][624];
+    __shared__ int rank[1025];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 624; i += 1024) mt[0][i] = rng->mt[i];
+    for (int r = wave; r < B; r += 16) {
+        bool a = false;
+        for (int j = lane; j < N; j += 64) a |= s[(size_t)r * N + j] != 0;
+        const uint64_t m = __ballot(a);
+        if (lane == 0) rank[r + 1] = m != 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rank[0] = 0;
+        for (int r = 0; r < B; ++r) rank[r + 1] += rank[r];
+        cursor[1] = 0;
+    }
+    __syncthreads();
+    const int rows = rank[B];
+    if (rows == 0) return;
+    const long long pos = rng->pos;
+    const long long E = pos + 2ll * rows * N;          // one past the last 32-bit output consumed
+    const int ntw = (int)((E - 1) / 624);              // twists the lazy generator performs
+    const long long total = (long long)B * N;
+    for (int m = 0; m <= ntw; ++m) {
+        const uint32_t *cur = mt[m & 1];
+        for (long long idx = tid; idx < total; idx += 1024) {
+            if (!s[idx]) continue;
+            const int b = (int)(idx / N), j = (int)(idx - (long long)b * N);
+            if (rank[b + 1] == rank[b]) continue;
+            const long long d = (long long)rank[b] * N + j;
+            const long long w0 = pos + 2 * d, w1 = w0 + 1;
+            const int m0 = (int)(w0 / 624), m1 = (int)(w1 / 624);
+            if (m0 == m && m1 == m) {
+                qbuf[d] = exp1_from_words(mt_temper(cur[w0 - 624ll * m]), mt_temper(cur[w1 - 624ll * m]));
+            } else if (m0 == m) {                        // pair straddles a twist: park the high word
+                qbuf[d] = __uint_as_float(mt_temper(cur[w0 - 624ll * m]));
+            } else if (m1 == m) {
+                qbuf[d] = exp1_from_words(__float_as_uint(qbuf[d]), mt_temper(cur[w1 - 624ll * m]));
+            }
+        }
+        __syncthreads();
+        if (m < ntw) mt_twist_block(mt[m & 1], mt[(m + 1) & 1], tid, 1024);
+    }
+    for (int i = tid; i < 624; i += 1024) rng->mt[i] = mt[ntw & 1][i];
+    if (tid == 0) {
+        rng->pos = (int)(E - 624ll * ntw);
+        rng->consumed += (long long)rows * N;
+    }
+}
+
+int snn_launch_rng_fill(snn_rng_state *rng, const uint8_t *s, int B, int N, float *qbuf, long long *cursor,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_rng_fill, dim3(1), dim3(1024), 0, st, rng, s, B, N, qbuf, cursor);
     return snn_check_launch();
+}
+
+extern "C" int snn_rng_fill_exponential(snn_rng_state *rng, const uint8_t *crossings, int B, int N, float *qbuf,
+                                        long long *cursor, snn_stream_t stream) {
+    if (!rng || !crossings || !qbuf || !cursor || B <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (B > 1024) return SNN_ERR_UNSUPPORTED;
+    return snn_launch_rng_fill(rng, crossings, B, N, qbuf, cursor, (hipStream_t)stream);
 }
 
 // =============================================================================================

@@ -20,6 +20,13 @@ extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                          hipStream_t st, int *handled);
 
+int snn_launch_dc_membrane(float *v, float *refrac, uint8_t *s, float *theta, const float *I, int B, int N,
+                           const snn_dc_params &p, long long *cursor, float *raster_v, hipStream_t st);
+int snn_launch_dc_arbitrate(uint8_t *s, float *x, int B, int N, const snn_dc_params &p, const float *Q, long long q_len,
+                            long long *cursor, int *status, uint8_t *raster_s, hipStream_t st);
+int snn_launch_rng_fill(snn_rng_state *rng, const uint8_t *s, int B, int N, float *qbuf, long long *cursor,
+                        hipStream_t st);
+
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
@@ -34,7 +41,9 @@ static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
                 break;
             case SNN_LAYER_DC:
                 if (!d.theta) return SNN_ERR_INVALID;
-                if (d.p.one_spike && (!R->noise_q || !R->cursor || !R->status)) return SNN_ERR_INVALID;
+                if (d.p.one_spike && (!R->cursor || !R->status)) return SNN_ERR_INVALID;
+                if (d.p.one_spike && !R->noise_q && !(R->rng && R->qbuf)) return SNN_ERR_INVALID;
+                if (R->B > 1024) return SNN_ERR_UNSUPPORTED;
                 /* fallthrough */
             case SNN_LAYER_LIF:
                 if (!d.v || !d.refrac || !d.s || !d.current) return SNN_ERR_INVALID;
@@ -95,8 +104,13 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
             }
             if (!fed[l]) TRY(snn_check(hipMemsetAsync(d.current, 0, sizeof(float) * (size_t)B * d.n, st)));  // :409-413
             if (d.kind == SNN_LAYER_LIF) TRY(snn_lif_step(d.v, d.refrac, d.s, d.x, d.current, B, d.n, &d.p.lif, rs, rv, st));
-            else TRY(snn_dc_step(d.v, d.refrac, d.s, d.x, d.theta, d.current, B, d.n, &d.p, R->noise_q, R->q_len,
-                                 R->cursor, R->status, rs, rv, st));
+            else if (R->rng && d.p.one_spike) {   // device generator: membrane -> draws for this step -> arbitration
+                TRY(snn_launch_dc_membrane(d.v, d.refrac, d.s, d.theta, d.current, B, d.n, d.p, R->cursor, rv, st));
+                TRY(snn_launch_rng_fill(R->rng, d.s, B, d.n, R->qbuf, R->cursor, st));
+                TRY(snn_launch_dc_arbitrate(d.s, d.x, B, d.n, d.p, R->qbuf, (long long)B * d.n, R->cursor, R->status,
+                                            rs, st));
+            } else TRY(snn_dc_step(d.v, d.refrac, d.s, d.x, d.theta, d.current, B, d.n, &d.p, R->noise_q, R->q_len,
+                                   R->cursor, R->status, rs, rv, st));
         }
         // (3) network.py:431-454 learning rules, connection order
         if (R->learning)

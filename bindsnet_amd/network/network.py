@@ -13,7 +13,7 @@ from typing import Dict, Optional, Type
 import torch
 
 from .. import _lib
-from ..rng import NoiseStream
+from ..rng import DeviceGenerator
 from .monitors import AbstractMonitor, Monitor
 from .nodes import DiehlAndCookNodes, Input, LIFNodes, Nodes, _f
 from .topology import AbstractConnection, Connection, Conv2dConnection, MulticompartmentConnection
@@ -166,7 +166,7 @@ class Network(torch.nn.Module):
             if isinstance(layer, DiehlAndCookNodes):
                 d.kind, d.p, d.theta = _lib.LAYER_DC, layer._dc_params(), _dptr(layer.theta)
                 if layer.one_spike:
-                    max_draws += B * layer.n * T
+                    max_draws = max(max_draws, B * layer.n)
             elif isinstance(layer, LIFNodes):
                 d.kind = _lib.LAYER_LIF
                 d.p.lif = layer._lif_params()
@@ -180,8 +180,8 @@ class Network(torch.nn.Module):
 
         R = _lib.RunDesc()
         R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
-        with NoiseStream(dev, max_draws) as ns:
-            R.noise_q, R.q_len = _dptr(ns.q), (0 if ns.q is None else ns.q.numel())
+        with DeviceGenerator(dev, max_draws) as ns:      # host generator <-> device, exact (rng.py)
+            R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
             R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
             rc = _lib.lib().snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R),
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))

@@ -117,3 +117,11 @@ def normalize(W, norm, use_abs, ws=None):
     if ws is None:
         ws = torch.empty(N, dtype=F32, device=W.device)
     check(lib().snn_normalize(_ptr(W, F32), Nin, N, norm, int(use_abs), _ptr(ws, F32), _stream()), "normalize")
+
+
+def rng_fill_exponential(rng_state, crossings, qbuf, cursor):
+    """Device generator: draws for the rows of `crossings` [B,N] that have a non-zero entry."""
+    B = crossings.shape[0]
+    N = crossings.numel() // B
+    check(lib().snn_rng_fill_exponential(_ptr(rng_state, torch.int32), _ptr(crossings, "spike"), B, N, _ptr(qbuf, F32),
+                                         _ptr(cursor, torch.int64), _stream()), "rng_fill_exponential")

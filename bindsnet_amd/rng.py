@@ -53,3 +53,86 @@ class NoiseStream:
         elif self._state0 is not None:
             torch.set_rng_state(self._state0)
         return False
+
+
+# ---------------------------------------------------------------------------------------------
+# Device generator: the same stream, produced on the MI355X (csrc/snn_rng.hpp), so a run costs no
+# host draws at all.  Layout of torch.get_rng_state() for the CPU generator (5056 bytes,
+# at::CPUGeneratorImplState): u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | normal-
+# distribution cache.  at::mt19937 outputs state[next++] after `if (--left == 0) twist`, so
+# left == 1 means "twist before the next output" (our pos == 624) and otherwise left == 625 - next.
+# ---------------------------------------------------------------------------------------------
+import struct
+
+import numpy as np
+
+_STATE_OFF, _N = 24, 624
+RNG_STATE_BYTES = _N * 4 + 4 + 4 + 8          # sizeof(snn_rng_state)
+
+
+def torch_state_to_words(state: torch.Tensor) -> np.ndarray:
+    """torch CPU generator state -> int32[630] image of snn_rng_state (mt[624], pos, reserved, consumed)."""
+    raw = state.numpy().tobytes()
+    if len(raw) != 5056:
+        raise RuntimeError(f"unexpected CPU generator state size {len(raw)} (torch {torch.__version__})")
+    _seed, left, _seeded, nxt = struct.unpack_from("<QiiQ", raw, 0)
+    mt = np.frombuffer(raw, dtype=np.uint64, count=_N, offset=_STATE_OFF).astype(np.uint32)
+    pos = _N if left == 1 else int(nxt)
+    if left != 1 and left != _N + 1 - nxt:
+        raise RuntimeError("inconsistent mt19937 state (left/next)")
+    img = np.zeros(RNG_STATE_BYTES // 4, dtype=np.uint32)
+    img[:_N] = mt
+    img[_N] = pos
+    return img.view(np.int32)
+
+
+def words_to_torch_state(img: np.ndarray, template: torch.Tensor) -> torch.Tensor:
+    """Inverse of torch_state_to_words: patch mt / left / next into a copy of `template`."""
+    img = np.ascontiguousarray(img).view(np.uint32)
+    raw = bytearray(template.numpy().tobytes())
+    pos = int(img[_N])
+    struct.pack_into("<i", raw, 8, _N + 1 - pos)          # left
+    struct.pack_into("<Q", raw, 16, pos)                  # next
+    raw[_STATE_OFF:_STATE_OFF + _N * 8] = img[:_N].astype(np.uint64).tobytes()
+    return torch.frombuffer(raw, dtype=torch.uint8).clone()
+
+
+class DeviceGenerator:
+    """Context manager: upload the host generator at entry, write it back (advanced by what the
+    device consumed) at exit.  `consumed` is the number of Exp(1) draws used."""
+
+    def __init__(self, device, qbuf_floats: int):
+        self.device = torch.device(device)
+        self.enabled = qbuf_floats > 0
+        self.cursor = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.state = self.qbuf = None
+        self.consumed = 0
+        self._n = qbuf_floats
+
+    def __enter__(self):
+        if self.enabled:
+            self._host0 = torch.get_rng_state()
+            self.state = torch.from_numpy(torch_state_to_words(self._host0).copy()).to(self.device)
+            self.qbuf = torch.empty(self._n, dtype=torch.float32, device=self.device)
+        return self
+
+    def finish(self) -> int:
+        if not self.enabled:
+            return 0
+        img = self.state.cpu().numpy()                     # synchronises with the run
+        st = int(self.status.item())
+        if st != 0:
+            from ._lib import SnnError
+            torch.set_rng_state(self._host0)
+            raise SnnError(f"device run reported status {st}")
+        self.consumed = int(img.view(np.int64)[(RNG_STATE_BYTES - 8) // 8])
+        torch.set_rng_state(words_to_torch_state(img, self._host0))
+        return self.consumed
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.finish()
+        elif self.enabled:
+            torch.set_rng_state(self._host0)
+        return False

@@ -111,6 +111,26 @@ int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta, con
                 const float *noise_q, long long q_len, long long *cursor, int *status,
                 uint8_t *raster_s, float *raster_v, snn_stream_t stream);
 
+/* ---- device-resident emulation of torch's CPU generator --------------------------------------
+ * Replaces the pre-drawn noise_q stream: the library reproduces the draws torch.multinomial
+ * (bindsnet/network/nodes.py:1100-1102) would consume -- mt19937 -> random64 -> u in [0,1) ->
+ * (float)(-log1p(-u)) -- on the device, bit-exactly, from the generator state the host uploads
+ * (parsed from torch.get_rng_state()).  pos: index of the next output inside the current 624-word
+ * block, 624 = "twist before the next output" (at::mt19937's left_ == 1).  consumed counts draws.
+ * After the run the host downloads the struct and writes it back with torch.set_rng_state(). */
+typedef struct {
+    uint32_t mt[624];
+    int32_t pos;
+    int32_t reserved;
+    long long consumed;
+} snn_rng_state;
+
+/* For the rows of `crossings` [B,N] that contain a non-zero entry (r of them, in row order) write
+ * the draws of the [r, N] operand's candidate positions to qbuf[rank*N + j], advance *rng by r*N
+ * draws and zero cursor[1], so that snn_dc_step-style arbitration can index qbuf from 0.      */
+int snn_rng_fill_exponential(snn_rng_state *rng, const uint8_t *crossings, int B, int N, float *qbuf,
+                             long long *cursor, snn_stream_t stream);
+
 /* ---- a8 / a9: PostPre -----------------------------------------------------------------------
  * MCC: bindsnet/learning/MCC_learning.py:224-302 + :86-110 (use_dt = 1: each reduced update
  * is multiplied by connection.dt).  Dense: bindsnet/learning/learning.py:390-420 + :87-104
@@ -194,8 +214,10 @@ typedef struct {
     int B, T;
     float dt;
     int learning;               /* Network.learning */
-    const float *noise_q;       /* Exp(1) stream for one_spike (see snn_dc_step); nullable */
+    const float *noise_q;       /* pre-drawn Exp(1) stream for one_spike (see snn_dc_step); nullable */
     long long q_len;
+    snn_rng_state *rng;         /* OR: device generator state (preferred; noise_q ignored when set) */
+    float *qbuf;                /* with rng: scratch of B * max(DC layer n) floats */
     long long *cursor;          /* device int64[2] */
     int *status;                /* device int32[1]: 0 or SNN_ERR_NOISE after the run */
 } snn_run_desc;

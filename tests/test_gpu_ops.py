@@ -237,3 +237,36 @@ def test_mstdp_vs_oracle():
         np.testing.assert_array_equal(bits(host(Wd)), bits(W), err_msg=f"step {t}")
     np.testing.assert_array_equal(bits(host(ppd)), bits(pp))
     np.testing.assert_array_equal(bits(host(pmd)), bits(pm))
+
+
+@pytest.mark.parametrize("B,N,p_row,seed,warm", [(5, 70, 0.5, 1, 0), (32, 400, 0.3, 2, 1000), (32, 400, 1.0, 3, 311),
+                                                 (3, 100, 0.7, 4, 623), (64, 312, 0.9, 5, 0), (8, 39, 0.5, 6, 12345)])
+def test_device_generator_matches_torch_stream(B, N, p_row, seed, warm):
+    """snn_rng_fill_exponential == the draws torch.multinomial would consume, and the generator
+    state it leaves == torch's state after the same number of draws (several consecutive steps)."""
+    from bindsnet_amd import ops, rng
+    torch.manual_seed(seed)
+    if warm:
+        torch.rand(warm)          # start somewhere inside a 624-block
+    st0 = torch.get_rng_state()
+    state = torch.from_numpy(rng.torch_state_to_words(st0).copy()).to(DEV)
+    qbuf = torch.zeros(B * N, device=DEV)
+    cursor = torch.zeros(2, dtype=torch.int64, device=DEV)
+    rs = np.random.RandomState(seed)
+    total = 0
+    for step in range(6):
+        rows = rs.uniform(size=B) < p_row
+        cr = (rs.uniform(size=(B, N)) < 0.1) & rows[:, None]
+        if step == 3:
+            cr[:] = False                                       # a silent step consumes nothing
+        ops.rng_fill_exponential(state, dev(cr.astype(u8)), qbuf, cursor)
+        anyrow = cr.any(axis=1)
+        r = int(anyrow.sum())
+        ref = torch.empty(r * N).exponential_(1).numpy().reshape(r, N) if r else np.zeros((0, N), f32)
+        got = host(qbuf)[: r * N].reshape(r, N)
+        mask = cr[anyrow]
+        np.testing.assert_array_equal(bits(got[mask]), bits(ref[mask]), err_msg=f"step {step}")
+        total += r * N
+    img = host(state)
+    assert int(img.view(np.int64)[(rng.RNG_STATE_BYTES - 8) // 8]) == total
+    assert torch.equal(rng.words_to_torch_state(img, st0), torch.get_rng_state())
