@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: simulated timesteps/sec, DiehlAndCook2015
+784->400 excitatory neurons, batch 32, T = 250 ms @ dt = 1 ms, PostPre STDP on (configs[1]).
+
+A "step" (--steps K) is ONE network.run() of T = 250 timesteps over one resident synthetic input
+batch [250, 32, 784] u8 followed by network.reset_state_variables() (what eth_mnist.py does per
+sample); `value` = timesteps simulated per second summed over all ranks.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+
+N > 1 (weak scaling): every rank simulates its own batch of 32 with replicated weights; after
+each input the weight and threshold deltas are all-reduced over RCCL and re-normalised
+(bindsnet_amd.parallel.sharded_run; BASELINE.json north-star schedule -- DESIGN.md section
+"Multi-GPU" explains how it differs from a single global batch).
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak) and
+"cpu_baseline" (the C oracle -- a scalar port of the reference algorithm -- on one host core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_IN, N_EXC, BATCH, T = 784, 400, 32, 250
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_timestep(Nin=N_IN, N=N_EXC, B=BATCH):
+    """SURVEY.md 8(d) dense accounting for the D&C graph."""
+    return 4 * (3 * Nin * N + 2 * N * N) + B * (Nin * 10 + N * 26 + N * 18) + 8 * N
+
+
+def make_inputs(seed, n_batches, device):
+    import synth
+    out = []
+    for k in range(n_batches):
+        sp = synth.spike_train(seed + k, T, BATCH, N_IN)
+        out.append(torch.from_numpy(sp).view(T, BATCH, 1, 28, 28).to(device))
+    return out
+
+
+def build_network(device):
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=N_IN, n_neurons=N_EXC, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05,
+                           inpt_shape=(1, 28, 28))
+    for l in ("Ae", "Ai"):                       # spike monitors, as eth_mnist.py registers
+        net.add_monitor(Monitor(net.layers[l], ["s"], time=T), l + "_spikes")
+    net.to(device)
+    return net
+
+
+def cpu_baseline():
+    """Oracle (scalar C port of the reference algorithm) on one host core: one full input."""
+    import cases
+    import oracle
+    import synth
+    from test_oracle_golden import dc_params
+    g = cases.gold("run_dc_n400_b32")
+    P = dc_params(g)
+    P.T, P.B, P.N = T, BATCH, N_EXC
+    st = cases.dc_state(N_EXC, BATCH)
+    sp = synth.spike_train(20, T, BATCH, N_IN)
+    Q = cases.exp_noise(2, 400_000)
+    cur = np.zeros(1, np.int64)
+    t0 = time.perf_counter()
+    try:
+        oracle.run_dc2015(P, st, sp, Q, cur, rasters=False)
+    except RuntimeError:
+        return None
+    dt = time.perf_counter() - t0
+    return {"value": round(T / dt, 2), "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"1 input: T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, oracle/snn_oracle.c ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plan", default="auto", choices=["auto", "generic"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from bindsnet_amd import _lib, parallel
+    _lib.lib().snn_set_plan_mode(1 if args.plan == "generic" else 0)
+    net = build_network(dev)
+    pool = make_inputs(1000 + 17 * rank, 4, dev)           # resident in HBM before the timed region
+
+    def one(k):
+        torch.manual_seed(2 + k)
+        x = {"X": pool[k % len(pool)]}
+        if world > 1:
+            parallel.sharded_run(net, x, T)
+        else:
+            net.run(x, time=T)
+        net.reset_state_variables()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one(args.warmup + k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel: HIP events around single launches, after the timed region
+    roof = None
+    if rank == 0:
+        prof = _lib.profile_run(net, {"X": pool[0]}, T)
+        if prof is not None:
+            ab = algorithmic_bytes_per_timestep() * prof["timesteps_per_launch"]
+            ach = ab / (prof["avg_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": prof["kernel"], "avg_launch_us": round(prof["avg_ms"] * 1e3, 3),
+                    "launches_timed": prof["n"], "algorithmic_bytes_per_launch": ab, "achieved": round(ach, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
+
+    if rank == 0:
+        steps_total = world * args.steps * T
+        line = {
+            "metric": "simulated timesteps/sec (whole node), DiehlAndCook2015 784->400 batch32",
+            "value": round(steps_total / elapsed, 2), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: DiehlAndCook2015 784->400 exc, batch 32/GPU, 250 timesteps per "
+                                   "network.run(), PostPre STDP on, 2 spike monitors, reset_state_variables() per input",
+                       "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
+                       "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
+                       "plan": net.last_plan, "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+            "roofline": roof,
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

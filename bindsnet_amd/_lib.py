@@ -53,6 +53,7 @@ class ConnDesc(C.Structure):
 class RunDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
                 ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_ulonglong),
                 ("cursor", C.c_void_p), ("status", C.c_void_p)]
 
 
@@ -79,8 +80,11 @@ _SIGS = {
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
     "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
+    "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),
     "snn_plan_name": ([], C.c_char_p),
     "snn_set_plan_mode": ([_i], None),
+    "snn_profile_enable": ([_i], None),
+    "snn_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int)], _i),
 }
 
 
@@ -113,3 +117,24 @@ def check(rc: int, what: str = ""):
         if rc == -3:
             msg += ": " + L.snn_last_hip_error().decode()
         raise SnnError(f"libsnnhip {what}: {msg} (code {rc})")
+
+
+def profile_run(net, inputs, time, stride=4):
+    """One extra run() with HIP events around every `stride`-th timestep's launches (bench.py).
+    Returns {"kernel", "avg_ms", "n", "timesteps_per_launch"} or None."""
+    import torch
+    L = lib()
+    L.snn_profile_enable(stride)
+    try:
+        net.run(dict(inputs), time=time)
+        torch.cuda.synchronize()
+        s, n = C.c_double(0), C.c_int(0)
+        check(L.snn_profile_collect(C.byref(s), C.byref(n)), "profile_collect")
+    finally:
+        L.snn_profile_enable(0)
+    net.reset_state_variables()
+    if n.value == 0:
+        return None
+    plan = net.last_plan
+    kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
+    return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}

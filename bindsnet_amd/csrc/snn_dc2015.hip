@@ -1,0 +1,817 @@
+// snn_dc2015.hip -- fused plan "dc2015-fused": ONE kernel launch per timestep for the
+// DiehlAndCook2015 graph (Input -X->Ae (PostPre)-> DiehlAndCookNodes <-> LIFNodes), i.e. the loop body
+// of bindsnet/network/network.py:380-461 for the wiring of bindsnet/models/models.py:156-244.
+//
+// Decomposition.  Workgroup g owns 32 consecutive target columns (neurons c0..c0+31 of BOTH Ae and
+// Ai) for every sample of the batch: their membrane state, adaptive thresholds, post-synaptic
+// traces and the [Nin x 8] column slice of the learned weights.  Everything a step needs from
+// other columns is spikes, exchanged as bit masks through global memory across the kernel boundary:
+//   crossE[t&1][b][byte]  Ae threshold crossings of step t (before one_spike arbitration), 1 byte per workgroup
+//   spikeI[t&1][b][byte]  Ai spikes of step t                                          (read back as u32 words)
+// The only cross-column computation -- the one_spike arbitration, which needs every crossing of a row
+// and the host generator's noise stream -- is tiny, so every workgroup repeats it redundantly instead
+// of paying a second exchange.  That makes the step a software pipeline: launch t
+//   phase A  finishes step t-1: arbitration -> final Ae spikes -> Ae trace, raster, STDP on own columns
+//   phase B  starts step t:     currents from step t-1 spikes -> Ae/Ai membrane update -> publish bits,
+//                               X-trace update for an own slice of input rows
+// and launch T runs phase A only.  All arithmetic follows the reference's f32 operation order
+// (snn_order.hpp, snn_common.hpp, snn_rng.hpp); results are bit-identical to the generic plan.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../include/snnhip.h"
+#include "snn_common.hpp"
+#include "snn_order.hpp"
+#include "snn_rng.hpp"
+
+using namespace snn;
+
+bool snn_prof_begin(int t, hipStream_t st);
+void snn_prof_end(hipStream_t st);
+
+namespace {
+
+// A single wave retires roughly one instruction every 4 cycles however idle the chip is, so the cost of a
+// launch is the instruction count on each thread's critical path.  Hence: MANY workgroups (8 columns each)
+// so the per-column work of a thread is small, each with MANY threads (1024) so the work every workgroup
+// repeats (staging the step's spikes, arbitration) and the STDP items are spread thin.
+constexpr int CW = 8;           // columns per workgroup
+constexpr int MAXB = 32;        // samples (batch) per workgroup
+constexpr int TT = MAXB * CW;   // "tile threads": thread tid < TT <-> (sample tid / CW, column tid % CW)
+constexpr int NT = 1024;        // threads per workgroup
+constexpr int NU = 2;           // staged 16-byte pieces per thread: B*Nin <= NU*NT*16 = 32 KiB
+
+// Barrier for LDS-only hand-offs: waits for this wave's LDS traffic but NOT for its outstanding global
+// stores (a plain __syncthreads() drains vmcnt and costs a full memory round trip every time).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct DcCtx {
+    int B, Nin, N, T, NW, NinW, G, RS;     // NW = ceil(N/32), NinW = ceil(Nin/32), G workgroups, RS input rows per WG
+    float dt; int learning;
+    // X (Input)
+    const uint8_t *in;          // [T,B,Nin]
+    const uint8_t *sX0;         // [B,Nin] X.s at entry
+    float *xX[2];               // trace after step t lives in xX[t&1]; entry trace in xX[1]
+    int x_traces; float x_decay, x_scale; int x_additive;
+    // Ae (DiehlAndCookNodes)
+    float *vE, *rE, *xE, *theta; uint8_t *sE;
+    snn_dc_params pE;
+    uint8_t *rasE; float *rasVE;
+    // Ai (LIFNodes)
+    float *vI, *rI, *xI; uint8_t *sI;
+    snn_lif_params pI;
+    uint8_t *rasI; float *rasVI;
+    // weights
+    float *Wxe; const float *Wei; const float *Wie;
+    int rule; float nu0, nu1; int use_dt; int has_min; float wmin; int has_max; float wmax;
+    // exchange + generator
+    uint32_t *crossE[2], *spikeI[2];
+    snn_rng_state *rng[2];
+    float inv_hwps, inv_NW, inv_RS;   // reciprocals of Nin/16, NW, RS for the exact float-multiply divisions
+    int dbg_wg;
+    long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
+};
+
+#define DBG_MARK(slot) do { if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+
+__device__ __forceinline__ bool bit_of(const uint32_t *w, int j) { return (w[j >> 5] >> (j & 31)) & 1u; }
+
+// Input currents of neuron j of sample b from the previous step's spikes, in connection insertion
+// order (network.py:225-248): Ae <- (zeros + X->Ae) + Ai->Ae ; Ai <- zeros + Ae->Ai.  SUM selects the
+// ATen column class of j (multi_row_sum for j < 32*floor(N/32), row_sum otherwise).
+// ---- small helpers ----------------------------------------------------------------------------
+// 4-bit mask of the non-zero bytes of a 32-bit word (byte k -> bit k).
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {
+    const uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
+}
+
+// Ordered sum of W[i, j] * value(i) over the sources i whose bit is set in `words`, visited in
+// ascending i: `wmask` has one bit per NON-ZERO word, so silent stretches cost nothing.  Weight loads
+// are issued 8 at a time before the (order-constrained) adds.  vals == nullptr: all spikes are 1.
+template <class SUM>
+__device__ __forceinline__ float ordered_dot(const float *__restrict__ W, int N, int j, const uint32_t *words,
+                                             uint64_t wmask, const uint8_t *__restrict__ vals, int n_terms) {
+    SUM a; a.init();
+    int idx[8]; float wv[8];
+    int nq = 0;
+    while (wmask) {
+        const int w = __ffsll((unsigned long long)wmask) - 1; wmask &= wmask - 1;
+        uint32_t m = words[w];
+        while (m) {
+            idx[nq++] = w * 32 + __ffs(m) - 1; m &= m - 1;
+            if (nq == 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = W[idx[u] * N + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a.add(idx[u], wv[u] * (vals ? (float)vals[idx[u]] : 1.0f), n_terms);
+                nq = 0;
+            }
+        }
+    }
+    if (nq) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = W[idx[u < nq ? u : 0] * N + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < nq) a.add(idx[u], wv[u] * (vals ? (float)vals[idx[u]] : 1.0f), n_terms);
+    }
+    return a.finish(n_terms);
+}
+
+// PostPre for (row, column) items of the own weight slice (MCC_learning.py:224-302, :86-110): rows listed in
+// `arows` (all rows when FULL) x the CW own columns.  SUM is CascadeT unless the [Nin*N] element index can
+// fall into ATen's <32-element tail (OuterSum).  sbytes: the step's X spike bytes when some spike value
+// is not 0/1 (else nullptr: every spike counts 1.0).
+template <class SUM, bool FULL>
+__device__ __forceinline__ void stdp_rows(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
+                                          const uint32_t *colmask, const uint8_t *__restrict__ sbytes,
+                                          const float *xnu0, const float *__restrict__ xsrc, float *wtile, int c0, int tid,
+                                          int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N;
+    const int nitems = nact * CW;
+    const int q = tid % CW;                                       // NT % CW == 0: a thread keeps its column
+    for (int base = 0; base < nitems; base += NT * 8) {
+        float wv[8]; int ev[8]; int iv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int item = base + u * NT + tid;
+            ev[u] = -1; iv[u] = 0; wv[u] = 0.f;
+            if (item < nitems) {
+                const int i = FULL ? (item / CW) : (int)arows[item / CW];
+                const int jq = c0 + q;
+                if (jq < N) { iv[u] = i; ev[u] = i * N + jq; wv[u] = c.Wxe[ev[u]]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ev[u] < 0) continue;
+            const int i = iv[u];
+            float w = wv[u];
+            if (c.nu0 != 0.f) {                                  // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+                uint32_t m = rowmask[i];
+                float uu = 0.f;
+                if (m) {
+                    SUM acc; acc.init(ev[u] >= Emain);
+                    while (m) {
+                        const int b = __ffs(m) - 1; m &= m - 1;
+                        const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                        acc.add(b, sv * xnu0[b * CW + q], B);
+                    }
+                    uu = acc.finish(B);
+                }
+                if (c.use_dt) uu = uu * c.dt;
+                w = w - uu;
+            }
+            if (c.nu1 != 0.f) {                                  // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+                uint32_t m = colmask[q];
+                float uu = 0.f;
+                if (m) {
+                    SUM acc; acc.init(ev[u] >= Emain);
+                    while (m) {
+                        const int b = __ffs(m) - 1; m &= m - 1;
+                        acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+                    }
+                    uu = acc.finish(B);
+                }
+                if (c.use_dt) uu = uu * c.dt;
+                w = w + uu;
+            }
+            if (c.has_min && w < c.wmin) w = c.wmin;
+            if (c.has_max && w > c.wmax) w = c.wmax;
+            c.Wxe[ev[u]] = w;
+            wtile[((base + u * NT + tid) / CW) * CW + q] = w;     // compact row index x column, read back by phase B
+        }
+    }
+}
+
+// Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike (those rows were not
+// visited by stdp_rows): w = (w - 0) + dt * sum_b ... ; clamp.
+template <class SUM>
+__device__ __forceinline__ void stdp_cols(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
+                                          const uint32_t *colmask, const float *__restrict__ xsrc, int c0, int tid,
+                                          int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N;
+    while (active_cols) {
+        const int q = __ffs(active_cols) - 1; active_cols &= active_cols - 1;
+        const uint32_t cm = colmask[q];
+        const int jq = c0 + q;
+        for (int i = tid; i < Nin; i += NT) {
+            if (rowmask[i]) continue;
+            const int e = i * N + jq;
+            float w = c.Wxe[e];
+            SUM acc; acc.init(e >= Emain);
+            uint32_t m = cm;
+            while (m) {
+                const int b = __ffs(m) - 1; m &= m - 1;
+                acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+            }
+            float uu = acc.finish(B);
+            if (c.use_dt) uu = uu * c.dt;
+            w = w + uu;
+            if (c.has_min && w < c.wmin) w = c.wmin;
+            if (c.has_max && w > c.wmax) w = c.wmax;
+            c.Wxe[e] = w;
+        }
+    }
+}
+
+// Cascade taking (and ignoring) the `tail` flag at init, interface-compatible with OuterSum.
+struct CascadeT {
+    Cascade c;
+    __device__ __forceinline__ void init(bool) { c.init(); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
+    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+};
+
+constexpr int LX = 32, LR = 8;   // per-sample event-list capacities (X sources / recurrent sources)
+
+// One wave turns a row of spike bit words into the ascending list of set-bit indices (first `cap`
+// entries stored) and returns the total count.  nwords <= 64.
+__device__ __forceinline__ int build_list(const uint32_t *words, int nwords, int lane, uint16_t *out, int cap) {
+    uint32_t m = lane < nwords ? words[lane] : 0u;
+    const int cn = __popc(m);
+    // exclusive prefix of cn over lanes = sum_k popc(ballot(cn > k) & lanes_below): counts are tiny, so a
+    // few ballots beat a 6-step cross-lane scan
+    const uint64_t below = (1ull << lane) - 1ull;
+    int offp = 0, total = 0;
+    for (int k = 0; ; ++k) {
+        const uint64_t bm = __ballot(cn > k);
+        if (!bm) break;
+        offp += __popcll(bm & below);
+        total += __popcll(bm);
+    }
+    while (m) {
+        const int i = lane * 32 + __ffs(m) - 1; m &= m - 1;
+        if (offp < cap) out[offp] = (uint16_t)i;
+        ++offp;
+    }
+    return total;
+}
+
+// Input currents of neuron j of sample b from the previous step's spikes, in connection insertion order
+// (network.py:225-248): Ae <- (zeros + X->Ae) + Ai->Ae ; Ai <- zeros + Ae->Ai, each summed in ascending source
+// order.  X->Ae weights come from the LDS tile the STDP pass just refreshed (wtile != nullptr: row `rowpos[i]`
+// of the compacted active rows, or row i itself when rowpos == nullptr) or from global memory; the recurrent
+// weights wi / we were prefetched by the caller.
+template <class SUM>
+__device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx, int nX, const uint16_t *li, int nI,
+                                              const uint16_t *le, int nE, const float *wi, const float *we,
+                                              const float *wtile, const uint16_t *rowpos, int jj,
+                                              const uint8_t *__restrict__ xb, int j, float &curE, float &curI) {
+    const int Nin = c.Nin, N = c.N;
+    int ix[16]; float wx[16];
+    // unconditional, clamped gathers (entries past nX are stale but in range): the 16 reads of each stage
+    // are independent, so the three dependent LDS stages cost three latencies, not forty-eight
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ix[u] = min((int)lx[u], Nin - 1);
+    if (wtile) {
+        int rr[16];
+        if (rowpos) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rr[u] = min((int)rowpos[ix[u]], Nin - 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rr[u] = ix[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wx[u] = wtile[rr[u] * CW + jj];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wx[u] = c.Wxe[ix[u] * N + j];
+    }
+    SUM a; a.init();
+    if (xb) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nX) a.add(ix[u], wx[u] * (float)xb[ix[u]], Nin);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nX) a.add(ix[u], wx[u] * 1.0f, Nin);
+    }
+    curE = 0.0f + a.finish(Nin);
+    a.init();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u < nI) a.add((int)li[u], wi[u] * 1.0f, N);
+    curE = curE + a.finish(N);
+    a.init();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u < nE) a.add((int)le[u], we[u] * 1.0f, N);
+    curI = 0.0f + a.finish(N);
+}
+
+__global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW;
+    // ---- LDS carve-up (all offsets multiples of 16 bytes)
+    size_t off = 0;
+    uint32_t *sXw = (uint32_t *)(smem + off); off += ((size_t)B * NinW * 4 + 15) & ~(size_t)15;   // [B][NinW] X spike bits, step t-1
+    uint32_t *crs = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;     // Ae crossings t-1
+    uint32_t *finE = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;    // Ae final spikes t-1
+    uint32_t *spI = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;     // Ai spikes t-1
+    uint32_t *rowmask = (uint32_t *)(smem + off); off += ((size_t)Nin * 4 + 15) & ~(size_t)15;    // samples in which row i spiked
+    uint16_t *arows = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;      // compacted active rows
+    float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * CW * 4;                            // [B][CW] x_tgt*nu0
+    uint32_t *mt = (uint32_t *)(smem + off); off += 4 * 624 * 4;                                  // mt19937 blocks m, m+1, ... in slot (block & 3)
+    unsigned long long *keys = (unsigned long long *)(smem + off); off += MAXB * 8;               // argmax keys per sample
+    uint16_t *lstX = (uint16_t *)(smem + off); off += MAXB * LX * 2;                              // per-sample X event lists
+    uint16_t *lstI = (uint16_t *)(smem + off); off += MAXB * LR * 2;                              // ... Ai spikes
+    uint16_t *lstE = (uint16_t *)(smem + off); off += MAXB * LR * 2;                              // ... final Ae spikes
+    int *cntX = (int *)(smem + off); off += MAXB * 4;
+    int *cntI = (int *)(smem + off); off += MAXB * 4;
+    int *cntE = (int *)(smem + off); off += MAXB * 4;
+    int *cnt = (int *)(smem + off); off += 32 * 4;                                                // crossings per column
+    uint32_t *colmask = (uint32_t *)(smem + off); off += 32 * 4;                                  // samples whose final Ae spike is column jj
+    int *misc = (int *)(smem + off); off += 16;      // [0] n active rows, [1] active column mask, [2] spike value > 1, [3] samples with a crossing
+    uint16_t *rowpos = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;     // row -> compact active-row index
+    float *wtile = (float *)(smem + off); off += (size_t)Nin * CW * 4;                            // refreshed own weights of active rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, c0 = g * CW;
+    const int jj = tid % CW, bl = tid / CW;          // tile threads (tid < TT) <-> (sample bl, column c0+jj)
+    const int j = c0 + jj;
+    const bool colv = j < N;
+    const bool tailcol = c0 >= (N / 32) * 32;
+    const bool phaseA = t >= 1, phaseB = t < c.T;
+    const int pprev = (t + 1) & 1, pcur = t & 1;     // parity of step t-1 / step t
+    const int BW = B * NW;
+    DBG_MARK(0);
+    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + 8] = (long long)clock64();
+
+    // ------------------------------------------------------------------ stage inputs
+    // Every global load that does not depend on this launch's arbitration is issued here, together,
+    // so the prologue costs ONE memory round trip: X spikes of step t-1, exchanged bit words, generator
+    // state, the own tile's membrane state and the own slice of the X trace.
+    const bool mine = tid < TT && bl < B && colv;
+    const int kst = bl * N + j;
+    const int stepoff = t * B * Nin;                                   // < 2^31 (host check)
+    uint4 st4[NU];
+    const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
+    const int total16 = (B * Nin) >> 4;                                // Nin % 16 == 0 (host check)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int k16 = tid + u * NT;
+        st4[u] = (k16 < total16) ? ((const uint4 *)sprev_g)[k16] : make_uint4(0, 0, 0, 0);
+    }
+    // exchange word owned by this thread: (sample wb, word wj)
+    const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;
+    uint32_t r_crs = 0, r_spi = 0, r_mt = 0;                           // B*NW <= NT and 624 <= NT
+    int rng_pos = 0; long long rng_consumed = 0;
+    if (tid < BW) {
+        if (phaseA) { r_crs = c.crossE[pprev][tid]; r_spi = c.spikeI[pprev][tid]; }
+        else {   // t == 0: previous spikes come from the layers' `s` tensors (bytes -> bits)
+            uint32_t me = 0, mi = 0;
+            for (int qq = 0; qq < 32; ++qq) {
+                const int jx = wj * 32 + qq;
+                if (jx < N) { me |= (uint32_t)(c.sE[wb * N + jx] != 0) << qq; mi |= (uint32_t)(c.sI[wb * N + jx] != 0) << qq; }
+            }
+            r_crs = me; r_spi = mi;
+        }
+    }
+    const bool use_rng = phaseA && c.pE.one_spike;
+    if (use_rng) {
+        if (tid < 624) r_mt = c.rng[pprev]->mt[tid];
+        rng_pos = c.rng[pprev]->pos; rng_consumed = c.rng[pprev]->consumed;
+    }
+    float r_vE = 0.f, r_rE = 0.f, r_vI = 0.f, r_rI = 0.f, r_xE = 0.f, r_xI = 0.f, r_theta = 0.f;
+    if (mine) {
+        if (phaseB) {
+            r_vE = c.vE[kst]; r_rE = c.rE[kst]; r_vI = c.vI[kst]; r_rI = c.rI[kst]; r_theta = c.theta[j];
+            if (c.pI.traces) r_xI = c.xI[kst];
+        }
+        if (phaseA && c.pE.lif.traces) r_xE = c.xE[kst];
+    }
+    // own slice of the X trace: RS rows x B samples, one item per thread (loop below covers larger slices)
+    const int xr0 = g * c.RS, xr1 = min(Nin, xr0 + c.RS);
+    const int xb_ = (int)(((float)tid + 0.5f) * c.inv_RS), xi_ = xr0 + (tid - xb_ * c.RS);
+    const bool xmine = phaseB && c.x_traces && xb_ < B && xi_ < xr1;
+    float r_xo = 0.f; uint8_t r_xs = 0;
+    if (xmine) { r_xo = c.xX[pprev][xb_ * Nin + xi_]; r_xs = c.in[stepoff + xb_ * Nin + xi_]; }
+    if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
+    if (tid < 4) misc[tid] = 0;
+    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
+    if (tid < MAXB) keys[tid] = 0ull;
+    DBG_MARK(10);
+    __syncthreads();                                   // zeroed arrays visible; the loads above have landed
+    DBG_MARK(11);
+    // ---- into LDS: 16-bit spike masks straight from the registers, row masks for STDP
+    {
+        const int hwps = Nin >> 4, HS = NinW * 2;      // halfwords per sample / per padded LDS row
+        uint16_t *sXh = (uint16_t *)sXw;
+        uint32_t big = 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int k16 = tid + u * NT;
+            if (k16 < total16) {
+                const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps);     // k16 / hwps (exact for these ranges)
+                const int hw = k16 - b * hwps;
+                const uint32_t any = st4[u].x | st4[u].y | st4[u].z | st4[u].w;
+                uint32_t m16 = 0;
+                if (any) {
+                    if (any & 0xFEFEFEFEu) {       // some byte is not 0/1: generic non-zero test
+                        big = 1;
+                        m16 = nz4(st4[u].x) | (nz4(st4[u].y) << 4) | (nz4(st4[u].z) << 8) | (nz4(st4[u].w) << 12);
+                    } else {                       // 0/1 bytes: gather the four LSBs with one multiply
+                        // (byte k contributes 2^(8k) * 2^(24-7k) = 2^(24+k); all cross terms fall on distinct
+                        //  lower bits or overflow, so bits 24..27 are exactly b0..b3)
+                        m16 = ((st4[u].x * 0x01020408u) >> 24) | (((st4[u].y * 0x01020408u) >> 24) << 4) |
+                              (((st4[u].z * 0x01020408u) >> 24) << 8) | (((st4[u].w * 0x01020408u) >> 24) << 12);
+                    }
+                }
+                sXh[b * HS + hw] = (uint16_t)m16;
+                if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
+                while (m16) {
+                    const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
+                    atomicOr(&rowmask[i], 1u << b);
+                }
+            }
+        }
+        if (big) atomicOr((unsigned int *)&misc[2], 1u);   // a spike byte other than 0/1: multiply by its value
+        if (tid < BW) { (phaseA ? crs : finE)[tid] = r_crs; spI[tid] = r_spi; }
+        if (use_rng && tid < 624) mt[tid] = r_mt;
+    }
+    lds_barrier();
+    const uint8_t *sbytes = (misc[2] & 1) ? sprev_g : nullptr;
+    // ---- per sample (one wave each, in turns): event lists of X and Ai spikes; does it have an Ae crossing?
+    //      Meanwhile the LAST wave runs the generator two blocks ahead (lockstep, no barrier): a step with up to
+    //      ~1.5 crossing rows then needs no further twisting on the critical path.
+    constexpr int NWV = NT / 64;
+    if (wave == NWV - 1 && use_rng) {
+        mt_twist_block_wave(mt, mt + 624, lane);
+        mt_twist_block_wave(mt + 624, mt + 2 * 624, lane);
+    } else if (wave < NWV - 1 || !use_rng) {
+        const int stride = use_rng ? NWV - 1 : NWV;
+        for (int b = wave; b < B; b += stride) {
+            const int nx = build_list(sXw + b * NinW, NinW, lane, lstX + b * LX, LX);
+            const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
+            const uint64_t mc = __ballot(use_rng && lane < NW && crs[b * NW + lane] != 0);
+            if (lane == 0) {
+                cntX[b] = nx; cntI[b] = ni;
+                if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
+                if (nx > 16 || ni > 4) atomicOr((unsigned int *)&misc[2], 2u);   // a busy sample: phase B takes the generic path
+            }
+        }
+    }
+    DBG_MARK(1);
+    lds_barrier();
+    // recurrent Ai->Ae weights of the own tile: issued now, consumed in phase B
+    float wi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mine && phaseB) {
+        const int nI = cntI[bl];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (u < nI) wi[u] = c.Wie[(int)lstI[bl * LR + u] * N + j];
+    }
+
+    // ================================================================== phase A: finish step t-1
+    int E = 0, ntw = 0, rows = 0;
+    if (use_rng) {
+        // ---- A1: one_spike arbitration, identical in every workgroup (nodes.py:1097-1105)
+        DBG_MARK(12);
+        const uint32_t anym = (uint32_t)misc[3];
+        rows = __popc(anym);
+        const int pos = rng_pos;                               // <= 624
+        E = pos + 2 * rows * N;
+        ntw = rows ? (E - 1) / 624 : 0;
+        const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));   // rank of sample wb among rows with a crossing
+        uint32_t parked = 0;
+        // blocks [lo, hi] of the generator output are resident in the ring (slot = block & 3); candidates whose
+        // words fall in them are evaluated in one pass; only a step that consumes more than two further blocks
+        // pays for extra twists (last wave, lockstep) between two barriers.
+        int lo = 0, hi = min(ntw, 2);
+        while (rows) {
+            if (tid < BW) {
+                uint32_t bits = crs[tid];
+                while (bits) {
+                    const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                    const int d = myrank * N + jx;
+                    const int w0 = pos + 2 * d, w1 = w0 + 1;
+                    const int m0 = w0 / 624, m1 = w1 / 624;
+                    float q; bool have = false;
+                    if (m0 >= lo && m1 <= hi) {
+                        q = exp1_from_words(mt_temper(mt[(m0 & 3) * 624 + w0 - 624 * m0]),
+                                            mt_temper(mt[(m1 & 3) * 624 + w1 - 624 * m1])); have = true;
+                    } else if (m0 >= lo && m0 <= hi) {                 // pair straddles the resident range: park the high word
+                        parked = mt_temper(mt[(m0 & 3) * 624 + w0 - 624 * m0]);
+                    } else if (m1 >= lo && m1 <= hi) {
+                        q = exp1_from_words(parked, mt_temper(mt[(m1 & 3) * 624 + w1 - 624 * m1])); have = true;
+                    }
+                    if (have) {
+                        const float val = 1.0f / q;                     // p / q with p = 1
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                        atomicMax(&keys[wb], key);                      // max value, ties -> lowest index
+                    }
+                }
+            }
+            if (hi >= ntw) break;
+            lds_barrier();                                             // everyone is done reading blocks <= hi
+            if (wave == NWV - 1) {
+                mt_twist_block_wave(mt + (hi & 3) * 624, mt + ((hi + 1) & 3) * 624, lane);
+                if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((hi + 1) & 3) * 624, mt + ((hi + 2) & 3) * 624, lane);
+            }
+            lo = hi + 1; hi = min(ntw, hi + 2);
+            lds_barrier();
+        }
+        lds_barrier();                                                 // keys final
+        DBG_MARK(13);
+        if (tid < BW) {        // final spikes: the winner's bit, or nothing
+            uint32_t wbits = 0;
+            if ((anym >> wb) & 1u) {
+                const int win = (int)(0xFFFFFFFFu - (uint32_t)(keys[wb] & 0xFFFFFFFFull));
+                if ((win >> 5) == wj) wbits = 1u << (win & 31);
+            }
+            finE[tid] = wbits;
+        }
+        if (g == 0) {   // publish the advanced generator for the next launch
+            snn_rng_state *wr = c.rng[pcur];
+            const uint32_t *fin = mt + (ntw & 3) * 624;
+            if (tid < 624) wr->mt[tid] = fin[tid];
+            if (tid == 0) {
+                wr->pos = E - 624 * ntw;
+                wr->consumed = rng_consumed + (long long)rows * N;
+            }
+        }
+    } else if (phaseA) {
+        if (tid < BW) finE[tid] = crs[tid];
+    }
+    lds_barrier();
+    DBG_MARK(14);
+    for (int b = wave; b < B; b += NT / 64) {          // event lists of the final Ae spikes
+        const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
+        if (lane == 0) { cntE[b] = ne; if (ne > 4) atomicOr((unsigned int *)&misc[2], 2u); }
+    }
+    DBG_MARK(2);
+    if (phaseA) {
+        // ---- A2: final Ae spikes of step t-1 for the own tile: trace, raster, layer.s
+        if (tid < TT && bl < B) {
+            const bool sp = colv && bit_of(finE + bl * NW, j);
+            float xn = 0.f;
+            if (colv) {
+                if (c.pE.lif.traces) {
+                    xn = trace_next(r_xE, sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    c.xE[kst] = xn;
+                }
+                c.sE[kst] = sp;
+                if (c.rasE) c.rasE[(size_t)(t - 1) * B * N + kst] = sp;
+            }
+            xnu0[bl * CW + jj] = xn * c.nu0;                           // target_x * nu[0] (MCC_learning.py:235)
+            if (sp) atomicOr(&colmask[jj], 1u << bl);
+        }
+    }
+    lds_barrier();
+    // recurrent Ae->Ai weights of the own tile: issued now, consumed in phase B
+    float we[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mine && phaseB) {
+        const int nE = cntE[bl];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (u < nE) we[u] = c.Wei[(int)lstE[bl * LR + u] * N + j];
+    }
+    bool tile_fresh = false;       // the STDP pass below left the active rows of the own slice in `wtile`
+    bool tile_full = false;
+    if (phaseA) {
+        DBG_MARK(3);
+        // ---- A3: PostPre on the own [Nin x CW] weight slice
+        if (c.learning && c.rule == SNN_RULE_POSTPRE) {
+            const bool full = (t == 1);        // first update of a run touches (clamps) every element
+            tile_fresh = true; tile_full = full;
+            const int Etot = Nin * N, Emain = (Etot / 32) * 32;
+            const bool anytail = Etot != Emain;
+            const float *xsrc = c.xX[pprev];
+            if (full) {
+                if (anytail) stdp_rows<OuterSum, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                else stdp_rows<CascadeT, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+            } else {
+                if (wave == 0) {
+                    const uint64_t m = __ballot(lane < CW && colmask[lane & 31] != 0);
+                    if (lane == 0) misc[1] = (int)(uint32_t)m;
+                }
+                for (int base = 0; base < Nin; base += NT) {   // compact the rows with a pre-synaptic spike
+                    const int i = base + tid;
+                    const bool o = i < Nin && rowmask[i] != 0;
+                    const uint64_t m = __ballot(o);
+                    int wbase = 0;
+                    if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
+                    wbase = __shfl(wbase, 0);
+                    if (o) { const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull)); arows[cp] = (uint16_t)i; rowpos[i] = (uint16_t)cp; }
+                }
+                lds_barrier();
+                const int nact = misc[0];
+                const uint32_t acols = c.nu1 != 0.f ? (uint32_t)misc[1] : 0u;
+                if (anytail) {
+                    stdp_rows<OuterSum, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    stdp_cols<OuterSum>(c, acols, rowmask, colmask, xsrc, c0, tid, Emain);
+                } else {
+                    stdp_rows<CascadeT, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    stdp_cols<CascadeT>(c, acols, rowmask, colmask, xsrc, c0, tid, Emain);
+                }
+            }
+        }
+    }
+    const bool busy = (misc[2] & 2) != 0;              // uniform: some sample overflowed the fixed-size fast path
+    if (busy) __syncthreads();     // generic path re-reads the own weight slice from global: drain the STDP stores
+    else lds_barrier();            // fast path reads the refreshed weights from the LDS tile
+    DBG_MARK(4);
+    if (!phaseB) return;
+
+    // ================================================================== phase B: start step t
+    // ---- B1: input currents of the own tile from step t-1 spikes
+    float curE = 0.f, curI = 0.f;
+    if (mine) {
+        const int nX = cntX[bl], nI = cntI[bl], nE = cntE[bl];
+        const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
+        if (!busy) {
+            const float *wt = tile_fresh ? wtile : nullptr;
+            const uint16_t *rp = tile_full ? nullptr : rowpos;
+            if (tailcol) tile_currents<RowSum4>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
+            else tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
+        } else {   // generic bit-scan path
+            const uint32_t *xw = sXw + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
+            const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
+            if (tailcol) {
+                curE = 0.0f + ordered_dot<RowSum4>(c.Wxe, N, j, xw, ax, xb, Nin);
+                curE = curE + ordered_dot<RowSum4>(c.Wie, N, j, iw, ar, nullptr, N);
+                curI = 0.0f + ordered_dot<RowSum4>(c.Wei, N, j, ew, ar, nullptr, N);
+            } else {
+                curE = 0.0f + ordered_dot<CascadeN>(c.Wxe, N, j, xw, ax, xb, Nin);
+                curE = curE + ordered_dot<CascadeN>(c.Wie, N, j, iw, ar, nullptr, N);
+                curI = 0.0f + ordered_dot<CascadeN>(c.Wei, N, j, ew, ar, nullptr, N);
+            }
+        }
+    }
+    DBG_MARK(5);
+    // ---- B2: membrane updates
+    bool spE = false, spIn = false;
+    float o_vE = 0.f, o_rE = 0.f, o_vI = 0.f, o_rI = 0.f, th = 0.f;
+    if (mine) {
+        th = r_theta;
+        if (c.pE.learning) th = th * c.pE.theta_decay;                 // nodes.py:1079
+        o_vE = r_vE; o_rE = r_rE;
+        spE = dc_update(o_vE, o_rE, curE, c.pE.lif.thresh + th, c.pE.lif);   // nodes.py:1088
+        if (spE) atomicAdd(&cnt[jj], 1);
+        o_vI = r_vI; o_rI = r_rI;
+        float ci = curI;
+        if (o_rI > 0.f) ci = 0.f;                                      // nodes.py:511
+        spIn = lif_update(o_vI, o_rI, ci, c.pI);
+    }
+    lds_barrier();
+    if (mine) {
+        if (bl == 0) {                                                 // one thread per column owns theta
+            if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[jj];   // nodes.py:1094
+            c.theta[j] = th;
+        }
+        c.vE[kst] = o_vE; c.rE[kst] = o_rE;
+        if (c.rasVE) c.rasVE[(size_t)t * B * N + kst] = o_vE;
+        c.vI[kst] = o_vI; c.rI[kst] = o_rI;
+        c.sI[kst] = spIn;
+        if (c.pI.traces) c.xI[kst] = trace_next(r_xI, spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
+        if (c.rasI) c.rasI[(size_t)t * B * N + kst] = spIn;
+        if (c.rasVI) c.rasVI[(size_t)t * B * N + kst] = o_vI;
+    }
+    {   // publish crossing / spike bits: a wave holds 64/CW samples x CW columns -> one byte per sample
+        const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
+        constexpr int SPW = 64 / CW;                               // samples per wave
+        const int sidx = lane / CW, b = wave * SPW + sidx;
+        if (tid < TT && (lane % CW) == 0 && b < B) {
+            ((uint8_t *)c.crossE[pcur])[(b * NW) * 4 + g] = (uint8_t)(mE >> (sidx * CW));
+            ((uint8_t *)c.spikeI[pcur])[(b * NW) * 4 + g] = (uint8_t)(mI >> (sidx * CW));
+        }
+    }
+    DBG_MARK(6);
+    // ---- B3: X trace of step t for an own slice of input rows (nodes.py:96-103)
+    if (c.x_traces) {
+        float *xn = c.xX[pcur];
+        if (xmine) xn[xb_ * Nin + xi_] = trace_next(r_xo, r_xs, c.x_decay, c.x_scale, c.x_additive);
+        for (int item = tid + NT; item < B * c.RS; item += NT) {        // only when the slice has > NT items
+            const int b = item / c.RS, i = xr0 + (item - b * c.RS);
+            if (i < xr1) {
+                const int k = b * Nin + i;
+                xn[k] = trace_next(c.xX[pprev][k], c.in[stepoff + k], c.x_decay, c.x_scale, c.x_additive);
+            }
+        }
+    }
+    DBG_MARK(7);
+    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + 9] = (long long)clock64();
+}
+
+size_t lds_bytes(int B, int Nin, int N) {
+    const int NW = (N + 31) / 32, NinW = (Nin + 31) / 32;
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return al((size_t)B * NinW * 4) + 3 * al((size_t)B * NW * 4) + al((size_t)Nin * 4) + al((size_t)Nin * 2) +
+           (size_t)MAXB * CW * 4 + 4 * 624 * 4 + MAXB * 8 + MAXB * LX * 2 + 2 * MAXB * LR * 2 + 3 * MAXB * 4 + 2 * 32 * 4 + 16 +
+           al((size_t)Nin * 2) + (size_t)Nin * CW * 4;
+}
+
+}  // namespace
+
+// Device scratch the fused plan needs (bytes); 0 if the graph does not match the plan.
+static size_t fused_workspace(int B, int Nin, int N) {
+    const int NW = (N + 31) / 32;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return 4 * al((size_t)B * NW * 4) + al((size_t)B * Nin * 4) + al(sizeof(snn_rng_state));
+}
+
+static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
+    if (nL != 3 || nC != 3) return false;
+    if (L[0].kind != SNN_LAYER_INPUT || L[1].kind != SNN_LAYER_DC || L[2].kind != SNN_LAYER_LIF) return false;
+    if (L[1].n != L[2].n) return false;
+    for (int k = 0; k < 3; ++k) if (C[k].kind != SNN_CONN_MCC || C[k].bias) return false;
+    if (C[0].src != 0 || C[0].dst != 1 || C[1].src != 1 || C[1].dst != 2 || C[2].src != 2 || C[2].dst != 1) return false;
+    if (C[1].rule != SNN_RULE_NONE || C[2].rule != SNN_RULE_NONE) return false;
+    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE) return false;
+    if (C[0].rule == SNN_RULE_POSTPRE && (C[0].wdecay != 1.0f || !L[0].x || !L[1].x)) return false;
+    if (R->B > MAXB) return false;
+    if (L[0].n > 2048 || L[0].n % 16 != 0 || L[1].n > 1024 || R->B * ((L[1].n + 31) / 32) > NT) return false;
+    if ((size_t)R->B * L[0].n > (size_t)NU * NT * 16) return false;
+    if ((double)(R->T + 1) * R->B * L[0].n >= 2147483648.0) return false;
+    if (L[1].p.one_spike && !R->rng) return false;
+    if (R->T < 1) return false;
+    if (lds_bytes(R->B, L[0].n, L[1].n) > 64 * 1024) return false;
+    if (!R->workspace || R->workspace_bytes < fused_workspace(R->B, L[0].n, L[1].n)) return false;
+    return true;
+}
+
+extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
+                                          const snn_run_desc *R) {
+    if (!L || !R || nL != 3 || nC != 3 || !C) return 0;
+    return fused_workspace(R->B, L[0].n, L[1].n);
+}
+
+void snn_set_plan_name(const char *name);
+
+int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                         hipStream_t st, int *handled) {
+    *handled = 0;
+    if (!matches(L, nL, C, nC, R)) return SNN_OK;
+    const int B = R->B, Nin = L[0].n, N = L[1].n;
+    DcCtx c;
+    memset(&c, 0, sizeof(c));
+    c.B = B; c.Nin = Nin; c.N = N; c.T = R->T; c.NW = (N + 31) / 32; c.NinW = (Nin + 31) / 32;
+    c.G = (N + CW - 1) / CW; c.RS = (Nin + c.G - 1) / c.G;
+    c.dt = R->dt; c.learning = R->learning;
+    c.inv_hwps = 1.0f / (float)(Nin >> 4); c.inv_NW = 1.0f / (float)c.NW; c.inv_RS = 1.0f / (float)c.RS;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    unsigned char *ws = (unsigned char *)R->workspace;
+    const size_t wb = al((size_t)B * c.NW * 4);
+    c.crossE[0] = (uint32_t *)ws; c.crossE[1] = (uint32_t *)(ws + wb);
+    c.spikeI[0] = (uint32_t *)(ws + 2 * wb); c.spikeI[1] = (uint32_t *)(ws + 3 * wb);
+    float *xscratch = (float *)(ws + 4 * wb);
+    snn_rng_state *rng2 = (snn_rng_state *)(ws + 4 * wb + al((size_t)B * Nin * 4));
+    c.in = L[0].ext_spikes; c.sX0 = L[0].s;
+    c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
+    c.x_additive = L[0].p.lif.traces_additive;
+    c.xX[1] = L[0].x; c.xX[0] = xscratch;
+    c.vE = L[1].v; c.rE = L[1].refrac; c.xE = L[1].x; c.theta = L[1].theta; c.sE = L[1].s; c.pE = L[1].p;
+    c.rasE = L[1].raster_s; c.rasVE = L[1].raster_v;
+    c.vI = L[2].v; c.rI = L[2].refrac; c.xI = L[2].x; c.sI = L[2].s; c.pI = L[2].p.lif;
+    c.rasI = L[2].raster_s; c.rasVI = L[2].raster_v;
+    c.Wxe = C[0].w; c.Wei = C[1].w; c.Wie = C[2].w;
+    c.rule = C[0].rule; c.nu0 = C[0].nu0; c.nu1 = C[0].nu1; c.use_dt = C[0].use_dt;
+    c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
+    // generator: launch t reads rng[(t-1)&1], workgroup 0 writes rng[t&1]; entry state must sit in rng[0]
+    c.rng[0] = R->rng; c.rng[1] = rng2;
+    static long long *dbg = nullptr;
+    static int dbg_T = 0;
+    if (getenv("SNN_DC_TIMING")) {
+        if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * 16 * (R->T + 1)); dbg_T = R->T + 1; }
+        (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 16 * (R->T + 1), st);
+        c.dbg = dbg; c.dbg_wg = atoi(getenv("SNN_DC_TIMING")); if (c.dbg_wg < 0 || c.dbg_wg >= c.G) c.dbg_wg = c.G - 1;
+    }
+    // exchange words: pad bytes (columns >= N) are never written by a workgroup, so clear them once
+    { int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, st)); if (rc0) return rc0; }
+    const size_t lds = lds_bytes(B, Nin, N);
+    for (int t = 0; t <= R->T; ++t) {
+        const bool prof = snn_prof_begin(t, st);
+        hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, st, c, t);
+        if (prof) snn_prof_end(st);
+    }
+    int rc = snn_check_launch();
+    if (rc) return rc;
+    // final X trace sits in xX[(T-1)&1]; final generator in rng[T&1]
+    if (c.x_traces && ((R->T - 1) & 1) == 0)
+        if ((rc = snn_check(hipMemcpyAsync(L[0].x, xscratch, sizeof(float) * (size_t)B * Nin, hipMemcpyDeviceToDevice, st)))) return rc;
+    if (L[1].p.one_spike && (R->T & 1))
+        if ((rc = snn_check(hipMemcpyAsync(R->rng, rng2, sizeof(snn_rng_state), hipMemcpyDeviceToDevice, st)))) return rc;
+    if (c.dbg) {   // developer aid: average phase durations (100 MHz wall clock ticks -> us)
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h((size_t)16 * (R->T + 1));
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double acc[8] = {0}; int n = 0;
+        for (int t = 2; t < R->T; ++t, ++n)
+            for (int k = 1; k < 8; ++k) acc[k] += (double)(h[(size_t)t * 16 + k] - h[(size_t)t * 16 + k - 1]) / 100.0;
+        double cyc = 0, us = 0;
+        for (int t = 2; t < R->T; ++t) { cyc += (double)(h[(size_t)t * 16 + 9] - h[(size_t)t * 16 + 8]); us += (double)(h[(size_t)t * 16 + 7] - h[(size_t)t * 16]) / 100.0; }
+        fprintf(stderr, "[dc2015 clock] %.0f MHz shader clock during the kernel\n", cyc / us);
+        double sub[3] = {0, 0, 0};
+        for (int t = 2; t < R->T; ++t) { sub[0] += (h[(size_t)t*16+10]-h[(size_t)t*16+0])/100.0; sub[1] += (h[(size_t)t*16+11]-h[(size_t)t*16+10])/100.0; sub[2] += (h[(size_t)t*16+1]-h[(size_t)t*16+11])/100.0; }
+        fprintf(stderr, "[dc2015 stage detail, us] issue-loads %.2f | barrier(loads land) %.2f | lds-fill %.2f\n", sub[0]/n, sub[1]/n, sub[2]/n);
+        double ab[4] = {0, 0, 0, 0};
+        for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 16]; ab[0] += (r[12]-r[1])/100.0; ab[1] += (r[13]-r[12])/100.0; ab[2] += (r[14]-r[13])/100.0; ab[3] += (r[2]-r[14])/100.0; }
+        fprintf(stderr, "[dc2015 arb detail, us] barrier %.2f | candidates+twist %.2f | winners+publish+barrier %.2f | lstE %.2f\n", ab[0]/n, ab[1]/n, ab[2]/n, ab[3]/n);
+        fprintf(stderr, "[dc2015 timing, us] stage %.2f | arb %.2f | A2 %.2f | stdp %.2f | cur %.2f | membrane %.2f | xtrace %.2f\n",
+                acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
+    }
+    snn_set_plan_name("dc2015-fused");
+    *handled = 1;
+    return SNN_OK;
+}

@@ -87,6 +87,45 @@ struct RowSum4 {
     }
 };
 
+// Branch-free Cascade for sums of fewer than 4096 terms (the level-3 accumulator is never reached):
+// same arithmetic as Cascade, written with selects so a wave whose lanes are at different points of
+// different samples' event lists does not diverge.
+struct CascadeFlat {
+    float a0, a1, a2;
+    int cb;
+    __device__ __forceinline__ void init() { a0 = a1 = a2 = 0.f; cb = -1; }
+    __device__ __forceinline__ void add(int pos, float term, int n) {
+        const int nfull = n >> 4;
+        int blk = pos >> 4;
+        blk = blk < nfull ? blk : nfull;
+        const bool nb = blk != cb, ng = (blk >> 4) != (cb >> 4);
+        const float s1 = a1 + a0;              // what a1 becomes if block cb is closed
+        a1 = nb ? s1 : a1;
+        a0 = nb ? 0.f : a0;
+        const float s2 = a2 + a1;              // ... and a2 if a 256-term group is closed too
+        a2 = ng ? s2 : a2;
+        a1 = ng ? 0.f : a1;
+        cb = blk;
+        a0 += term;
+    }
+    __device__ __forceinline__ float finish(int n) {
+        const int nfull = n >> 4;
+        if (cb != nfull) {
+            a1 += a0; a0 = 0.f;
+            if ((nfull >> 4) != (cb >> 4)) { a2 += a1; a1 = 0.f; }
+        }
+        return ((a0 + a1) + a2) + 0.0f;
+    }
+};
+
+// Cascade with the (pos, term, n) interface of RowSum4, for code templated on the column class.
+struct CascadeN {
+    Cascade c;
+    __device__ __forceinline__ void init() { c.init(); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
+    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+};
+
 // One output element's reduction; `tail` selects row_sum (column >= 32*floor(ncols/32)).
 struct OuterSum {
     Cascade c;

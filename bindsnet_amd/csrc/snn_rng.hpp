@@ -45,6 +45,48 @@ __device__ __forceinline__ void mt_twist_block(const uint32_t *src, uint32_t *ds
     __syncthreads();
 }
 
+// Same twist performed by ONE wave in lockstep, no workgroup barrier: lane l produces elements 4l..4l+3 of
+// each of the three dependent stripes.  LDS operations of a wave execute in program order, so a stripe's
+// reads see the previous stripe's writes.  All 64 lanes must call it.
+__device__ __forceinline__ void mt_twist_block_wave(const uint32_t *src, uint32_t *dst, int lane) {
+    {   // i in [0, 227): dst[i] = src[i+397] ^ mix(src[i], src[i+1])
+        const int i0 = lane * 4;
+        if (i0 < 227) {
+            uint32_t a[5], b[4];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] = src[min(i0 + k, 623)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = src[min(i0 + k + 397, 623)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < 227) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
+        }
+    }
+    {   // i in [227, 454): dst[i] = dst[i-227] ^ mix(src[i], src[i+1])
+        const int i0 = 227 + lane * 4;
+        if (i0 < 454) {
+            uint32_t a[5], b[4];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] = src[min(i0 + k, 623)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = dst[i0 + k - 227];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < 454) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
+        }
+    }
+    {   // i in [454, 624): dst[i] = dst[i-227] ^ mix(src[i], i == 623 ? dst[0] : src[i+1])
+        const int i0 = 454 + lane * 4;
+        if (i0 < 624) {
+            uint32_t a[5], b[4];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] = (i0 + k <= 623) ? src[i0 + k] : dst[0];   // element 623 pairs with NEW dst[0]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = dst[min(i0 + k, 623) - 227];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < 624) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
+        }
+    }
+}
+
 __device__ __forceinline__ int32_t dbl_hi(double x) { return (int32_t)(__double_as_longlong(x) >> 32); }
 __device__ __forceinline__ double dbl_set_hi(double x, int32_t h) {
     const uint64_t u = ((uint64_t)__double_as_longlong(x) & 0xffffffffull) | ((uint64_t)(uint32_t)h << 32);

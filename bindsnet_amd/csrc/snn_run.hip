@@ -14,7 +14,40 @@
 static thread_local const char *g_plan = "none";
 static int g_plan_mode = 0;
 
+// ---- profiling samples (bench.py roofline) ------------------------------------------------------
+static int g_prof_stride = 0;
+static constexpr int kMaxSamples = 64;
+static hipEvent_t g_ev0[kMaxSamples], g_ev1[kMaxSamples];
+static int g_nsamples = 0;
+static bool g_ev_ready = false;
+
+extern "C" void snn_profile_enable(int stride) { g_prof_stride = stride > 0 ? stride : 0; g_nsamples = 0; }
+
+bool snn_prof_begin(int t, hipStream_t st) {
+    if (!g_prof_stride || t % g_prof_stride || g_nsamples >= kMaxSamples) return false;
+    if (!g_ev_ready) {
+        for (int i = 0; i < kMaxSamples; ++i) { (void)hipEventCreate(&g_ev0[i]); (void)hipEventCreate(&g_ev1[i]); }
+        g_ev_ready = true;
+    }
+    (void)hipEventRecord(g_ev0[g_nsamples], st);
+    return true;
+}
+void snn_prof_end(hipStream_t st) { (void)hipEventRecord(g_ev1[g_nsamples++], st); }
+
+extern "C" int snn_profile_collect(double *sum_ms, int *n) {
+    if (!sum_ms || !n) return SNN_ERR_INVALID;
+    double acc = 0.0;
+    for (int i = 0; i < g_nsamples; ++i) {
+        float ms = 0.f;
+        if (snn_check(hipEventElapsedTime(&ms, g_ev0[i], g_ev1[i]))) return SNN_ERR_LAUNCH;
+        acc += ms;
+    }
+    *sum_ms = acc; *n = g_nsamples; g_nsamples = 0;
+    return SNN_OK;
+}
+
 extern "C" const char *snn_plan_name(void) { return g_plan; }
+void snn_set_plan_name(const char *name) { g_plan = name; }
 extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
@@ -78,6 +111,7 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
     bool fed[64];
     if (nL > 64) return SNN_ERR_UNSUPPORTED;
     for (int t = 0; t < R->T; ++t) {
+        const bool prof = snn_prof_begin(t, st);
         // (1) network.py:384 _get_inputs(): previous-step spikes through every connection, in order
         for (int l = 0; l < nL; ++l) fed[l] = false;
         for (int c = 0; c < nC; ++c) {
@@ -127,6 +161,7 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                                        d.reward, d.reward_vec, d.nu0, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus,
                                        d.wdecay, d.has_min, d.wmin, d.has_max, d.wmax, st));
             }
+        if (prof) snn_prof_end(st);
     }
     return SNN_OK;
 }
@@ -148,9 +183,3 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     return SNN_OK;
 }
 
-// --- fused plans: filled in below -------------------------------------------------------------
-int snn_try_fused_dc2015(const snn_layer_desc *, int, const snn_conn_desc *, int, const snn_run_desc *, hipStream_t,
-                         int *handled) {
-    *handled = 0;
-    return SNN_OK;
-}

@@ -180,6 +180,12 @@ class Network(torch.nn.Module):
 
         R = _lib.RunDesc()
         R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
+        need = int(_lib.lib().snn_net_workspace_bytes(L, len(names), Cn, len(self.connections), C.byref(R)))
+        if need:
+            ws = getattr(self, "_workspace", None)
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            R.workspace, R.workspace_bytes = _dptr(ws), need
         with DeviceGenerator(dev, max_draws) as ns:      # host generator <-> device, exact (rng.py)
             R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
             R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)

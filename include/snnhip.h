@@ -4,13 +4,13 @@
  *
  * BindsNET has no FFI / operator-plugin interface of its own (it is pure Python on PyTorch),
  * so the entry points below are what a binding of that path needs: one per reference function
- * of SURVEY.md section 8(a), plus fused multi-step drivers.  Each declaration cites the
+ * of SURVEY.md section 8(a), plus the multi-step driver snn_net_run.  Each declaration cites the
  * reference function it replaces (paths relative to the BindsNET repository root).
  *
  * Conventions
  *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer unless the
- *     parameter name starts with `h_`.  The caller owns every buffer; nothing is allocated
- *     behind the caller's back except inside an snn_ctx (workspace, created explicitly).
+ *     parameter name starts with `h_`.  The caller owns every buffer, scratch included;
+ *     the library allocates no device memory.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All calls are
  *     asynchronous and stream-ordered; none synchronises the device.
  *   - return value: 0 = SNN_OK, negative = error (snn_error_string()).  No C++ exception ever
@@ -218,6 +218,8 @@ typedef struct {
     long long q_len;
     snn_rng_state *rng;         /* OR: device generator state (preferred; noise_q ignored when set) */
     float *qbuf;                /* with rng: scratch of B * max(DC layer n) floats */
+    void *workspace;            /* device scratch for fused plans (snn_net_workspace_bytes); nullable */
+    unsigned long long workspace_bytes;
     long long *cursor;          /* device int64[2] */
     int *status;                /* device int32[1]: 0 or SNN_ERR_NOISE after the run */
 } snn_run_desc;
@@ -226,8 +228,18 @@ typedef struct {
  * cursor[0].  Picks a fused plan when the graph matches one (snn_plan_name reports which).  */
 int snn_net_run(const snn_layer_desc *h_layers, int n_layers, const snn_conn_desc *h_conns, int n_conns,
                 const snn_run_desc *h_run, snn_stream_t stream);
+/* Device scratch (bytes) a fused plan would need for this network; 0 if none applies.  A run
+ * whose descriptor carries less falls back to the generic plan.                               */
+unsigned long long snn_net_workspace_bytes(const snn_layer_desc *h_layers, int n_layers, const snn_conn_desc *h_conns,
+                                           int n_conns, const snn_run_desc *h_run);
 /* Name of the plan the last snn_net_run on this thread used ("generic", "dc2015-fused", ...). */
 const char *snn_plan_name(void);
+/* Profiling aid (bench.py roofline): when stride > 0, snn_net_run brackets the launches of every
+ * stride-th timestep with hipEvents recorded on the run's stream (at most 64 samples per run).
+ * snn_profile_collect (call after synchronising the stream) returns the summed elapsed
+ * milliseconds and the sample count, and clears the samples.                                 */
+void snn_profile_enable(int stride);
+int snn_profile_collect(double *h_sum_ms, int *h_samples);
 /* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only. */
 void snn_set_plan_mode(int mode);
 

@@ -76,7 +76,7 @@ def test_dc2015_network_run_matches_reference(name, plan):
             np.testing.assert_array_equal(bits(host(mv.get("v"))[-1]), bits(g[f"r{r}_vE"]))
             if r % 2 == 0:
                 net.reset_state_variables()
-        assert net.last_plan == ("generic" if plan == "generic" else net.last_plan)
+        assert net.last_plan == ("generic" if plan == "generic" else "dc2015-fused")
     finally:
         _lib.lib().snn_set_plan_mode(0)
 
