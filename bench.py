@@ -162,7 +162,7 @@ def main():
                                    "network.run(), PostPre STDP on, 2 spike monitors, reset_state_variables() per input",
                        "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
-                       "plan": net.last_plan, "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+                       "plan": net.last_plan, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
             "roofline": roof,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
         }

@@ -83,6 +83,7 @@ _SIGS = {
     "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),
     "snn_plan_name": ([], C.c_char_p),
     "snn_set_plan_mode": ([_i], None),
+    "snn_graph_stats": ([C.POINTER(C.c_int)] * 3, None),
     "snn_profile_enable": ([_i], None),
     "snn_profile_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_int)], _i),
 }
@@ -138,3 +139,10 @@ def profile_run(net, inputs, time, stride=4):
     plan = net.last_plan
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}
+
+
+def graph_stats():
+    """(plain, captured, replayed) run counts of the fused plan."""
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib().snn_graph_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -30,6 +30,7 @@
 using namespace snn;
 
 bool snn_prof_begin(int t, hipStream_t st);
+bool snn_prof_active();
 void snn_prof_end(hipStream_t st);
 
 namespace {
@@ -75,7 +76,7 @@ struct DcCtx {
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
 };
 
-#define DBG_MARK(slot) do { if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+#define DBG_MARK(slot) do { if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + (slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ bool bit_of(const uint32_t *w, int j) { return (w[j >> 5] >> (j & 31)) & 1u; }
 
@@ -227,6 +228,7 @@ struct CascadeT {
 };
 
 constexpr int LX = 32, LR = 8;   // per-sample event-list capacities (X sources / recurrent sources)
+constexpr int NCAND = 2048;      // one_spike candidates evaluated one per thread (more: serial fallback)
 
 // One wave turns a row of spike bit words into the ascending list of set-bit indices (first `cap`
 // entries stored) and returns the total count.  nwords <= 64.
@@ -262,7 +264,9 @@ __device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx
                                               const float *wtile, const uint16_t *rowpos, int jj,
                                               const uint8_t *__restrict__ xb, int j, float &curE, float &curI) {
     const int Nin = c.Nin, N = c.N;
-    int ix[16]; float wx[16];
+    int ix[16], ii[4], ie[4]; float wx[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ii[u] = (int)li[u]; ie[u] = (int)le[u]; }
     // unconditional, clamped gathers (entries past nX are stale but in range): the 16 reads of each stage
     // are independent, so the three dependent LDS stages cost three latencies, not forty-eight
 #pragma unroll
@@ -293,12 +297,39 @@ __device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx
     curE = 0.0f + a.finish(Nin);
     a.init();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (u < nI) a.add((int)li[u], wi[u] * 1.0f, N);
+    for (int u = 0; u < 4; ++u) if (u < nI) a.add(ii[u], wi[u] * 1.0f, N);
     curE = curE + a.finish(N);
     a.init();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (u < nE) a.add((int)le[u], we[u] * 1.0f, N);
+    for (int u = 0; u < 4; ++u) if (u < nE) a.add(ie[u], we[u] * 1.0f, N);
     curI = 0.0f + a.finish(N);
+}
+
+// ATen "row_sum" columns (j >= 32*floor(N/32)): the reference sums the sources in four interleaved lanes
+// (source index mod 4), each lane a cascade over its n/4 sources, leftovers (n % 4) added to lane 0, lanes
+// combined ((l0+l1)+l2)+l3.  Four adjacent threads take one lane each of the same (sample, column) -- the
+// lanes really are independent -- and lane 0 combines them with quad shuffles.
+template <int NMAX>
+__device__ __forceinline__ float quad_lane_sum(const int *ix, int cnt, const float *wv, const uint8_t *vals, int n, int L) {
+    const int n4 = n >> 2;
+    CascadeFlat a; a.init();
+    float tailsum = 0.f;                 // lane 0 only: its combined cascade + leftovers, once the first leftover arrives
+    bool closed = false;
+#pragma unroll
+    for (int u = 0; u < NMAX; ++u) {
+        if (u < cnt) {
+            const int i = ix[u];
+            const float term = wv[u] * (vals ? (float)vals[i] : 1.0f);
+            if (i >= (n4 << 2)) {
+                if (L == 0) { if (!closed) { tailsum = a.finish(n4); closed = true; } tailsum += term; }
+            } else if ((i & 3) == L) {
+                a.add(i >> 2, term, n4);
+            }
+        }
+    }
+    float v = closed ? tailsum : a.finish(n4);
+    const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
+    return ((v + v1) + v2) + v3;         // meaningful in lane 0 of the quad
 }
 
 __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
@@ -313,7 +344,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     uint32_t *rowmask = (uint32_t *)(smem + off); off += ((size_t)Nin * 4 + 15) & ~(size_t)15;    // samples in which row i spiked
     uint16_t *arows = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;      // compacted active rows
     float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * CW * 4;                            // [B][CW] x_tgt*nu0
-    uint32_t *mt = (uint32_t *)(smem + off); off += 4 * 624 * 4;                                  // mt19937 blocks m, m+1, ... in slot (block & 3)
+    uint32_t *mt = (uint32_t *)(smem + off); off += 8 * 624 * 4;                                  // mt19937 blocks m, m+1, ... in slot (block & 7)
+    uint32_t *cand = (uint32_t *)(smem + off); off += NCAND * 4;                                  // one_spike candidates (sample << 16 | column)
     unsigned long long *keys = (unsigned long long *)(smem + off); off += MAXB * 8;               // argmax keys per sample
     uint16_t *lstX = (uint16_t *)(smem + off); off += MAXB * LX * 2;                              // per-sample X event lists
     uint16_t *lstI = (uint16_t *)(smem + off); off += MAXB * LR * 2;                              // ... Ai spikes
@@ -323,9 +355,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     int *cntE = (int *)(smem + off); off += MAXB * 4;
     int *cnt = (int *)(smem + off); off += 32 * 4;                                                // crossings per column
     uint32_t *colmask = (uint32_t *)(smem + off); off += 32 * 4;                                  // samples whose final Ae spike is column jj
-    int *misc = (int *)(smem + off); off += 16;      // [0] n active rows, [1] active column mask, [2] spike value > 1, [3] samples with a crossing
+    int *misc = (int *)(smem + off); off += 32;      // [4] number of one_spike candidates; [0] n active rows, [1] active column mask, [2] spike value > 1, [3] samples with a crossing
     uint16_t *rowpos = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;     // row -> compact active-row index
     float *wtile = (float *)(smem + off); off += (size_t)Nin * CW * 4;                            // refreshed own weights of active rows
+    float *curbuf = (float *)(smem + off); off += 2 * MAXB * CW * 4;                              // tail-column currents handed to the tile threads
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, c0 = g * CW;
@@ -337,7 +370,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     const int pprev = (t + 1) & 1, pcur = t & 1;     // parity of step t-1 / step t
     const int BW = B * NW;
     DBG_MARK(0);
-    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + 8] = (long long)clock64();
+    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 8] = (long long)clock64();
+    if (c.dbg && threadIdx.x == 0) atomicMin((unsigned long long *)&c.dbg[(size_t)t * 24 + 20], (unsigned long long)wall_clock64());
 
     // ------------------------------------------------------------------ stage inputs
     // Every global load that does not depend on this launch's arbitration is issued here, together,
@@ -389,7 +423,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     float r_xo = 0.f; uint8_t r_xs = 0;
     if (xmine) { r_xo = c.xX[pprev][xb_ * Nin + xi_]; r_xs = c.in[stepoff + xb_ * Nin + xi_]; }
     if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
-    if (tid < 4) misc[tid] = 0;
+    if (tid < 8) misc[tid] = 0;
     for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
     if (tid < MAXB) keys[tid] = 0ull;
     DBG_MARK(10);
@@ -455,12 +489,17 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     }
     DBG_MARK(1);
     lds_barrier();
-    // recurrent Ai->Ae weights of the own tile: issued now, consumed in phase B
+    // who computes input currents: the tile threads, or -- in a workgroup of ATen row_sum columns -- every
+    // thread as (sample, column, lane) with four lanes per (sample, column)
+    const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
+    const int cjg = c0 + cj_;
+    const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
+    // recurrent Ai->Ae weights: issued now, consumed in phase B
     float wi[4] = {0.f, 0.f, 0.f, 0.f};
-    if (mine && phaseB) {
-        const int nI = cntI[bl];
+    if (cvalid) {
+        const int nI = cntI[cb_];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (u < nI) wi[u] = c.Wie[(int)lstI[bl * LR + u] * N + j];
+        for (int u = 0; u < 4; ++u) if (u < nI) wi[u] = c.Wie[(int)lstI[cb_ * LR + u] * N + cjg];
     }
 
     // ================================================================== phase A: finish step t-1
@@ -474,44 +513,76 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
         E = pos + 2 * rows * N;
         ntw = rows ? (E - 1) / 624 : 0;
         const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));   // rank of sample wb among rows with a crossing
-        uint32_t parked = 0;
-        // blocks [lo, hi] of the generator output are resident in the ring (slot = block & 3); candidates whose
-        // words fall in them are evaluated in one pass; only a step that consumes more than two further blocks
-        // pays for extra twists (last wave, lockstep) between two barriers.
-        int lo = 0, hi = min(ntw, 2);
-        while (rows) {
-            if (tid < BW) {
-                uint32_t bits = crs[tid];
+        // ---- enumerate the candidates (threshold crossers of rows that crossed) into a compact list
+        if (tid < BW) {
+            uint32_t bits = crs[tid];
+            if (bits) {
+                int at = atomicAdd(&misc[4], __popc(bits));
                 while (bits) {
                     const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
-                    const int d = myrank * N + jx;
-                    const int w0 = pos + 2 * d, w1 = w0 + 1;
-                    const int m0 = w0 / 624, m1 = w1 / 624;
-                    float q; bool have = false;
-                    if (m0 >= lo && m1 <= hi) {
-                        q = exp1_from_words(mt_temper(mt[(m0 & 3) * 624 + w0 - 624 * m0]),
-                                            mt_temper(mt[(m1 & 3) * 624 + w1 - 624 * m1])); have = true;
-                    } else if (m0 >= lo && m0 <= hi) {                 // pair straddles the resident range: park the high word
-                        parked = mt_temper(mt[(m0 & 3) * 624 + w0 - 624 * m0]);
-                    } else if (m1 >= lo && m1 <= hi) {
-                        q = exp1_from_words(parked, mt_temper(mt[(m1 & 3) * 624 + w1 - 624 * m1])); have = true;
-                    }
-                    if (have) {
-                        const float val = 1.0f / q;                     // p / q with p = 1
-                        const unsigned long long key =
-                            ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
-                        atomicMax(&keys[wb], key);                      // max value, ties -> lowest index
-                    }
+                    if (at < NCAND) cand[at] = ((uint32_t)wb << 16) | (uint32_t)jx;
+                    ++at;
                 }
             }
-            if (hi >= ntw) break;
-            lds_barrier();                                             // everyone is done reading blocks <= hi
-            if (wave == NWV - 1) {
-                mt_twist_block_wave(mt + (hi & 3) * 624, mt + ((hi + 1) & 3) * 624, lane);
-                if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((hi + 1) & 3) * 624, mt + ((hi + 2) & 3) * 624, lane);
+        }
+        // the generator blocks the step consumes: 0..2 were produced speculatively; up to 7 fit in the ring
+        if (ntw > 2 && ntw <= 7 && wave == NWV - 1)
+            for (int m = 2; m < ntw; ++m) mt_twist_block_wave(mt + (m & 7) * 624, mt + ((m + 1) & 7) * 624, lane);
+        lds_barrier();
+        const int ncand = misc[4];
+        if (ncand <= NCAND && ntw <= 7) {
+            // fast path: every block is resident, one candidate per thread
+            for (int k = tid; k < ncand; k += NT) {
+                const uint32_t cd = cand[k];
+                const int b = (int)(cd >> 16), jx = (int)(cd & 0xFFFFu);
+                const int d = __popc(anym & ((1u << b) - 1u)) * N + jx;
+                const int w0 = pos + 2 * d, w1 = w0 + 1;
+                const int m0 = w0 / 624, m1 = w1 / 624;
+                const float q = exp1_from_words(mt_temper(mt[(m0 & 7) * 624 + w0 - 624 * m0]),
+                                                mt_temper(mt[(m1 & 7) * 624 + w1 - 624 * m1]));
+                const float val = 1.0f / q;                             // p / q with p = 1
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                atomicMax(&keys[b], key);                              // max value, ties -> lowest index
             }
-            lo = hi + 1; hi = min(ntw, hi + 2);
-            lds_barrier();
+        } else {
+            // slow path (very many crossing rows / candidates): walk the stream block by block
+            uint32_t parked = 0;
+            int lo = 0, hi = min(ntw, 2);
+            while (rows) {
+                if (tid < BW) {
+                    uint32_t bits = crs[tid];
+                    while (bits) {
+                        const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                        const int d = myrank * N + jx;
+                        const int w0 = pos + 2 * d, w1 = w0 + 1;
+                        const int m0 = w0 / 624, m1 = w1 / 624;
+                        float q; bool have = false;
+                        if (m0 >= lo && m1 <= hi) {
+                            q = exp1_from_words(mt_temper(mt[(m0 & 7) * 624 + w0 - 624 * m0]),
+                                                mt_temper(mt[(m1 & 7) * 624 + w1 - 624 * m1])); have = true;
+                        } else if (m0 >= lo && m0 <= hi) {             // pair straddles the resident range: park the high word
+                            parked = mt_temper(mt[(m0 & 7) * 624 + w0 - 624 * m0]);
+                        } else if (m1 >= lo && m1 <= hi) {
+                            q = exp1_from_words(parked, mt_temper(mt[(m1 & 7) * 624 + w1 - 624 * m1])); have = true;
+                        }
+                        if (have) {
+                            const float val = 1.0f / q;
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                            atomicMax(&keys[wb], key);
+                        }
+                    }
+                }
+                if (hi >= ntw) break;
+                lds_barrier();                                         // everyone is done reading blocks <= hi
+                if (wave == NWV - 1) {
+                    mt_twist_block_wave(mt + (hi & 7) * 624, mt + ((hi + 1) & 7) * 624, lane);
+                    if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((hi + 1) & 7) * 624, mt + ((hi + 2) & 7) * 624, lane);
+                }
+                lo = hi + 1; hi = min(ntw, hi + 2);
+                lds_barrier();
+            }
         }
         lds_barrier();                                                 // keys final
         DBG_MARK(13);
@@ -525,7 +596,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
         }
         if (g == 0) {   // publish the advanced generator for the next launch
             snn_rng_state *wr = c.rng[pcur];
-            const uint32_t *fin = mt + (ntw & 3) * 624;
+            const uint32_t *fin = mt + (ntw & 7) * 624;
             if (tid < 624) wr->mt[tid] = fin[tid];
             if (tid == 0) {
                 wr->pos = E - 624 * ntw;
@@ -560,12 +631,12 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
         }
     }
     lds_barrier();
-    // recurrent Ae->Ai weights of the own tile: issued now, consumed in phase B
+    // recurrent Ae->Ai weights: issued now, consumed in phase B
     float we[4] = {0.f, 0.f, 0.f, 0.f};
-    if (mine && phaseB) {
-        const int nE = cntE[bl];
+    if (cvalid) {
+        const int nE = cntE[cb_];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (u < nE) we[u] = c.Wei[(int)lstE[bl * LR + u] * N + j];
+        for (int u = 0; u < 4; ++u) if (u < nE) we[u] = c.Wei[(int)lstE[cb_ * LR + u] * N + cjg];
     }
     bool tile_fresh = false;       // the STDP pass below left the active rows of the own slice in `wtile`
     bool tile_full = false;
@@ -617,14 +688,45 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     // ================================================================== phase B: start step t
     // ---- B1: input currents of the own tile from step t-1 spikes
     float curE = 0.f, curI = 0.f;
-    if (mine) {
+    if (!busy && tailcol) {
+        // row_sum columns: quad of threads per (sample, column)
+        if (cvalid) {
+            const int nX = cntX[cb_], nI = cntI[cb_], nE = cntE[cb_];
+            const uint16_t *lx = lstX + cb_ * LX;
+            const uint8_t *xb = sbytes ? sbytes + cb_ * Nin : nullptr;
+            int ix[16], ii[4], ie[4];
+            float wx[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) ix[u] = min((int)lx[u], Nin - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ii[u] = min((int)lstI[cb_ * LR + u], N - 1); ie[u] = min((int)lstE[cb_ * LR + u], N - 1); }
+            if (tile_fresh) {
+                int rr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) rr[u] = tile_full ? ix[u] : min((int)rowpos[ix[u]], Nin - 1);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wx[u] = wtile[rr[u] * CW + cj_];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wx[u] = c.Wxe[ix[u] * N + cjg];
+            }
+            const float e1 = quad_lane_sum<16>(ix, nX, wx, xb, Nin, cL);
+            const float e2 = quad_lane_sum<4>(ii, nI, wi, nullptr, N, cL);
+            const float e3 = quad_lane_sum<4>(ie, nE, we, nullptr, N, cL);
+            if (cL == 0) {
+                curbuf[(cb_ * CW + cj_) * 2] = (0.0f + e1) + e2;        // (zeros + X->Ae) + Ai->Ae
+                curbuf[(cb_ * CW + cj_) * 2 + 1] = 0.0f + e3;            // zeros + Ae->Ai
+            }
+        }
+        lds_barrier();
+        if (mine) { curE = curbuf[(bl * CW + jj) * 2]; curI = curbuf[(bl * CW + jj) * 2 + 1]; }
+    } else if (mine) {
         const int nX = cntX[bl], nI = cntI[bl], nE = cntE[bl];
         const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
         if (!busy) {
             const float *wt = tile_fresh ? wtile : nullptr;
             const uint16_t *rp = tile_full ? nullptr : rowpos;
-            if (tailcol) tile_currents<RowSum4>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
-            else tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
+            tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
         } else {   // generic bit-scan path
             const uint32_t *xw = sXw + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
             const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
@@ -691,15 +793,16 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
         }
     }
     DBG_MARK(7);
-    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 16 + 9] = (long long)clock64();
+    if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 9] = (long long)clock64();
+    if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
 }
 
 size_t lds_bytes(int B, int Nin, int N) {
     const int NW = (N + 31) / 32, NinW = (Nin + 31) / 32;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return al((size_t)B * NinW * 4) + 3 * al((size_t)B * NW * 4) + al((size_t)Nin * 4) + al((size_t)Nin * 2) +
-           (size_t)MAXB * CW * 4 + 4 * 624 * 4 + MAXB * 8 + MAXB * LX * 2 + 2 * MAXB * LR * 2 + 3 * MAXB * 4 + 2 * 32 * 4 + 16 +
-           al((size_t)Nin * 2) + (size_t)Nin * CW * 4;
+           (size_t)MAXB * CW * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + MAXB * LX * 2 + 2 * MAXB * LR * 2 + 3 * MAXB * 4 + 2 * 32 * 4 + 32 +
+           al((size_t)Nin * 2) + (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
 }
 
 }  // namespace
@@ -726,7 +829,7 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
     if ((double)(R->T + 1) * R->B * L[0].n >= 2147483648.0) return false;
     if (L[1].p.one_spike && !R->rng) return false;
     if (R->T < 1) return false;
-    if (lds_bytes(R->B, L[0].n, L[1].n) > 64 * 1024) return false;
+    if (lds_bytes(R->B, L[0].n, L[1].n) > 150 * 1024) return false;
     if (!R->workspace || R->workspace_bytes < fused_workspace(R->B, L[0].n, L[1].n)) return false;
     return true;
 }
@@ -738,6 +841,13 @@ extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, i
 }
 
 void snn_set_plan_name(const char *name);
+int g_graph_stats[3] = {0, 0, 0};   // runs enqueued as plain launches / captured / replayed
+
+extern "C" void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed) {
+    if (h_plain) *h_plain = g_graph_stats[0];
+    if (h_captured) *h_captured = g_graph_stats[1];
+    if (h_replayed) *h_replayed = g_graph_stats[2];
+}
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                          hipStream_t st, int *handled) {
@@ -773,40 +883,105 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static long long *dbg = nullptr;
     static int dbg_T = 0;
     if (getenv("SNN_DC_TIMING")) {
-        if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * 16 * (R->T + 1)); dbg_T = R->T + 1; }
-        (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 16 * (R->T + 1), st);
+        if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * 24 * (R->T + 1)); dbg_T = R->T + 1; }
+        (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 24 * (R->T + 1), st);
+        for (int t = 0; t <= R->T; ++t) (void)hipMemsetAsync(dbg + (size_t)t * 24 + 20, 0x7F, sizeof(long long), st);
         c.dbg = dbg; c.dbg_wg = atoi(getenv("SNN_DC_TIMING")); if (c.dbg_wg < 0 || c.dbg_wg >= c.G) c.dbg_wg = c.G - 1;
     }
-    // exchange words: pad bytes (columns >= N) are never written by a workgroup, so clear them once
-    { int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, st)); if (rc0) return rc0; }
     const size_t lds = lds_bytes(B, Nin, N);
-    for (int t = 0; t <= R->T; ++t) {
-        const bool prof = snn_prof_begin(t, st);
-        hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, st, c, t);
-        if (prof) snn_prof_end(st);
+    static bool lds_attr = false;
+    if (!lds_attr) {   // the kernel may use more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_step, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        lds_attr = true;
     }
-    int rc = snn_check_launch();
+    // One run = memset of the exchange words (pad bytes for columns >= N are never written by a workgroup),
+    // T+1 launches, and up to two small copies (final X trace sits in xX[(T-1)&1], final generator in rng[T&1]).
+    auto enqueue = [&](bool with_events) -> int {
+        int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, st));
+        if (rc0) return rc0;
+        for (int t = 0; t <= R->T; ++t) {
+            const bool prof = with_events && snn_prof_begin(t, st);
+            hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, st, c, t);
+            if (prof) snn_prof_end(st);
+        }
+        if ((rc0 = snn_check_launch())) return rc0;
+        if (c.x_traces && ((R->T - 1) & 1) == 0)
+            if ((rc0 = snn_check(hipMemcpyAsync(L[0].x, xscratch, sizeof(float) * (size_t)B * Nin, hipMemcpyDeviceToDevice, st)))) return rc0;
+        if (L[1].p.one_spike && (R->T & 1))
+            if ((rc0 = snn_check(hipMemcpyAsync(R->rng, rng2, sizeof(snn_rng_state), hipMemcpyDeviceToDevice, st)))) return rc0;
+        return SNN_OK;
+    };
+
+
+    // hipGraph replay: the launch sequence of a run is fully determined by the context (pointers + sizes), and
+    // training loops present the same contexts again and again (same network, recycled input / monitor buffers).
+    // First sight of a context: plain launches.  Second sight: capture + instantiate.  Afterwards: one
+    // hipGraphLaunch per run instead of T+1 kernel launches (the host stops being the bottleneck).
+    struct GraphEntry { DcCtx key; hipGraphExec_t exec; unsigned long long stamp; };
+    static std::vector<GraphEntry> cache;
+    static unsigned long long clock_ = 0;
+    static const bool graphs_on = getenv("SNN_NO_GRAPH") == nullptr;
+    int rc = SNN_OK;
+    if (!graphs_on || c.dbg || snn_prof_active()) {
+        rc = enqueue(true); g_graph_stats[0]++;
+    } else {
+        GraphEntry *hit = nullptr;
+        for (auto &e : cache) if (memcmp(&e.key, &c, sizeof(DcCtx)) == 0) { hit = &e; break; }
+        if (hit && hit->exec) {
+            hit->stamp = ++clock_; g_graph_stats[2]++;
+            rc = snn_check(hipGraphLaunch(hit->exec, st));
+        } else if (hit) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rce = enqueue(false);
+                ok = hipStreamEndCapture(st, &graph) == hipSuccess && rce == SNN_OK && graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) {
+                hit->exec = exec; hit->stamp = ++clock_; g_graph_stats[1]++;
+                rc = snn_check(hipGraphLaunch(exec, st));
+            } else {
+                (void)hipGetLastError();
+                rc = enqueue(false);          // capture unavailable: stay on plain launches
+            }
+        } else {
+            if (cache.size() >= 16) {           // evict the least recently used context
+                size_t v = 0;
+                for (size_t k = 1; k < cache.size(); ++k) if (cache[k].stamp < cache[v].stamp) v = k;
+                if (cache[v].exec) (void)hipGraphExecDestroy(cache[v].exec);
+                cache.erase(cache.begin() + v);
+            }
+            cache.push_back(GraphEntry{c, nullptr, ++clock_});
+            rc = enqueue(false); g_graph_stats[0]++;
+        }
+    }
     if (rc) return rc;
-    // final X trace sits in xX[(T-1)&1]; final generator in rng[T&1]
-    if (c.x_traces && ((R->T - 1) & 1) == 0)
-        if ((rc = snn_check(hipMemcpyAsync(L[0].x, xscratch, sizeof(float) * (size_t)B * Nin, hipMemcpyDeviceToDevice, st)))) return rc;
-    if (L[1].p.one_spike && (R->T & 1))
-        if ((rc = snn_check(hipMemcpyAsync(R->rng, rng2, sizeof(snn_rng_state), hipMemcpyDeviceToDevice, st)))) return rc;
     if (c.dbg) {   // developer aid: average phase durations (100 MHz wall clock ticks -> us)
         (void)hipStreamSynchronize(st);
-        std::vector<long long> h((size_t)16 * (R->T + 1));
+        std::vector<long long> h((size_t)24 * (R->T + 1));
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         double acc[8] = {0}; int n = 0;
         for (int t = 2; t < R->T; ++t, ++n)
-            for (int k = 1; k < 8; ++k) acc[k] += (double)(h[(size_t)t * 16 + k] - h[(size_t)t * 16 + k - 1]) / 100.0;
+            for (int k = 1; k < 8; ++k) acc[k] += (double)(h[(size_t)t * 24 + k] - h[(size_t)t * 24 + k - 1]) / 100.0;
         double cyc = 0, us = 0;
-        for (int t = 2; t < R->T; ++t) { cyc += (double)(h[(size_t)t * 16 + 9] - h[(size_t)t * 16 + 8]); us += (double)(h[(size_t)t * 16 + 7] - h[(size_t)t * 16]) / 100.0; }
+        for (int t = 2; t < R->T; ++t) { cyc += (double)(h[(size_t)t * 24 + 9] - h[(size_t)t * 24 + 8]); us += (double)(h[(size_t)t * 24 + 7] - h[(size_t)t * 24]) / 100.0; }
+        {   // whole-grid view: first workgroup start -> last workgroup end, and the gap to the next launch
+            double span = 0, gap = 0; int m = 0;
+            for (int t = 2; t + 1 < R->T; ++t, ++m) {
+                span += (double)(h[(size_t)t * 24 + 21] - h[(size_t)t * 24 + 20]) / 100.0;
+                gap += (double)(h[(size_t)(t + 1) * 24 + 20] - h[(size_t)t * 24 + 21]) / 100.0;
+            }
+            fprintf(stderr, "[dc2015 grid, us] first-WG-start -> last-WG-end %.2f | last-WG-end -> next launch first-WG-start %.2f\n", span / m, gap / m);
+        }
         fprintf(stderr, "[dc2015 clock] %.0f MHz shader clock during the kernel\n", cyc / us);
         double sub[3] = {0, 0, 0};
         for (int t = 2; t < R->T; ++t) { sub[0] += (h[(size_t)t*16+10]-h[(size_t)t*16+0])/100.0; sub[1] += (h[(size_t)t*16+11]-h[(size_t)t*16+10])/100.0; sub[2] += (h[(size_t)t*16+1]-h[(size_t)t*16+11])/100.0; }
         fprintf(stderr, "[dc2015 stage detail, us] issue-loads %.2f | barrier(loads land) %.2f | lds-fill %.2f\n", sub[0]/n, sub[1]/n, sub[2]/n);
         double ab[4] = {0, 0, 0, 0};
-        for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 16]; ab[0] += (r[12]-r[1])/100.0; ab[1] += (r[13]-r[12])/100.0; ab[2] += (r[14]-r[13])/100.0; ab[3] += (r[2]-r[14])/100.0; }
+        for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 24]; ab[0] += (r[12]-r[1])/100.0; ab[1] += (r[13]-r[12])/100.0; ab[2] += (r[14]-r[13])/100.0; ab[3] += (r[2]-r[14])/100.0; }
         fprintf(stderr, "[dc2015 arb detail, us] barrier %.2f | candidates+twist %.2f | winners+publish+barrier %.2f | lstE %.2f\n", ab[0]/n, ab[1]/n, ab[2]/n, ab[3]/n);
         fprintf(stderr, "[dc2015 timing, us] stage %.2f | arb %.2f | A2 %.2f | stdp %.2f | cur %.2f | membrane %.2f | xtrace %.2f\n",
                 acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);

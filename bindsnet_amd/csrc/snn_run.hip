@@ -23,6 +23,8 @@ static bool g_ev_ready = false;
 
 extern "C" void snn_profile_enable(int stride) { g_prof_stride = stride > 0 ? stride : 0; g_nsamples = 0; }
 
+bool snn_prof_active() { return g_prof_stride > 0; }
+
 bool snn_prof_begin(int t, hipStream_t st) {
     if (!g_prof_stride || t % g_prof_stride || g_nsamples >= kMaxSamples) return false;
     if (!g_ev_ready) {

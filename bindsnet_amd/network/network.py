@@ -158,8 +158,7 @@ class Network(torch.nn.Module):
                                           "outside the accelerated path")
             self._check_state(layer, B, dev)
             mon_s, mon_v = self._monitor_buffers(layer, T, B, dev, rasters)
-            cur = torch.empty(B, layer.n, device=dev)
-            keep.append(cur)
+            cur = self._scratch("cur_" + name, (B, layer.n), torch.float32, dev)
             d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
             d.x = _dptr(layer.x) if layer.traces else None
             d.raster_s, d.raster_v = _dptr(mon_s), _dptr(mon_v)
@@ -186,7 +185,11 @@ class Network(torch.nn.Module):
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             R.workspace, R.workspace_bytes = _dptr(ws), need
-        with DeviceGenerator(dev, max_draws) as ns:      # host generator <-> device, exact (rng.py)
+        gen_bufs = None
+        if max_draws:
+            gen_bufs = (self._scratch("rng_state", (628,), torch.int32, dev), self._scratch("rng_qbuf", (max_draws,), torch.float32, dev),
+                        self._scratch("rng_cursor", (2,), torch.int64, dev), self._scratch("rng_status", (1,), torch.int32, dev))
+        with DeviceGenerator(dev, max_draws, gen_bufs) as ns:      # host generator <-> device, exact (rng.py)
             R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
             R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
             rc = _lib.lib().snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R),
@@ -202,6 +205,15 @@ class Network(torch.nn.Module):
         self._keep = keep
 
     # ------------------------------------------------------------------ helpers
+    def _scratch(self, key, shape, dtype, dev):
+        """Persistent device scratch: the same addresses run after run keep the library's captured launch
+        graphs valid (csrc/snn_dc2015.hip) and avoid allocator traffic."""
+        pool = self.__dict__.setdefault("_scratch_pool", {})
+        t = pool.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev:
+            t = pool[key] = torch.empty(shape, dtype=dtype, device=dev)
+        return t
+
     def _normalize_all(self):
         for c in self.connections.values():
             c.normalize()
@@ -268,8 +280,7 @@ class Network(torch.nn.Module):
             if feat.norm is not None:
                 if isinstance(feat.norm, torch.Tensor):
                     raise NotImplementedError("bindsnet_amd: tensor norms are not supported")
-                ws = torch.empty(conn.target.n, device=dev)
-                keep.append(ws)
+                ws = self._scratch(f"norm_{src}_{dst}", (conn.target.n,), torch.float32, dev)
                 d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(feat.norm), 0, _dptr(ws)
             return
         if not isinstance(conn, AbstractConnection):
@@ -318,6 +329,5 @@ class Network(torch.nn.Module):
         if conn.norm is not None:
             if isinstance(conn, Conv2dConnection):
                 raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not supported")
-            ws = torch.empty(conn.target.n, device=dev)
-            keep.append(ws)
+            ws = self._scratch(f"norm_{src}_{dst}", (conn.target.n,), torch.float32, dev)
             d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(conn.norm), 1, _dptr(ws)

@@ -101,11 +101,17 @@ class DeviceGenerator:
     """Context manager: upload the host generator at entry, write it back (advanced by what the
     device consumed) at exit.  `consumed` is the number of Exp(1) draws used."""
 
-    def __init__(self, device, qbuf_floats: int):
+    def __init__(self, device, qbuf_floats: int, buffers=None):
+        """buffers: optional persistent (state int32[628], qbuf f32[n], cursor i64[2], status i32[1]) tensors."""
         self.device = torch.device(device)
         self.enabled = qbuf_floats > 0
-        self.cursor = torch.zeros(2, dtype=torch.int64, device=self.device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bufs = buffers
+        if buffers is not None:
+            self.cursor, self.status = buffers[2], buffers[3]
+            self.cursor.zero_(); self.status.zero_()
+        else:
+            self.cursor = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.state = self.qbuf = None
         self.consumed = 0
         self._n = qbuf_floats
@@ -113,8 +119,13 @@ class DeviceGenerator:
     def __enter__(self):
         if self.enabled:
             self._host0 = torch.get_rng_state()
-            self.state = torch.from_numpy(torch_state_to_words(self._host0).copy()).to(self.device)
-            self.qbuf = torch.empty(self._n, dtype=torch.float32, device=self.device)
+            img = torch.from_numpy(torch_state_to_words(self._host0).copy())
+            if self._bufs is not None:
+                self.state, self.qbuf = self._bufs[0], self._bufs[1]
+                self.state.copy_(img)
+            else:
+                self.state = img.to(self.device)
+                self.qbuf = torch.empty(self._n, dtype=torch.float32, device=self.device)
         return self
 
     def finish(self) -> int:

@@ -240,6 +240,8 @@ const char *snn_plan_name(void);
  * milliseconds and the sample count, and clears the samples.                                 */
 void snn_profile_enable(int stride);
 int snn_profile_collect(double *h_sum_ms, int *h_samples);
+/* Fused-plan bookkeeping: runs issued as plain launches / captured into a hipGraph / replayed from one. */
+void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed);
 /* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only. */
 void snn_set_plan_mode(int mode);
 
