@@ -896,57 +896,72 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     }
     // One run = memset of the exchange words (pad bytes for columns >= N are never written by a workgroup),
     // T+1 launches, and up to two small copies (final X trace sits in xX[(T-1)&1], final generator in rng[T&1]).
+    hipStream_t qs = st;           // stream the run is enqueued on (a private one when graphs are in play)
     auto enqueue = [&](bool with_events) -> int {
-        int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, st));
+        int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
         for (int t = 0; t <= R->T; ++t) {
-            const bool prof = with_events && snn_prof_begin(t, st);
-            hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, st, c, t);
-            if (prof) snn_prof_end(st);
+            const bool prof = with_events && snn_prof_begin(t, qs);
+            hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, qs, c, t);
+            if (prof) snn_prof_end(qs);
         }
         if ((rc0 = snn_check_launch())) return rc0;
         if (c.x_traces && ((R->T - 1) & 1) == 0)
-            if ((rc0 = snn_check(hipMemcpyAsync(L[0].x, xscratch, sizeof(float) * (size_t)B * Nin, hipMemcpyDeviceToDevice, st)))) return rc0;
+            if ((rc0 = snn_check(hipMemcpyAsync(L[0].x, xscratch, sizeof(float) * (size_t)B * Nin, hipMemcpyDeviceToDevice, qs)))) return rc0;
         if (L[1].p.one_spike && (R->T & 1))
-            if ((rc0 = snn_check(hipMemcpyAsync(R->rng, rng2, sizeof(snn_rng_state), hipMemcpyDeviceToDevice, st)))) return rc0;
+            if ((rc0 = snn_check(hipMemcpyAsync(R->rng, rng2, sizeof(snn_rng_state), hipMemcpyDeviceToDevice, qs)))) return rc0;
         return SNN_OK;
     };
 
 
-    // hipGraph replay: the launch sequence of a run is fully determined by the context (pointers + sizes), and
+    // hipGraph replay (opt-in, SNN_GRAPH=1): the launch sequence of a run is fully determined by the context (pointers + sizes), and
     // training loops present the same contexts again and again (same network, recycled input / monitor buffers).
     // First sight of a context: plain launches.  Second sight: capture + instantiate.  Afterwards: one
     // hipGraphLaunch per run instead of T+1 kernel launches (the host stops being the bottleneck).
     struct GraphEntry { DcCtx key; hipGraphExec_t exec; unsigned long long stamp; };
     static std::vector<GraphEntry> cache;
     static unsigned long long clock_ = 0;
-    static const bool graphs_on = getenv("SNN_NO_GRAPH") == nullptr;
+    static const bool graphs_on = getenv("SNN_GRAPH") != nullptr;   // opt-in: replay measured no faster than eager launches
     int rc = SNN_OK;
     if (!graphs_on || c.dbg || snn_prof_active()) {
         rc = enqueue(true); g_graph_stats[0]++;
     } else {
+        // capture is not allowed on the legacy default stream torch usually runs on: fork to a private
+        // non-blocking stream (event edge in, event edge out), so `st` still orders everything around the run
+        static hipStream_t side = nullptr;
+        static hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        if (!side) {
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) { side = nullptr; (void)hipGetLastError(); }
+        }
         GraphEntry *hit = nullptr;
         for (auto &e : cache) if (memcmp(&e.key, &c, sizeof(DcCtx)) == 0) { hit = &e; break; }
-        if (hit && hit->exec) {
-            hit->stamp = ++clock_; g_graph_stats[2]++;
-            rc = snn_check(hipGraphLaunch(hit->exec, st));
+        if (!side) {
+            rc = enqueue(false); g_graph_stats[0]++;
         } else if (hit) {
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                const int rce = enqueue(false);
-                ok = hipStreamEndCapture(st, &graph) == hipSuccess && rce == SNN_OK && graph;
-            }
-            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void)hipGraphDestroy(graph);
-            if (ok) {
-                hit->exec = exec; hit->stamp = ++clock_; g_graph_stats[1]++;
-                rc = snn_check(hipGraphLaunch(exec, st));
+            if ((rc = snn_check(hipEventRecord(ev_in, st))) || (rc = snn_check(hipStreamWaitEvent(side, ev_in, 0)))) return rc;
+            qs = side;
+            if (!hit->exec) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                bool ok = hipStreamBeginCapture(side, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    const int rce = enqueue(false);
+                    ok = hipStreamEndCapture(side, &graph) == hipSuccess && rce == SNN_OK && graph;
+                }
+                if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (ok) { hit->exec = exec; g_graph_stats[1]++; }
+                else { (void)hipGetLastError(); hit->exec = nullptr; }
             } else {
-                (void)hipGetLastError();
-                rc = enqueue(false);          // capture unavailable: stay on plain launches
+                g_graph_stats[2]++;
             }
+            hit->stamp = ++clock_;
+            if (hit->exec) rc = snn_check(hipGraphLaunch(hit->exec, side));
+            else { rc = enqueue(false); g_graph_stats[0]++; }
+            if (rc) return rc;
+            if ((rc = snn_check(hipEventRecord(ev_out, side))) || (rc = snn_check(hipStreamWaitEvent(st, ev_out, 0)))) return rc;
         } else {
             if (cache.size() >= 16) {           // evict the least recently used context
                 size_t v = 0;

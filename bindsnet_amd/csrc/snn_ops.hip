@@ -618,21 +618,75 @@ extern "C" int snn_mstdp_step(float *W, float *p_plus, float *p_minus, uint8_t *
 // a11: normalize.  k_colsum: thread <-> column, rows walked in order through the ATen-ordered
 // accumulator (dense: every row is a term).  k_scale: elementwise W *= norm * (1/colsum).
 // =============================================================================================
+// Four threads per column.  The ATen order makes that possible without changing a single rounding:
+//  * multi_row_sum columns: the sums of the 16-row blocks are independent of each other (each is a plain
+//    sequential sum of its 16 terms); thread s takes blocks s, s+4, ... and the quad leader then folds the
+//    block sums in block order through the upper cascade levels.
+//  * row_sum columns: the four interleaved lanes (row mod 4) are independent cascades; thread s IS lane s.
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ W, int Nin, int N, float norm,
                                                 int use_abs, float *__restrict__ scale) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    OuterSum acc;
-    acc.init(j >= (N / 32) * 32);
-    for (int i = 0; i < Nin; ++i) {
-        float w = W[(size_t)i * N + j];
-        if (use_abs) w = fabsf(w);
-        acc.add(i, w, Nin);
+    __shared__ float bs[64][65];                       // block sums of one 64-column tile: [block % 64][column]
+    const int tid = threadIdx.x, cl = tid >> 2, s4 = tid & 3;
+    const int j = blockIdx.x * 64 + cl;
+    const bool valid = j < N;
+    const int jc = valid ? j : N - 1;
+    const bool tail = j >= (N / 32) * 32;
+    const int nfull = Nin >> 4;
+    float result = 0.f;
+    {   // multi_row_sum columns (every thread walks the barrier loop; row_sum columns just idle through it)
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;            // upper cascade levels, quad leader only
+        for (int base = 0; base < nfull; base += 64) { // 64 blocks (1024 rows) per round
+            if (!tail)
+                for (int blk = base + s4; blk < min(nfull, base + 64); blk += 4) {
+                    float v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { const float w = W[(size_t)(blk * 16 + k) * N + jc]; v[k] = use_abs ? fabsf(w) : w; }
+                    float a0 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a0 += v[k];
+                    bs[blk - base][cl] = a0;
+                }
+            __syncthreads();
+            if (!tail && s4 == 0)
+                for (int blk = base; blk < min(nfull, base + 64); ++blk) {
+                    a1 += bs[blk - base][cl];
+                    const int m = blk + 1;             // boundary after this block
+                    if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+                }
+            __syncthreads();
+        }
+        if (!tail && s4 == 0) {
+            float a0 = 0.f;                            // rows past the last complete block
+            for (int i = nfull * 16; i < Nin; ++i) { const float w = W[(size_t)i * N + jc]; a0 += use_abs ? fabsf(w) : w; }
+            result = ((a0 + a1) + a2) + a3;
+        }
     }
-    float cs = acc.finish(Nin);
-    if (cs == 0.f) cs = 1.0f;                           // topology_features.py:265
-    const float rc = 1.0f / cs;                         // torch: python_scalar / tensor == reciprocal * scalar
-    scale[j] = rc * norm;
+    if (tail) {   // quads are never split between the two column classes (class is a function of the column)
+        const int n4 = Nin >> 2;
+        Cascade c; c.init();
+        const int nf4 = n4 >> 4;
+        for (int p0 = 0; p0 < n4; p0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int p = min(p0 + k, n4 - 1);
+                const float w = W[(size_t)(4 * p + s4) * N + jc]; v[k] = use_abs ? fabsf(w) : w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (p0 + k < n4) c.add(p0 + k, v[k], nf4);
+        }
+        float lane = c.finish(nf4);
+        if (s4 == 0)
+            for (int i = n4 * 4; i < Nin; ++i) { const float w = W[(size_t)i * N + jc]; lane += use_abs ? fabsf(w) : w; }
+        const float l1 = __shfl_down(lane, 1, 4), l2 = __shfl_down(lane, 2, 4), l3 = __shfl_down(lane, 3, 4);
+        result = ((lane + l1) + l2) + l3;
+    }
+    if (valid && s4 == 0) {
+        float cs = result;
+        if (cs == 0.f) cs = 1.0f;                       // topology_features.py:265
+        const float rc = 1.0f / cs;                     // torch: python_scalar / tensor == reciprocal * scalar
+        scale[j] = rc * norm;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scale_cols(float *__restrict__ W, long E, int N,
@@ -645,7 +699,7 @@ extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, 
                              snn_stream_t stream) {
     if (!W || !colsum_ws || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
     if (Nin > kMaxTerms) return SNN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_colsum, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Nin, N, norm,
+    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, W, Nin, N, norm,
                        use_abs, colsum_ws);
     int rc = snn_check_launch();
     if (rc) return rc;
