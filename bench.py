@@ -59,6 +59,16 @@ def build_network(device):
     return net
 
 
+def pmc_traffic(plan):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if plan != "dc2015-fused" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")
+
+
 def cpu_baseline():
     """Oracle (scalar C port of the reference algorithm) on one host core: one full input."""
     import cases
@@ -149,7 +159,8 @@ def main():
             ach = ab / (prof["avg_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": prof["kernel"], "avg_launch_us": round(prof["avg_ms"] * 1e3, 3),
                     "launches_timed": prof["n"], "algorithmic_bytes_per_launch": ab, "achieved": round(ach, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "traffic": pmc_traffic(net.last_plan)}
 
     if rank == 0:
         steps_total = world * args.steps * T
