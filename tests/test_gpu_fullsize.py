@@ -1,0 +1,97 @@
+"""BASELINE configs[1] at FULL size (D&C 784->400, batch 32, T = 250, PostPre on) on the GPU:
+ * the fused plan and the generic per-operator plan are bit-identical (rasters, weights, theta, state,
+   generator position) over three consecutive inputs -- two independent implementations of the same order;
+ * the first 40 timesteps agree bit-for-bit with the CPU oracle (which is pinned to the reference);
+ * size-independent properties of the domain hold: at most one excitatory spike per sample per step
+   (one_spike), weights stay in [wmin, wmax] before normalisation and every column sums to `norm` after it,
+   theta only grows by multiples of theta_plus, refractory counters stay in range."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+import synth
+from cases import u8
+from test_oracle_golden import dc_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N, B, T = 400, 32, 250
+
+
+def build(plan_generic):
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05,
+                           inpt_shape=(1, 28, 28))
+    net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(synth.weights_q12(10, 784, N)))
+    mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
+    for l, m in mons.items():
+        net.add_monitor(m, l)
+    net.to(DEV)
+    return net, mons
+
+
+def run_plan(generic, n_inputs=3):
+    from bindsnet_amd import _lib
+    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    try:
+        net, mons = build(generic)
+        out = []
+        for r in range(n_inputs):
+            spikes = synth.spike_train(50 + r, T, B, 784)
+            torch.manual_seed(7 + r)
+            net.run({"X": torch.from_numpy(spikes).view(T, B, 1, 28, 28).to(DEV)}, time=T)
+            probe = torch.rand(2)
+            st = {k: v.detach().cpu().numpy().copy() for k, v in dict(
+                W=net.connections[("X", "Ae")].pipeline[0].value, theta=net.layers["Ae"].theta, vE=net.layers["Ae"].v,
+                rE=net.layers["Ae"].refrac_count, xE=net.layers["Ae"].x, xX=net.layers["X"].x, vI=net.layers["Ai"].v,
+                rI=net.layers["Ai"].refrac_count).items()}
+            st["sE"] = mons["Ae"].get("s").cpu().numpy().reshape(T, B, N).astype(u8)
+            st["sI"] = mons["Ai"].get("s").cpu().numpy().reshape(T, B, N).astype(u8)
+            st["probe"] = probe.numpy()
+            out.append(st)
+            assert net.last_plan == ("generic" if generic else "dc2015-fused")
+            net.reset_state_variables()
+        return out
+    finally:
+        _lib.lib().snn_set_plan_mode(0)
+
+
+def test_fused_equals_generic_and_properties_at_full_size():
+    fused, generic = run_plan(False), run_plan(True)
+    for r, (a, b) in enumerate(zip(fused, generic)):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"input {r}: {k}")
+    for r, a in enumerate(fused):
+        assert a["sE"].sum(axis=2).max() <= 1, "one_spike violated"
+        assert a["sE"].sum() > 50 and a["sI"].sum() > 50, "network is silent: test is vacuous"
+        np.testing.assert_allclose(a["W"].sum(0), 78.4, rtol=1e-5)          # normalised columns
+        assert a["W"].min() >= 0.0
+        assert (a["rE"] <= 5).all() and (a["rI"] <= 2).all()
+        assert (a["theta"] >= 0).all() and a["theta"].max() > 0
+    # theta grows monotonically across inputs (tc_theta_decay = 1e7)
+    assert (fused[2]["theta"] >= fused[0]["theta"] * 0.999).all()
+
+
+def test_first_steps_match_oracle_at_full_size():
+    Ts = 40
+    from bindsnet_amd.network.monitors import Monitor
+    net, _ = build(False)
+    net.monitors.clear()
+    m = Monitor(net.layers["Ae"], ["s"], time=Ts)
+    net.add_monitor(m, "Ae")
+    spikes = synth.spike_train(50, Ts, B, 784)
+    torch.manual_seed(7)
+    net.run({"X": torch.from_numpy(spikes).view(Ts, B, 1, 28, 28).to(DEV)}, time=Ts)
+    g = cases.gold("run_dc_n400_b32")
+    P = dc_params(g); P.T = Ts
+    st = cases.dc_state(N, B)
+    cur = np.zeros(1, np.int64)
+    rasE, _ = oracle.run_dc2015(P, st, spikes, cases.exp_noise(7, 400_000), cur)
+    np.testing.assert_array_equal(m.get("s").cpu().numpy().reshape(Ts, B, N).astype(u8), rasE)
+    W = net.connections[("X", "Ae")].pipeline[0].value.cpu().numpy()
+    np.testing.assert_array_equal(W.view(np.uint32), st["W_xe"].view(np.uint32))
+    np.testing.assert_array_equal(net.layers["Ae"].theta.cpu().numpy().view(np.uint32), st["theta"].view(np.uint32))
