@@ -72,6 +72,10 @@ struct DcCtx {
     uint32_t *crossE[2], *spikeI[2];
     snn_rng_state *rng[2];
     float inv_hwps, inv_NW, inv_RS;   // reciprocals of Nin/16, NW, RS for the exact float-multiply divisions
+    // per-step digest of the X spikes, produced once per run by k_dc2015_prep (entry e <-> spikes of step e-1):
+    // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
+    // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index
+    uint32_t *dig; int DW, DGW;
     int dbg_wg;
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
 };
@@ -130,7 +134,7 @@ template <class SUM, bool FULL>
 __device__ __forceinline__ void stdp_rows(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
                                           const uint32_t *colmask, const uint8_t *__restrict__ sbytes,
                                           const float *xnu0, const float *__restrict__ xsrc, float *wtile, int c0, int tid,
-                                          int Emain) {
+                                          int Emain, const float *pre_w) {
     const int B = c.B, Nin = c.Nin, N = c.N;
     const int nitems = nact * CW;
     const int q = tid % CW;                                       // NT % CW == 0: a thread keeps its column
@@ -143,7 +147,7 @@ __device__ __forceinline__ void stdp_rows(const DcCtx &c, int nact, const uint16
             if (item < nitems) {
                 const int i = FULL ? (item / CW) : (int)arows[item / CW];
                 const int jq = c0 + q;
-                if (jq < N) { iv[u] = i; ev[u] = i * N + jq; wv[u] = c.Wxe[ev[u]]; }
+                if (jq < N) { iv[u] = i; ev[u] = i * N + jq; wv[u] = (base == 0) ? pre_w[u] : c.Wxe[ev[u]]; }
             }
         }
 #pragma unroll
@@ -332,31 +336,96 @@ __device__ __forceinline__ float quad_lane_sum(const int *ix, int cnt, const flo
     return ((v + v1) + v2) + v3;         // meaningful in lane 0 of the quad
 }
 
+// Once per run: digest the X spikes of every step (entry 0 = the layer's `s` at entry, entry e = inputs[e-1]),
+// fully parallel over steps and off the per-timestep critical path.  One workgroup per entry.
+__global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, NinW = c.NinW;
+    uint32_t *sXw = (uint32_t *)smem;                               // [B][NinW]
+    uint32_t *rowmask = sXw + B * NinW;                             // [Nin]
+    int *misc = (int *)(rowmask + Nin);                             // [0] nact, [1] flags
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
+    const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
+    uint32_t *D = c.dig + (size_t)e * c.DW;
+    uint32_t *D_xw = D, *D_xl = D + B * NinW, *D_meta = D_xl + B * (LX / 2), *D_rm = D_meta + 40;
+    uint16_t *D_ar = (uint16_t *)(D_rm + Nin), *D_rp = D_ar + 2 * ((Nin + 1) / 2);
+    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
+    if (tid < 2) misc[tid] = 0;
+    __syncthreads();
+    {
+        const int total16 = (B * Nin) >> 4, hwps = Nin >> 4, HS = NinW * 2;
+        uint16_t *sXh = (uint16_t *)sXw;
+        uint32_t big = 0;
+        for (int k16 = tid; k16 < total16; k16 += NT) {
+            const uint4 v = ((const uint4 *)src)[k16];
+            const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps), hw = k16 - b * hwps;
+            const uint32_t any = v.x | v.y | v.z | v.w;
+            uint32_t m16 = 0;
+            if (any) {
+                if (any & 0xFEFEFEFEu) {           // some byte is not 0/1: generic non-zero test
+                    big = 1;
+                    m16 = nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12);
+                } else {                           // 0/1 bytes: byte k contributes 2^(8k) * 2^(24-7k) = 2^(24+k); the cross
+                    m16 = ((v.x * 0x01020408u) >> 24) | (((v.y * 0x01020408u) >> 24) << 4) |      // terms fall on distinct
+                          (((v.z * 0x01020408u) >> 24) << 8) | (((v.w * 0x01020408u) >> 24) << 12);   // lower bits or overflow
+                }
+            }
+            sXh[b * HS + hw] = (uint16_t)m16;
+            if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
+            while (m16) {
+                const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
+                atomicOr(&rowmask[i], 1u << b);
+            }
+        }
+        if (big) atomicOr((unsigned int *)&misc[1], 1u);
+    }
+    __syncthreads();
+    for (int b = wave; b < B; b += NT / 64) {
+        const int nx = build_list(sXw + b * NinW, NinW, lane, (uint16_t *)D_xl + b * LX, LX);
+        if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > 16) atomicOr((unsigned int *)&misc[1], 2u); }
+    }
+    for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
+    for (int base = 0; base < Nin; base += NT) {       // compact the rows with a spike in any sample
+        const int i = base + tid;
+        const bool o = i < Nin && rowmask[i] != 0;
+        const uint64_t m = __ballot(o);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (o) { const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull)); D_ar[cp] = (uint16_t)i; D_rp[i] = (uint16_t)cp; }
+        if (i < Nin) D_rm[i] = rowmask[i];
+    }
+    __syncthreads();
+    if (tid == 0) { D_meta[32] = (uint32_t)misc[0]; D_meta[33] = (uint32_t)misc[1]; }
+}
+
 __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW;
     // ---- LDS carve-up (all offsets multiples of 16 bytes)
     size_t off = 0;
-    uint32_t *sXw = (uint32_t *)(smem + off); off += ((size_t)B * NinW * 4 + 15) & ~(size_t)15;   // [B][NinW] X spike bits, step t-1
+    // digest of the X spikes of step t-1, copied verbatim from c.dig (layout: see DcCtx)
+    uint32_t *dg = (uint32_t *)(smem + off); off += ((size_t)c.DGW * 4 + 15) & ~(size_t)15;
+    uint16_t *lstX = (uint16_t *)dg;                                  // [B][LX] per-sample X event lists
+    int *meta = (int *)(dg + B * (LX / 2));                           // [0..31] list lengths, [32] n active rows, [33] flags
+    int *cntX = meta;
+    uint32_t *rowmask = dg + B * (LX / 2) + 40;                       // [Nin] samples in which row i spiked
+    uint16_t *arows = (uint16_t *)(rowmask + Nin);                    // compacted active rows
+    uint16_t *rowpos = arows + 2 * ((Nin + 1) / 2);                   // row -> compact active-row index
     uint32_t *crs = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;     // Ae crossings t-1
     uint32_t *finE = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;    // Ae final spikes t-1
     uint32_t *spI = (uint32_t *)(smem + off); off += ((size_t)B * NW * 4 + 15) & ~(size_t)15;     // Ai spikes t-1
-    uint32_t *rowmask = (uint32_t *)(smem + off); off += ((size_t)Nin * 4 + 15) & ~(size_t)15;    // samples in which row i spiked
-    uint16_t *arows = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;      // compacted active rows
     float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * CW * 4;                            // [B][CW] x_tgt*nu0
     uint32_t *mt = (uint32_t *)(smem + off); off += 8 * 624 * 4;                                  // mt19937 blocks m, m+1, ... in slot (block & 7)
     uint32_t *cand = (uint32_t *)(smem + off); off += NCAND * 4;                                  // one_spike candidates (sample << 16 | column)
     unsigned long long *keys = (unsigned long long *)(smem + off); off += MAXB * 8;               // argmax keys per sample
-    uint16_t *lstX = (uint16_t *)(smem + off); off += MAXB * LX * 2;                              // per-sample X event lists
     uint16_t *lstI = (uint16_t *)(smem + off); off += MAXB * LR * 2;                              // ... Ai spikes
     uint16_t *lstE = (uint16_t *)(smem + off); off += MAXB * LR * 2;                              // ... final Ae spikes
-    int *cntX = (int *)(smem + off); off += MAXB * 4;
     int *cntI = (int *)(smem + off); off += MAXB * 4;
     int *cntE = (int *)(smem + off); off += MAXB * 4;
     int *cnt = (int *)(smem + off); off += 32 * 4;                                                // crossings per column
     uint32_t *colmask = (uint32_t *)(smem + off); off += 32 * 4;                                  // samples whose final Ae spike is column jj
     int *misc = (int *)(smem + off); off += 32;      // [4] number of one_spike candidates; [0] n active rows, [1] active column mask, [2] spike value > 1, [3] samples with a crossing
-    uint16_t *rowpos = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;     // row -> compact active-row index
     float *wtile = (float *)(smem + off); off += (size_t)Nin * CW * 4;                            // refreshed own weights of active rows
     float *curbuf = (float *)(smem + off); off += 2 * MAXB * CW * 4;                              // tail-column currents handed to the tile threads
 
@@ -380,14 +449,11 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     const bool mine = tid < TT && bl < B && colv;
     const int kst = bl * N + j;
     const int stepoff = t * B * Nin;                                   // < 2^31 (host check)
-    uint4 st4[NU];
     const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
-    const int total16 = (B * Nin) >> 4;                                // Nin % 16 == 0 (host check)
+    const uint32_t *Dg = c.dig + (size_t)t * c.DW + B * NinW;        // digest of step t-1 (entry t), past the bit words
+    uint32_t r_dg[3];                                                  // DGW <= 3 * NT (host check)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int k16 = tid + u * NT;
-        st4[u] = (k16 < total16) ? ((const uint4 *)sprev_g)[k16] : make_uint4(0, 0, 0, 0);
-    }
+    for (int u = 0; u < 3; ++u) { const int k = tid + u * NT; r_dg[u] = k < c.DGW ? Dg[k] : 0u; }
     // exchange word owned by this thread: (sample wb, word wj)
     const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;
     uint32_t r_crs = 0, r_spi = 0, r_mt = 0;                           // B*NW <= NT and 624 <= NT
@@ -424,50 +490,36 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     if (xmine) { r_xo = c.xX[pprev][xb_ * Nin + xi_]; r_xs = c.in[stepoff + xb_ * Nin + xi_]; }
     if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
     if (tid < 8) misc[tid] = 0;
-    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
     if (tid < MAXB) keys[tid] = 0ull;
     DBG_MARK(10);
     __syncthreads();                                   // zeroed arrays visible; the loads above have landed
     DBG_MARK(11);
-    // ---- into LDS: 16-bit spike masks straight from the registers, row masks for STDP
-    {
-        const int hwps = Nin >> 4, HS = NinW * 2;      // halfwords per sample / per padded LDS row
-        uint16_t *sXh = (uint16_t *)sXw;
-        uint32_t big = 0;
+    // ---- into LDS: the digest verbatim, the exchanged bit words, the generator block
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int k16 = tid + u * NT;
-            if (k16 < total16) {
-                const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps);     // k16 / hwps (exact for these ranges)
-                const int hw = k16 - b * hwps;
-                const uint32_t any = st4[u].x | st4[u].y | st4[u].z | st4[u].w;
-                uint32_t m16 = 0;
-                if (any) {
-                    if (any & 0xFEFEFEFEu) {       // some byte is not 0/1: generic non-zero test
-                        big = 1;
-                        m16 = nz4(st4[u].x) | (nz4(st4[u].y) << 4) | (nz4(st4[u].z) << 8) | (nz4(st4[u].w) << 12);
-                    } else {                       // 0/1 bytes: gather the four LSBs with one multiply
-                        // (byte k contributes 2^(8k) * 2^(24-7k) = 2^(24+k); all cross terms fall on distinct
-                        //  lower bits or overflow, so bits 24..27 are exactly b0..b3)
-                        m16 = ((st4[u].x * 0x01020408u) >> 24) | (((st4[u].y * 0x01020408u) >> 24) << 4) |
-                              (((st4[u].z * 0x01020408u) >> 24) << 8) | (((st4[u].w * 0x01020408u) >> 24) << 12);
-                    }
-                }
-                sXh[b * HS + hw] = (uint16_t)m16;
-                if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
-                while (m16) {
-                    const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
-                    atomicOr(&rowmask[i], 1u << b);
-                }
-            }
-        }
-        if (big) atomicOr((unsigned int *)&misc[2], 1u);   // a spike byte other than 0/1: multiply by its value
-        if (tid < BW) { (phaseA ? crs : finE)[tid] = r_crs; spI[tid] = r_spi; }
-        if (use_rng && tid < 624) mt[tid] = r_mt;
-    }
+    for (int u = 0; u < 3; ++u) { const int k = tid + u * NT; if (k < c.DGW) dg[k] = r_dg[u]; }
+    if (tid < BW) { (phaseA ? crs : finE)[tid] = r_crs; spI[tid] = r_spi; }
+    if (use_rng && tid < 624) mt[tid] = r_mt;
     lds_barrier();
-    const uint8_t *sbytes = (misc[2] & 1) ? sprev_g : nullptr;
-    // ---- per sample (one wave each, in turns): event lists of X and Ai spikes; does it have an Ae crossing?
+    DBG_MARK(15);
+    const uint8_t *sbytes = (meta[33] & 1) ? sprev_g : nullptr;    // a spike byte other than 0/1: multiply by its value
+    if (tid == 0 && (meta[33] & 2)) atomicOr((unsigned int *)&misc[2], 2u);   // a busy sample: phase B takes the generic path
+    // ---- PostPre weight rows: which (row, column) items this thread updates is known from the digest, so the
+    //      loads are issued NOW and complete behind the arbitration
+    const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
+    const bool stdp_full = t == 1;                     // first update of a run touches (clamps) every element
+    const int nact = stdp_full ? Nin : meta[32];
+    float pre_w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pre_w[u] = 0.f;
+        const int item = u * NT + tid;
+        if (do_stdp && item < nact * CW && c0 + (tid % CW) < N) {
+            const int i = stdp_full ? item / CW : (int)arows[item / CW];
+            pre_w[u] = c.Wxe[i * N + c0 + (tid % CW)];
+        }
+    }
+    DBG_MARK(16);
+    // ---- per sample (one wave each, in turns): event list of its Ai spikes; does it have an Ae crossing?
     //      Meanwhile the LAST wave runs the generator two blocks ahead (lockstep, no barrier): a step with up to
     //      ~1.5 crossing rows then needs no further twisting on the critical path.
     constexpr int NWV = NT / 64;
@@ -477,13 +529,12 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     } else if (wave < NWV - 1 || !use_rng) {
         const int stride = use_rng ? NWV - 1 : NWV;
         for (int b = wave; b < B; b += stride) {
-            const int nx = build_list(sXw + b * NinW, NinW, lane, lstX + b * LX, LX);
             const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
             const uint64_t mc = __ballot(use_rng && lane < NW && crs[b * NW + lane] != 0);
             if (lane == 0) {
-                cntX[b] = nx; cntI[b] = ni;
+                cntI[b] = ni;
                 if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
-                if (nx > 16 || ni > 4) atomicOr((unsigned int *)&misc[2], 2u);   // a busy sample: phase B takes the generic path
+                if (ni > 4) atomicOr((unsigned int *)&misc[2], 2u);   // a busy sample: phase B takes the generic path
             }
         }
     }
@@ -643,37 +694,26 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     if (phaseA) {
         DBG_MARK(3);
         // ---- A3: PostPre on the own [Nin x CW] weight slice
-        if (c.learning && c.rule == SNN_RULE_POSTPRE) {
-            const bool full = (t == 1);        // first update of a run touches (clamps) every element
+        if (do_stdp) {
+            const bool full = stdp_full;
             tile_fresh = true; tile_full = full;
             const int Etot = Nin * N, Emain = (Etot / 32) * 32;
             const bool anytail = Etot != Emain;
             const float *xsrc = c.xX[pprev];
             if (full) {
-                if (anytail) stdp_rows<OuterSum, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                else stdp_rows<CascadeT, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                if (anytail) stdp_rows<OuterSum, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain, pre_w);
+                else stdp_rows<CascadeT, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain, pre_w);
             } else {
-                if (wave == 0) {
-                    const uint64_t m = __ballot(lane < CW && colmask[lane & 31] != 0);
-                    if (lane == 0) misc[1] = (int)(uint32_t)m;
+                uint32_t acols = 0;                     // own columns with a post-synaptic spike
+                if (c.nu1 != 0.f) {
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
                 }
-                for (int base = 0; base < Nin; base += NT) {   // compact the rows with a pre-synaptic spike
-                    const int i = base + tid;
-                    const bool o = i < Nin && rowmask[i] != 0;
-                    const uint64_t m = __ballot(o);
-                    int wbase = 0;
-                    if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
-                    wbase = __shfl(wbase, 0);
-                    if (o) { const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull)); arows[cp] = (uint16_t)i; rowpos[i] = (uint16_t)cp; }
-                }
-                lds_barrier();
-                const int nact = misc[0];
-                const uint32_t acols = c.nu1 != 0.f ? (uint32_t)misc[1] : 0u;
                 if (anytail) {
-                    stdp_rows<OuterSum, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    stdp_rows<OuterSum, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain, pre_w);
                     stdp_cols<OuterSum>(c, acols, rowmask, colmask, xsrc, c0, tid, Emain);
                 } else {
-                    stdp_rows<CascadeT, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    stdp_rows<CascadeT, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain, pre_w);
                     stdp_cols<CascadeT>(c, acols, rowmask, colmask, xsrc, c0, tid, Emain);
                 }
             }
@@ -728,7 +768,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
             const uint16_t *rp = tile_full ? nullptr : rowpos;
             tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
         } else {   // generic bit-scan path
-            const uint32_t *xw = sXw + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
+            const uint32_t *xw = c.dig + (size_t)t * c.DW + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
             const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
             if (tailcol) {
                 curE = 0.0f + ordered_dot<RowSum4>(c.Wxe, N, j, xw, ax, xb, Nin);
@@ -797,13 +837,19 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
 }
 
+// words of one digest entry / of its part that the step kernel copies into LDS
+int digest_words(int B, int Nin) { const int NinW = (Nin + 31) / 32; return ((B * NinW + B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2)) + 3) & ~3; }
+int digest_lds_words(int B, int Nin) { return digest_words(B, Nin) - B * ((Nin + 31) / 32); }
+
 size_t lds_bytes(int B, int Nin, int N) {
-    const int NW = (N + 31) / 32, NinW = (Nin + 31) / 32;
+    const int NW = (N + 31) / 32;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    return al((size_t)B * NinW * 4) + 3 * al((size_t)B * NW * 4) + al((size_t)Nin * 4) + al((size_t)Nin * 2) +
-           (size_t)MAXB * CW * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + MAXB * LX * 2 + 2 * MAXB * LR * 2 + 3 * MAXB * 4 + 2 * 32 * 4 + 32 +
-           al((size_t)Nin * 2) + (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
+    return al((size_t)digest_lds_words(B, Nin) * 4) + 3 * al((size_t)B * NW * 4) +
+           (size_t)MAXB * CW * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
+           (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
 }
+
+size_t prep_lds_bytes(int B, int Nin) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4; }
 
 }  // namespace
 
@@ -812,6 +858,10 @@ static size_t fused_workspace(int B, int Nin, int N) {
     const int NW = (N + 31) / 32;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return 4 * al((size_t)B * NW * 4) + al((size_t)B * Nin * 4) + al(sizeof(snn_rng_state));
+}
+
+static size_t fused_workspace_total(int B, int Nin, int N, int T) {
+    return fused_workspace(B, Nin, N) + (size_t)(T + 1) * digest_words(B, Nin) * 4;
 }
 
 static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
@@ -830,14 +880,15 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
     if (L[1].p.one_spike && !R->rng) return false;
     if (R->T < 1) return false;
     if (lds_bytes(R->B, L[0].n, L[1].n) > 150 * 1024) return false;
-    if (!R->workspace || R->workspace_bytes < fused_workspace(R->B, L[0].n, L[1].n)) return false;
+    if (!R->workspace || R->workspace_bytes < fused_workspace_total(R->B, L[0].n, L[1].n, R->T)) return false;
+    if (digest_lds_words(R->B, L[0].n) > 3 * NT) return false;
     return true;
 }
 
 extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
                                           const snn_run_desc *R) {
     if (!L || !R || nL != 3 || nC != 3 || !C) return 0;
-    return fused_workspace(R->B, L[0].n, L[1].n);
+    return fused_workspace_total(R->B, L[0].n, L[1].n, R->T);
 }
 
 void snn_set_plan_name(const char *name);
@@ -867,6 +918,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     c.spikeI[0] = (uint32_t *)(ws + 2 * wb); c.spikeI[1] = (uint32_t *)(ws + 3 * wb);
     float *xscratch = (float *)(ws + 4 * wb);
     snn_rng_state *rng2 = (snn_rng_state *)(ws + 4 * wb + al((size_t)B * Nin * 4));
+    c.dig = (uint32_t *)(ws + fused_workspace(B, Nin, N));
+    c.DW = digest_words(B, Nin); c.DGW = digest_lds_words(B, Nin);
     c.in = L[0].ext_spikes; c.sX0 = L[0].s;
     c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
     c.x_additive = L[0].p.lif.traces_additive;
@@ -900,6 +953,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     auto enqueue = [&](bool with_events) -> int {
         int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
+        hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
         for (int t = 0; t <= R->T; ++t) {
             const bool prof = with_events && snn_prof_begin(t, qs);
             hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, qs, c, t);
@@ -994,7 +1048,11 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         fprintf(stderr, "[dc2015 clock] %.0f MHz shader clock during the kernel\n", cyc / us);
         double sub[3] = {0, 0, 0};
         for (int t = 2; t < R->T; ++t) { sub[0] += (h[(size_t)t*16+10]-h[(size_t)t*16+0])/100.0; sub[1] += (h[(size_t)t*16+11]-h[(size_t)t*16+10])/100.0; sub[2] += (h[(size_t)t*16+1]-h[(size_t)t*16+11])/100.0; }
-        fprintf(stderr, "[dc2015 stage detail, us] issue-loads %.2f | barrier(loads land) %.2f | lds-fill %.2f\n", sub[0]/n, sub[1]/n, sub[2]/n);
+        {
+            double q[5] = {0, 0, 0, 0, 0};
+            for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 24]; q[0] += (r[10]-r[0])/100.0; q[1] += (r[11]-r[10])/100.0; q[2] += (r[15]-r[11])/100.0; q[3] += (r[16]-r[15])/100.0; q[4] += (r[1]-r[16])/100.0; }
+            fprintf(stderr, "[dc2015 stage detail, us] issue-loads %.2f | barrier(loads land) %.2f | lds-store+barrier %.2f | stdp-prefetch issue %.2f | Ai lists + twists %.2f\n", q[0]/n, q[1]/n, q[2]/n, q[3]/n, q[4]/n);
+        }
         double ab[4] = {0, 0, 0, 0};
         for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 24]; ab[0] += (r[12]-r[1])/100.0; ab[1] += (r[13]-r[12])/100.0; ab[2] += (r[14]-r[13])/100.0; ab[3] += (r[2]-r[14])/100.0; }
         fprintf(stderr, "[dc2015 arb detail, us] barrier %.2f | candidates+twist %.2f | winners+publish+barrier %.2f | lstE %.2f\n", ab[0]/n, ab[1]/n, ab[2]/n, ab[3]/n);

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs (parity-test cases, not the headline bench line) on one
+MI355X, through the public API.  Prints one JSON object per config.
+
+    python tools/bench_configs.py [--runs 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+
+DEV = "cuda"
+
+
+def timed(net, inputs, T, runs, **kw):
+    for _ in range(2):
+        net.run(dict(inputs), time=T, **kw); net.reset_state_variables()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        net.run(dict(inputs), time=T, **kw); net.reset_state_variables()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"timesteps_per_s": round(runs * T / dt, 1), "ms_per_timestep": round(dt / (runs * T) * 1e3, 4), "plan": net.last_plan}
+
+
+def cfg1():
+    from bindsnet_amd.models import DiehlAndCook2015
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=100, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28)).to(DEV)
+    x = torch.from_numpy(synth.spike_train(1, 250, 1, 784)).view(250, 1, 1, 28, 28).to(DEV)
+    return "cfg1 D&C 784->100 B=1 T=250 PostPre", net, {"X": x}, 250, {}
+
+
+def cfg3():
+    from bindsnet_amd.models import TwoLayerNetwork
+    torch.manual_seed(0)
+    net = TwoLayerNetwork(n_inpt=784, n_neurons=1600, reduction=torch.sum).to(DEV)
+    x = torch.from_numpy(synth.dense_spikes(2, (100, 128, 784), 0.012)).to(DEV)
+    return "cfg3 TwoLayer 784->1600 B=128 T=100 PostPre (one GPU)", net, {"X": x}, 100, {}
+
+
+def cfg4():
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    torch.manual_seed(0)
+    net = Network(dt=1.0, learning=False)
+    net.add_layer(Input(shape=(1, 28, 28)), "X")
+    net.add_layer(LIFNodes(shape=(32, 24, 24)), "Y")
+    net.add_connection(Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=5, stride=1, w=0.3 * torch.rand(32, 1, 5, 5)), "X", "Y")
+    net.to(DEV)
+    x = torch.from_numpy(synth.dense_spikes(3, (250, 64, 1, 28, 28), 0.05)).to(DEV)
+    return "cfg4 Conv2d 5x5x32 -> LIF B=64 T=250 no learning", net, {"X": x}, 250, {}
+
+
+def cfg5():
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    torch.manual_seed(0)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=6400, shape=(1, 80, 80), traces=True), "X")
+    net.add_layer(LIFNodes(n=500, traces=True), "Y")
+    net.add_connection(Connection(net.layers["X"], net.layers["Y"], wmin=0, wmax=1, update_rule=MSTDP, nu=1e-1, norm=0.5 * 6400,
+                                  reduction=torch.sum), "X", "Y")
+    net.to(DEV)
+    x = torch.from_numpy(synth.dense_spikes(4, (100, 16, 1, 80, 80), 0.05)).to(DEV)
+    return "cfg5 6400->500 LIF MSTDP B=16 T=100", net, {"X": x}, 100, {"reward": 1.0}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=5)
+    a = ap.parse_args()
+    for make in (cfg1, cfg3, cfg4, cfg5):
+        name, net, inputs, T, kw = make()
+        r = timed(net, inputs, T, a.runs, **kw)
+        r["config"] = name
+        print(json.dumps(r), flush=True)
