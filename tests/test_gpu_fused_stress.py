@@ -1,0 +1,103 @@
+"""Stress the rarely-taken paths of the fused D&C plan by comparing it bit-for-bit with the generic
+per-operator plan (itself pinned to the reference):
+  * dense inputs (hundreds of active sources per sample -> "busy" generic bit-scan path inside the kernel),
+  * spike bytes other than 0/1 (value-weighted propagation and STDP),
+  * very strong drive (every neuron of every sample crosses threshold at once: thousands of one_spike
+    candidates, dozens of generator twists in one step -> serial fallback of the arbitration),
+  * odd sizes (N not a multiple of 8 / 32, B < 32, tiny T), learning off, shapes the plan must refuse."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def run(generic, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0):
+    from bindsnet_amd import _lib
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    try:
+        torch.manual_seed(0)
+        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape)
+        W0 = synth.uniform_f32(3, (Nin, N), 0.0, w_scale)
+        net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(W0, 1.0)))
+        mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
+        for l, m in mons.items():
+            net.add_monitor(m, l)
+        net.train(learning)
+        net.to(DEV)
+        out = []
+        for r in range(n_inputs):
+            torch.manual_seed(11 + r)
+            net.run({"X": torch.from_numpy(spikes[r]).view(T, B, *shape).to(DEV)}, time=T)
+            probe = torch.rand(3).numpy()
+            out.append(dict(
+                sE=mons["Ae"].get("s").cpu().numpy().copy(), sI=mons["Ai"].get("s").cpu().numpy().copy(),
+                W=net.connections[("X", "Ae")].pipeline[0].value.cpu().numpy().copy(),
+                theta=net.layers["Ae"].theta.cpu().numpy().copy(), vE=net.layers["Ae"].v.cpu().numpy().copy(),
+                xE=net.layers["Ae"].x.cpu().numpy().copy(), xX=net.layers["X"].x.cpu().numpy().copy(),
+                vI=net.layers["Ai"].v.cpu().numpy().copy(), probe=probe))
+            plan = net.last_plan
+            if r % 2 == 0:
+                net.reset_state_variables()
+        return out, plan
+    finally:
+        _lib.lib().snn_set_plan_mode(0)
+
+
+def same(a, b):
+    for r, (x, y) in enumerate(zip(a, b)):
+        for k in x:
+            np.testing.assert_array_equal(x[k].view(np.uint8), y[k].view(np.uint8), err_msg=f"input {r}: {k}")
+
+
+CASES = {
+    # name: (N, B, T, density, w_scale, value_max)
+    "dense_inputs_busy_path": (400, 32, 12, 0.30, 0.02, 1),
+    "multivalued_bytes": (100, 8, 25, 0.02, 0.3, 3),
+    "all_cross_many_candidates": (400, 32, 8, 0.5, 1.0, 1),
+    "n100_b32_many_rows": (100, 32, 20, 0.15, 0.6, 1),
+    "odd_sizes_n37_b5": (37, 5, 40, 0.03, 0.5, 1),
+    "n12_b1_tiny": (12, 1, 30, 0.05, 1.0, 1),
+    "n1000_b16": (1000, 16, 10, 0.02, 0.3, 1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_equals_generic_under_stress(name):
+    N, B, T, dens, wsc, vmax = CASES[name]
+    rs = np.random.RandomState(5)
+    spikes = []
+    for r in range(2):
+        s = synth.dense_spikes(70 + r, (T, B, 784), dens)
+        if vmax > 1:
+            s = (s * rs.randint(1, vmax + 1, size=s.shape)).astype(np.uint8)
+        spikes.append(s)
+    fused, plan = run(False, N, B, T, spikes, w_scale=wsc)
+    assert plan == "dc2015-fused"
+    generic, plan_g = run(True, N, B, T, spikes, w_scale=wsc)
+    assert plan_g == "generic"
+    same(fused, generic)
+    assert sum(int(x["sE"].sum()) for x in fused) > 0, "no excitatory spike at all: vacuous"
+    assert all(x["sE"].reshape(T, B, N).sum(axis=2).max() <= 1 for x in fused)
+
+
+def test_learning_off_and_weak_inhibition():
+    spikes = [synth.dense_spikes(80 + r, (30, 6, 784), 0.03) for r in range(2)]
+    f, _ = run(False, 100, 6, 30, spikes, learning=False, inh=17.5)
+    g, _ = run(True, 100, 6, 30, spikes, learning=False, inh=17.5)
+    same(f, g)
+
+
+def test_plan_refuses_unsupported_shapes_and_falls_back():
+    # Nin not a multiple of 16 and batch > 32 are outside the fused plan: the generic plan must take over
+    spikes = [synth.dense_spikes(90, (6, 3, 100), 0.1)] * 2
+    out, plan = run(False, 20, 3, 6, spikes, Nin=100, shape=(100,))
+    assert plan == "generic"
+    spikes = [synth.dense_spikes(91, (5, 40, 784), 0.02)] * 2
+    out, plan = run(False, 64, 40, 5, spikes)
+    assert plan == "generic"
