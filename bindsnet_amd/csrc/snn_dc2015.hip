@@ -29,6 +29,8 @@
 
 using namespace snn;
 
+unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
+                                                const snn_run_desc *R);
 bool snn_prof_begin(int t, hipStream_t st);
 bool snn_prof_active();
 void snn_prof_end(hipStream_t st);
@@ -887,11 +889,15 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
 
 extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
                                           const snn_run_desc *R) {
-    if (!L || !R || nL != 3 || nC != 3 || !C) return 0;
+    if (!L || !R || !C) return 0;
+    if (nL == 2 && nC == 1) return snn_twolayer_workspace_bytes(L, nL, C, nC, R);
+    if (nL != 3 || nC != 3) return 0;
     return fused_workspace_total(R->B, L[0].n, L[1].n, R->T);
 }
 
 void snn_set_plan_name(const char *name);
+unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
+                                                const snn_run_desc *R);
 int g_graph_stats[3] = {0, 0, 0};   // runs enqueued as plain launches / captured / replayed
 
 extern "C" void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed) {

@@ -1,0 +1,521 @@
+// snn_twolayer.hip -- fused plan "twolayer-fused": Input -> {Connection | MulticompartmentConnection+Weight}
+// (PostPre or no rule) -> LIFNodes, i.e. bindsnet/models/models.py:21-91 (TwoLayerNetwork) and every graph
+// of that shape, for B <= 32 samples per GPU.
+//
+// Nothing couples two target neurons of such a network: no lateral connection, no shared threshold, no
+// arbitration.  The only state a column slice of the weights needs from outside is SOURCE-side -- the
+// input spikes and the input layer's trace -- and both are functions of the inputs alone, which are known
+// for the whole run when run() starts.  So:
+//   k_two_xtrace  precomputes the input trace after every step           (parallel over (sample, source))
+//   k_two_prep    digests every step's spikes: per-sample ascending event lists (CSR), the rows that carry a
+//                 spike in any sample with their sample masks, a bitmap of those rows   (parallel over steps)
+//   k_two_run     ONE launch for the whole run: workgroup g owns CW target columns; its [Nin x CW] weight slice
+//                 lives in LDS and the membrane state of its (sample, column) pairs in registers for all T
+//                 steps; per step it applies PostPre of the previous step to the LDS tile, sums the currents in
+//                 the reference's order, steps the LIF neurons, writes the rasters.  No launch boundary, no
+//                 inter-workgroup traffic, no weight traffic to HBM until the final write-back.
+// Arithmetic order is the reference's (snn_order.hpp / snn_common.hpp); results are bit-identical to the
+// generic plan (tests/test_gpu_twolayer.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/snnhip.h"
+#include "snn_common.hpp"
+#include "snn_order.hpp"
+
+using namespace snn;
+
+bool snn_prof_active();
+void snn_set_plan_name(const char *name);
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int MAXB = 32;
+constexpr int META = 40;        // [0] list entries, [1] active rows, [2] flags (1: spike byte > 1, 2: list overflow), [4..36] CSR offsets
+constexpr int PF = 16;          // digest words prefetched per thread per step
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct TwoCtx {
+    int B, Nin, N, T, NinW, CW, G;
+    float dt; int learning;
+    const uint8_t *in; const uint8_t *sX0;
+    const float *xX0; float *xXout; float *xall;       // entry trace, exit trace, [T][B][Nin] trace after each step
+    int x_traces; float x_decay, x_scale; int x_additive;
+    float *vY, *rY, *xY; uint8_t *sY;
+    snn_lif_params pY;
+    uint8_t *rasY; float *rasVY;
+    float *W; const float *bias;
+    int cascade;                                         // 1: MCC (ATen sum order), 0: dense Connection (ascending sequential)
+    int rule; float nu0, nu1; int use_dt; float wdecay; int has_min; float wmin; int has_max; float wmax;
+    uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
+    float inv_hwps;
+};
+
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {
+    const uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
+}
+
+// ---------------------------------------------------------------------------------------------- input trace
+__global__ __launch_bounds__(256) void k_two_xtrace(const TwoCtx c) {
+    const int n = c.B * c.Nin;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float x = c.xX0[k];
+    int t = 0;
+    for (; t + 4 <= c.T; t += 4) {           // the four spike loads are independent of x: issue them together
+        uint8_t s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xall[(size_t)(t + u) * n + k] = x; }
+    }
+    for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); c.xall[(size_t)t * n + k] = x; }
+    c.xXout[k] = x;
+}
+
+// ---------------------------------------------------------------------------------------------- spike digest
+// Entry e digests the source spikes the step kernel sees as "previous step" in iteration e:
+// e = 0 the layer's `s` at entry, e >= 1 inputs[e-1].  One workgroup per entry.
+__global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, NinW = c.NinW;
+    uint32_t *sXw = (uint32_t *)smem;                    // [B][NinW] bit words
+    uint32_t *rowmask = sXw + B * NinW;                  // [Nin]
+    int *cntb = (int *)(rowmask + Nin);                  // [B+1] per-sample counts -> offsets
+    int *misc = cntb + MAXB + 1;                         // [0] nact, [1] flags
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
+    const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
+    uint32_t *D = c.dig + (size_t)e * c.DW;
+    uint16_t *D_ent = (uint16_t *)(D + c.o_ent), *D_ar = (uint16_t *)(D + c.o_ar);
+    uint32_t *D_am = D + c.o_am, *D_ab = D + c.o_ab, *D_xw = D + c.o_xw;
+    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
+    for (int k = tid; k < NinW; k += NT) D_ab[k] = 0;    // (own entry; finished before the atomics below by the barrier)
+    if (tid < 2) misc[tid] = 0;
+    __syncthreads();
+    {
+        const int total16 = (B * Nin) >> 4, hwps = Nin >> 4, HS = NinW * 2;
+        uint16_t *sXh = (uint16_t *)sXw;
+        uint32_t big = 0;
+        for (int k16 = tid; k16 < total16; k16 += NT) {
+            const uint4 v = ((const uint4 *)src)[k16];
+            const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps), hw = k16 - b * hwps;
+            const uint32_t any = v.x | v.y | v.z | v.w;
+            uint32_t m16 = 0;
+            if (any) {
+                if (any & 0xFEFEFEFEu) {
+                    big = 1;
+                    m16 = nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12);
+                } else {                                  // 0/1 bytes: the multiply gathers the four LSBs into bits 24..27
+                    m16 = ((v.x * 0x01020408u) >> 24) | (((v.y * 0x01020408u) >> 24) << 4) |
+                          (((v.z * 0x01020408u) >> 24) << 8) | (((v.w * 0x01020408u) >> 24) << 12);
+                }
+            }
+            sXh[b * HS + hw] = (uint16_t)m16;
+            if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
+            while (m16) {
+                const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
+                atomicOr(&rowmask[i], 1u << b);
+            }
+        }
+        if (big) atomicOr((unsigned int *)&misc[1], 1u);
+    }
+    __syncthreads();
+    // per-sample spike counts (one wave per sample), then CSR offsets
+    for (int b = wave; b < B; b += NT / 64) {
+        int n = 0;
+        for (int w = lane; w < NinW; w += 64) n += __popc(sXw[b * NinW + w]);
+        for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+        if (lane == 0) cntb[b + 1] = n;
+    }
+    __syncthreads();
+    if (tid == 0) { cntb[0] = 0; for (int b = 0; b < B; ++b) cntb[b + 1] += cntb[b]; }
+    __syncthreads();
+    const int total = cntb[B];
+    // ascending event lists: wave per sample, 64 words per round, running offset
+    for (int b = wave; b < B; b += NT / 64) {
+        int base = cntb[b];
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (int w0 = 0; w0 < NinW; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t m = w < NinW ? sXw[b * NinW + w] : 0u;
+            const int cn = __popc(m);
+            int offp = 0, tot = 0;
+            for (int k = 0;; ++k) {
+                const uint64_t bm = __ballot(cn > k);
+                if (!bm) break;
+                offp += __popcll(bm & below); tot += __popcll(bm);
+            }
+            offp += base;
+            while (m) {
+                const int i = w * 32 + __ffs(m) - 1; m &= m - 1;
+                if (offp < c.LCAP) D_ent[offp] = (uint16_t)i;
+                ++offp;
+            }
+            base += tot;
+        }
+    }
+    for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
+    for (int base = 0; base < Nin; base += NT) {          // rows with a spike in any sample, with their sample masks
+        const int i = base + tid;
+        const bool o = i < Nin && rowmask[i] != 0;
+        const uint64_t m = __ballot(o);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (o) {
+            const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull));
+            D_ar[cp] = (uint16_t)i; D_am[cp] = rowmask[i];
+            atomicOr(&D_ab[i >> 5], 1u << (i & 31));
+        }
+    }
+    __syncthreads();
+    if (tid <= B) D[4 + tid] = (uint32_t)cntb[tid];
+    if (tid == 0) { D[0] = (uint32_t)total; D[1] = (uint32_t)misc[0]; D[2] = (uint32_t)(misc[1] | (total > c.LCAP ? 2 : 0)); }
+}
+
+// ---------------------------------------------------------------------------------------------- the run
+template <class SUM>
+__device__ __forceinline__ float list_dot(const float *wt, int CW, int jj, const uint16_t *ent, int n0, int n1,
+                                          const uint8_t *__restrict__ vals, int n_terms) {
+    SUM a; a.init();
+    for (int k = n0; k < n1; k += 8) {       // eight independent LDS reads per round, then the ordered adds
+        int ix[8]; float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ix[u] = (int)ent[min(k + u, n1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = wt[ix[u] * CW + jj];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k + u < n1) a.add(ix[u], wv[u] * (vals ? (float)vals[ix[u]] : 1.0f), n_terms);
+    }
+    return a.finish(n_terms);
+}
+
+struct RowSumN {          // RowSum4 with the init() signature of the other accumulators
+    RowSum4 r;
+    __device__ __forceinline__ void init() { r.init(); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { r.add(pos, term, n); }
+    __device__ __forceinline__ float finish(int n) { return r.finish(n); }
+};
+struct SeqN {
+    float a;
+    __device__ __forceinline__ void init() { a = 0.f; }
+    __device__ __forceinline__ void add(int, float term, int) { a += term; }
+    __device__ __forceinline__ float finish(int) { return a; }
+};
+
+__global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW;
+    size_t off = 0;
+    float *wt = (float *)(smem + off); off += (size_t)Nin * CW * 4;                       // own weight slice [Nin][CW]
+    int *meta = (int *)(smem + off); off += META * 4;
+    uint16_t *ent = (uint16_t *)(smem + off); off += ((size_t)c.LCAP * 2 + 15) & ~(size_t)15;
+    uint32_t *am = (uint32_t *)(smem + off); off += (size_t)Nin * 4;
+    uint16_t *ar = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;
+    uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
+    float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                     // [B][CW] x_tgt * nu0
+    uint32_t *colmask = (uint32_t *)(smem + off); off += 16 * 4;                          // [2][8]: samples whose neuron (column q) spiked
+
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, c0 = g * CW;
+    const int jj = tid & (CW - 1), bl = tid >> (31 - __clz(CW)), j = c0 + jj;
+    const bool mine = tid < B * CW && j < N;
+    const int kst = bl * N + j;
+    const bool tailcol = c.cascade && j >= (N / 32) * 32;
+    const int Etot = Nin * N, Emain = (Etot / 32) * 32;
+    const int cwl = 31 - __clz(CW);                      // CW is a power of two
+    const bool do_stdp = c.learning && c.rule == SNN_RULE_POSTPRE;
+
+    // ---- prologue: own weight slice and membrane state
+    for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; wt[k] = c0 + q < N ? c.W[i * N + c0 + q] : 0.f; }
+    float v = 0.f, rc = 0.f, xy = 0.f, bias = 0.f;
+    uint8_t sp_prev = 0;
+    if (mine) {
+        v = c.vY[kst]; rc = c.rY[kst];
+        if (c.pY.traces) xy = c.xY[kst];
+        if (c.bias) bias = c.bias[j];
+    }
+    if (tid < 16) colmask[tid] = 0;
+    // digest words copied into LDS each step: [meta | entries | row masks | active rows | row bitmap]
+    const int region4 = NinW;
+    uint32_t r_dg[PF];
+    auto issue = [&](int e) {     // loads of digest entry e (lengths clipped to what the entry uses)
+        const uint32_t *D = c.dig + (size_t)e * c.DW;
+        const int tot = min((int)D[0], c.LCAP), nact = (int)D[1];
+        const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            int k = tid + u * NT;
+            uint32_t val = 0;
+            if (k < META) val = D[k];
+            else if ((k -= META) < n1) val = D[c.o_ent + k];
+            else if ((k -= n1) < n2) val = D[c.o_am + k];
+            else if ((k -= n2) < n3) val = D[c.o_ar + k];
+            else if ((k -= n3) < n4) val = D[c.o_ab + k];
+            r_dg[u] = val;
+        }
+    };
+    issue(0);
+    __syncthreads();
+
+    for (int t = 0; t <= c.T; ++t) {
+        // ---- stage the digest of step t-1 (entry t) from the prefetch registers
+        // sizes first (they sit in the first META words = thread tid < META, u = 0)
+        if (tid < META) meta[tid] = (int)r_dg[0];
+        lds_barrier();
+        {
+            const int tot = min(meta[0], c.LCAP), nact = meta[1];
+            const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                int k = tid + u * NT;
+                if (k < META) continue;
+                if ((k -= META) < n1) ((uint32_t *)ent)[k] = r_dg[u];
+                else if ((k -= n1) < n2) am[k] = r_dg[u];
+                else if ((k -= n2) < n3) ((uint32_t *)ar)[k] = r_dg[u];
+                else if ((k -= n3) < n4) ab[k] = r_dg[u];
+            }
+        }
+        lds_barrier();
+        if (t + 1 <= c.T) issue(t + 1);                  // next step's digest: in flight behind this step's work
+        const int tot = meta[0], nact = meta[1], flags = meta[2];
+        const bool overflow = (flags & 2) != 0;          // more events than the LDS list holds: walk bit words from global
+        const uint8_t *sbytes = (flags & 1) ? ((t == 0) ? c.sX0 : c.in + (size_t)(t - 1) * B * Nin) : nullptr;
+        const uint32_t *cm = colmask + ((t + 1) & 1) * 8;   // spikes of step t-1 (written in iteration t-1)
+
+        // ================================================== phase A: PostPre of step t-1 on the LDS weight tile
+        if (t >= 1 && do_stdp) {
+            const bool full = (t == 1) || c.wdecay != 1.0f;   // first update of a run (or a real decay) touches every element
+            const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
+            // pass 1: rows with a pre-synaptic spike x own columns
+            for (int item = tid; item < (nact << cwl); item += NT) {
+                const int kq = item >> cwl, q = item & (CW - 1);
+                if (c0 + q >= N) continue;
+                const int i = (int)ar[kq];
+                const uint32_t m = am[kq];
+                const int e = i * N + c0 + q;
+                const bool tl = e >= Emain;
+                float w = wt[i * CW + q];
+                if (c.nu0 != 0.f) {                       // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+                    OuterSum acc; acc.init(tl);
+                    uint32_t mm = m;
+                    while (mm) {
+                        const int b = __ffs(mm) - 1; mm &= mm - 1;
+                        const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                        acc.add(b, sv * xnu0[b * 8 + q], B);
+                    }
+                    float uu = acc.finish(B);
+                    if (c.use_dt) uu = uu * c.dt;
+                    w = w - uu;
+                }
+                if (c.nu1 != 0.f) {                       // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+                    float uu = 0.f;
+                    uint32_t mm = cm[q];
+                    if (mm) {
+                        OuterSum acc; acc.init(tl);
+                        while (mm) {
+                            const int b = __ffs(mm) - 1; mm &= mm - 1;
+                            acc.add(b, xs[b * Nin + i] * (1.0f * c.nu1), B);
+                        }
+                        uu = acc.finish(B);
+                    }
+                    if (c.use_dt) uu = uu * c.dt;
+                    w = w + uu;
+                }
+                w = w * c.wdecay;
+                if (c.has_min && w < c.wmin) w = c.wmin;
+                if (c.has_max && w > c.wmax) w = c.wmax;
+                wt[i * CW + q] = w;
+            }
+            // pass 2: rows WITHOUT a pre-synaptic spike: the columns that spiked (every column when `full`)
+            for (int q = 0; q < CW; ++q) {
+                const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
+                if ((!cq && !full) || c0 + q >= N) continue;
+                for (int i = tid; i < Nin; i += NT) {
+                    if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
+                    const int e = i * N + c0 + q;
+                    float w = wt[i * CW + q];
+                    if (c.nu0 != 0.f) w = w - (c.use_dt ? 0.0f * c.dt : 0.0f);
+                    if (c.nu1 != 0.f) {
+                        float uu = 0.f;
+                        if (cq) {
+                            OuterSum acc; acc.init(e >= Emain);
+                            uint32_t mm = cq;
+                            while (mm) {
+                                const int b = __ffs(mm) - 1; mm &= mm - 1;
+                                acc.add(b, xs[b * Nin + i] * (1.0f * c.nu1), B);
+                            }
+                            uu = acc.finish(B);
+                        }
+                        if (c.use_dt) uu = uu * c.dt;
+                        w = w + uu;
+                    }
+                    w = w * c.wdecay;
+                    if (c.has_min && w < c.wmin) w = c.wmin;
+                    if (c.has_max && w > c.wmax) w = c.wmax;
+                    wt[i * CW + q] = w;
+                }
+            }
+        }
+        lds_barrier();
+        if (t == c.T) break;
+
+        // ================================================== phase B: step t
+        uint32_t *cmn = colmask + (t & 1) * 8;
+        if (tid < 8) cmn[tid] = 0;
+        uint8_t sp = 0;
+        float cur = 0.f;
+        if (mine) {
+            const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
+            float r;
+            if (!overflow) {
+                const int n0 = meta[4 + bl], n1 = meta[5 + bl];
+                if (!c.cascade) r = list_dot<SeqN>(wt, CW, jj, ent, n0, n1, xb, Nin);
+                else if (tailcol) r = list_dot<RowSumN>(wt, CW, jj, ent, n0, n1, xb, Nin);
+                else if (Nin < 4096) r = list_dot<CascadeFlat>(wt, CW, jj, ent, n0, n1, xb, Nin);
+                else r = list_dot<CascadeN>(wt, CW, jj, ent, n0, n1, xb, Nin);
+            } else {             // walk the bit words of the sample from the global digest (rare)
+                const uint32_t *xw = c.dig + (size_t)t * c.DW + c.o_xw + bl * NinW;
+                OuterSum a; a.init(tailcol);
+                float seq = 0.f;
+                for (int w = 0; w < NinW; ++w) {
+                    uint32_t m = xw[w];
+                    while (m) {
+                        const int i = w * 32 + __ffs(m) - 1; m &= m - 1;
+                        const float term = wt[i * CW + jj] * (xb ? (float)xb[i] : 1.0f);
+                        if (c.cascade) a.add(i, term, Nin); else seq += term;
+                    }
+                }
+                r = c.cascade ? a.finish(Nin) : seq;
+            }
+            if (c.bias) r = r + bias;                     // topology.py:345
+            cur = 0.0f + r;                               // network.py:240-248
+            if (rc > 0.f) cur = 0.f;                      // nodes.py:511
+            sp = lif_update(v, rc, cur, c.pY);
+            if (c.pY.traces) xy = trace_next(xy, sp, c.pY.trace_decay, c.pY.trace_scale, c.pY.traces_additive);
+            sp_prev = sp;
+        }
+        lds_barrier();                                   // cmn zeroed before the atomics
+        if (mine) {
+            xnu0[bl * 8 + jj] = xy * c.nu0;               // target_x * nu[0]
+            if (sp) atomicOr(&cmn[jj], 1u << bl);
+            if (c.rasY) c.rasY[(size_t)t * B * N + kst] = sp;
+            if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
+        }
+        (void)tot;
+    }
+
+    // ---- epilogue: write the weight slice and the membrane state back
+    __syncthreads();
+    for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; if (c0 + q < N) c.W[i * N + c0 + q] = wt[k]; }
+    if (mine) {
+        c.vY[kst] = v; c.rY[kst] = rc; c.sY[kst] = sp_prev;
+        if (c.pY.traces) c.xY[kst] = xy;
+    }
+}
+
+int digest_layout(TwoCtx &c) {
+    c.o_ent = META;
+    c.o_am = c.o_ent + c.LCAP / 2;
+    c.o_ar = c.o_am + c.Nin;
+    c.o_ab = c.o_ar + (c.Nin + 1) / 2;
+    c.o_xw = c.o_ab + c.NinW;
+    return (c.o_xw + c.B * c.NinW + 3) & ~3;
+}
+
+size_t run_lds(const TwoCtx &c) {
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
+           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4;
+}
+
+bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, TwoCtx &c) {
+    if (nL != 2 || nC != 1) return false;
+    if (L[0].kind != SNN_LAYER_INPUT || L[1].kind != SNN_LAYER_LIF) return false;
+    if (C[0].src != 0 || C[0].dst != 1) return false;
+    if (C[0].kind != SNN_CONN_MCC && C[0].kind != SNN_CONN_DENSE) return false;
+    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE) return false;
+    if (C[0].rule == SNN_RULE_POSTPRE && (!L[0].x || !L[1].x || !L[0].p.lif.traces || !L[1].p.lif.traces)) return false;
+    if (C[0].kind == SNN_CONN_MCC && C[0].bias) return false;
+    const int B = R->B, Nin = L[0].n, N = L[1].n;
+    if (B > MAXB || R->T < 1 || Nin % 16 != 0 || Nin > 65535 || Nin > kMaxTerms) return false;
+    if ((double)Nin * N >= 2147483648.0 || (double)(R->T + 1) * B * Nin >= 2147483648.0) return false;
+    memset(&c, 0, sizeof(c));
+    c.B = B; c.Nin = Nin; c.N = N; c.T = R->T; c.NinW = (Nin + 31) / 32;
+    c.dt = R->dt; c.learning = R->learning;
+    // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
+    c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
+    // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
+    int cw = 8;
+    while (cw > 1) {
+        c.CW = cw;
+        if (B * cw <= NT && run_lds(c) <= 140 * 1024) break;
+        cw >>= 1;
+    }
+    c.CW = cw;
+    if (B * cw > NT || run_lds(c) > 140 * 1024) return false;
+    c.G = (N + cw - 1) / cw;
+    // the per-step digest copy must fit the prefetch registers
+    if (META + c.LCAP / 2 + Nin + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
+    return true;
+}
+
+}  // namespace
+
+static size_t two_workspace(const TwoCtx &c0) {
+    TwoCtx c = c0;
+    const int DW = digest_layout(c);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al((size_t)(c.T + 1) * DW * 4) + al((size_t)c.T * c.B * c.Nin * 4);
+}
+
+unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
+                                                const snn_run_desc *R) {
+    TwoCtx c;
+    if (!L || !C || !R || !plan(L, nL, C, nC, R, c)) return 0;
+    return two_workspace(c);
+}
+
+int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                           hipStream_t st, int *handled) {
+    *handled = 0;
+    TwoCtx c;
+    if (!plan(L, nL, C, nC, R, c)) return SNN_OK;
+    if (!R->workspace || R->workspace_bytes < two_workspace(c)) return SNN_OK;
+    if (snn_prof_active()) return SNN_OK;                 // per-timestep event timing only exists for per-step plans
+    const int B = c.B, Nin = c.Nin;
+    c.DW = digest_layout(c);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    unsigned char *ws = (unsigned char *)R->workspace;
+    c.dig = (uint32_t *)ws;
+    c.xall = (float *)(ws + al((size_t)(c.T + 1) * c.DW * 4));
+    c.inv_hwps = 1.0f / (float)(Nin >> 4);
+    c.in = L[0].ext_spikes; c.sX0 = L[0].s;
+    c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
+    c.x_additive = L[0].p.lif.traces_additive;
+    c.xX0 = L[0].x; c.xXout = L[0].x;
+    c.vY = L[1].v; c.rY = L[1].refrac; c.xY = L[1].x; c.sY = L[1].s; c.pY = L[1].p.lif;
+    c.rasY = L[1].raster_s; c.rasVY = L[1].raster_v;
+    c.W = C[0].w; c.bias = C[0].bias; c.cascade = C[0].kind == SNN_CONN_MCC;
+    c.rule = C[0].rule; c.nu0 = C[0].nu0; c.nu1 = C[0].nu1; c.use_dt = C[0].use_dt; c.wdecay = C[0].wdecay;
+    c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
+    static bool attr = false;
+    if (!attr) {
+        if (snn_check(hipFuncSetAttribute((const void *)k_two_run, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        if (snn_check(hipFuncSetAttribute((const void *)k_two_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        attr = true;
+    }
+    const size_t prep_lds = (size_t)(B * c.NinW + Nin + MAXB + 1 + 4) * 4;
+    if (prep_lds > 150 * 1024) return SNN_OK;
+    if (c.x_traces) hipLaunchKernelGGL(k_two_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_two_prep, dim3(c.T + 1), dim3(NT), prep_lds, st, c);
+    hipLaunchKernelGGL(k_two_run, dim3(c.G), dim3(NT), run_lds(c), st, c);
+    int rc = snn_check_launch();
+    if (rc) return rc;
+    snn_set_plan_name("twolayer-fused");
+    *handled = 1;
+    return SNN_OK;
+}

@@ -1,0 +1,100 @@
+"""Fused plan "twolayer-fused" (one launch per run for Input -> Connection/MCC -> LIF) vs the generic
+per-operator plan, bit for bit, over consecutive inputs; plus plan selection."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(kind, Nin, N, rule, bias):
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.learning.MCC_learning import PostPre as MCCPostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection, MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    torch.manual_seed(0)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True, lbound=-70.0 if bias else None), "Y")
+    W0 = torch.from_numpy(synth.weights_q12(11, Nin, N))
+    if kind == "dense":
+        kw = dict(update_rule=PostPre, nu=(1e-4, 1e-2), reduction=torch.sum) if rule else {}
+        b = torch.from_numpy(synth.uniform_f32(5, (N,), -0.5, 0.5)) if bias else None
+        conn = Connection(net.layers["X"], net.layers["Y"], w=W0.clone(), b=b, wmin=0.0, wmax=1.0, norm=78.4 * Nin / 784, **kw)
+    else:
+        f = Weight("weight", W0.clone(), range=[0.0, 1.0], norm=78.4 * Nin / 784, nu=(1e-4, 1e-2) if rule else None,
+                   learning_rule=MCCPostPre if rule else None, reduction=torch.sum if rule else None)
+        conn = MulticompartmentConnection(net.layers["X"], net.layers["Y"], device="cpu", pipeline=[f])
+    net.add_connection(conn, "X", "Y")
+    return net
+
+
+def run(generic, kind, Nin, N, B, T, rule=True, bias=False, n_inputs=2, dens=0.03, learning=True):
+    from bindsnet_amd import _lib
+    from bindsnet_amd.network.monitors import Monitor
+    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    try:
+        net = build(kind, Nin, N, rule, bias)
+        ms, mv = Monitor(net.layers["Y"], ["s"], time=T), Monitor(net.layers["Y"], ["v"], time=T)
+        net.add_monitor(ms, "s"); net.add_monitor(mv, "v")
+        net.train(learning)
+        net.to(DEV)
+        out = []
+        for r in range(n_inputs):
+            sp = synth.dense_spikes(40 + r, (T, B, Nin), dens)
+            net.run({"X": torch.from_numpy(sp).to(DEV)}, time=T)
+            conn = net.connections[("X", "Y")]
+            W = (conn.w if kind == "dense" else conn.pipeline[0].value).detach().cpu().numpy().copy()
+            out.append(dict(s=ms.get("s").cpu().numpy().copy(), v=mv.get("v").cpu().numpy().copy(), W=W,
+                            vY=net.layers["Y"].v.cpu().numpy().copy(), rY=net.layers["Y"].refrac_count.cpu().numpy().copy(),
+                            xY=net.layers["Y"].x.cpu().numpy().copy(), xX=net.layers["X"].x.cpu().numpy().copy(),
+                            sY=net.layers["Y"].s.cpu().numpy().copy()))
+            plan = net.last_plan
+            if r == 0:
+                net.reset_state_variables()
+        return out, plan
+    finally:
+        _lib.lib().snn_set_plan_mode(0)
+
+
+CASES = {
+    "dense_postpre_b16": ("dense", 784, 200, 16, 40, True, False),
+    "dense_postpre_b32_bias": ("dense", 784, 96, 32, 30, True, True),
+    "dense_postpre_b1": ("dense", 256, 40, 1, 50, True, False),
+    "dense_norule_b8": ("dense", 784, 64, 8, 30, False, True),
+    "mcc_postpre_b5_tailcols": ("mcc", 784, 100, 5, 40, True, False),
+    "mcc_postpre_b32_n37": ("mcc", 400, 37, 32, 25, True, False),
+    "mcc_norule_b3": ("mcc", 784, 50, 3, 30, False, False),
+    "dense_wide_input_b16": ("dense", 6400, 64, 16, 12, True, False),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_twolayer_fused_equals_generic(name):
+    kind, Nin, N, B, T, rule, bias = CASES[name]
+    dens = 0.05 if Nin <= 784 else 0.02
+    f, plan = run(False, kind, Nin, N, B, T, rule, bias, dens=dens)
+    assert plan == "twolayer-fused"
+    g, plan_g = run(True, kind, Nin, N, B, T, rule, bias, dens=dens)
+    assert plan_g == "generic"
+    for r, (a, b) in enumerate(zip(f, g)):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"{name} input {r}: {k}")
+    assert sum(int(x["s"].sum()) for x in f) > 0, "silent network: vacuous"
+
+
+def test_twolayer_learning_off_and_big_batch_fallback():
+    f, plan = run(False, "dense", 784, 64, 8, 25, learning=False)
+    g, _ = run(True, "dense", 784, 64, 8, 25, learning=False)
+    assert plan == "twolayer-fused"
+    for a, b in zip(f, g):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
+    _, plan = run(False, "dense", 784, 64, 48, 5)       # batch > 32: generic plan
+    assert plan == "generic"
