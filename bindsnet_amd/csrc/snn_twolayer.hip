@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 #include "../../include/snnhip.h"
 #include "snn_common.hpp"
 #include "snn_order.hpp"
@@ -51,7 +54,11 @@ struct TwoCtx {
     int rule; float nu0, nu1; int use_dt; float wdecay; int has_min; float wmin; int has_max; float wmax;
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
     float inv_hwps;
+    int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= NT)
+    long long *dbg;                                      // developer aid (SNN_TWO_TIMING=1): phase timestamps of workgroup 0
 };
+
+#define TMARK(slot) do { if (c.dbg && blockIdx.x == 0 && threadIdx.x == 0) c.dbg[(size_t)t * 8 + (slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ uint32_t nz4(uint32_t w) {
     const uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
@@ -206,6 +213,97 @@ struct SeqN {
     __device__ __forceinline__ float finish(int) { return a; }
 };
 
+// PostPre of one step on the LDS weight tile (MCC_learning.py:224-302 / learning.py:390-420 + base update).
+// SUM = CascadeT unless an element index can fall in ATen's <32-element tail of the [Nin*N] batch reduction.
+// All global loads a thread needs (source traces of the samples whose neuron spiked) are issued before the
+// order-constrained arithmetic; the first contributing sample of a column -- almost always the only one -- is
+// prefetched, further ones are fetched on demand.
+struct CascT {
+    Cascade c;
+    __device__ __forceinline__ void init(bool) { c.init(); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
+    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+};
+
+template <class SUM>
+__device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
+                                         const uint32_t *ab, const float *xnu0, const uint32_t *cm,
+                                         const float *__restrict__ xs, const float *xsl, const uint8_t *__restrict__ sbytes,
+                                         int nact, bool full, int c0, int tid, int cwl, int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW;
+    // source trace of sample b at row i, for the post-synaptic term of column q: the first spiking sample of q is
+    // staged in LDS (xsl), any further one comes from global memory
+    auto xsrc = [&](int q, int b, int i, uint32_t colmask_q) -> float {
+        return (xsl && b == __ffs(colmask_q) - 1) ? xsl[q * Nin + i] : xs[b * Nin + i];
+    };
+    // ---- pass 1: rows with a pre-synaptic spike x own columns
+    for (int item = tid; item < (nact << cwl); item += NT) {
+        const int kq = item >> cwl, q = item & (CW - 1);
+        const int i = (int)ar[kq];
+        const uint32_t m = am[kq];
+        const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
+        if (c0 + q >= N) continue;
+        const bool tl = i * N + c0 + q >= Emain;
+        float w = wt[i * CW + q];
+        if (c.nu0 != 0.f) {                               // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+            SUM acc; acc.init(tl);
+            uint32_t mm = m;
+            while (mm) {
+                const int b = __ffs(mm) - 1; mm &= mm - 1;
+                const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                acc.add(b, sv * xnu0[b * 8 + q], B);
+            }
+            float uu = acc.finish(B);
+            if (c.use_dt) uu = uu * c.dt;
+            w = w - uu;
+        }
+        if (c.nu1 != 0.f) {                               // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+            float uu = 0.f;
+            if (cq) {
+                SUM acc; acc.init(tl);
+                uint32_t mm = cq;
+                while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, cq) * (1.0f * c.nu1), B); }
+                uu = acc.finish(B);
+            }
+            if (c.use_dt) uu = uu * c.dt;
+            w = w + uu;
+        }
+        w = w * c.wdecay;
+        if (c.has_min && w < c.wmin) w = c.wmin;
+        if (c.has_max && w > c.wmax) w = c.wmax;
+        wt[i * CW + q] = w;
+    }
+    // ---- pass 2: rows WITHOUT a pre-synaptic spike: the columns that spiked (every column when `full`)
+    uint32_t todo = 0;                                    // columns to visit, as a bit mask
+    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || (c.nu1 != 0.f && cm[q]))) todo |= 1u << q;
+    if (!todo) return;
+    for (int i = tid; i < Nin; i += NT) {
+        if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
+        uint32_t td = todo;
+        while (td) {
+            const int q = __ffs(td) - 1; td &= td - 1;
+            const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
+            float w = wt[i * CW + q];
+            if (c.nu0 != 0.f) w = w - (c.use_dt ? 0.0f * c.dt : 0.0f);
+            if (c.nu1 != 0.f) {
+                float uu = 0.f;
+                if (cq) {
+                    SUM acc; acc.init(i * N + c0 + q >= Emain);
+                    uint32_t mm = cq;
+                    while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, cq) * (1.0f * c.nu1), B); }
+                    uu = acc.finish(B);
+                }
+                if (c.use_dt) uu = uu * c.dt;
+                w = w + uu;
+            }
+            w = w * c.wdecay;
+            if (c.has_min && w < c.wmin) w = c.wmin;
+            if (c.has_max && w > c.wmax) w = c.wmax;
+            wt[i * CW + q] = w;
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW;
@@ -218,6 +316,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
     float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                     // [B][CW] x_tgt * nu0
     uint32_t *colmask = (uint32_t *)(smem + off); off += 16 * 4;                          // [2][8]: samples whose neuron (column q) spiked
+    int *szt = (int *)(smem + off); off += (size_t)(c.T + 1) * 8;                         // (events, active rows) of every digest entry
+    float *xsl = (float *)(smem + off); off += c.use_xsl ? (size_t)Nin * CW * 4 : 0;      // source trace of the first spiking sample of each column
 
     const int tid = threadIdx.x;
     const int g = blockIdx.x, c0 = g * CW;
@@ -241,13 +341,20 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     if (tid < 16) colmask[tid] = 0;
     // digest words copied into LDS each step: [meta | entries | row masks | active rows | row bitmap]
     const int region4 = NinW;
+    for (int k = tid; k < (c.T + 1) * 2; k += NT) szt[k] = (int)c.dig[(size_t)(k >> 1) * c.DW + (k & 1)];
+    __syncthreads();
     uint32_t r_dg[PF];
-    auto issue = [&](int e) {     // loads of digest entry e (lengths clipped to what the entry uses)
+    float x_pf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x_pf[q] = 0.f;
+    auto issue = [&](int e) {     // loads of digest entry e; lengths from the LDS size table, so no dependent global read
         const uint32_t *D = c.dig + (size_t)e * c.DW;
-        const int tot = min((int)D[0], c.LCAP), nact = (int)D[1];
+        const int tot = min(szt[2 * e], c.LCAP), nact = szt[2 * e + 1];
         const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+        const int nw = META + n1 + n2 + n3 + n4;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
+            if (u * NT >= nw) break;
             int k = tid + u * NT;
             uint32_t val = 0;
             if (k < META) val = D[k];
@@ -259,28 +366,37 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         }
     };
     issue(0);
-    __syncthreads();
 
     for (int t = 0; t <= c.T; ++t) {
+        TMARK(0);
         // ---- stage the digest of step t-1 (entry t) from the prefetch registers
         // sizes first (they sit in the first META words = thread tid < META, u = 0)
-        if (tid < META) meta[tid] = (int)r_dg[0];
-        lds_barrier();
         {
-            const int tot = min(meta[0], c.LCAP), nact = meta[1];
+            const int tot = min(szt[2 * t], c.LCAP), nact = szt[2 * t + 1];
             const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+            const int nw = META + n1 + n2 + n3 + n4;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
+                if (u * NT >= nw) break;
                 int k = tid + u * NT;
-                if (k < META) continue;
-                if ((k -= META) < n1) ((uint32_t *)ent)[k] = r_dg[u];
+                if (k < META) meta[k] = (int)r_dg[u];
+                else if ((k -= META) < n1) ((uint32_t *)ent)[k] = r_dg[u];
                 else if ((k -= n1) < n2) am[k] = r_dg[u];
                 else if ((k -= n2) < n3) ((uint32_t *)ar)[k] = r_dg[u];
                 else if ((k -= n3) < n4) ab[k] = r_dg[u];
             }
+            // traces prefetched at the end of the previous iteration, and the spike masks this iteration will fill
+            if (c.use_xsl && t >= 1 && tid < Nin) {
+                const uint32_t *cmp = colmask + ((t + 1) & 1) * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < CW && cmp[q]) xsl[q * Nin + tid] = x_pf[q];
+            }
+            if (tid < 8) colmask[(t & 1) * 8 + tid] = 0;
         }
         lds_barrier();
+        TMARK(1);
         if (t + 1 <= c.T) issue(t + 1);                  // next step's digest: in flight behind this step's work
+        TMARK(2);
         const int tot = meta[0], nact = meta[1], flags = meta[2];
         const bool overflow = (flags & 2) != 0;          // more events than the LDS list holds: walk bit words from global
         const uint8_t *sbytes = (flags & 1) ? ((t == 0) ? c.sX0 : c.in + (size_t)(t - 1) * B * Nin) : nullptr;
@@ -290,82 +406,16 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (t >= 1 && do_stdp) {
             const bool full = (t == 1) || c.wdecay != 1.0f;   // first update of a run (or a real decay) touches every element
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
-            // pass 1: rows with a pre-synaptic spike x own columns
-            for (int item = tid; item < (nact << cwl); item += NT) {
-                const int kq = item >> cwl, q = item & (CW - 1);
-                if (c0 + q >= N) continue;
-                const int i = (int)ar[kq];
-                const uint32_t m = am[kq];
-                const int e = i * N + c0 + q;
-                const bool tl = e >= Emain;
-                float w = wt[i * CW + q];
-                if (c.nu0 != 0.f) {                       // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
-                    OuterSum acc; acc.init(tl);
-                    uint32_t mm = m;
-                    while (mm) {
-                        const int b = __ffs(mm) - 1; mm &= mm - 1;
-                        const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
-                        acc.add(b, sv * xnu0[b * 8 + q], B);
-                    }
-                    float uu = acc.finish(B);
-                    if (c.use_dt) uu = uu * c.dt;
-                    w = w - uu;
-                }
-                if (c.nu1 != 0.f) {                       // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
-                    float uu = 0.f;
-                    uint32_t mm = cm[q];
-                    if (mm) {
-                        OuterSum acc; acc.init(tl);
-                        while (mm) {
-                            const int b = __ffs(mm) - 1; mm &= mm - 1;
-                            acc.add(b, xs[b * Nin + i] * (1.0f * c.nu1), B);
-                        }
-                        uu = acc.finish(B);
-                    }
-                    if (c.use_dt) uu = uu * c.dt;
-                    w = w + uu;
-                }
-                w = w * c.wdecay;
-                if (c.has_min && w < c.wmin) w = c.wmin;
-                if (c.has_max && w > c.wmax) w = c.wmax;
-                wt[i * CW + q] = w;
-            }
-            // pass 2: rows WITHOUT a pre-synaptic spike: the columns that spiked (every column when `full`)
-            for (int q = 0; q < CW; ++q) {
-                const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
-                if ((!cq && !full) || c0 + q >= N) continue;
-                for (int i = tid; i < Nin; i += NT) {
-                    if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
-                    const int e = i * N + c0 + q;
-                    float w = wt[i * CW + q];
-                    if (c.nu0 != 0.f) w = w - (c.use_dt ? 0.0f * c.dt : 0.0f);
-                    if (c.nu1 != 0.f) {
-                        float uu = 0.f;
-                        if (cq) {
-                            OuterSum acc; acc.init(e >= Emain);
-                            uint32_t mm = cq;
-                            while (mm) {
-                                const int b = __ffs(mm) - 1; mm &= mm - 1;
-                                acc.add(b, xs[b * Nin + i] * (1.0f * c.nu1), B);
-                            }
-                            uu = acc.finish(B);
-                        }
-                        if (c.use_dt) uu = uu * c.dt;
-                        w = w + uu;
-                    }
-                    w = w * c.wdecay;
-                    if (c.has_min && w < c.wmin) w = c.wmin;
-                    if (c.has_max && w > c.wmax) w = c.wmax;
-                    wt[i * CW + q] = w;
-                }
-            }
+            if (Etot != Emain) two_stdp<OuterSum>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            else two_stdp<CascT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
         }
+        TMARK(3);
         lds_barrier();
+        TMARK(4);
         if (t == c.T) break;
 
         // ================================================== phase B: step t
         uint32_t *cmn = colmask + (t & 1) * 8;
-        if (tid < 8) cmn[tid] = 0;
         uint8_t sp = 0;
         float cur = 0.f;
         if (mine) {
@@ -398,14 +448,21 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             if (c.pY.traces) xy = trace_next(xy, sp, c.pY.trace_decay, c.pY.trace_scale, c.pY.traces_additive);
             sp_prev = sp;
         }
-        lds_barrier();                                   // cmn zeroed before the atomics
+        TMARK(5);
         if (mine) {
             xnu0[bl * 8 + jj] = xy * c.nu0;               // target_x * nu[0]
             if (sp) atomicOr(&cmn[jj], 1u << bl);
             if (c.rasY) c.rasY[(size_t)t * B * N + kst] = sp;
             if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
         }
+        lds_barrier();                                   // this step's spike masks are final
+        if (c.use_xsl && do_stdp && tid < Nin) {         // source traces the next PostPre needs: in flight across the loop edge
+            const float *xs = c.xall + (size_t)t * B * Nin;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const uint32_t m = q < CW ? cmn[q] : 0u; x_pf[q] = m ? xs[(__ffs(m) - 1) * Nin + tid] : 0.f; }
+        }
         (void)tot;
+        TMARK(6);
     }
 
     // ---- epilogue: write the weight slice and the membrane state back
@@ -429,7 +486,7 @@ int digest_layout(TwoCtx &c) {
 size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
-           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4;
+           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)(c.T + 1) * 8 + (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
 
 bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, TwoCtx &c) {
@@ -458,6 +515,9 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.CW = cw;
     if (B * cw > NT || run_lds(c) > 140 * 1024) return false;
     c.G = (N + cw - 1) / cw;
+    if (c.T + 1 > 4096) return false;
+    c.use_xsl = 0;
+    if (Nin <= NT) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
     if (META + c.LCAP / 2 + Nin + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
     return true;
@@ -512,9 +572,27 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     if (prep_lds > 150 * 1024) return SNN_OK;
     if (c.x_traces) hipLaunchKernelGGL(k_two_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_two_prep, dim3(c.T + 1), dim3(NT), prep_lds, st, c);
+    static long long *dbg = nullptr;
+    if (getenv("SNN_TWO_TIMING")) {
+        if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 8 * 4096);
+        if (c.T + 1 <= 4096) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * (c.T + 1), st); c.dbg = dbg; }
+    }
     hipLaunchKernelGGL(k_two_run, dim3(c.G), dim3(NT), run_lds(c), st, c);
     int rc = snn_check_launch();
     if (rc) return rc;
+    if (c.dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h((size_t)8 * (c.T + 1));
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double a[7] = {0}; int n = 0;
+        for (int t = 2; t < c.T; ++t, ++n) {
+            const long long *r = &h[(size_t)t * 8];
+            for (int k = 1; k < 7; ++k) a[k] += (double)(r[k] - r[k - 1]) / 100.0;
+            a[0] += (double)(h[(size_t)(t + 1) * 8] - r[0]) / 100.0;
+        }
+        fprintf(stderr, "[twolayer timing, us/step %.2f] commit %.2f | issue %.2f | stdp %.2f | barrier %.2f | currents+lif %.2f | publish %.2f\n",
+                a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n);
+    }
     snn_set_plan_name("twolayer-fused");
     *handled = 1;
     return SNN_OK;

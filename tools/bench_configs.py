@@ -40,12 +40,20 @@ def cfg1():
     return "cfg1 D&C 784->100 B=1 T=250 PostPre", net, {"X": x}, 250, {}
 
 
-def cfg3():
+def cfg3(B=128):
     from bindsnet_amd.models import TwoLayerNetwork
     torch.manual_seed(0)
     net = TwoLayerNetwork(n_inpt=784, n_neurons=1600, reduction=torch.sum).to(DEV)
-    x = torch.from_numpy(synth.dense_spikes(2, (100, 128, 784), 0.012)).to(DEV)
-    return "cfg3 TwoLayer 784->1600 B=128 T=100 PostPre (one GPU)", net, {"X": x}, 100, {}
+    x = torch.from_numpy(synth.dense_spikes(2, (100, B, 784), 0.012)).to(DEV)
+    return f"cfg3 TwoLayer 784->1600 B={B} T=100 PostPre (one GPU)", net, {"X": x}, 100, {}
+
+
+def cfg3_shard():
+    return cfg3(16)      # the per-GPU share of cfg3's batch of 128 over 8 GPUs
+
+
+def cfg3_b32():
+    return cfg3(32)
 
 
 def cfg4():
@@ -81,8 +89,11 @@ def cfg5():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=5)
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
-    for make in (cfg1, cfg3, cfg4, cfg5):
+    for make in (cfg1, cfg3_shard, cfg3_b32, cfg3, cfg4, cfg5):
+        if a.only and make.__name__ != a.only:
+            continue
         name, net, inputs, T, kw = make()
         r = timed(net, inputs, T, a.runs, **kw)
         r["config"] = name
