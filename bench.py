@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--plan", default="auto", choices=["auto", "generic"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "generic", "per-step"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +118,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from bindsnet_amd import _lib, parallel
-    _lib.lib().snn_set_plan_mode(1 if args.plan == "generic" else 0)
+    _lib.lib().snn_set_plan_mode({"auto": 0, "generic": 1, "per-step": 2}[args.plan])
     net = build_network(dev)
     pool = make_inputs(1000 + 17 * rank, 4, dev)           # resident in HBM before the timed region
 

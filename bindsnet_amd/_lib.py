@@ -137,6 +137,9 @@ def profile_run(net, inputs, time, stride=4):
     if n.value == 0:
         return None
     plan = net.last_plan
+    if plan == "dc2015-resident":
+        return {"kernel": "k_dc2015_run (one launch per network.run())", "avg_ms": s.value / n.value, "n": n.value,
+                "timesteps_per_launch": int(round(time / net.dt))}
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}
 

@@ -23,6 +23,7 @@ extern "C" const char *snn_error_string(int code) {
         case SNN_ERR_LAUNCH: return "HIP runtime / launch error";
         case SNN_ERR_NOISE: return "one_spike noise stream exhausted";
         case SNN_ERR_NO_DEVICE: return "no HIP device";
+        case SNN_ERR_TIMEOUT: return "in-kernel workgroup hand-off timed out";
         default: return "unknown error";
     }
 }

@@ -76,8 +76,14 @@ struct DcCtx {
     float inv_hwps, inv_NW, inv_RS;   // reciprocals of Nin/16, NW, RS for the exact float-multiply divisions
     // per-step digest of the X spikes, produced once per run by k_dc2015_prep (entry e <-> spikes of step e-1):
     // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
-    // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index
+    // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index | [B*LX/2] u16 event lists grouped by row_sum lane |
+    // [B] group sizes (5 bits each: lanes 0..3, leftover sources)
     uint32_t *dig; int DW, DGW;
+    // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
+    // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
+    unsigned long long *ex; int KB;
+    float *xtr;
+    int *status;
     int dbg_wg;
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
 };
@@ -382,9 +388,32 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
         if (big) atomicOr((unsigned int *)&misc[1], 1u);
     }
     __syncthreads();
+    uint16_t *D_l2 = D_rp + 2 * ((Nin + 1) / 2);                     // [B][LX] events grouped by row_sum lane
+    uint32_t *D_gc = (uint32_t *)(D_l2 + B * LX);                    // [B] five 5-bit group sizes
+    uint16_t *lscr = (uint16_t *)(misc + 4) + wave * LX;             // this wave's scratch list
     for (int b = wave; b < B; b += NT / 64) {
-        const int nx = build_list(sXw + b * NinW, NinW, lane, (uint16_t *)D_xl + b * LX, LX);
+        const int nx = build_list(sXw + b * NinW, NinW, lane, lscr, LX);
         if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > 16) atomicOr((unsigned int *)&misc[1], 2u); }
+        // (LDS operations of one wave execute in program order: the list is readable right away)
+        const bool have = lane < LX && lane < nx;
+        const int i = have ? (int)lscr[lane] : 0;
+        if (lane < LX) ((uint16_t *)D_xl)[b * LX + lane] = (uint16_t)i;
+        // the same events grouped by ATen row_sum lane (index mod 4; group 4 = the n % 4 leftover sources), ascending
+        // inside a group: what a quad of threads walks for a column >= 32*floor(N/32)
+        const bool in16 = have && lane < 16;
+        const int grp = (i >= ((Nin >> 2) << 2)) ? 4 : (i & 3);
+        int start = 0, my = 0; uint32_t gc = 0;
+        for (int k = 0; k < 5; ++k) {
+            const uint64_t mk = __ballot(in16 && grp == k);
+            const int ck = __popcll(mk);
+            if (grp == k) my = start + __popcll(mk & ((1ull << lane) - 1ull));
+            start += ck; gc |= (uint32_t)ck << (5 * k);
+        }
+        uint16_t *perm = lscr + (NT / 64) * LX;        // second per-wave scratch: permute in LDS, store each slot once
+        if (lane < LX) perm[lane] = 0;
+        if (in16) perm[my] = (uint16_t)i;
+        if (lane < LX) D_l2[b * LX + lane] = perm[lane];
+        if (lane == 0) D_gc[b] = gc;
     }
     for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
     for (int base = 0; base < Nin; base += NT) {       // compact the rows with a spike in any sample
@@ -839,8 +868,624 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
 }
 
+
+// =====================================================================================================
+// Resident plan "dc2015-resident": the SAME decomposition and arithmetic as k_dc2015_step, but ONE launch for
+// the whole run.  What used to cross the kernel boundary now stays put or moves through tagged granules:
+//   * the [Nin x CW] weight slice lives in LDS for all T steps, membrane state / traces / theta in registers;
+//   * the X trace of every step is precomputed (k_dc2015_xtrace) -- it depends on the inputs alone;
+//   * each workgroup keeps its own copy of the generator (all copies advance identically);
+//   * the per-step spike exchange uses 8-byte {epoch, bits} granules written with ONE relaxed agent-scope
+//     (write-through) store and polled with relaxed agent-scope loads: the data is the flag, no fence
+//     (cdna_hip_programming.md Guideline 16, form R2).  Granule k of workgroup g carries samples 2k, 2k+1:
+//     crossing byte | Ai spike byte << 8 | (same for the odd sample) << 16.  Two buffers by epoch parity: a
+//     workgroup overwrites a buffer only after every other workgroup has published the epoch in between,
+//     which it does only after consuming the overwritten one.
+// All G <= 128 workgroups are co-resident (one 1024-thread workgroup per CU), polls are bounded (status word).
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// PostPre on the LDS-resident slice: (row, column) items, rows listed in `arows` (all rows when FULL).
+template <class SUM, bool FULL>
+__device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
+                                              const uint32_t *colmask, const uint8_t *__restrict__ sbytes,
+                                              const float *xnu0, const float *__restrict__ xsrc, float *wtile, int c0,
+                                              int tid, int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N;
+    const int nitems = nact * CW;
+    const int q = tid % CW, jq = c0 + q;                          // NT % CW == 0: a thread keeps its column
+    if (jq >= N) return;
+    const uint32_t cm = (c.nu1 != 0.f) ? colmask[q] : 0u;
+    for (int item = tid; item < nitems; item += NT) {
+        const int i = FULL ? (item / CW) : (int)arows[item / CW];
+        const int e = i * N + jq;
+        float w = wtile[i * CW + q];
+        if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+            uint32_t m = rowmask[i];
+            float uu = 0.f;
+            if (m) {
+                SUM acc; acc.init(e >= Emain);
+                while (m) {
+                    const int b = __ffs(m) - 1; m &= m - 1;
+                    const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                    acc.add(b, sv * xnu0[b * CW + q], B);
+                }
+                uu = acc.finish(B);
+            }
+            if (c.use_dt) uu = uu * c.dt;
+            w = w - uu;
+        }
+        if (c.nu1 != 0.f) {                                      // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+            uint32_t m = cm;
+            float uu = 0.f;
+            if (m) {
+                SUM acc; acc.init(e >= Emain);
+                while (m) {
+                    const int b = __ffs(m) - 1; m &= m - 1;
+                    acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+                }
+                uu = acc.finish(B);
+            }
+            if (c.use_dt) uu = uu * c.dt;
+            w = w + uu;
+        }
+        if (c.has_min && w < c.wmin) w = c.wmin;
+        if (c.has_max && w > c.wmax) w = c.wmax;
+        wtile[i * CW + q] = w;
+    }
+}
+
+// Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike, on the LDS-resident slice.
+template <class SUM>
+__device__ __forceinline__ void stdp_cols_lds(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
+                                              const uint32_t *colmask, const float *__restrict__ xsrc, float *wtile,
+                                              int c0, int tid, int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N;
+    while (active_cols) {
+        const int q = __ffs(active_cols) - 1; active_cols &= active_cols - 1;
+        const uint32_t cm = colmask[q];
+        const int jq = c0 + q;
+        for (int i = tid; i < Nin; i += NT) {
+            if (rowmask[i]) continue;
+            const int e = i * N + jq;
+            float w = wtile[i * CW + q];
+            SUM acc; acc.init(e >= Emain);
+            uint32_t m = cm;
+            while (m) {
+                const int b = __ffs(m) - 1; m &= m - 1;
+                acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+            }
+            float uu = acc.finish(B);
+            if (c.use_dt) uu = uu * c.dt;
+            w = w + uu;
+            if (c.has_min && w < c.wmin) w = c.wmin;
+            if (c.has_max && w > c.wmax) w = c.wmax;
+            wtile[i * CW + q] = w;
+        }
+    }
+}
+
+// X trace after every step: entry 0 = trace at run entry, entry e = trace after step e-1 (nodes.py:96-103).
+__global__ __launch_bounds__(256) void k_dc2015_xtrace(const DcCtx c) {
+    const int n = c.B * c.Nin;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float x = c.xX[1][k];
+    c.xtr[k] = x;
+    int t = 0;
+    for (; t + 8 <= c.T; t += 8) {            // the spike loads do not depend on x: issue them together
+        uint8_t s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
+    }
+    for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + 1) * n + k] = x; }
+    c.xX[1][k] = x;
+}
+
+// ---- cold paths of the resident kernel, kept out of line so that their register needs do not spill the
+//      per-step state of the hot path (LDS pointers arrive as generic pointers: slower, and irrelevant here)
+struct Cur2 { float e, i; };
+
+// Input currents by bit-scan over the spike words (a sample overflowed the fixed-size event lists).
+__device__ __attribute__((noinline)) Cur2 busy_currents(const float *wtile, const float *wieT, const float *weiT,
+                                                        const uint32_t *xw, const uint32_t *iw, const uint32_t *ew,
+                                                        const uint8_t *xb, int NinW, int NW, int Nin, int N, int jj, bool tail) {
+    const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
+    Cur2 r;
+    if (tail) {
+        r.e = 0.0f + ordered_dot<RowSum4>(wtile, CW, jj, xw, ax, xb, Nin);
+        r.e = r.e + ordered_dot<RowSum4>(wieT, CW, jj, iw, ar, nullptr, N);
+        r.i = 0.0f + ordered_dot<RowSum4>(weiT, CW, jj, ew, ar, nullptr, N);
+    } else {
+        r.e = 0.0f + ordered_dot<CascadeN>(wtile, CW, jj, xw, ax, xb, Nin);
+        r.e = r.e + ordered_dot<CascadeN>(wieT, CW, jj, iw, ar, nullptr, N);
+        r.i = 0.0f + ordered_dot<CascadeN>(weiT, CW, jj, ew, ar, nullptr, N);
+    }
+    return r;
+}
+
+// one_spike arbitration when the step needs more generator blocks than the ring holds or has more candidates
+// than the compact list: walk the stream block by block.  Blocks 0..min(ntw,2) (relative to slot mb) are resident
+// on entry; everything beyond is (re)computed on the way.  Every thread of the workgroup must call it.
+__device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uint32_t *crs, unsigned long long *keys,
+                                                         int mb, int pos, int N, int ntw, int rows, int myrank,
+                                                         int wb, int wj, int BW, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = NT / 64;
+    uint32_t parked = 0;
+    int lo = 0, hi = min(ntw, 2);
+    while (rows) {
+        if (tid < BW) {
+            uint32_t bits = crs[tid];
+            while (bits) {
+                const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                const int d = myrank * N + jx;
+                const int w0 = pos + 2 * d, w1 = w0 + 1;
+                const int m0 = w0 / 624, m1 = w1 / 624;
+                float q; bool have = false;
+                if (m0 >= lo && m1 <= hi) {
+                    q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                        mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1])); have = true;
+                } else if (m0 >= lo && m0 <= hi) {             // pair straddles the resident range: park the high word
+                    parked = mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]);
+                } else if (m1 >= lo && m1 <= hi) {
+                    q = exp1_from_words(parked, mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1])); have = true;
+                }
+                if (have) {
+                    const float val = 1.0f / q;
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                    atomicMax(&keys[wb], key);
+                }
+            }
+        }
+        if (hi >= ntw) break;
+        lds_barrier();
+        if (wave == NWV - 1) {
+            mt_twist_block_wave(mt + ((mb + hi) & 7) * 624, mt + ((mb + hi + 1) & 7) * 624, lane);
+            if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((mb + hi + 1) & 7) * 624, mt + ((mb + hi + 2) & 7) * 624, lane);
+        }
+        lo = hi + 1; hi = min(ntw, hi + 2);
+        lds_barrier();
+    }
+}
+
+constexpr unsigned kPollLimit = 400000u;
+constexpr size_t kResidentFixedLds = 3 * NT * 4 + MAXB * CW * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 +
+                                     2 * MAXB * 4 + 2 * 32 * 4 + 32 + 2 * MAXB * CW * 4;     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
+
+__global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
+    // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
+    //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.
+    constexpr size_t O_CRS = 0, O_FINE = O_CRS + NT * 4, O_SPI = O_FINE + NT * 4, O_XNU0 = O_SPI + NT * 4,
+                     O_MT = O_XNU0 + MAXB * CW * 4, O_CAND = O_MT + 8 * 624 * 4, O_KEYS = O_CAND + NCAND * 4,
+                     O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
+                     O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
+                     O_CURB = O_MISC + 32, O_WT = O_CURB + 2 * MAXB * CW * 4;
+    static_assert(O_WT == kResidentFixedLds && O_WT % 16 == 0, "fixed LDS part");
+    uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
+    uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
+    uint32_t *spI = (uint32_t *)(smem + O_SPI);            // ... Ai spikes
+    float *xnu0 = (float *)(smem + O_XNU0);
+    uint32_t *mt = (uint32_t *)(smem + O_MT);              // generator ring: block base+m in slot (mb + m) & 7
+    uint32_t *cand = (uint32_t *)(smem + O_CAND);
+    unsigned long long *keys = (unsigned long long *)(smem + O_KEYS);
+    uint16_t *lstI = (uint16_t *)(smem + O_LSTI);
+    uint16_t *lstE = (uint16_t *)(smem + O_LSTE);
+    int *cntI = (int *)(smem + O_CNTI);
+    int *cntE = (int *)(smem + O_CNTE);
+    int *cnt = (int *)(smem + O_CNT);
+    uint32_t *colmask = (uint32_t *)(smem + O_COLM);
+    int *misc = (int *)(smem + O_MISC);
+    float *curbuf = (float *)(smem + O_CURB);
+    float *wtile = (float *)(smem + O_WT);                 // [Nin][CW] the own weight slice, resident for the run
+    float *wieT = wtile + (size_t)Nin * CW;                // [N][CW] own column slices of the recurrent weights
+    float *weiT = wieT + (size_t)N * CW;
+    const int DGS = (c.DGW + 63) & ~63;                    // digest buffer stride (words): whole wave chunks
+    uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW); // digests of iteration t (buffer t & 1) and t + 1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, c0 = g * CW;
+    const int jj = tid % CW, bl = tid / CW;
+    const int j = c0 + jj;
+    const bool colv = j < N;
+    const bool tailcol = c0 >= (N / 32) * 32;
+    const int BW = B * NW;
+    const bool mine = tid < TT && bl < B && colv;
+    const unsigned kst = (unsigned)(bl * N + j);
+    const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;   // exchange word (sample wb, word wj)
+    const int KB = c.KB, NG = c.G * KB;                    // granules per epoch
+    const int Etot = Nin * N, Emain = (Etot / 32) * 32;
+    const bool anytail = Etot != Emain;
+    constexpr int NWV = NT / 64;
+
+    // ---- one-time staging: weight slice, state, generator, zeroed scratch
+    for (int k = tid; k < Nin * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wtile[k] = (c0 + q < N) ? c.Wxe[i * N + c0 + q] : 0.f;
+    }
+    for (int k = tid; k < N * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wieT[k] = (c0 + q < N) ? c.Wie[i * N + c0 + q] : 0.f;
+        weiT[k] = (c0 + q < N) ? c.Wei[i * N + c0 + q] : 0.f;
+    }
+    // digest of iteration e straight into LDS (global_load_lds: no register round trip); wave-uniform 256-byte chunks
+    auto fetch_digest = [&](int e) {
+        const uint32_t *Dg = c.dig + (size_t)e * c.DW + B * NinW;
+        uint32_t *dst = dgbuf + (e & 1) * DGS;
+        for (int base = wave * 64; base < c.DGW; base += NT) {
+            const int ub = __builtin_amdgcn_readfirstlane(base);
+            if (ub + lane < c.DGW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane),
+                                                 (__attribute__((address_space(3))) void *)(dst + ub), 4, 0, 0);
+        }
+    };
+    fetch_digest(0);
+    float r_vE = 0.f, r_rE = 0.f, r_vI = 0.f, r_rI = 0.f, r_xE = 0.f, r_xI = 0.f, th = 0.f;
+    bool last_sE = false, last_sI = false;
+    if (mine) {
+        r_vE = c.vE[kst]; r_rE = c.rE[kst]; r_vI = c.vI[kst]; r_rI = c.rI[kst]; th = c.theta[j];
+        if (c.pI.traces) r_xI = c.xI[kst];
+        if (c.pE.lif.traces) r_xE = c.xE[kst];
+        last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
+    }
+    int rng_pos = 0, mb = 0, ahead = 0; long long rng_consumed = 0;
+    if (c.pE.one_spike) {
+        if (tid < 624) mt[tid] = c.rng[0]->mt[tid];
+        rng_pos = __builtin_amdgcn_readfirstlane(c.rng[0]->pos);
+        const long long cons0 = c.rng[0]->consumed;
+        rng_consumed = ((long long)__builtin_amdgcn_readfirstlane((int)(cons0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cons0);
+    }
+    if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
+    if (tid < 8) misc[tid] = 0;
+    if (tid < MAXB) keys[tid] = 0ull;
+    if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI[tid] = 0; }
+    bool failed = false;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t <= T; ++t) {
+        const bool phaseA = t >= 1, phaseB = t < T;
+        DBG_MARK(0);
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 8] = (long long)clock64();
+        if (c.dbg && threadIdx.x == 0) atomicMin((unsigned long long *)&c.dbg[(size_t)t * 24 + 20], (unsigned long long)wall_clock64());
+        const int stepoff = t * B * Nin;
+        const uint32_t *dg = dgbuf + (t & 1) * DGS;                       // digest of the X spikes of step t-1
+        const uint16_t *lstX = (const uint16_t *)dg;
+        const int *meta = (const int *)(dg + B * (LX / 2));
+        const int *cntX = meta;
+        const uint32_t *rowmask = dg + B * (LX / 2) + 40;
+        const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
+        const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);              // X events grouped by row_sum lane
+        const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
+        const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
+        // ------------------------------------------------------------------ receive step t-1
+        const bool use_rng = phaseA && c.pE.one_spike;
+        if (use_rng) {
+            // while the other waves wait for the exchange, the LAST wave runs the generator ahead (lockstep twists,
+            // no barrier) until the ring is full: blocks base+1 .. base+7.  A step consumes 2 * N words per sample
+            // with a crossing, i.e. a few blocks, so the arbitration below finds its blocks already there.
+            if (wave == NWV - 1)
+                for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
+            ahead = 7;
+        }
+        if (phaseA) {
+            const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
+            for (int k0 = tid; k0 < NG; k0 += 2 * NT) {
+                const int k1 = k0 + NT;
+                const bool two = k1 < NG;
+                unsigned long long x0 = 0, x1 = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    x0 = granule_load(exr + k0);
+                    if (two) x1 = granule_load(exr + k1);
+                    const bool ok = (uint32_t)(x0 >> 32) == (uint32_t)t && (!two || (uint32_t)(x1 >> 32) == (uint32_t)t);
+                    if (ok || failed) break;
+                    if (++spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) break;
+                    const int k = h ? k1 : k0;
+                    const uint32_t v = (uint32_t)(h ? x1 : x0);
+                    const int gg = k / KB, b0 = (k - gg * KB) * 2;
+                    ((uint8_t *)crs)[(b0 * NW) * 4 + gg] = (uint8_t)v;
+                    ((uint8_t *)spI)[(b0 * NW) * 4 + gg] = (uint8_t)(v >> 8);
+                    if (b0 + 1 < B) {
+                        ((uint8_t *)crs)[((b0 + 1) * NW) * 4 + gg] = (uint8_t)(v >> 16);
+                        ((uint8_t *)spI)[((b0 + 1) * NW) * 4 + gg] = (uint8_t)(v >> 24);
+                    }
+                }
+            }
+        } else if (tid < BW) {   // t == 0: previous spikes come from the layers' `s` tensors (bytes -> bits)
+            uint32_t me = 0, mi = 0;
+            for (int qq = 0; qq < 32; ++qq) {
+                const int jx = wj * 32 + qq;
+                if (jx < N) { me |= (uint32_t)(c.sE[wb * N + jx] != 0) << qq; mi |= (uint32_t)(c.sI[wb * N + jx] != 0) << qq; }
+            }
+            finE[tid] = me; spI[tid] = mi;
+        }
+        DBG_MARK(10);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's digest (issued one iteration ago) has landed
+        DBG_MARK(11);
+        lds_barrier();
+        DBG_MARK(15);
+        if (tid < 32) cnt[tid] = 0;                        // last read at the end of the previous iteration
+        if (t < T) fetch_digest(t + 1);                    // next iteration's digest: in flight behind this one
+        DBG_MARK(16);
+        const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
+        const uint8_t *sbytes = (mflags & 1) ? sprev_g : nullptr;
+        if (tid == 0 && (mflags & 2)) atomicOr((unsigned int *)&misc[2], 2u);
+        const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
+        const bool stdp_full = t == 1;
+        const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
+        // ---- per sample (one wave each, in turns): event list of its Ai spikes; does it have an Ae crossing?
+        {
+            for (int b = wave; b < B; b += NWV) {
+                const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
+                const uint64_t mc = __ballot(use_rng && lane < NW && crs[b * NW + lane] != 0);
+                if (lane == 0) {
+                    cntI[b] = ni;
+                    if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
+                    if (ni > 4) atomicOr((unsigned int *)&misc[2], 2u);
+                }
+            }
+        }
+        DBG_MARK(1);
+        lds_barrier();
+        const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
+        const int cjg = c0 + cj_;
+        const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
+
+        // ================================================================== phase A: finish step t-1
+        if (use_rng) {
+            DBG_MARK(12);
+            const uint32_t anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
+            const int rows = __popc(anym);
+            const int pos = rng_pos;
+            const int E = pos + 2 * rows * N;
+            const int ntw = rows ? (E - 1) / 624 : 0;
+            const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
+            if (tid < BW) {
+                uint32_t bits = crs[tid];
+                if (bits) {
+                    int at = atomicAdd(&misc[4], __popc(bits));
+                    while (bits) {
+                        const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                        if (at < NCAND) cand[at] = ((uint32_t)wb << 16) | (uint32_t)jx;
+                        ++at;
+                    }
+                }
+            }
+            lds_barrier();
+            const int ncand = __builtin_amdgcn_readfirstlane(misc[4]);
+            if (ncand <= NCAND && ntw <= 7) {
+                for (int k = tid; k < ncand; k += NT) {
+                    const uint32_t cd = cand[k];
+                    const int b = (int)(cd >> 16), jx = (int)(cd & 0xFFFFu);
+                    const int d = __popc(anym & ((1u << b) - 1u)) * N + jx;
+                    const int w0 = pos + 2 * d, w1 = w0 + 1;
+                    const int m0 = w0 / 624, m1 = w1 / 624;
+                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                    mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                    const float val = 1.0f / q;
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                    atomicMax(&keys[b], key);
+                }
+            } else {
+                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid);
+                ahead = ntw;            // blocks beyond ntw may have been overwritten by the walk
+            }
+            lds_barrier();
+            DBG_MARK(13);
+            if (tid < BW) {
+                uint32_t wbits = 0;
+                if ((anym >> wb) & 1u) {
+                    const int win = (int)(0xFFFFFFFFu - (uint32_t)(keys[wb] & 0xFFFFFFFFull));
+                    if ((win >> 5) == wj) wbits = 1u << (win & 31);
+                }
+                finE[tid] = wbits;
+            }
+            mb = (mb + ntw) & 7; ahead -= ntw;
+            rng_pos = E - 624 * ntw;
+            rng_consumed += (long long)rows * N;
+        } else if (phaseA) {
+            if (tid < BW) finE[tid] = crs[tid];
+        }
+        lds_barrier();
+        DBG_MARK(14);
+        for (int b = wave; b < B; b += NT / 64) {
+            const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
+            if (lane == 0) { cntE[b] = ne; if (ne > 4) atomicOr((unsigned int *)&misc[2], 2u); }
+        }
+        DBG_MARK(2);
+        if (phaseA) {
+            if (tid < TT && bl < B) {
+                const bool sp = colv && bit_of(finE + bl * NW, j);
+                float xn = 0.f;
+                if (colv) {
+                    if (c.pE.lif.traces) { xn = trace_next(r_xE, sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); r_xE = xn; }
+                    last_sE = sp;
+                    if (c.rasE) (c.rasE + (size_t)(t - 1) * B * N)[kst] = sp;
+                }
+                xnu0[bl * CW + jj] = xn * c.nu0;
+                if (sp) atomicOr(&colmask[jj], 1u << bl);
+            }
+        }
+        lds_barrier();
+        if (phaseA) {
+            DBG_MARK(3);
+            if (do_stdp) {
+                const float *xsrc = c.xtr + (size_t)t * B * Nin;          // X trace after step t-1
+                if (stdp_full) {
+                    if (anytail) stdp_rows_lds<OuterSum, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    else stdp_rows_lds<CascadeT, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                } else {
+                    uint32_t acols = 0;
+                    if (c.nu1 != 0.f) {
+#pragma unroll
+                        for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
+                    }
+                    if (anytail) {
+                        stdp_rows_lds<OuterSum, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<OuterSum>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                    } else {
+                        stdp_rows_lds<CascadeT, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<CascadeT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                    }
+                }
+            }
+        }
+        const bool busy = (__builtin_amdgcn_readfirstlane(misc[2]) & 2) != 0;
+        lds_barrier();
+        DBG_MARK(4);
+        if (!phaseB) break;
+        // scratch of phase A: everyone is past its last read
+        if (tid < 32) colmask[tid] = 0;
+        if (tid >= 34 && tid <= 36) misc[tid - 32] = 0;      // busy flag, crossing-sample mask, candidate count
+        if (tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;
+
+        // ================================================================== phase B: start step t
+        float curE = 0.f, curI = 0.f;
+        if (!busy && tailcol) {
+            if (cvalid) {
+                const int nX = cntX[cb_], nI = cntI[cb_], nE = cntE[cb_];
+                const uint8_t *xb = sbytes ? sbytes + cb_ * Nin : nullptr;
+                int ii[4], ie[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ii[u] = min((int)lstI[cb_ * LR + u], N - 1); ie[u] = min((int)lstE[cb_ * LR + u], N - 1); }
+                float wi[4], we[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { wi[u] = wieT[ii[u] * CW + cj_]; we[u] = weiT[ie[u] * CW + cj_]; }
+                // X -> Ae: this thread's row_sum lane walks ITS sub-list of the sample's events (digest, grouped by
+                // source index mod 4), lane 0 then adds the n % 4 leftover sources in order
+                float e1;
+                {
+                    (void)nX;
+                    const uint32_t gc = gcnt[cb_];
+                    const int st = (cL > 0 ? (int)(gc & 31u) : 0) + (cL > 1 ? (int)((gc >> 5) & 31u) : 0) + (cL > 2 ? (int)((gc >> 10) & 31u) : 0);
+                    const int nL = (int)((gc >> (5 * cL)) & 31u);
+                    const uint16_t *l2 = lst2 + cb_ * LX;
+                    const int n4 = Nin >> 2;
+                    int ix[8]; float wx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + cj_];
+                    CascadeFlat a; a.init();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u] >> 2, wx[u] * (xb ? (float)xb[ix[u]] : 1.0f), n4);
+                    for (int u = 8; u < nL; ++u) {
+                        const int i = (int)l2[st + u];
+                        a.add(i >> 2, wtile[i * CW + cj_] * (xb ? (float)xb[i] : 1.0f), n4);
+                    }
+                    float v = a.finish(n4);
+                    if (cL == 0) {
+                        const int s4 = (int)(gc & 31u) + (int)((gc >> 5) & 31u) + (int)((gc >> 10) & 31u) + (int)((gc >> 15) & 31u);
+                        const int n5 = (int)((gc >> 20) & 31u);
+                        for (int u = 0; u < n5; ++u) {
+                            const int i = (int)l2[s4 + u];
+                            v += wtile[i * CW + cj_] * (xb ? (float)xb[i] : 1.0f);
+                        }
+                    }
+                    const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
+                    e1 = ((v + v1) + v2) + v3;
+                }
+                const float e2 = quad_lane_sum<4>(ii, nI, wi, nullptr, N, cL);
+                const float e3 = quad_lane_sum<4>(ie, nE, we, nullptr, N, cL);
+                if (cL == 0) {
+                    curbuf[(cb_ * CW + cj_) * 2] = (0.0f + e1) + e2;
+                    curbuf[(cb_ * CW + cj_) * 2 + 1] = 0.0f + e3;
+                }
+            }
+            lds_barrier();
+            if (mine) { curE = curbuf[(bl * CW + jj) * 2]; curI = curbuf[(bl * CW + jj) * 2 + 1]; }
+        } else if (mine) {
+            const int nX = cntX[bl], nI = cntI[bl], nE = cntE[bl];
+            const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
+            if (!busy) {
+                float wi[4], we[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wi[u] = wieT[min((int)lstI[bl * LR + u], N - 1) * CW + jj];
+                    we[u] = weiT[min((int)lstE[bl * LR + u], N - 1) * CW + jj];
+                }
+                tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wtile, nullptr, jj, xb, j, curE, curI);
+            } else {   // generic bit-scan path
+                const Cur2 r = busy_currents(wtile, wieT, weiT, c.dig + (size_t)t * c.DW + bl * NinW, spI + bl * NW,
+                                             finE + bl * NW, xb, NinW, NW, Nin, N, jj, tailcol);
+                curE = r.e; curI = r.i;
+            }
+        }
+        DBG_MARK(5);
+        // ---- B2: membrane updates
+        bool spE = false, spIn = false;
+        if (mine) {
+            if (c.pE.learning) th = th * c.pE.theta_decay;
+            spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
+            if (spE) atomicAdd(&cnt[jj], 1);
+            float ci = curI;
+            if (r_rI > 0.f) ci = 0.f;
+            spIn = lif_update(r_vI, r_rI, ci, c.pI);
+            last_sI = spIn;
+        }
+        {   // publish crossing / spike bits of step t: epoch t+1
+            const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
+            constexpr int SPW = 64 / CW;
+            const int sidx = lane / CW, b = wave * SPW + sidx;
+            const uint32_t v16 = (uint32_t)((mE >> (sidx * CW)) & 0xFFu) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFu) << 8);
+            const uint32_t vhi = __shfl_down(v16, CW);
+            if (tid < TT && (lane % CW) == 0 && (sidx & 1) == 0 && b < B) {
+                const uint32_t v = v16 | ((b + 1 < B) ? (vhi << 16) : 0u);
+                granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + (b >> 1), ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+            }
+        }
+        lds_barrier();
+        if (mine) {
+            if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[jj];
+            if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
+            if (c.pI.traces) r_xI = trace_next(r_xI, spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
+            if (c.rasI) (c.rasI + (size_t)t * B * N)[kst] = spIn;
+            if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
+        }
+        DBG_MARK(6);
+        DBG_MARK(7);
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 9] = (long long)clock64();
+        if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
+    }
+
+    // ---- epilogue: state and weights back to the tensors the caller owns
+    if (mine) {
+        c.vE[kst] = r_vE; c.rE[kst] = r_rE; c.vI[kst] = r_vI; c.rI[kst] = r_rI;
+        if (bl == 0) c.theta[j] = th;
+        if (c.pI.traces) c.xI[kst] = r_xI;
+        if (c.pE.lif.traces) c.xE[kst] = r_xE;
+        c.sE[kst] = last_sE; c.sI[kst] = last_sI;
+    }
+    if (c.learning && c.rule == SNN_RULE_POSTPRE)
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k];
+        }
+    if (g == 0 && c.pE.one_spike) {
+        snn_rng_state *wr = c.rng[0];
+        if (tid < 624) wr->mt[tid] = mt[mb * 624 + tid];
+        if (tid == 0) { wr->pos = rng_pos; wr->consumed = rng_consumed; }
+    }
+}
+
 // words of one digest entry / of its part that the step kernel copies into LDS
-int digest_words(int B, int Nin) { const int NinW = (Nin + 31) / 32; return ((B * NinW + B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2)) + 3) & ~3; }
+int digest_words(int B, int Nin) { const int NinW = (Nin + 31) / 32; return ((B * NinW + B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + B) + 3) & ~3; }
 int digest_lds_words(int B, int Nin) { return digest_words(B, Nin) - B * ((Nin + 31) / 32); }
 
 size_t lds_bytes(int B, int Nin, int N) {
@@ -851,7 +1496,12 @@ size_t lds_bytes(int B, int Nin, int N) {
            (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
 }
 
-size_t prep_lds_bytes(int B, int Nin) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4; }
+size_t lds_bytes_resident(int B, int Nin, int N) {
+    const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
+    return kResidentFixedLds + (size_t)Nin * CW * 4 + (size_t)2 * N * CW * 4 + (size_t)2 * DGS * 4;
+}
+
+size_t prep_lds_bytes(int B, int Nin) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4 + 2 * (NT / 64) * LX * 2; }
 
 }  // namespace
 
@@ -862,8 +1512,15 @@ static size_t fused_workspace(int B, int Nin, int N) {
     return 4 * al((size_t)B * NW * 4) + al((size_t)B * Nin * 4) + al(sizeof(snn_rng_state));
 }
 
+static size_t resident_extra(int B, int Nin, int N, int T) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int G = (N + CW - 1) / CW, KB = (B + 1) / 2;
+    return al((size_t)2 * G * KB * 8) + al((size_t)(T + 1) * B * Nin * 4);
+}
+
 static size_t fused_workspace_total(int B, int Nin, int N, int T) {
-    return fused_workspace(B, Nin, N) + (size_t)(T + 1) * digest_words(B, Nin) * 4;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return fused_workspace(B, Nin, N) + al((size_t)(T + 1) * digest_words(B, Nin) * 4) + resident_extra(B, Nin, N, T);
 }
 
 static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
@@ -907,7 +1564,7 @@ extern "C" void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed) 
 }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int *handled) {
+                         hipStream_t st, int resident, int *handled) {
     *handled = 0;
     if (!matches(L, nL, C, nC, R)) return SNN_OK;
     const int B = R->B, Nin = L[0].n, N = L[1].n;
@@ -939,6 +1596,17 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
     // generator: launch t reads rng[(t-1)&1], workgroup 0 writes rng[t&1]; entry state must sit in rng[0]
     c.rng[0] = R->rng; c.rng[1] = rng2;
+    {
+        auto al2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        unsigned char *p = (unsigned char *)c.dig + al2((size_t)(R->T + 1) * c.DW * 4);
+        c.KB = (B + 1) / 2;
+        c.ex = (unsigned long long *)p;
+        c.xtr = (float *)(p + al2((size_t)2 * c.G * c.KB * 8));
+        c.status = R->status;
+    }
+    // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
+    if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
+    if (c.G > 128 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N) > 150 * 1024) resident = 0;
     static long long *dbg = nullptr;
     static int dbg_T = 0;
     if (getenv("SNN_DC_TIMING")) {
@@ -951,13 +1619,25 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static bool lds_attr = false;
     if (!lds_attr) {   // the kernel may use more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_step, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         lds_attr = true;
     }
     // One run = memset of the exchange words (pad bytes for columns >= N are never written by a workgroup),
     // T+1 launches, and up to two small copies (final X trace sits in xX[(T-1)&1], final generator in rng[T&1]).
     hipStream_t qs = st;           // stream the run is enqueued on (a private one when graphs are in play)
     auto enqueue = [&](bool with_events) -> int {
-        int rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
+        int rc0;
+        if (resident) {
+            // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
+            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)2 * c.G * c.KB * 8, qs)))) return rc0;
+            hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
+            if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
+            const bool prof = with_events && snn_prof_begin(0, qs);
+            hipLaunchKernelGGL(k_dc2015_run, dim3(c.G), dim3(NT), lds_bytes_resident(B, Nin, N), qs, c);
+            if (prof) snn_prof_end(qs);
+            return snn_check_launch();
+        }
+        rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
         hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
         for (int t = 0; t <= R->T; ++t) {
@@ -983,7 +1663,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static unsigned long long clock_ = 0;
     static const bool graphs_on = getenv("SNN_GRAPH") != nullptr;   // opt-in: replay measured no faster than eager launches
     int rc = SNN_OK;
-    if (!graphs_on || c.dbg || snn_prof_active()) {
+    if (!graphs_on || resident || c.dbg || snn_prof_active()) {
         rc = enqueue(true); g_graph_stats[0]++;
     } else {
         // capture is not allowed on the legacy default stream torch usually runs on: fork to a private
@@ -1057,7 +1737,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         {
             double q[5] = {0, 0, 0, 0, 0};
             for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 24]; q[0] += (r[10]-r[0])/100.0; q[1] += (r[11]-r[10])/100.0; q[2] += (r[15]-r[11])/100.0; q[3] += (r[16]-r[15])/100.0; q[4] += (r[1]-r[16])/100.0; }
-            fprintf(stderr, "[dc2015 stage detail, us] issue-loads %.2f | barrier(loads land) %.2f | lds-store+barrier %.2f | stdp-prefetch issue %.2f | Ai lists + twists %.2f\n", q[0]/n, q[1]/n, q[2]/n, q[3]/n, q[4]/n);
+            fprintf(stderr, "[dc2015 stage detail, us] issue-loads (resident: poll) %.2f | barrier(loads land) (resident: digest->LDS) %.2f | lds-store+barrier %.2f | prefetch issue %.2f | Ai lists + twists %.2f\n", q[0]/n, q[1]/n, q[2]/n, q[3]/n, q[4]/n);
         }
         double ab[4] = {0, 0, 0, 0};
         for (int t = 2; t < R->T; ++t) { const long long *r = &h[(size_t)t * 24]; ab[0] += (r[12]-r[1])/100.0; ab[1] += (r[13]-r[12])/100.0; ab[2] += (r[14]-r[13])/100.0; ab[3] += (r[2]-r[14])/100.0; }
@@ -1065,7 +1745,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         fprintf(stderr, "[dc2015 timing, us] stage %.2f | arb %.2f | A2 %.2f | stdp %.2f | cur %.2f | membrane %.2f | xtrace %.2f\n",
                 acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
     }
-    snn_set_plan_name("dc2015-fused");
+    snn_set_plan_name(resident ? "dc2015-resident" : "dc2015-fused");
     *handled = 1;
     return SNN_OK;
 }

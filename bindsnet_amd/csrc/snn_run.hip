@@ -53,7 +53,7 @@ void snn_set_plan_name(const char *name) { g_plan = name; }
 extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int *handled);
+                         hipStream_t st, int resident, int *handled);
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            hipStream_t st, int *handled);
 
@@ -175,8 +175,8 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     TRY(validate(L, nL, C, nC, R));
     hipStream_t st = (hipStream_t)stream;
     int handled = 0;
-    if (g_plan_mode == 0) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, &handled));
-    if (g_plan_mode == 0 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled));
+    if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled));
+    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled));
     if (!handled) {
         g_plan = "generic";
         TRY(run_generic(L, nL, C, nC, R, st));

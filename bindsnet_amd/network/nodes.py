@@ -20,9 +20,19 @@ def _f(t) -> float:
     """Python float of a 0-dim parameter.  Per-neuron (tensor-valued) parameters are outside
     the accelerated path (SURVEY.md 8(b) fallback rule) and are rejected loudly."""
     if isinstance(t, torch.Tensor):
+        # .item() on a device tensor is a blocking copy (~15 us each, ~20 per run()): remember the value on the
+        # tensor object itself, keyed by its in-place version counter
+        hit = getattr(t, "_snn_scalar", None)
+        if hit is not None and hit[0] == t._version:
+            return hit[1]
         if t.numel() != 1:
             raise NotImplementedError("bindsnet_amd: tensor-valued per-neuron parameters are not supported")
-        return float(t.reshape(()).item())
+        val = float(t.reshape(()).item())
+        try:
+            t._snn_scalar = (t._version, val)
+        except AttributeError:
+            pass
+        return val
     return float(t)
 
 

@@ -39,7 +39,8 @@ enum {
     SNN_ERR_UNSUPPORTED = -2,  /* size outside what the kernels were built for */
     SNN_ERR_LAUNCH = -3,       /* hip launch / runtime error (see snn_last_hip_error) */
     SNN_ERR_NOISE = -4,        /* one_spike noise stream exhausted (device status word) */
-    SNN_ERR_NO_DEVICE = -5
+    SNN_ERR_NO_DEVICE = -5,
+    SNN_ERR_TIMEOUT = -6       /* an in-kernel workgroup hand-off gave up waiting (device status word) */
 };
 
 int snn_abi_version(void);
@@ -242,7 +243,8 @@ void snn_profile_enable(int stride);
 int snn_profile_collect(double *h_sum_ms, int *h_samples);
 /* Fused-plan bookkeeping: runs issued as plain launches / captured into a hipGraph / replayed from one. */
 void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed);
-/* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only. */
+/* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only,
+ * 2 = fused plans in their one-launch-per-timestep form (no resident kernel). */
 void snn_set_plan_mode(int mode);
 
 #ifdef __cplusplus

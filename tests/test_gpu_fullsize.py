@@ -34,11 +34,11 @@ def build(plan_generic):
     return net, mons
 
 
-def run_plan(generic, n_inputs=3):
+def run_plan(mode, n_inputs=3):
     from bindsnet_amd import _lib
-    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    _lib.lib().snn_set_plan_mode(mode)                # 0 resident kernel, 1 generic, 2 one launch per timestep
     try:
-        net, mons = build(generic)
+        net, mons = build(mode)
         out = []
         for r in range(n_inputs):
             spikes = synth.spike_train(50 + r, T, B, 784)
@@ -53,7 +53,7 @@ def run_plan(generic, n_inputs=3):
             st["sI"] = mons["Ai"].get("s").cpu().numpy().reshape(T, B, N).astype(u8)
             st["probe"] = probe.numpy()
             out.append(st)
-            assert net.last_plan == ("generic" if generic else "dc2015-fused")
+            assert net.last_plan == ("dc2015-resident", "generic", "dc2015-fused")[mode]
             net.reset_state_variables()
         return out
     finally:
@@ -61,10 +61,11 @@ def run_plan(generic, n_inputs=3):
 
 
 def test_fused_equals_generic_and_properties_at_full_size():
-    fused, generic = run_plan(False), run_plan(True)
-    for r, (a, b) in enumerate(zip(fused, generic)):
-        for k in a:
-            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"input {r}: {k}")
+    fused, generic, stepped = run_plan(0), run_plan(1), run_plan(2)
+    for other in (generic, stepped):
+        for r, (a, b) in enumerate(zip(fused, other)):
+            for k in a:
+                np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"input {r}: {k}")
     for r, a in enumerate(fused):
         assert a["sE"].sum(axis=2).max() <= 1, "one_spike violated"
         assert a["sE"].sum() > 50 and a["sI"].sum() > 50, "network is silent: test is vacuous"

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run(generic, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0):
+def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0):
     from bindsnet_amd import _lib
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
-    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    _lib.lib().snn_set_plan_mode(int(mode))          # 0 auto (resident kernel), 1 generic, 2 one launch per timestep
     try:
         torch.manual_seed(0)
         net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape)
@@ -77,27 +77,32 @@ def test_fused_equals_generic_under_stress(name):
         if vmax > 1:
             s = (s * rs.randint(1, vmax + 1, size=s.shape)).astype(np.uint8)
         spikes.append(s)
-    fused, plan = run(False, N, B, T, spikes, w_scale=wsc)
-    assert plan == "dc2015-fused"
-    generic, plan_g = run(True, N, B, T, spikes, w_scale=wsc)
+    fused, plan = run(0, N, B, T, spikes, w_scale=wsc)
+    assert plan == "dc2015-resident"
+    stepped, plan_s = run(2, N, B, T, spikes, w_scale=wsc)
+    assert plan_s == "dc2015-fused"
+    generic, plan_g = run(1, N, B, T, spikes, w_scale=wsc)
     assert plan_g == "generic"
     same(fused, generic)
+    same(stepped, generic)
     assert sum(int(x["sE"].sum()) for x in fused) > 0, "no excitatory spike at all: vacuous"
     assert all(x["sE"].reshape(T, B, N).sum(axis=2).max() <= 1 for x in fused)
 
 
 def test_learning_off_and_weak_inhibition():
     spikes = [synth.dense_spikes(80 + r, (30, 6, 784), 0.03) for r in range(2)]
-    f, _ = run(False, 100, 6, 30, spikes, learning=False, inh=17.5)
-    g, _ = run(True, 100, 6, 30, spikes, learning=False, inh=17.5)
+    f, _ = run(0, 100, 6, 30, spikes, learning=False, inh=17.5)
+    h, _ = run(2, 100, 6, 30, spikes, learning=False, inh=17.5)
+    g, _ = run(1, 100, 6, 30, spikes, learning=False, inh=17.5)
     same(f, g)
+    same(h, g)
 
 
 def test_plan_refuses_unsupported_shapes_and_falls_back():
     # Nin not a multiple of 16 and batch > 32 are outside the fused plan: the generic plan must take over
     spikes = [synth.dense_spikes(90, (6, 3, 100), 0.1)] * 2
-    out, plan = run(False, 20, 3, 6, spikes, Nin=100, shape=(100,))
+    out, plan = run(0, 20, 3, 6, spikes, Nin=100, shape=(100,))
     assert plan == "generic"
     spikes = [synth.dense_spikes(91, (5, 40, 784), 0.02)] * 2
-    out, plan = run(False, 64, 40, 5, spikes)
+    out, plan = run(0, 64, 40, 5, spikes)
     assert plan == "generic"

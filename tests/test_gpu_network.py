@@ -34,7 +34,11 @@ def build_dc(N, B, inh):
     return net
 
 
-@pytest.mark.parametrize("plan", ["auto", "generic"])
+PLAN_MODE = {"auto": 0, "generic": 1, "per-step": 2}
+PLAN_NAME = {"auto": "dc2015-resident", "generic": "generic", "per-step": "dc2015-fused"}
+
+
+@pytest.mark.parametrize("plan", ["auto", "per-step", "generic"])
 @pytest.mark.parametrize("name", DC_RUNS)
 def test_dc2015_network_run_matches_reference(name, plan):
     from bindsnet_amd import _lib
@@ -49,7 +53,7 @@ def test_dc2015_network_run_matches_reference(name, plan):
     mv = Monitor(net.layers["Ae"], ["v"], time=T)
     net.add_monitor(mv, "Ae_v")
     net.to(DEV)
-    _lib.lib().snn_set_plan_mode(1 if plan == "generic" else 0)
+    _lib.lib().snn_set_plan_mode(PLAN_MODE[plan])
     try:
         for r in range(runs):
             spikes = synth.spike_train(20 + r, T, B, 784, max_rate=float(g["max_rate"]))
@@ -76,7 +80,7 @@ def test_dc2015_network_run_matches_reference(name, plan):
             np.testing.assert_array_equal(bits(host(mv.get("v"))[-1]), bits(g[f"r{r}_vE"]))
             if r % 2 == 0:
                 net.reset_state_variables()
-        assert net.last_plan == ("generic" if plan == "generic" else "dc2015-fused")
+        assert net.last_plan == PLAN_NAME[plan]
     finally:
         _lib.lib().snn_set_plan_mode(0)
 
