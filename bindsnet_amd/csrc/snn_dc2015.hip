@@ -84,6 +84,7 @@ struct DcCtx {
     unsigned long long *ex; int KB;
     float *xtr;
     int *status;
+    int has_norm; float norm; int norm_abs;   // post-run normalisation of Wxe, done in the resident kernel's epilogue
     int dbg_wg;
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
 };
@@ -900,12 +901,9 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
     const int q = tid % CW, jq = c0 + q;                          // NT % CW == 0: a thread keeps its column
     if (jq >= N) return;
     const uint32_t cm = (c.nu1 != 0.f) ? colmask[q] : 0u;
-    for (int item = tid; item < nitems; item += NT) {
-        const int i = FULL ? (item / CW) : (int)arows[item / CW];
+    auto update = [&](int i, uint32_t m, float w) -> float {
         const int e = i * N + jq;
-        float w = wtile[i * CW + q];
         if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
-            uint32_t m = rowmask[i];
             float uu = 0.f;
             if (m) {
                 SUM acc; acc.init(e >= Emain);
@@ -920,12 +918,12 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
             w = w - uu;
         }
         if (c.nu1 != 0.f) {                                      // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
-            uint32_t m = cm;
+            uint32_t mm = cm;
             float uu = 0.f;
-            if (m) {
+            if (mm) {
                 SUM acc; acc.init(e >= Emain);
-                while (m) {
-                    const int b = __ffs(m) - 1; m &= m - 1;
+                while (mm) {
+                    const int b = __ffs(mm) - 1; mm &= mm - 1;
                     acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
                 }
                 uu = acc.finish(B);
@@ -935,7 +933,18 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
         }
         if (c.has_min && w < c.wmin) w = c.wmin;
         if (c.has_max && w > c.wmax) w = c.wmax;
-        wtile[i * CW + q] = w;
+        return w;
+    };
+    // two items per round: their (independent) row index / mask / weight reads share the LDS latencies
+    for (int it0 = tid; it0 < nitems; it0 += 2 * NT) {
+        const int it1 = it0 + NT;
+        const bool h1 = it1 < nitems;
+        const int i0 = FULL ? (it0 / CW) : (int)arows[it0 / CW];
+        const int i1 = h1 ? (FULL ? (it1 / CW) : (int)arows[it1 / CW]) : i0;
+        const uint32_t m0 = rowmask[i0], m1 = rowmask[i1];
+        const float w0 = wtile[i0 * CW + q], w1 = wtile[i1 * CW + q];
+        wtile[i0 * CW + q] = update(i0, m0, w0);
+        if (h1) wtile[i1 * CW + q] = update(i1, m1, w1);
     }
 }
 
@@ -1472,11 +1481,61 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         if (c.pE.lif.traces) c.xE[kst] = r_xE;
         c.sE[kst] = last_sE; c.sI[kst] = last_sI;
     }
-    if (c.learning && c.rule == SNN_RULE_POSTPRE)
+    if (c.has_norm) {
+        // network.py:464-465 + topology_features.py:250-266: column sums in ATen's sum(dim=0) order over the
+        // LDS-resident slice, zero -> 1, W *= norm * (1 / colsum)   (same arithmetic as k_colsum / k_scale_cols)
+        float *bsum = (float *)dgbuf;                  // [nfull][CW] block sums; the digest buffers are free now
+        float *sc = xnu0;                              // [CW] column scales
+        const int nfull = Nin >> 4;
+        __syncthreads();
+        if (!tailcol) {
+            for (int item = tid; item < nfull * CW; item += NT) {
+                const int blk = item / CW, q = item % CW;
+                float a0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const float w = wtile[(blk * 16 + k) * CW + q]; a0 += c.norm_abs ? fabsf(w) : w; }
+                bsum[item] = a0;
+            }
+            __syncthreads();
+            if (tid < CW) {
+                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int blk = 0; blk < nfull; ++blk) {
+                    a1 += bsum[blk * CW + tid];
+                    const int m = blk + 1;
+                    if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+                }
+                float a0 = 0.f;
+                for (int i = nfull * 16; i < Nin; ++i) { const float w = wtile[i * CW + tid]; a0 += c.norm_abs ? fabsf(w) : w; }
+                float cs = ((a0 + a1) + a2) + a3;
+                if (cs == 0.f) cs = 1.0f;
+                sc[tid] = (1.0f / cs) * c.norm;
+            }
+        } else {
+            __syncthreads();
+            if (tid < CW * 4) {                         // row_sum columns: four interleaved lanes per column
+                const int q = tid >> 2, s4 = tid & 3, n4 = Nin >> 2, nf4 = n4 >> 4;
+                Cascade cc; cc.init();
+                for (int p_ = 0; p_ < n4; ++p_) { const float w = wtile[(4 * p_ + s4) * CW + q]; cc.add(p_, c.norm_abs ? fabsf(w) : w, nf4); }
+                float lsum = cc.finish(nf4);
+                if (s4 == 0)
+                    for (int i = n4 * 4; i < Nin; ++i) { const float w = wtile[i * CW + q]; lsum += c.norm_abs ? fabsf(w) : w; }
+                const float l1 = __shfl_down(lsum, 1, 4), l2 = __shfl_down(lsum, 2, 4), l3 = __shfl_down(lsum, 3, 4);
+                float cs = ((lsum + l1) + l2) + l3;
+                if (cs == 0.f) cs = 1.0f;
+                if (s4 == 0) sc[q] = (1.0f / cs) * c.norm;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k] * sc[q];
+        }
+    } else if (c.learning && c.rule == SNN_RULE_POSTPRE) {
         for (int k = tid; k < Nin * CW; k += NT) {
             const int i = k / CW, q = k % CW;
             if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k];
         }
+    }
     if (g == 0 && c.pE.one_spike) {
         snn_rng_state *wr = c.rng[0];
         if (tid < 624) wr->mt[tid] = mt[mb * 624 + tid];
@@ -1564,8 +1623,9 @@ extern "C" void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed) 
 }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int resident, int *handled) {
+                         hipStream_t st, int resident, int *handled, unsigned *normalized) {
     *handled = 0;
+    *normalized = 0;
     if (!matches(L, nL, C, nC, R)) return SNN_OK;
     const int B = R->B, Nin = L[0].n, N = L[1].n;
     DcCtx c;
@@ -1603,6 +1663,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         c.ex = (unsigned long long *)p;
         c.xtr = (float *)(p + al2((size_t)2 * c.G * c.KB * 8));
         c.status = R->status;
+        c.has_norm = C[0].has_norm; c.norm = C[0].norm; c.norm_abs = C[0].norm_abs;
     }
     // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
     if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
@@ -1745,6 +1806,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         fprintf(stderr, "[dc2015 timing, us] stage %.2f | arb %.2f | A2 %.2f | stdp %.2f | cur %.2f | membrane %.2f | xtrace %.2f\n",
                 acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
     }
+    if (resident && c.has_norm) *normalized |= 1u;          // connection 0 was normalised in the kernel's epilogue
     snn_set_plan_name(resident ? "dc2015-resident" : "dc2015-fused");
     *handled = 1;
     return SNN_OK;

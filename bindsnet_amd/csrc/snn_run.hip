@@ -53,7 +53,7 @@ void snn_set_plan_name(const char *name) { g_plan = name; }
 extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int resident, int *handled);
+                         hipStream_t st, int resident, int *handled, unsigned *normalized);
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            hipStream_t st, int *handled);
 
@@ -175,7 +175,8 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     TRY(validate(L, nL, C, nC, R));
     hipStream_t st = (hipStream_t)stream;
     int handled = 0;
-    if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled));
+    unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
+    if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled, &normalized));
     if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled));
     if (!handled) {
         g_plan = "generic";
@@ -183,7 +184,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     }
     // network.py:464-465: normalise every connection after the loop (learning or not)
     for (int c = 0; c < nC; ++c)
-        if (C[c].has_norm)
+        if (C[c].has_norm && !((normalized >> c) & 1u))
             TRY(snn_normalize(C[c].w, L[C[c].src].n, L[C[c].dst].n, C[c].norm, C[c].norm_abs, C[c].norm_ws, st));
     return SNN_OK;
 }

@@ -70,8 +70,24 @@ class Network(torch.nn.Module):
         return torch.load(f, weights_only=False)
 
     def reset_state_variables(self) -> None:
+        # Layers of the stock classes are reset together: a handful of multi-tensor launches instead of ~4 fills
+        # per layer (same values: s, x, refrac_count -> 0, v -> rest; theta is NOT reset, nodes.py:1113-1120).
+        zero, vs, rests = [], [], []
         for l in self.layers.values():
-            l.reset_state_variables()
+            if type(l) in (Input, LIFNodes, DiehlAndCookNodes) and l.s.is_cuda:
+                zero.append(l.s)
+                if l.traces:
+                    zero.append(l.x)
+                if type(l) is not Input:
+                    zero += [l.refrac_count, l.v]
+                    vs.append(l.v)
+                    rests.append(_f(l.rest))
+            else:
+                l.reset_state_variables()
+        if zero:
+            torch._foreach_zero_(zero)
+        if vs:
+            torch._foreach_add_(vs, rests)             # 0 + rest == rest exactly
         for c in self.connections.values():
             c.reset_state_variables()
         for m in self.monitors.values():

@@ -96,3 +96,44 @@ def test_first_steps_match_oracle_at_full_size():
     W = net.connections[("X", "Ae")].pipeline[0].value.cpu().numpy()
     np.testing.assert_array_equal(W.view(np.uint32), st["W_xe"].view(np.uint32))
     np.testing.assert_array_equal(net.layers["Ae"].theta.cpu().numpy().view(np.uint32), st["theta"].view(np.uint32))
+
+
+def _final_state(net, mons):
+    return {
+        "W": net.connections[("X", "Ae")].pipeline[0].value.detach().cpu().numpy().copy(),
+        "theta": net.layers["Ae"].theta.detach().cpu().numpy().copy(),
+        "sE": mons["Ae"].get("s").cpu().numpy().reshape(T, B, N).astype(u8),
+        "sI": mons["Ai"].get("s").cpu().numpy().reshape(T, B, N).astype(u8),
+    }
+
+
+def test_resident_kernel_soak_and_competing_load():
+    """The resident plan hands spikes between workgroups INSIDE one launch (tagged granules).  Run it many
+    times back to back, with another stream keeping the chip busy (uneven load, delayed workgroup
+    start), and require bit-identical results to the one-launch-per-timestep form run on an idle chip."""
+    from bindsnet_amd import _lib
+    n_inputs = 12
+    outs = {}
+    for mode in (2, 0):
+        _lib.lib().snn_set_plan_mode(mode)
+        try:
+            net, mons = build(mode)
+            side = torch.cuda.Stream()
+            a = torch.randn(2048, 2048, device=DEV)
+            for r in range(n_inputs):
+                spikes = torch.from_numpy(synth.spike_train(300 + r, T, B, 784)).view(T, B, 1, 28, 28).to(DEV)
+                torch.manual_seed(40 + r)
+                if mode == 0:
+                    with torch.cuda.stream(side):      # ~10 ms of GEMMs racing the resident kernel for CUs
+                        for _ in range(40):
+                            a = torch.tanh(a @ a * 1e-3)
+                net.run({"X": spikes}, time=T)
+                net.reset_state_variables() if r % 3 == 0 else None
+            torch.cuda.synchronize()
+            assert net.last_plan == ("dc2015-resident", "generic", "dc2015-fused")[mode]
+            outs[mode] = _final_state(net, mons)
+        finally:
+            _lib.lib().snn_set_plan_mode(0)
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k].view(np.uint8), outs[2][k].view(np.uint8), err_msg=k)
+    assert outs[0]["sE"].sum() > 20
