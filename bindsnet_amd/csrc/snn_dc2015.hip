@@ -266,6 +266,29 @@ __device__ __forceinline__ int build_list(const uint32_t *words, int nwords, int
     return total;
 }
 
+// Two rows per wave: lanes 0..31 list row A, lanes 32..63 row B (nwords <= 32).  `words` / `out` are the calling
+// lane's own row; returns that row's total count.  Rows past the end: pass words == nullptr.
+__device__ __forceinline__ int build_list_half(const uint32_t *words, int nwords, int lane, uint16_t *out, int cap) {
+    const int hl = lane & 31;
+    const uint64_t halfmask = (lane & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+    uint32_t m = (words && hl < nwords) ? words[hl] : 0u;
+    const int cn = __popc(m);
+    const uint64_t below = ((1ull << lane) - 1ull) & halfmask;
+    int offp = 0, total = 0;
+    for (int k = 0; ; ++k) {
+        const uint64_t bm = __ballot(cn > k);
+        if (!bm) break;
+        offp += __popcll(bm & below);
+        total += __popcll(bm & halfmask);
+    }
+    while (m) {
+        const int i = hl * 32 + __ffs(m) - 1; m &= m - 1;
+        if (offp < cap) out[offp] = (uint16_t)i;
+        ++offp;
+    }
+    return total;
+}
+
 // Input currents of neuron j of sample b from the previous step's spikes, in connection insertion order
 // (network.py:225-248): Ae <- (zeros + X->Ae) + Ai->Ae ; Ai <- zeros + Ae->Ai, each summed in ascending source
 // order.  X->Ae weights come from the LDS tile the STDP pass just refreshed (wtile != nullptr: row `rowpos[i]`
@@ -1238,7 +1261,21 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         const bool stdp_full = t == 1;
         const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
         // ---- per sample (one wave each, in turns): event list of its Ai spikes; does it have an Ae crossing?
-        {
+        if (NW <= 32) {                                    // two samples per wave, one per half
+            const int hl = lane & 31;
+            const uint64_t halfmask = (lane & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+            for (int b2 = wave * 2; b2 < B; b2 += NWV * 2) {
+                const int b = b2 + (lane >> 5);
+                const bool bv = b < B;
+                const int ni = build_list_half(bv ? spI + b * NW : nullptr, NW, lane, lstI + (bv ? b : 0) * LR, LR);
+                const uint64_t mc = __ballot(use_rng && bv && hl < NW && crs[b * NW + hl] != 0) & halfmask;
+                if (hl == 0 && bv) {
+                    cntI[b] = ni;
+                    if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
+                    if (ni > 4) atomicOr((unsigned int *)&misc[2], 2u);
+                }
+            }
+        } else {
             for (int b = wave; b < B; b += NWV) {
                 const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
                 const uint64_t mc = __ballot(use_rng && lane < NW && crs[b * NW + lane] != 0);
@@ -1297,14 +1334,15 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             }
             lds_barrier();
             DBG_MARK(13);
-            if (tid < BW) {
+            if (tid < BW) {        // final spikes: the winner's bit, or nothing -- and with them the event lists (<= 1 entry)
                 uint32_t wbits = 0;
                 if ((anym >> wb) & 1u) {
                     const int win = (int)(0xFFFFFFFFu - (uint32_t)(keys[wb] & 0xFFFFFFFFull));
-                    if ((win >> 5) == wj) wbits = 1u << (win & 31);
+                    if ((win >> 5) == wj) { wbits = 1u << (win & 31); lstE[wb * LR] = (uint16_t)win; }
                 }
                 finE[tid] = wbits;
             }
+            if (tid < B) cntE[tid] = (int)((anym >> tid) & 1u);
             mb = (mb + ntw) & 7; ahead -= ntw;
             rng_pos = E - 624 * ntw;
             rng_consumed += (long long)rows * N;
@@ -1313,10 +1351,11 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         }
         lds_barrier();
         DBG_MARK(14);
-        for (int b = wave; b < B; b += NT / 64) {
-            const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
-            if (lane == 0) { cntE[b] = ne; if (ne > 4) atomicOr((unsigned int *)&misc[2], 2u); }
-        }
+        if (!use_rng)                                      // (one_spike: the winners above already are the lists)
+            for (int b = wave; b < B; b += NT / 64) {
+                const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
+                if (lane == 0) { cntE[b] = ne; if (ne > 4) atomicOr((unsigned int *)&misc[2], 2u); }
+            }
         DBG_MARK(2);
         if (phaseA) {
             if (tid < TT && bl < B) {
