@@ -1286,6 +1286,17 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 }
             }
         }
+        if (use_rng && tid < BW) {                         // threshold crossers of this (sample, word) -> compact candidate list
+            uint32_t bits = crs[tid];
+            if (bits) {
+                int at = atomicAdd(&misc[4], __popc(bits));
+                while (bits) {
+                    const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                    if (at < NCAND) cand[at] = ((uint32_t)wb << 16) | (uint32_t)jx;
+                    ++at;
+                }
+            }
+        }
         DBG_MARK(1);
         lds_barrier();
         const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
@@ -1293,26 +1304,15 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
 
         // ================================================================== phase A: finish step t-1
+        uint32_t anym = 0;                                 // samples with an Ae crossing at step t-1
         if (use_rng) {
             DBG_MARK(12);
-            const uint32_t anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
+            anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
             const int rows = __popc(anym);
             const int pos = rng_pos;
             const int E = pos + 2 * rows * N;
             const int ntw = rows ? (E - 1) / 624 : 0;
             const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
-            if (tid < BW) {
-                uint32_t bits = crs[tid];
-                if (bits) {
-                    int at = atomicAdd(&misc[4], __popc(bits));
-                    while (bits) {
-                        const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
-                        if (at < NCAND) cand[at] = ((uint32_t)wb << 16) | (uint32_t)jx;
-                        ++at;
-                    }
-                }
-            }
-            lds_barrier();
             const int ncand = __builtin_amdgcn_readfirstlane(misc[4]);
             if (ncand <= NCAND && ntw <= 7) {
                 for (int k = tid; k < ncand; k += NT) {
@@ -1346,20 +1346,23 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             mb = (mb + ntw) & 7; ahead -= ntw;
             rng_pos = E - 624 * ntw;
             rng_consumed += (long long)rows * N;
-        } else if (phaseA) {
-            if (tid < BW) finE[tid] = crs[tid];
-        }
-        lds_barrier();
-        DBG_MARK(14);
-        if (!use_rng)                                      // (one_spike: the winners above already are the lists)
-            for (int b = wave; b < B; b += NT / 64) {
+            // (no barrier: the trace stage below takes the winners straight from `keys`; finE / lstE / cntE are for
+            //  the stages behind its barrier)
+        } else {
+            if (phaseA && tid < BW) finE[tid] = crs[tid];
+            lds_barrier();
+            for (int b = wave; b < B; b += NT / 64) {      // event lists of the final Ae spikes
                 const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
                 if (lane == 0) { cntE[b] = ne; if (ne > 4) atomicOr((unsigned int *)&misc[2], 2u); }
             }
+        }
+        DBG_MARK(14);
         DBG_MARK(2);
         if (phaseA) {
             if (tid < TT && bl < B) {
-                const bool sp = colv && bit_of(finE + bl * NW, j);
+                bool sp;
+                if (use_rng) sp = colv && ((anym >> bl) & 1u) && (int)(0xFFFFFFFFu - (uint32_t)(keys[bl] & 0xFFFFFFFFull)) == j;
+                else sp = colv && bit_of(finE + bl * NW, j);
                 float xn = 0.f;
                 if (colv) {
                     if (c.pE.lif.traces) { xn = trace_next(r_xE, sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); r_xE = xn; }
