@@ -1452,8 +1452,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                     const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
                     e1 = ((v + v1) + v2) + v3;
                 }
-                const float e2 = quad_lane_sum<4>(ii, nI, wi, nullptr, N, cL);
-                const float e3 = quad_lane_sum<4>(ie, nE, we, nullptr, N, cL);
+                // recurrent sums: with at most one spiking source the row_sum of a column is that one term (every other
+                // lane and level contributes +0.0), so the quad machinery is only needed for two or more
+                const float e2 = nI <= 1 ? (nI ? wi[0] * 1.0f + 0.0f : 0.0f) : quad_lane_sum<4>(ii, nI, wi, nullptr, N, cL);
+                const float e3 = nE <= 1 ? (nE ? we[0] * 1.0f + 0.0f : 0.0f) : quad_lane_sum<4>(ie, nE, we, nullptr, N, cL);
                 if (cL == 0) {
                     curbuf[(cb_ * CW + cj_) * 2] = (0.0f + e1) + e2;
                     curbuf[(cb_ * CW + cj_) * 2 + 1] = 0.0f + e3;
