@@ -62,8 +62,9 @@ def build_network(device):
 def pmc_traffic(plan):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
     command (profiles/r01_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    if plan != "dc2015-fused" or not os.path.exists(path):
+    name = {"dc2015-resident": "r01_resident_pmc_hbm_traffic.json", "dc2015-fused": "r01_pmc_hbm_traffic.json"}.get(plan)
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
         return None
     with open(path) as f:
         return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")

@@ -261,12 +261,13 @@ class Network(torch.nn.Module):
                 continue
             for var in m.state_vars:
                 if var == "s":
-                    if mon_s is None:          # bool like layer.s; the kernels store 0/1 bytes
-                        mon_s = torch.zeros(T, B, *layer.shape, dtype=torch.bool, device=dev)
+                    if mon_s is None:          # bool like layer.s; the node kernels store a 0/1 byte for EVERY
+                        # (step, sample, neuron), so the buffer needs no initialisation
+                        mon_s = torch.empty(T, B, *layer.shape, dtype=torch.bool, device=dev)
                     rasters.append((m, "s", mon_s))
                 elif var == "v" and hasattr(layer, "v"):
                     if mon_v is None:
-                        mon_v = torch.zeros(T, B, *layer.shape, device=dev)
+                        mon_v = torch.empty(T, B, *layer.shape, device=dev)
                     rasters.append((m, "v", mon_v))
                 else:
                     raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "

@@ -40,7 +40,8 @@ def main():
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)
-    st.sort_stats("cumulative").print_stats(28)
+    st.sort_stats("cumulative").print_stats(18)
+    st.sort_stats("tottime").print_stats(22)
 
 
 if __name__ == "__main__":
