@@ -56,6 +56,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                          hipStream_t st, int resident, int *handled, unsigned *normalized);
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            hipStream_t st, int *handled);
+int snn_try_fused_convlif(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
+                          hipStream_t st, int *handled);
 
 int snn_launch_dc_membrane(float *v, float *refrac, uint8_t *s, float *theta, const float *I, int B, int N,
                            const snn_dc_params &p, long long *cursor, float *raster_v, hipStream_t st);
@@ -178,6 +180,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled, &normalized));
     if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled));
+    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));
     if (!handled) {
         g_plan = "generic";
         TRY(run_generic(L, nL, C, nC, R, st));
