@@ -55,6 +55,10 @@ struct TwoCtx {
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
     float inv_hwps;
     int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= NT)
+    // MSTDP (learning.py:1504-1574), factored eligibility: p_plus / p_minus traces, previous-step spike factors
+    float *p_plus, *p_minus; uint8_t *s_src_prev, *s_tgt_prev;
+    float *pall;                                         // [T+1][B][Nin] p_plus at entry / after every step
+    float a_plus, a_minus, d_plus, d_minus, reward; const float *reward_vec;
     long long *dbg;                                      // developer aid (SNN_TWO_TIMING=1): phase timestamps of workgroup 0
 };
 
@@ -77,10 +81,30 @@ __global__ __launch_bounds__(256) void k_two_xtrace(const TwoCtx c) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xall[(size_t)(t + u) * n + k] = x; }
+        for (int u = 0; u < 4; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); if (c.xall) c.xall[(size_t)(t + u) * n + k] = x; }
     }
-    for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); c.xall[(size_t)t * n + k] = x; }
+    for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); if (c.xall) c.xall[(size_t)t * n + k] = x; }
     c.xXout[k] = x;
+}
+
+// MSTDP's source trace p_plus after every step (learning.py:1564-1565): entry 0 = value at run entry, entry
+// k+1 = after step k.  It depends on the inputs alone, like the X trace.
+__global__ __launch_bounds__(256) void k_two_pplus(const TwoCtx c) {
+    const int n = c.B * c.Nin;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    float x = c.p_plus[k];
+    c.pall[k] = x;
+    int t = 0;
+    for (; t + 4 <= c.T; t += 4) {
+        uint8_t s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float p = x * c.d_plus; x = p + c.a_plus * (float)s[u]; c.pall[(size_t)(t + u + 1) * n + k] = x; }
+    }
+    for (; t < c.T; ++t) { const float p = x * c.d_plus; x = p + c.a_plus * (float)c.in[(size_t)t * n + k]; c.pall[(size_t)(t + 1) * n + k] = x; }
+    c.p_plus[k] = x;
 }
 
 // ---------------------------------------------------------------------------------------------- spike digest
@@ -94,7 +118,8 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     int *cntb = (int *)(rowmask + Nin);                  // [B+1] per-sample counts -> offsets
     int *misc = cntb + MAXB + 1;                         // [0] nact, [1] flags
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
-    const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
+    // (MSTDP: one more entry, T+1 = the source spikes the rule remembers from its last update before this run)
+    const uint8_t *src = (e == 0) ? c.sX0 : (e == c.T + 1 ? c.s_src_prev : c.in + (size_t)(e - 1) * B * Nin);
     uint32_t *D = c.dig + (size_t)e * c.DW;
     uint16_t *D_ent = (uint16_t *)(D + c.o_ent), *D_ar = (uint16_t *)(D + c.o_ar);
     uint32_t *D_am = D + c.o_am, *D_ab = D + c.o_ab, *D_xw = D + c.o_xw;
@@ -304,6 +329,54 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
     }
 }
 
+// MSTDP update of one step on the LDS weight tile (learning.py:1504-1574 with the eligibility factored as in
+// snn_mstdp_step): w += nu0 * sum_b reward[b] * (p_plus[b,i] * s_tgt[b,j] + s_src[b,i] * p_minus[b,j]), decay, clamp,
+// all four factors being those of the PREVIOUS step.  Samples in which neither side spiked contribute +0.0 and are
+// skipped; p_plus >= +0 (a_plus >= 0, host check) so a silent target contributes exactly +0.0 without loading it.
+template <class SUM>
+__device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
+                                          const uint32_t *ab, const float *pml, const uint32_t *cm, const float *rvl,
+                                          const float *__restrict__ pp, const uint8_t *__restrict__ sbytes,
+                                          int nact, bool full, int c0, int tid, int cwl, int Emain) {
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW;
+    auto elem = [&](int i, int q, uint32_t m, uint32_t cq, float w) -> float {
+        SUM acc; acc.init(i * N + c0 + q >= Emain);
+        uint32_t mm = m | cq;
+        while (mm) {
+            const int b = __ffs(mm) - 1; mm &= mm - 1;
+            const float e1 = ((cq >> b) & 1u) ? pp[b * Nin + i] * 1.0f : 0.0f;                          // p_plus (x) s_tgt
+            const float sv = ((m >> b) & 1u) ? (sbytes ? (float)sbytes[b * Nin + i] : 1.0f) : 0.0f;
+            const float e2 = sv * pml[b * 8 + q];                                                       // s_src (x) p_minus
+            acc.add(b, rvl[b] * (e1 + e2), B);
+        }
+        const float u = acc.finish(B);
+        w = w + c.nu0 * u;                                // learning.py:1561
+        w = w * c.wdecay;
+        if (c.has_min && w < c.wmin) w = c.wmin;
+        if (c.has_max && w > c.wmax) w = c.wmax;
+        return w;
+    };
+    // ---- pass 1: rows whose source spiked x own columns
+    for (int item = tid; item < (nact << cwl); item += NT) {
+        const int kq = item >> cwl, q = item & (CW - 1);
+        if (c0 + q >= N) continue;
+        const int i = (int)ar[kq];
+        wt[i * CW + q] = elem(i, q, am[kq], cm[q], wt[i * CW + q]);
+    }
+    // ---- pass 2: the other rows: the columns whose target spiked (every column when `full`)
+    uint32_t todo = 0;
+    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || cm[q])) todo |= 1u << q;
+    if (!todo) return;
+    for (int i = tid; i < Nin; i += NT) {
+        if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
+        uint32_t td = todo;
+        while (td) {
+            const int q = __ffs(td) - 1; td &= td - 1;
+            wt[i * CW + q] = elem(i, q, 0u, cm[q], wt[i * CW + q]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW;
@@ -316,7 +389,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
     float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                     // [B][CW] x_tgt * nu0
     uint32_t *colmask = (uint32_t *)(smem + off); off += 16 * 4;                          // [2][8]: samples whose neuron (column q) spiked
-    int *szt = (int *)(smem + off); off += (size_t)(c.T + 1) * 8;                         // (events, active rows) of every digest entry
+    float *rvl = (float *)(smem + off); off += (size_t)MAXB * 4;                          // MSTDP: reward per sample
+    int *szt = (int *)(smem + off); off += (size_t)(c.T + 2) * 8;                         // (events, active rows) of every digest entry
     float *xsl = (float *)(smem + off); off += c.use_xsl ? (size_t)Nin * CW * 4 : 0;      // source trace of the first spiking sample of each column
 
     const int tid = threadIdx.x;
@@ -328,20 +402,28 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     const int Etot = Nin * N, Emain = (Etot / 32) * 32;
     const int cwl = 31 - __clz(CW);                      // CW is a power of two
     const bool do_stdp = c.learning && c.rule == SNN_RULE_POSTPRE;
+    const bool do_mstdp = c.learning && c.rule == SNN_RULE_MSTDP;
 
     // ---- prologue: own weight slice and membrane state
     for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; wt[k] = c0 + q < N ? c.W[i * N + c0 + q] : 0.f; }
-    float v = 0.f, rc = 0.f, xy = 0.f, bias = 0.f;
+    float v = 0.f, rc = 0.f, xy = 0.f, bias = 0.f, pm = 0.f;
     uint8_t sp_prev = 0;
     if (mine) {
         v = c.vY[kst]; rc = c.rY[kst];
         if (c.pY.traces) xy = c.xY[kst];
         if (c.bias) bias = c.bias[j];
+        if (do_mstdp) pm = c.p_minus[kst];
     }
     if (tid < 16) colmask[tid] = 0;
+    if (tid < MAXB) rvl[tid] = (do_mstdp && tid < B) ? (c.reward_vec ? c.reward_vec[tid] : c.reward) : 0.f;
+    if (do_mstdp) {      // the target spikes the rule remembers from its last update: "previous step" of iteration 0
+        __syncthreads();
+        if (mine && c.s_tgt_prev[kst]) atomicOr(&colmask[8 + jj], 1u << bl);
+    }
     // digest words copied into LDS each step: [meta | entries | row masks | active rows | row bitmap]
     const int region4 = NinW;
-    for (int k = tid; k < (c.T + 1) * 2; k += NT) szt[k] = (int)c.dig[(size_t)(k >> 1) * c.DW + (k & 1)];
+    for (int k = tid; k < (c.T + 2) * 2; k += NT)
+        szt[k] = ((k >> 1) <= c.T || do_mstdp) ? (int)c.dig[(size_t)(k >> 1) * c.DW + (k & 1)] : 0;
     __syncthreads();
     uint32_t r_dg[PF];
     float x_pf[8];
@@ -450,6 +532,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         }
         TMARK(5);
         if (mine) {
+            if (do_mstdp) {
+                xnu0[bl * 8 + jj] = pm;                   // p_minus of the PREVIOUS step: a factor of this step's update
+                const float p = pm * c.d_minus;           // learning.py:1566-1567
+                pm = p + c.a_minus * (float)sp;
+            } else
             xnu0[bl * 8 + jj] = xy * c.nu0;               // target_x * nu[0]
             if (sp) atomicOr(&cmn[jj], 1u << bl);
             if (c.rasY) c.rasY[(size_t)t * B * N + kst] = sp;
@@ -461,6 +548,28 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const uint32_t m = q < CW ? cmn[q] : 0u; x_pf[q] = m ? xs[(__ffs(m) - 1) * Nin + tid] : 0.f; }
         }
+        if (do_mstdp) {
+            // ---- MSTDP update of step t (applied before step t+1 propagates): factors of step t-1 = this iteration's
+            //      source digest, the spike masks of iteration t-1, p_minus staged above, p_plus after step t-1
+            const float *pp = c.pall + (size_t)t * B * Nin;
+            const uint8_t *sb = sbytes;
+            int na = nact;
+            if (t == 0) {
+                // the very first update pairs with what the rule remembers from before this run, not with the input
+                // layer's entry spikes: digest entry T+1 replaces the row tables (the event list is not needed)
+                const uint32_t *D = c.dig + (size_t)(c.T + 1) * c.DW;
+                na = szt[2 * (c.T + 1) + 1];
+                for (int k = tid; k < na; k += NT) am[k] = D[c.o_am + k];
+                for (int k = tid; k < (na + 1) / 2; k += NT) ((uint32_t *)ar)[k] = D[c.o_ar + k];
+                for (int k = tid; k < NinW; k += NT) ab[k] = D[c.o_ab + k];
+                sb = (D[2] & 1u) ? c.s_src_prev : nullptr;
+                __syncthreads();
+            }
+            const bool full = (t == 0) || c.wdecay != 1.0f;
+            if (Etot != Emain) two_mstdp<OuterSum>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            else two_mstdp<CascT>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            lds_barrier();                               // tile and row tables are free for the next iteration
+        }
         (void)tot;
         TMARK(6);
     }
@@ -471,6 +580,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     if (mine) {
         c.vY[kst] = v; c.rY[kst] = rc; c.sY[kst] = sp_prev;
         if (c.pY.traces) c.xY[kst] = xy;
+        if (do_mstdp) { c.p_minus[kst] = pm; c.s_tgt_prev[kst] = sp_prev; }
     }
 }
 
@@ -486,7 +596,8 @@ int digest_layout(TwoCtx &c) {
 size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
-           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)(c.T + 1) * 8 + (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
+           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)MAXB * 4 + (size_t)(c.T + 2) * 8 +
+           (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
 
 bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, TwoCtx &c) {
@@ -494,7 +605,9 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (L[0].kind != SNN_LAYER_INPUT || L[1].kind != SNN_LAYER_LIF) return false;
     if (C[0].src != 0 || C[0].dst != 1) return false;
     if (C[0].kind != SNN_CONN_MCC && C[0].kind != SNN_CONN_DENSE) return false;
-    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE) return false;
+    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE && C[0].rule != SNN_RULE_MSTDP) return false;
+    if (C[0].rule == SNN_RULE_MSTDP && (C[0].kind != SNN_CONN_DENSE || !C[0].p_plus || !C[0].p_minus || !C[0].s_src_prev ||
+                                        !C[0].s_tgt_prev || !(C[0].a_plus >= 0.f))) return false;
     if (C[0].rule == SNN_RULE_POSTPRE && (!L[0].x || !L[1].x || !L[0].p.lif.traces || !L[1].p.lif.traces)) return false;
     if (C[0].kind == SNN_CONN_MCC && C[0].bias) return false;
     const int B = R->B, Nin = L[0].n, N = L[1].n;
@@ -503,6 +616,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     memset(&c, 0, sizeof(c));
     c.B = B; c.Nin = Nin; c.N = N; c.T = R->T; c.NinW = (Nin + 31) / 32;
     c.dt = R->dt; c.learning = R->learning;
+    c.rule = C[0].rule;
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
     // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
@@ -517,7 +631,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.G = (N + cw - 1) / cw;
     if (c.T + 1 > 4096) return false;
     c.use_xsl = 0;
-    if (Nin <= NT) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
+    if (Nin <= NT && c.rule == SNN_RULE_POSTPRE) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
     if (META + c.LCAP / 2 + Nin + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
     return true;
@@ -529,7 +643,8 @@ static size_t two_workspace(const TwoCtx &c0) {
     TwoCtx c = c0;
     const int DW = digest_layout(c);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al((size_t)(c.T + 1) * DW * 4) + al((size_t)c.T * c.B * c.Nin * 4);
+    // digests (T+2 entries: MSTDP's extra one) | X trace of every step (PostPre) or p_plus of every step (MSTDP)
+    return al((size_t)(c.T + 2) * DW * 4) + al((size_t)(c.T + 1) * c.B * c.Nin * 4);
 }
 
 unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
@@ -551,7 +666,13 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     unsigned char *ws = (unsigned char *)R->workspace;
     c.dig = (uint32_t *)ws;
-    c.xall = (float *)(ws + al((size_t)(c.T + 1) * c.DW * 4));
+    float *big = (float *)(ws + al((size_t)(c.T + 2) * c.DW * 4));
+    const bool mstdp = C[0].rule == SNN_RULE_MSTDP && R->learning;
+    c.xall = (C[0].rule == SNN_RULE_POSTPRE) ? big : nullptr;
+    c.pall = mstdp ? big : nullptr;
+    c.p_plus = C[0].p_plus; c.p_minus = C[0].p_minus; c.s_src_prev = C[0].s_src_prev; c.s_tgt_prev = C[0].s_tgt_prev;
+    c.a_plus = C[0].a_plus; c.a_minus = C[0].a_minus; c.d_plus = C[0].decay_plus; c.d_minus = C[0].decay_minus;
+    c.reward = C[0].reward; c.reward_vec = C[0].reward_vec;
     c.inv_hwps = 1.0f / (float)(Nin >> 4);
     c.in = L[0].ext_spikes; c.sX0 = L[0].s;
     c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
@@ -571,7 +692,8 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     const size_t prep_lds = (size_t)(B * c.NinW + Nin + MAXB + 1 + 4) * 4;
     if (prep_lds > 150 * 1024) return SNN_OK;
     if (c.x_traces) hipLaunchKernelGGL(k_two_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_two_prep, dim3(c.T + 1), dim3(NT), prep_lds, st, c);
+    if (mstdp) hipLaunchKernelGGL(k_two_pplus, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_two_prep, dim3(mstdp ? c.T + 2 : c.T + 1), dim3(NT), prep_lds, st, c);
     static long long *dbg = nullptr;
     if (getenv("SNN_TWO_TIMING")) {
         if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 8 * 4096);
@@ -580,6 +702,8 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     hipLaunchKernelGGL(k_two_run, dim3(c.G), dim3(NT), run_lds(c), st, c);
     int rc = snn_check_launch();
     if (rc) return rc;
+    if (mstdp)       // the rule's memory of the source spikes = the last input slice
+        if ((rc = snn_check(hipMemcpyAsync(c.s_src_prev, c.in + (size_t)(c.T - 1) * B * Nin, (size_t)B * Nin, hipMemcpyDeviceToDevice, st)))) return rc;
     if (c.dbg) {
         (void)hipStreamSynchronize(st);
         std::vector<long long> h((size_t)8 * (c.T + 1));

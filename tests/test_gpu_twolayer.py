@@ -98,3 +98,84 @@ def test_twolayer_learning_off_and_big_batch_fallback():
             np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
     _, plan = run(False, "dense", 784, 64, 48, 5)       # batch > 32: generic plan
     assert plan == "generic"
+
+
+# ------------------------------------------------------------------------------------------------ MSTDP
+def run_mstdp(generic, Nin, N, B, T, reward, n_inputs=3, dens=0.05, vmax=1, learning=True):
+    """Input -> Connection(MSTDP) -> LIF (the cfg5 graph): fused plan vs generic plan, incl. the rule's state."""
+    from bindsnet_amd import _lib
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    try:
+        torch.manual_seed(0)
+        net = Network(dt=1.0)
+        net.add_layer(Input(n=Nin, traces=True), "X")
+        net.add_layer(LIFNodes(n=N, traces=True), "Y")
+        W0 = torch.from_numpy(synth.weights_q12(11, Nin, N))
+        conn = Connection(net.layers["X"], net.layers["Y"], w=W0.clone(), wmin=0.0, wmax=1.0, update_rule=MSTDP, nu=1e-1,
+                          norm=0.5 * Nin * 0.1, reduction=torch.sum)
+        net.add_connection(conn, "X", "Y")
+        ms = Monitor(net.layers["Y"], ["s"], time=T)
+        net.add_monitor(ms, "s")
+        net.train(learning)
+        net.to(DEV)
+        out = []
+        rs = np.random.RandomState(9)
+        for r in range(n_inputs):
+            sp = synth.dense_spikes(140 + r, (T, B, Nin), dens)
+            if vmax > 1:
+                sp = (sp * rs.randint(1, vmax + 1, size=sp.shape)).astype(np.uint8)
+            rw = reward if not isinstance(reward, str) else torch.from_numpy(synth.uniform_f32(17 + r, (B,), -1.0, 1.0)).to(DEV)
+            net.run({"X": torch.from_numpy(sp).to(DEV)}, time=T, reward=rw)
+            rule = conn.update_rule
+            st = dict(s=ms.get("s").cpu().numpy().copy(), W=conn.w.detach().cpu().numpy().copy(),
+                      vY=net.layers["Y"].v.cpu().numpy().copy(), xX=net.layers["X"].x.cpu().numpy().copy(),
+                      xY=net.layers["Y"].x.cpu().numpy().copy())
+            if learning:
+                st.update(pp=rule.p_plus.cpu().numpy().copy(), pm=rule.p_minus.cpu().numpy().copy(),
+                          ss=rule._s_src_prev.cpu().numpy().copy(), st=rule._s_tgt_prev.cpu().numpy().copy())
+            out.append(st)
+            plan = net.last_plan
+            if r == 0:
+                net.reset_state_variables()           # X.s is zeroed, the rule's memory is not
+        return out, plan
+    finally:
+        _lib.lib().snn_set_plan_mode(0)
+
+
+MSTDP_CASES = {
+    # name: (Nin, N, B, T, reward, density, value_max)
+    "b16_scalar_reward": (784, 100, 16, 40, 1.0, 0.06, 1),
+    "b32_negative_reward": (784, 64, 32, 30, -0.5, 0.06, 1),
+    "b5_reward_vector_tailcols": (400, 37, 5, 40, "vec", 0.08, 1),
+    "b1": (256, 40, 1, 50, 1.0, 0.08, 1),
+    "multivalued_source_bytes": (784, 48, 8, 30, 1.0, 0.05, 3),
+    "cfg5_shape_short": (6400, 500, 16, 8, 1.0, 0.05, 1),
+}
+
+
+@pytest.mark.parametrize("name", list(MSTDP_CASES))
+def test_twolayer_mstdp_fused_equals_generic(name):
+    Nin, N, B, T, reward, dens, vmax = MSTDP_CASES[name]
+    f, plan = run_mstdp(False, Nin, N, B, T, reward, dens=dens, vmax=vmax)
+    assert plan == "twolayer-fused"
+    g, plan_g = run_mstdp(True, Nin, N, B, T, reward, dens=dens, vmax=vmax)
+    assert plan_g == "generic"
+    for r, (a, b) in enumerate(zip(f, g)):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"{name} input {r}: {k}")
+    assert sum(int(x["s"].sum()) for x in f) > 0, "silent network: vacuous"
+    assert np.abs(f[-1]["pm"]).max() > 0 and not np.array_equal(f[0]["W"], f[-1]["W"])
+
+
+def test_twolayer_mstdp_learning_off():
+    f, plan = run_mstdp(False, 784, 64, 8, 25, 1.0, n_inputs=2, learning=False)
+    g, _ = run_mstdp(True, 784, 64, 8, 25, 1.0, n_inputs=2, learning=False)
+    assert plan == "twolayer-fused"
+    for a, b in zip(f, g):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
