@@ -54,6 +54,7 @@ struct TwoCtx {
     int rule; float nu0, nu1; int use_dt; float wdecay; int has_min; float wmin; int has_max; float wmax;
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
     float inv_hwps;
+    int prodw;                                           // floats of LDS for the staged products of the dense dot (0: off)
     int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= NT)
     // MSTDP (learning.py:1504-1574), factored eligibility: p_plus / p_minus traces, previous-step spike factors
     float *p_plus, *p_minus; uint8_t *s_src_prev, *s_tgt_prev;
@@ -243,11 +244,11 @@ struct SeqN {
 // All global loads a thread needs (source traces of the samples whose neuron spiked) are issued before the
 // order-constrained arithmetic; the first contributing sample of a column -- almost always the only one -- is
 // prefetched, further ones are fetched on demand.
-struct CascT {
-    Cascade c;
+struct CascT {             // batch sums have at most 32 terms: the branch-free cascade applies
+    CascadeFlat c;
     __device__ __forceinline__ void init(bool) { c.init(); }
-    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
-    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n); }
+    __device__ __forceinline__ float finish(int n) { return c.finish(n); }
 };
 
 template <class SUM>
@@ -335,13 +336,16 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
 // skipped; p_plus >= +0 (a_plus >= 0, host check) so a silent target contributes exactly +0.0 without loading it.
 template <class SUM>
 __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
-                                          const uint32_t *ab, const float *pml, const uint32_t *cm, const float *rvl,
-                                          const float *__restrict__ pp, const uint8_t *__restrict__ sbytes,
+                                          const uint32_t *ab, const float *pml, const float *zl, const uint32_t *cm,
+                                          const float *rvl, const float *__restrict__ pp, const uint8_t *__restrict__ sbytes,
                                           int nact, bool full, int c0, int tid, int cwl, int Emain) {
     const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW;
     auto elem = [&](int i, int q, uint32_t m, uint32_t cq, float w) -> float {
         SUM acc; acc.init(i * N + c0 + q >= Emain);
         uint32_t mm = m | cq;
+        if (!cq && !sbytes) {      // no target spike in this column, 0/1 source spikes: the term is zl[b][q], staged by the caller
+            while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, zl[b * 8 + q], B); }
+        } else
         while (mm) {
             const int b = __ffs(mm) - 1; mm &= mm - 1;
             const float e1 = ((cq >> b) & 1u) ? pp[b * Nin + i] * 1.0f : 0.0f;                          // p_plus (x) s_tgt
@@ -377,6 +381,9 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
     }
 }
 
+// CASC: MulticompartmentConnection (ATen cascade order) vs dense Connection (ascending sequential order);
+// RULE: the connection's learning rule.  Compile-time so that each variant carries only its own code (and registers).
+template <bool CASC, int RULE>
 __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW;
@@ -390,6 +397,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                     // [B][CW] x_tgt * nu0
     uint32_t *colmask = (uint32_t *)(smem + off); off += 16 * 4;                          // [2][8]: samples whose neuron (column q) spiked
     float *rvl = (float *)(smem + off); off += (size_t)MAXB * 4;                          // MSTDP: reward per sample
+    float *zl = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                       // MSTDP: reward * p_minus per (sample, column)
+    float *prod = (float *)(smem + off); off += c.prodw ? (size_t)c.prodw * 4 : 0;        // dense dot: staged products
     int *szt = (int *)(smem + off); off += (size_t)(c.T + 2) * 8;                         // (events, active rows) of every digest entry
     float *xsl = (float *)(smem + off); off += c.use_xsl ? (size_t)Nin * CW * 4 : 0;      // source trace of the first spiking sample of each column
 
@@ -398,11 +407,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     const int jj = tid & (CW - 1), bl = tid >> (31 - __clz(CW)), j = c0 + jj;
     const bool mine = tid < B * CW && j < N;
     const int kst = bl * N + j;
-    const bool tailcol = c.cascade && j >= (N / 32) * 32;
+    const bool tailcol = CASC && j >= (N / 32) * 32;
     const int Etot = Nin * N, Emain = (Etot / 32) * 32;
     const int cwl = 31 - __clz(CW);                      // CW is a power of two
-    const bool do_stdp = c.learning && c.rule == SNN_RULE_POSTPRE;
-    const bool do_mstdp = c.learning && c.rule == SNN_RULE_MSTDP;
+    const bool do_stdp = RULE == SNN_RULE_POSTPRE && c.learning;
+    const bool do_mstdp = RULE == SNN_RULE_MSTDP && c.learning;
 
     // ---- prologue: own weight slice and membrane state
     for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; wt[k] = c0 + q < N ? c.W[i * N + c0 + q] : 0.f; }
@@ -500,12 +509,46 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         uint32_t *cmn = colmask + (t & 1) * 8;
         uint8_t sp = 0;
         float cur = 0.f;
+        // dense Connection with long event lists (wide inputs): one thread per (sample, column) would chase ~hundreds of
+        // dependent LDS gathers.  Instead every wave takes (sample, column) pairs in turns: its 64 lanes gather 64
+        // products at once, then the sum walks them in ascending order through readlane -- the same sequential f32
+        // adds as the reference (topology.py:332-346), without a memory access in the dependency chain.
+        const bool wave_dot = !CASC && !overflow && c.prodw > 0 && tot >= 48 * B;
+        float r_dot = 0.f;
+        if (!CASC && wave_dot) {
+            // Phase P: all threads stage the products w[i,j] * s[b,i] of a chunk of every (sample, column) pair's event
+            // list in LDS (zero padded: x + 0.0f == x).  Phase S: the pair's own tile thread (lanes of ONE wave, in
+            // lockstep) adds its chunk in order -- the chain now holds nothing but the adds.
+            const int npairs = B << cwl;
+            const int CH = ((c.prodw / npairs) & ~3) - 4, ST = CH + 4;     // chunk length, row stride (banks staggered)
+            int maxn = 0;
+            for (int b = 0; b < B; ++b) maxn = max(maxn, meta[5 + b] - meta[4 + b]);
+            for (int e0 = 0; e0 < maxn; e0 += CH) {
+                const int lim = min(CH, (maxn - e0 + 3) & ~3);
+                for (int it = tid; it < npairs * lim; it += NT) {
+                    const int p = it / lim, e = it - p * lim;
+                    const int pb = p >> cwl, pq = p & (CW - 1);
+                    const int k = meta[4 + pb] + e0 + e;
+                    float term = 0.f;
+                    if (k < meta[5 + pb]) { const int i = (int)ent[k]; term = wt[i * CW + pq] * (sbytes ? (float)sbytes[pb * Nin + i] : 1.0f); }
+                    prod[p * ST + e] = term;
+                }
+                lds_barrier();
+                if (tid < npairs) {
+                    const float4 *row = (const float4 *)(prod + tid * ST);
+                    for (int e = 0; e < lim; e += 4) { const float4 x = row[e >> 2]; r_dot += x.x; r_dot += x.y; r_dot += x.z; r_dot += x.w; }
+                }
+                if (e0 + CH < maxn) lds_barrier();
+            }
+        }
         if (mine) {
             const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
             float r;
-            if (!overflow) {
+            if (!CASC && wave_dot) {
+                r = r_dot;
+            } else if (!overflow) {
                 const int n0 = meta[4 + bl], n1 = meta[5 + bl];
-                if (!c.cascade) r = list_dot<SeqN>(wt, CW, jj, ent, n0, n1, xb, Nin);
+                if (!CASC) r = list_dot<SeqN>(wt, CW, jj, ent, n0, n1, xb, Nin);
                 else if (tailcol) r = list_dot<RowSumN>(wt, CW, jj, ent, n0, n1, xb, Nin);
                 else if (Nin < 4096) r = list_dot<CascadeFlat>(wt, CW, jj, ent, n0, n1, xb, Nin);
                 else r = list_dot<CascadeN>(wt, CW, jj, ent, n0, n1, xb, Nin);
@@ -518,10 +561,10 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                     while (m) {
                         const int i = w * 32 + __ffs(m) - 1; m &= m - 1;
                         const float term = wt[i * CW + jj] * (xb ? (float)xb[i] : 1.0f);
-                        if (c.cascade) a.add(i, term, Nin); else seq += term;
+                        if (CASC) a.add(i, term, Nin); else seq += term;
                     }
                 }
-                r = c.cascade ? a.finish(Nin) : seq;
+                r = CASC ? a.finish(Nin) : seq;
             }
             if (c.bias) r = r + bias;                     // topology.py:345
             cur = 0.0f + r;                               // network.py:240-248
@@ -534,6 +577,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (mine) {
             if (do_mstdp) {
                 xnu0[bl * 8 + jj] = pm;                   // p_minus of the PREVIOUS step: a factor of this step's update
+                zl[bl * 8 + jj] = rvl[bl] * (0.0f + 1.0f * pm);   // its whole term when only the source spiked (value 1)
                 const float p = pm * c.d_minus;           // learning.py:1566-1567
                 pm = p + c.a_minus * (float)sp;
             } else
@@ -566,8 +610,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 __syncthreads();
             }
             const bool full = (t == 0) || c.wdecay != 1.0f;
-            if (Etot != Emain) two_mstdp<OuterSum>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
-            else two_mstdp<CascT>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            if (Etot != Emain) two_mstdp<OuterSum>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            else two_mstdp<CascT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
             lds_barrier();                               // tile and row tables are free for the next iteration
         }
         (void)tot;
@@ -596,7 +640,8 @@ int digest_layout(TwoCtx &c) {
 size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
-           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)MAXB * 4 + (size_t)(c.T + 2) * 8 +
+           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)MAXB * 4 + (size_t)MAXB * 8 * 4 + (size_t)c.prodw * 4 +
+           (size_t)(c.T + 2) * 8 +
            (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
 
@@ -630,6 +675,8 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (B * cw > NT || run_lds(c) > 140 * 1024) return false;
     c.G = (N + cw - 1) / cw;
     if (c.T + 1 > 4096) return false;
+    c.prodw = 0;
+    if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) { c.prodw = 4096; if (run_lds(c) > 140 * 1024) c.prodw = 0; }
     c.use_xsl = 0;
     if (Nin <= NT && c.rule == SNN_RULE_POSTPRE) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
@@ -685,7 +732,11 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
     static bool attr = false;
     if (!attr) {
-        if (snn_check(hipFuncSetAttribute((const void *)k_two_run, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        const void *variants[5] = {(const void *)k_two_run<true, SNN_RULE_NONE>, (const void *)k_two_run<true, SNN_RULE_POSTPRE>,
+                                   (const void *)k_two_run<false, SNN_RULE_NONE>, (const void *)k_two_run<false, SNN_RULE_POSTPRE>,
+                                   (const void *)k_two_run<false, SNN_RULE_MSTDP>};
+        for (const void *f : variants)
+            if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         if (snn_check(hipFuncSetAttribute((const void *)k_two_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         attr = true;
     }
@@ -699,7 +750,15 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 8 * 4096);
         if (c.T + 1 <= 4096) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * (c.T + 1), st); c.dbg = dbg; }
     }
-    hipLaunchKernelGGL(k_two_run, dim3(c.G), dim3(NT), run_lds(c), st, c);
+    {
+        const dim3 grid(c.G), blk(NT);
+        const size_t lds = run_lds(c);
+        if (c.cascade && c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
+        else if (c.cascade) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_NONE>), grid, blk, lds, st, c);
+        else if (c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
+        else if (c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_MSTDP>), grid, blk, lds, st, c);
+        else hipLaunchKernelGGL((k_two_run<false, SNN_RULE_NONE>), grid, blk, lds, st, c);
+    }
     int rc = snn_check_launch();
     if (rc) return rc;
     if (mstdp)       // the rule's memory of the source spikes = the last input slice
