@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         DBG_MARK(11);
         lds_barrier();
         DBG_MARK(15);
-        if (tid < 32) cnt[tid] = 0;                        // last read at the end of the previous iteration
+        if (tid < CW) cnt[(t & 1) * CW + tid] = 0;         // this step's spike counts (buffer last read one iteration ago)
         if (t < T) fetch_digest(t + 1);                    // next iteration's digest: in flight behind this one
         DBG_MARK(16);
         const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
@@ -1480,13 +1480,17 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 curE = r.e; curI = r.i;
             }
         }
+        if (busy) lds_barrier();       // (uniform) the bit-scan path reads the exchanged words the next poll overwrites
         DBG_MARK(5);
         // ---- B2: membrane updates
         bool spE = false, spIn = false;
         if (mine) {
-            if (c.pE.learning) th = th * c.pE.theta_decay;
+            // theta += theta_plus * (spikes of the previous step, summed over the batch), nodes.py:1094 -- applied
+            // here, right before this step's decay, instead of behind a barrier of its own at the end of that step
+            if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)cnt[((t - 1) & 1) * CW + jj];
+            if (c.pE.learning) th = th * c.pE.theta_decay;                 // nodes.py:1079
             spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
-            if (spE) atomicAdd(&cnt[jj], 1);
+            if (spE) atomicAdd(&cnt[(t & 1) * CW + jj], 1);
             float ci = curI;
             if (r_rI > 0.f) ci = 0.f;
             spIn = lif_update(r_vI, r_rI, ci, c.pI);
@@ -1503,9 +1507,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + (b >> 1), ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
             }
         }
-        lds_barrier();
         if (mine) {
-            if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[jj];
             if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
             if (c.pI.traces) r_xI = trace_next(r_xI, spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
             if (c.rasI) (c.rasI + (size_t)t * B * N)[kst] = spIn;
@@ -1519,6 +1521,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
 
     // ---- epilogue: state and weights back to the tensors the caller owns
     if (mine) {
+        if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[((T - 1) & 1) * CW + jj];   // the last step's spikes
         c.vE[kst] = r_vE; c.rE[kst] = r_rE; c.vI[kst] = r_vI; c.rI[kst] = r_rI;
         if (bl == 0) c.theta[j] = th;
         if (c.pI.traces) c.xI[kst] = r_xI;
