@@ -1624,9 +1624,14 @@ static size_t resident_extra(int B, int Nin, int N, int T) {
     return al((size_t)2 * G * KB * 8) + al((size_t)(T + 1) * B * Nin * 4);
 }
 
+// The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
+// take the one-launch-per-timestep form, whose scratch does not grow with B*Nin*T.
+constexpr size_t kResidentMaxExtra = (size_t)2 << 30;
+
 static size_t fused_workspace_total(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return fused_workspace(B, Nin, N) + al((size_t)(T + 1) * digest_words(B, Nin) * 4) + resident_extra(B, Nin, N, T);
+    const size_t extra = resident_extra(B, Nin, N, T);
+    return fused_workspace(B, Nin, N) + al((size_t)(T + 1) * digest_words(B, Nin) * 4) + (extra <= kResidentMaxExtra ? extra : 0);
 }
 
 static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
@@ -1714,7 +1719,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     }
     // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
     if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
-    if (c.G > 128 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N) > 150 * 1024) resident = 0;
+    if (c.G > 128 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N) > 150 * 1024 ||
+        resident_extra(B, Nin, N, R->T) > kResidentMaxExtra) resident = 0;
     static long long *dbg = nullptr;
     static int dbg_T = 0;
     if (getenv("SNN_DC_TIMING")) {
