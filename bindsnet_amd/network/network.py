@@ -201,10 +201,8 @@ class Network(torch.nn.Module):
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             R.workspace, R.workspace_bytes = _dptr(ws), need
-        gen_bufs = None
-        if max_draws:
-            gen_bufs = (self._scratch("rng_state", (628,), torch.int32, dev), self._scratch("rng_qbuf", (max_draws,), torch.float32, dev),
-                        self._scratch("rng_cursor", (2,), torch.int64, dev), self._scratch("rng_status", (1,), torch.int32, dev))
+        gen_bufs = (self._scratch("rng_block", (640,), torch.int32, dev),
+                    self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev))
         with DeviceGenerator(dev, max_draws, gen_bufs) as ns:      # host generator <-> device, exact (rng.py)
             R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
             R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)

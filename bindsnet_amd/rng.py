@@ -97,47 +97,51 @@ def words_to_torch_state(img: np.ndarray, template: torch.Tensor) -> torch.Tenso
     return torch.frombuffer(raw, dtype=torch.uint8).clone()
 
 
+_BLOCK_WORDS = 640          # int32 words of the run's host<->device block: state[628] | status | pad[3] | cursor (i64[2]) | pad
+_STATUS_AT, _CURSOR_AT = 628, 632
+
+
 class DeviceGenerator:
     """Context manager: upload the host generator at entry, write it back (advanced by what the
-    device consumed) at exit.  `consumed` is the number of Exp(1) draws used."""
+    device consumed) at exit.  `consumed` is the number of Exp(1) draws used.
+
+    State image, status word and cursor live in ONE device block, so a run costs one host->device copy at entry
+    (which also zeroes status and cursor) and one blocking device->host copy at exit."""
 
     def __init__(self, device, qbuf_floats: int, buffers=None):
-        """buffers: optional persistent (state int32[628], qbuf f32[n], cursor i64[2], status i32[1]) tensors."""
+        """buffers: optional persistent (block int32[640], qbuf f32[n]) tensors."""
         self.device = torch.device(device)
         self.enabled = qbuf_floats > 0
-        self._bufs = buffers
-        if buffers is not None:
-            self.cursor, self.status = buffers[2], buffers[3]
-            self.cursor.zero_(); self.status.zero_()
-        else:
-            self.cursor = torch.zeros(2, dtype=torch.int64, device=self.device)
-            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.state = self.qbuf = None
+        block = buffers[0] if buffers is not None else torch.zeros(_BLOCK_WORDS, dtype=torch.int32, device=self.device)
+        self._block = block
+        self.state = block[:RNG_STATE_BYTES // 4]
+        self.status = block[_STATUS_AT:_STATUS_AT + 1]
+        self.cursor = block[_CURSOR_AT:_CURSOR_AT + 4].view(torch.int64)
+        self.qbuf = buffers[1] if buffers is not None else None
         self.consumed = 0
         self._n = qbuf_floats
 
     def __enter__(self):
+        img = torch.zeros(_BLOCK_WORDS, dtype=torch.int32)
         if self.enabled:
             self._host0 = torch.get_rng_state()
-            img = torch.from_numpy(torch_state_to_words(self._host0).copy())
-            if self._bufs is not None:
-                self.state, self.qbuf = self._bufs[0], self._bufs[1]
-                self.state.copy_(img)
-            else:
-                self.state = img.to(self.device)
+            img[:RNG_STATE_BYTES // 4] = torch.from_numpy(torch_state_to_words(self._host0).copy())
+            if self.qbuf is None:
                 self.qbuf = torch.empty(self._n, dtype=torch.float32, device=self.device)
+        self._block.copy_(img)                             # state in, status = 0, cursor = 0
         return self
 
     def finish(self) -> int:
         if not self.enabled:
             return 0
-        img = self.state.cpu().numpy()                     # synchronises with the run
-        st = int(self.status.item())
+        blk = self._block.cpu().numpy()                    # synchronises with the run
+        st = int(blk[_STATUS_AT])
         if st != 0:
             from ._lib import SnnError
             torch.set_rng_state(self._host0)
             raise SnnError(f"device run reported status {st}")
-        self.consumed = int(img.view(np.int64)[(RNG_STATE_BYTES - 8) // 8])
+        img = blk[:RNG_STATE_BYTES // 4]
+        self.consumed = int(np.ascontiguousarray(img).view(np.int64)[(RNG_STATE_BYTES - 8) // 8])
         torch.set_rng_state(words_to_torch_state(img, self._host0))
         return self.consumed
 
