@@ -55,7 +55,7 @@ extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                          hipStream_t st, int resident, int *handled, unsigned *normalized);
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                           hipStream_t st, int *handled);
+                           hipStream_t st, int *handled, unsigned *normalized);
 int snn_try_fused_convlif(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                           hipStream_t st, int *handled);
 
@@ -179,7 +179,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled, &normalized));
-    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled));
+    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
     if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));
     if (!handled) {
         g_plan = "generic";

@@ -60,6 +60,7 @@ struct TwoCtx {
     float *p_plus, *p_minus; uint8_t *s_src_prev, *s_tgt_prev;
     float *pall;                                         // [T+1][B][Nin] p_plus at entry / after every step
     float a_plus, a_minus, d_plus, d_minus, reward; const float *reward_vec;
+    int has_norm; float norm; int norm_abs;              // post-run normalisation, done on the LDS tile in the epilogue
     long long *dbg;                                      // developer aid (SNN_TWO_TIMING=1): phase timestamps of workgroup 0
 };
 
@@ -620,6 +621,50 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
 
     // ---- epilogue: write the weight slice and the membrane state back
     __syncthreads();
+    if (c.has_norm) {
+        // network.py:464-465 + topology.py:383-392 / topology_features.py:250-266: column sums (of |w| for a dense
+        // Connection) in ATen's sum(dim=0) order over the LDS tile, zero -> 1, W *= norm * (1 / colsum); the same
+        // arithmetic as k_colsum / k_scale_cols
+        float *bsum = (float *)am;                     // [nfull][CW] 16-row block sums (the row tables are free now)
+        float *sc = xnu0;                              // [CW] column scales
+        const int nfull = Nin >> 4;
+        if (c0 < (N / 32) * 32) {                      // multi_row_sum columns (a tile never straddles the class boundary)
+            for (int item = tid; item < nfull * CW; item += NT) {
+                const int blk = item / CW, q = item - blk * CW;
+                float a0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const float w = wt[(blk * 16 + k) * CW + q]; a0 += c.norm_abs ? fabsf(w) : w; }
+                bsum[item] = a0;
+            }
+            __syncthreads();
+            if (tid < CW) {
+                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int blk = 0; blk < nfull; ++blk) {
+                    a1 += bsum[blk * CW + tid];
+                    const int m = blk + 1;
+                    if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+                }
+                float a0 = 0.f;
+                for (int i = nfull * 16; i < Nin; ++i) { const float w = wt[i * CW + tid]; a0 += c.norm_abs ? fabsf(w) : w; }
+                float cs = ((a0 + a1) + a2) + a3;
+                if (cs == 0.f) cs = 1.0f;
+                sc[tid] = (1.0f / cs) * c.norm;
+            }
+        } else if (tid < CW * 4) {                     // row_sum columns: four interleaved lanes per column
+            const int q = tid >> 2, s4 = tid & 3, n4 = Nin >> 2, nf4 = n4 >> 4;
+            Cascade cc; cc.init();
+            for (int p_ = 0; p_ < n4; ++p_) { const float w = wt[(4 * p_ + s4) * CW + q]; cc.add(p_, c.norm_abs ? fabsf(w) : w, nf4); }
+            float lsum = cc.finish(nf4);
+            if (s4 == 0)
+                for (int i = n4 * 4; i < Nin; ++i) { const float w = wt[i * CW + q]; lsum += c.norm_abs ? fabsf(w) : w; }
+            const float l1 = __shfl_down(lsum, 1, 4), l2 = __shfl_down(lsum, 2, 4), l3 = __shfl_down(lsum, 3, 4);
+            float cs = ((lsum + l1) + l2) + l3;
+            if (cs == 0.f) cs = 1.0f;
+            if (s4 == 0) sc[q] = (1.0f / cs) * c.norm;
+        }
+        __syncthreads();
+        for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; if (c0 + q < N) c.W[i * N + c0 + q] = wt[k] * sc[q]; }
+    } else
     for (int k = tid; k < Nin * CW; k += NT) { const int i = k / CW, q = k - i * CW; if (c0 + q < N) c.W[i * N + c0 + q] = wt[k]; }
     if (mine) {
         c.vY[kst] = v; c.rY[kst] = rc; c.sY[kst] = sp_prev;
@@ -702,7 +747,7 @@ unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL,
 }
 
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                           hipStream_t st, int *handled) {
+                           hipStream_t st, int *handled, unsigned *normalized) {
     *handled = 0;
     TwoCtx c;
     if (!plan(L, nL, C, nC, R, c)) return SNN_OK;
@@ -720,6 +765,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.p_plus = C[0].p_plus; c.p_minus = C[0].p_minus; c.s_src_prev = C[0].s_src_prev; c.s_tgt_prev = C[0].s_tgt_prev;
     c.a_plus = C[0].a_plus; c.a_minus = C[0].a_minus; c.d_plus = C[0].decay_plus; c.d_minus = C[0].decay_minus;
     c.reward = C[0].reward; c.reward_vec = C[0].reward_vec;
+    c.has_norm = C[0].has_norm; c.norm = C[0].norm; c.norm_abs = C[0].norm_abs;
     c.inv_hwps = 1.0f / (float)(Nin >> 4);
     c.in = L[0].ext_spikes; c.sX0 = L[0].s;
     c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
@@ -776,6 +822,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         fprintf(stderr, "[twolayer timing, us/step %.2f] commit %.2f | issue %.2f | stdp %.2f | barrier %.2f | currents+lif %.2f | publish %.2f\n",
                 a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n);
     }
+    if (c.has_norm) *normalized |= 1u;                    // connection 0 was normalised in the kernel's epilogue
     snn_set_plan_name("twolayer-fused");
     *handled = 1;
     return SNN_OK;
