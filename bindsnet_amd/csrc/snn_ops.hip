@@ -615,77 +615,94 @@ extern "C" int snn_mstdp_step(float *W, float *p_plus, float *p_minus, uint8_t *
 }
 
 // =============================================================================================
-// a11: normalize.  k_colsum: thread <-> column, rows walked in order through the ATen-ordered
-// accumulator (dense: every row is a term).  k_scale: elementwise W *= norm * (1/colsum).
+// a11: normalize.  k_colsum: column sums in ATen's sum(dim=0) order; k_scale: elementwise W *= norm * (1/colsum).
 // =============================================================================================
-// Four threads per column.  The ATen order makes that possible without changing a single rounding:
-//  * multi_row_sum columns: the sums of the 16-row blocks are independent of each other (each is a plain
-//    sequential sum of its 16 terms); thread s takes blocks s, s+4, ... and the quad leader then folds the
-//    block sums in block order through the upper cascade levels.
-//  * row_sum columns: the four interleaved lanes (row mod 4) are independent cascades; thread s IS lane s.
-__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ W, int Nin, int N, float norm,
-                                                int use_abs, float *__restrict__ scale) {
-    __shared__ float bs[64][65];                       // block sums of one 64-column tile: [block % 64][column]
-    const int tid = threadIdx.x, cl = tid >> 2, s4 = tid & 3;
-    const int j = blockIdx.x * 64 + cl;
+// The ATen order leaves a lot of parallelism without changing a single rounding:
+//  * multi_row_sum columns (j < 32*floor(N/32)): the sums of the 16-row blocks are independent of each other (each a
+//    plain sequential sum of its 16 terms); only folding them through the upper cascade levels is sequential.
+//  * row_sum columns: four interleaved lanes (row mod 4), each lane again a cascade over 16-position blocks.
+// Workgroup = 16 consecutive columns (never straddling the class boundary, 16 | 32) x 64 block-threads: every
+// thread sums one block per round (coalesced 64-byte row segments), one thread per column (or per lane) folds the
+// round's block sums in block order.
+constexpr int kCsCols = 16, kCsBlk = 64;
+__global__ __launch_bounds__(kCsCols * kCsBlk) void k_colsum(const float *__restrict__ W, int Nin, int N, float norm,
+                                                             int use_abs, float *__restrict__ scale) {
+    __shared__ float bs[kCsBlk][kCsCols + 1];          // block sums of one round: [block thread][column]
+    __shared__ float lanes[4][kCsCols + 1];
+    const int tid = threadIdx.x, cl = tid % kCsCols, bt = tid / kCsCols;
+    const int j = blockIdx.x * kCsCols + cl;
     const bool valid = j < N;
     const int jc = valid ? j : N - 1;
-    const bool tail = j >= (N / 32) * 32;
-    const int nfull = Nin >> 4;
-    float result = 0.f;
-    {   // multi_row_sum columns (every thread walks the barrier loop; row_sum columns just idle through it)
-        float a1 = 0.f, a2 = 0.f, a3 = 0.f;            // upper cascade levels, quad leader only
-        for (int base = 0; base < nfull; base += 64) { // 64 blocks (1024 rows) per round
-            if (!tail)
-                for (int blk = base + s4; blk < min(nfull, base + 64); blk += 4) {
-                    float v[16];
+    const bool tail = blockIdx.x * kCsCols >= (N / 32) * 32;      // uniform per workgroup
+    if (!tail) {
+        const int nfull = Nin >> 4;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;            // upper cascade levels (bt == 0 threads)
+        for (int base = 0; base < nfull; base += kCsBlk) {
+            const int blk = base + bt;
+            if (blk < nfull) {
+                float v[16];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) { const float w = W[(size_t)(blk * 16 + k) * N + jc]; v[k] = use_abs ? fabsf(w) : w; }
-                    float a0 = 0.f;
+                for (int k = 0; k < 16; ++k) { const float w = W[(size_t)(blk * 16 + k) * N + jc]; v[k] = use_abs ? fabsf(w) : w; }
+                float a0 = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) a0 += v[k];
-                    bs[blk - base][cl] = a0;
-                }
+                for (int k = 0; k < 16; ++k) a0 += v[k];
+                bs[bt][cl] = a0;
+            }
             __syncthreads();
-            if (!tail && s4 == 0)
-                for (int blk = base; blk < min(nfull, base + 64); ++blk) {
-                    a1 += bs[blk - base][cl];
-                    const int m = blk + 1;             // boundary after this block
+            if (bt == 0)
+                for (int b2 = base; b2 < min(nfull, base + kCsBlk); ++b2) {
+                    a1 += bs[b2 - base][cl];
+                    const int m = b2 + 1;              // boundary after this block
                     if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
                 }
             __syncthreads();
         }
-        if (!tail && s4 == 0) {
+        if (bt == 0 && valid) {
             float a0 = 0.f;                            // rows past the last complete block
             for (int i = nfull * 16; i < Nin; ++i) { const float w = W[(size_t)i * N + jc]; a0 += use_abs ? fabsf(w) : w; }
-            result = ((a0 + a1) + a2) + a3;
+            float cs = ((a0 + a1) + a2) + a3;
+            if (cs == 0.f) cs = 1.0f;                   // topology_features.py:265
+            scale[j] = (1.0f / cs) * norm;              // torch: python_scalar / tensor == reciprocal * scalar
         }
+        return;
     }
-    if (tail) {   // quads are never split between the two column classes (class is a function of the column)
-        const int n4 = Nin >> 2;
-        Cascade c; c.init();
-        const int nf4 = n4 >> 4;
-        for (int p0 = 0; p0 < n4; p0 += 16) {
+    // row_sum columns: thread = (column cl, lane s4, block group bg); lane s4 owns the rows 4p + s4, p < n4
+    const int s4 = bt & 3, bg = bt >> 2;               // 16 block groups
+    const int n4 = Nin >> 2, nf4 = n4 >> 4;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;                // (bg == 0 threads)
+    for (int base = 0; base < nf4; base += kCsBlk / 4) {
+        const int blk = base + bg;
+        if (blk < nf4) {
             float v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int p = min(p0 + k, n4 - 1);
-                const float w = W[(size_t)(4 * p + s4) * N + jc]; v[k] = use_abs ? fabsf(w) : w;
-            }
+            for (int k = 0; k < 16; ++k) { const float w = W[(size_t)(4 * (blk * 16 + k) + s4) * N + jc]; v[k] = use_abs ? fabsf(w) : w; }
+            float a0 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (p0 + k < n4) c.add(p0 + k, v[k], nf4);
+            for (int k = 0; k < 16; ++k) a0 += v[k];
+            bs[bt][cl] = a0;
         }
-        float lane = c.finish(nf4);
-        if (s4 == 0)
-            for (int i = n4 * 4; i < Nin; ++i) { const float w = W[(size_t)i * N + jc]; lane += use_abs ? fabsf(w) : w; }
-        const float l1 = __shfl_down(lane, 1, 4), l2 = __shfl_down(lane, 2, 4), l3 = __shfl_down(lane, 3, 4);
-        result = ((lane + l1) + l2) + l3;
+        __syncthreads();
+        if (bg == 0)
+            for (int b2 = base; b2 < min(nf4, base + kCsBlk / 4); ++b2) {
+                a1 += bs[(b2 - base) * 4 + s4][cl];
+                const int m = b2 + 1;
+                if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+            }
+        __syncthreads();
     }
-    if (valid && s4 == 0) {
-        float cs = result;
-        if (cs == 0.f) cs = 1.0f;                       // topology_features.py:265
-        const float rc = 1.0f / cs;                     // torch: python_scalar / tensor == reciprocal * scalar
-        scale[j] = rc * norm;
+    if (bg == 0) {
+        float a0 = 0.f;                                // positions past the lane's last complete block
+        for (int p_ = nf4 * 16; p_ < n4; ++p_) { const float w = W[(size_t)(4 * p_ + s4) * N + jc]; a0 += use_abs ? fabsf(w) : w; }
+        float lane = ((a0 + a1) + a2) + a3;
+        if (s4 == 0)                                   // the Nin % 4 leftover rows join lane 0 after its cascade
+            for (int i = n4 * 4; i < Nin; ++i) { const float w = W[(size_t)i * N + jc]; lane += use_abs ? fabsf(w) : w; }
+        lanes[s4][cl] = lane;
+    }
+    __syncthreads();
+    if (bt == 0 && valid) {
+        float cs = ((lanes[0][cl] + lanes[1][cl]) + lanes[2][cl]) + lanes[3][cl];
+        if (cs == 0.f) cs = 1.0f;
+        scale[j] = (1.0f / cs) * norm;
     }
 }
 
@@ -699,8 +716,8 @@ extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, 
                              snn_stream_t stream) {
     if (!W || !colsum_ws || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
     if (Nin > kMaxTerms) return SNN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_colsum, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, W, Nin, N, norm,
-                       use_abs, colsum_ws);
+    hipLaunchKernelGGL(k_colsum, dim3((N + kCsCols - 1) / kCsCols), dim3(kCsCols * kCsBlk), 0, (hipStream_t)stream, W, Nin, N,
+                       norm, use_abs, colsum_ws);
     int rc = snn_check_launch();
     if (rc) return rc;
     const long E = (long)Nin * N;
