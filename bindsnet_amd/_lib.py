@@ -120,20 +120,24 @@ def check(rc: int, what: str = ""):
         raise SnnError(f"libsnnhip {what}: {msg} (code {rc})")
 
 
-def profile_run(net, inputs, time, stride=4):
-    """One extra run() with HIP events around every `stride`-th timestep's launches (bench.py).
+def profile_run(net, inputs, time, stride=4, repeats=5):
+    """Extra run()s with HIP events around the plan's dominant launches (bench.py roofline): every `stride`-th
+    timestep's launch for the per-step plans, the one launch of each run for the resident plan (`repeats` runs).
     Returns {"kernel", "avg_ms", "n", "timesteps_per_launch"} or None."""
     import torch
     L = lib()
     L.snn_profile_enable(stride)
     try:
-        net.run(dict(inputs), time=time)
+        for _ in range(max(1, repeats)):
+            net.run(dict(inputs), time=time)
+            net.reset_state_variables()
+            if net.last_plan != "dc2015-resident":
+                break
         torch.cuda.synchronize()
         s, n = C.c_double(0), C.c_int(0)
         check(L.snn_profile_collect(C.byref(s), C.byref(n)), "profile_collect")
     finally:
         L.snn_profile_enable(0)
-    net.reset_state_variables()
     if n.value == 0:
         return None
     plan = net.last_plan
