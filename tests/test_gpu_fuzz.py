@@ -1,0 +1,99 @@
+"""Randomised differential test: every fused / resident plan against the generic per-operator plan, bit for bit, on
+seeded random shapes (column counts that do / do not leave ATen row_sum tail columns, batch 1..32, odd time lengths,
+sparse and busy inputs, multi-valued spike bytes).  The generic plan itself is pinned to the oracle and the reference
+fixtures by the other GPU tests."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+import test_gpu_convlif as conv
+import test_gpu_fused_stress as dc
+import test_gpu_twolayer as two
+
+pytestmark = pytest.mark.gpu
+u8 = np.uint8
+
+
+def _same(a, b, what):
+    for r, (x, y) in enumerate(zip(a, b)):
+        for k in x:
+            np.testing.assert_array_equal(x[k].view(u8), y[k].view(u8), err_msg=f"{what} input {r}: {k}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_dc2015(seed):
+    rs = np.random.RandomState(1000 + seed)
+    N = int(rs.choice([8, 24, 32, 40, 64, 100, 200, 333, 400, 512, 600]))
+    B = int(rs.choice([1, 2, 3, 8, 15, 16, 17, 31, 32]))
+    T = int(rs.randint(3, 30))
+    dens = float(rs.choice([0.005, 0.02, 0.05, 0.15, 0.4]))
+    wsc = float(rs.choice([0.05, 0.3, 1.0]))
+    vmax = int(rs.choice([1, 1, 1, 3]))
+    learning = bool(rs.rand() < 0.8)
+    inh = float(rs.choice([120.0, 17.5, 60.0]))
+    spikes = []
+    for r in range(2):
+        s = synth.dense_spikes(500 + 7 * seed + r, (T, B, 784), dens)
+        if vmax > 1:
+            s = (s * rs.randint(1, vmax + 1, size=s.shape)).astype(u8)
+        spikes.append(s)
+    res, plan = dc.run(0, N, B, T, spikes, w_scale=wsc, learning=learning, inh=inh)
+    assert plan == "dc2015-resident"
+    step, plan_s = dc.run(2, N, B, T, spikes, w_scale=wsc, learning=learning, inh=inh)
+    assert plan_s == "dc2015-fused"
+    gen, plan_g = dc.run(1, N, B, T, spikes, w_scale=wsc, learning=learning, inh=inh)
+    assert plan_g == "generic"
+    _same(res, gen, f"resident N={N} B={B} T={T} dens={dens}")
+    _same(step, gen, f"per-step N={N} B={B} T={T} dens={dens}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_twolayer(seed):
+    rs = np.random.RandomState(2000 + seed)
+    kind = str(rs.choice(["dense", "mcc"]))
+    Nin = int(rs.choice([16, 64, 256, 784, 1024, 2048]))
+    N = int(rs.choice([5, 32, 37, 64, 100, 257]))
+    B = int(rs.choice([1, 4, 7, 16, 23, 32]))
+    T = int(rs.randint(4, 30))
+    rule = bool(rs.rand() < 0.75)
+    bias = bool(kind == "dense" and rs.rand() < 0.5)
+    dens = float(rs.choice([0.01, 0.05, 0.2]))
+    f, plan = two.run(False, kind, Nin, N, B, T, rule, bias, dens=dens)
+    assert plan == "twolayer-fused"
+    g, plan_g = two.run(True, kind, Nin, N, B, T, rule, bias, dens=dens)
+    assert plan_g == "generic"
+    _same(f, g, f"twolayer {kind} Nin={Nin} N={N} B={B} T={T} rule={rule} bias={bias}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_twolayer_mstdp(seed):
+    rs = np.random.RandomState(3000 + seed)
+    Nin = int(rs.choice([64, 256, 784, 1600]))
+    N = int(rs.choice([8, 37, 64, 130]))
+    B = int(rs.choice([1, 3, 16, 32]))
+    T = int(rs.randint(4, 25))
+    reward = rs.choice([1.0, -1.0, 0.25, "vec"])
+    reward = "vec" if reward == "vec" else float(reward)
+    dens = float(rs.choice([0.02, 0.08, 0.3]))
+    vmax = int(rs.choice([1, 1, 2]))
+    f, plan = two.run_mstdp(False, Nin, N, B, T, reward, dens=dens, vmax=vmax)
+    assert plan == "twolayer-fused"
+    g, plan_g = two.run_mstdp(True, Nin, N, B, T, reward, dens=dens, vmax=vmax)
+    assert plan_g == "generic"
+    _same(f, g, f"mstdp Nin={Nin} N={N} B={B} T={T} reward={reward} dens={dens}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_convlif(seed):
+    rs = np.random.RandomState(4000 + seed)
+    k = int(rs.choice([1, 3, 5, 4]))
+    H, W = int(rs.randint(k + 1, 30)), int(rs.randint(k + 1, 30))
+    case = (int(rs.choice([1, 2, 5])), int(rs.randint(3, 25)), int(rs.choice([1, 1, 3])), H, W, int(rs.choice([1, 7, 8, 20])), k,
+            int(rs.choice([1, 2])), int(rs.choice([0, 1, 2])), float(rs.choice([0.05, 0.3])), int(rs.choice([1, 1, 2])),
+            bool(rs.rand() < 0.5), bool(rs.rand() < 0.5))
+    f, plan = conv.run(0, case)
+    assert plan == "convlif-fused"
+    g, plan_g = conv.run(1, case)
+    assert plan_g == "generic"
+    _same(f, g, f"conv {case}")
