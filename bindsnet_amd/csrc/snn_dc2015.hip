@@ -294,7 +294,7 @@ __device__ __forceinline__ int build_list_half(const uint32_t *words, int nwords
 // order.  X->Ae weights come from the LDS tile the STDP pass just refreshed (wtile != nullptr: row `rowpos[i]`
 // of the compacted active rows, or row i itself when rowpos == nullptr) or from global memory; the recurrent
 // weights wi / we were prefetched by the caller.
-template <class SUM>
+template <class SUM, int CWL = CW>
 __device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx, int nX, const uint16_t *li, int nI,
                                               const uint16_t *le, int nE, const float *wi, const float *we,
                                               const float *wtile, const uint16_t *rowpos, int jj,
@@ -317,7 +317,7 @@ __device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx
             for (int u = 0; u < 16; ++u) rr[u] = ix[u];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) wx[u] = wtile[rr[u] * CW + jj];
+        for (int u = 0; u < 16; ++u) wx[u] = wtile[rr[u] * CWL + jj];
     } else {
 #pragma unroll
         for (int u = 0; u < 16; ++u) wx[u] = c.Wxe[ix[u] * N + j];
@@ -914,11 +914,12 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned lo
 }
 
 // PostPre on the LDS-resident slice: (row, column) items, rows listed in `arows` (all rows when FULL).
-template <class SUM, bool FULL>
+template <class SUM, bool FULL, int CWL>
 __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
                                               const uint32_t *colmask, const uint8_t *__restrict__ sbytes,
                                               const float *xnu0, const float *__restrict__ xsrc, float *wtile, int c0,
                                               int tid, int Emain) {
+    constexpr int CW = CWL;                                       // (tile width of the calling kernel)
     const int B = c.B, Nin = c.Nin, N = c.N;
     const int nitems = nact * CW;
     const int q = tid % CW, jq = c0 + q;                          // NT % CW == 0: a thread keeps its column
@@ -972,10 +973,11 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
 }
 
 // Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike, on the LDS-resident slice.
-template <class SUM>
+template <class SUM, int CWL>
 __device__ __forceinline__ void stdp_cols_lds(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
                                               const uint32_t *colmask, const float *__restrict__ xsrc, float *wtile,
                                               int c0, int tid, int Emain) {
+    constexpr int CW = CWL;
     const int B = c.B, Nin = c.Nin, N = c.N;
     while (active_cols) {
         const int q = __ffs(active_cols) - 1; active_cols &= active_cols - 1;
@@ -1027,7 +1029,8 @@ struct Cur2 { float e, i; };
 // Input currents by bit-scan over the spike words (a sample overflowed the fixed-size event lists).
 __device__ __attribute__((noinline)) Cur2 busy_currents(const float *wtile, const float *wieT, const float *weiT,
                                                         const uint32_t *xw, const uint32_t *iw, const uint32_t *ew,
-                                                        const uint8_t *xb, int NinW, int NW, int Nin, int N, int jj, bool tail) {
+                                                        const uint8_t *xb, int NinW, int NW, int Nin, int N, int jj, bool tail,
+                                                        int CW) {
     const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
     Cur2 r;
     if (tail) {
@@ -1089,10 +1092,21 @@ __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uin
 }
 
 constexpr unsigned kPollLimit = 400000u;
-constexpr size_t kResidentFixedLds = 3 * NT * 4 + MAXB * CW * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 +
-                                     2 * MAXB * 4 + 2 * 32 * 4 + 32 + 2 * MAXB * CW * 4;     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
+constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 98.2 k, 2 -> 96.6 k timesteps/s (same GPU box)
+constexpr size_t resident_fixed_lds(int cw) {
+    return 3 * NT * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
+           2 * MAXB * cw * 4;
+}     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
+// CWR = columns per workgroup (8, 4 or 2): the PostPre stage is ALU-throughput bound inside a CU, so narrower tiles on
+// more CUs shorten it, while the stages every workgroup repeats (receive, lists, arbitration) stay as they are.
+template <int CWR>
 __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
+    constexpr int CW = CWR, TT = MAXB * CWR;               // (shadow the per-step kernel's tile constants)
+    constexpr int FB = 2 * CW;                             // exchange: bits per (workgroup, sample) = CW crossings + CW Ai spikes
+    constexpr int SPG = 32 / FB;                           //           samples per granule
+    constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
+    constexpr uint32_t FM = (1u << CW) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
@@ -1102,7 +1116,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
                      O_CURB = O_MISC + 32, O_WT = O_CURB + 2 * MAXB * CW * 4;
-    static_assert(O_WT == kResidentFixedLds && O_WT % 16 == 0, "fixed LDS part");
+    static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
     uint32_t *spI = (uint32_t *)(smem + O_SPI);            // ... Ai spikes
@@ -1211,31 +1225,36 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         }
         if (phaseA) {
             const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
-            for (int k0 = tid; k0 < NG; k0 += 2 * NT) {
-                const int k1 = k0 + NT;
-                const bool two = k1 < NG;
-                unsigned long long x0 = 0, x1 = 0;
+            const int NH = (c.G + WPB - 1) / WPB;           // bytes per sample = groups of WPB workgroups
+            for (int it = tid; it < NH * KB; it += NT) {
+                const int h = it / KB, k = it - h * KB;
+                unsigned long long x[WPB];
                 unsigned spins = 0;
                 for (;;) {
-                    x0 = granule_load(exr + k0);
-                    if (two) x1 = granule_load(exr + k1);
-                    const bool ok = (uint32_t)(x0 >> 32) == (uint32_t)t && (!two || (uint32_t)(x1 >> 32) == (uint32_t)t);
+                    bool ok = true;
+#pragma unroll
+                    for (int w = 0; w < WPB; ++w) {
+                        const int gi = h * WPB + w;
+                        x[w] = gi < c.G ? granule_load(exr + gi * KB + k) : ((unsigned long long)(uint32_t)t << 32);
+                        ok = ok && (uint32_t)(x[w] >> 32) == (uint32_t)t;
+                    }
                     if (ok || failed) break;
                     if (++spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (h == 1 && !two) break;
-                    const int k = h ? k1 : k0;
-                    const uint32_t v = (uint32_t)(h ? x1 : x0);
-                    const int gg = k / KB, b0 = (k - gg * KB) * 2;
-                    ((uint8_t *)crs)[(b0 * NW) * 4 + gg] = (uint8_t)v;
-                    ((uint8_t *)spI)[(b0 * NW) * 4 + gg] = (uint8_t)(v >> 8);
-                    if (b0 + 1 < B) {
-                        ((uint8_t *)crs)[((b0 + 1) * NW) * 4 + gg] = (uint8_t)(v >> 16);
-                        ((uint8_t *)spI)[((b0 + 1) * NW) * 4 + gg] = (uint8_t)(v >> 24);
+                for (int sidx = 0; sidx < SPG; ++sidx) {
+                    const int b = k * SPG + sidx;
+                    if (b >= B) break;
+                    uint32_t be = 0, bi = 0;
+#pragma unroll
+                    for (int w = 0; w < WPB; ++w) {
+                        const uint32_t f = (uint32_t)x[w] >> (sidx * FB);
+                        be |= (f & FM) << (w * CW);
+                        bi |= ((f >> CW) & FM) << (w * CW);
                     }
+                    ((uint8_t *)crs)[(b * NW) * 4 + h] = (uint8_t)be;
+                    ((uint8_t *)spI)[(b * NW) * 4 + h] = (uint8_t)bi;
                 }
             }
         } else if (tid < BW) {   // t == 0: previous spikes come from the layers' `s` tensors (bytes -> bits)
@@ -1379,8 +1398,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             if (do_stdp) {
                 const float *xsrc = c.xtr + (size_t)t * B * Nin;          // X trace after step t-1
                 if (stdp_full) {
-                    if (anytail) stdp_rows_lds<OuterSum, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                    else stdp_rows_lds<CascadeT, true>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    if (anytail) stdp_rows_lds<OuterSum, true, CW>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    else stdp_rows_lds<CascadeT, true, CW>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
                 } else {
                     uint32_t acols = 0;
                     if (c.nu1 != 0.f) {
@@ -1388,11 +1407,11 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                         for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
                     }
                     if (anytail) {
-                        stdp_rows_lds<OuterSum, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                        stdp_cols_lds<OuterSum>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                        stdp_rows_lds<OuterSum, false, CW>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<OuterSum, CW>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     } else {
-                        stdp_rows_lds<CascadeT, false>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                        stdp_cols_lds<CascadeT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                        stdp_rows_lds<CascadeT, false, CW>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<CascadeT, CW>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     }
                 }
             }
@@ -1473,10 +1492,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                     wi[u] = wieT[min((int)lstI[bl * LR + u], N - 1) * CW + jj];
                     we[u] = weiT[min((int)lstE[bl * LR + u], N - 1) * CW + jj];
                 }
-                tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wtile, nullptr, jj, xb, j, curE, curI);
+                tile_currents<CascadeFlat, CW>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wtile, nullptr, jj, xb, j, curE, curI);
             } else {   // generic bit-scan path
                 const Cur2 r = busy_currents(wtile, wieT, weiT, c.dig + (size_t)t * c.DW + bl * NinW, spI + bl * NW,
-                                             finE + bl * NW, xb, NinW, NW, Nin, N, jj, tailcol);
+                                             finE + bl * NW, xb, NinW, NW, Nin, N, jj, tailcol, CW);
                 curE = r.e; curI = r.i;
             }
         }
@@ -1496,16 +1515,17 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             spIn = lif_update(r_vI, r_rI, ci, c.pI);
             last_sI = spIn;
         }
-        {   // publish crossing / spike bits of step t: epoch t+1
+        {   // publish crossing / spike bits of step t: epoch t+1.  A wave holds 64/CW samples x CW columns; SPG
+            // consecutive samples share a granule
             const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
             constexpr int SPW = 64 / CW;
             const int sidx = lane / CW, b = wave * SPW + sidx;
-            const uint32_t v16 = (uint32_t)((mE >> (sidx * CW)) & 0xFFu) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFu) << 8);
-            const uint32_t vhi = __shfl_down(v16, CW);
-            if (tid < TT && (lane % CW) == 0 && (sidx & 1) == 0 && b < B) {
-                const uint32_t v = v16 | ((b + 1 < B) ? (vhi << 16) : 0u);
-                granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + (b >> 1), ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
-            }
+            const uint32_t fld = (uint32_t)((mE >> (sidx * CW)) & FM) | ((uint32_t)((mI >> (sidx * CW)) & FM) << CW);
+            uint32_t v = fld;
+#pragma unroll
+            for (int sn = 1; sn < SPG; ++sn) v |= (uint32_t)__shfl_down(fld, sn * CW) << (sn * FB);
+            if (tid < TT && (lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
+                granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
         }
         if (mine) {
             if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
@@ -1602,9 +1622,16 @@ size_t lds_bytes(int B, int Nin, int N) {
            (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
 }
 
-size_t lds_bytes_resident(int B, int Nin, int N) {
+size_t lds_bytes_resident(int B, int Nin, int N, int cw) {
     const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
-    return kResidentFixedLds + (size_t)Nin * CW * 4 + (size_t)2 * N * CW * 4 + (size_t)2 * DGS * 4;
+    return resident_fixed_lds(cw) + (size_t)Nin * cw * 4 + (size_t)2 * N * cw * 4 + (size_t)2 * DGS * 4;
+}
+
+// tile width of the resident kernel: the narrowest of 8 / 4 / 2 columns whose grid still fits one workgroup per CU with
+// room to spare (SNN_DC_CW overrides)
+int resident_cw(int N) {
+    if (const char *e = getenv("SNN_DC_CW")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) return v; }
+    return kResidentDefaultCW;
 }
 
 size_t prep_lds_bytes(int B, int Nin) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4 + 2 * (NT / 64) * LX * 2; }
@@ -1620,8 +1647,8 @@ static size_t fused_workspace(int B, int Nin, int N) {
 
 static size_t resident_extra(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const int G = (N + CW - 1) / CW, KB = (B + 1) / 2;
-    return al((size_t)2 * G * KB * 8) + al((size_t)(T + 1) * B * Nin * 4);
+    const size_t gran = (size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8;      // >= 2 * G * KB * 8 for every tile width
+    return al(gran) + al((size_t)(T + 1) * B * Nin * 4);
 }
 
 // The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
@@ -1711,16 +1738,19 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     {
         auto al2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
         unsigned char *p = (unsigned char *)c.dig + al2((size_t)(R->T + 1) * c.DW * 4);
-        c.KB = (B + 1) / 2;
         c.ex = (unsigned long long *)p;
-        c.xtr = (float *)(p + al2((size_t)2 * c.G * c.KB * 8));
+        c.xtr = (float *)(p + al2((size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8));
         c.status = R->status;
         c.has_norm = C[0].has_norm; c.norm = C[0].norm; c.norm_abs = C[0].norm_abs;
     }
     // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
     if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
-    if (c.G > 128 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N) > 150 * 1024 ||
+    int rcw = resident_cw(N);
+    while (rcw < 8 && (N + rcw - 1) / rcw > 224) rcw *= 2;          // one workgroup per CU, all co-resident
+    const int rG = (N + rcw - 1) / rcw, rKB = (B + 16 / rcw - 1) / (16 / rcw);
+    if (rG > 224 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N, rcw) > 150 * 1024 ||
         resident_extra(B, Nin, N, R->T) > kResidentMaxExtra) resident = 0;
+    if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
     static int dbg_T = 0;
     if (getenv("SNN_DC_TIMING")) {
@@ -1733,7 +1763,9 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static bool lds_attr = false;
     if (!lds_attr) {   // the kernel may use more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_step, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
-        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         lds_attr = true;
     }
     // One run = memset of the exchange words (pad bytes for columns >= N are never written by a workgroup),
@@ -1747,7 +1779,10 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
-            hipLaunchKernelGGL(k_dc2015_run, dim3(c.G), dim3(NT), lds_bytes_resident(B, Nin, N), qs, c);
+            const size_t rl = lds_bytes_resident(B, Nin, N, rcw);
+            if (rcw == 8) hipLaunchKernelGGL(k_dc2015_run<8>, dim3(c.G), dim3(NT), rl, qs, c);
+            else if (rcw == 4) hipLaunchKernelGGL(k_dc2015_run<4>, dim3(c.G), dim3(NT), rl, qs, c);
+            else hipLaunchKernelGGL(k_dc2015_run<2>, dim3(c.G), dim3(NT), rl, qs, c);
             if (prof) snn_prof_end(qs);
             return snn_check_launch();
         }
