@@ -78,7 +78,7 @@ struct DcCtx {
     // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
     // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index | [B*LX/2] u16 event lists grouped by row_sum lane |
     // [B] group sizes (5 bits each: lanes 0..3, leftover sources)
-    uint32_t *dig; int DW, DGW;
+    uint32_t *dig; int DW, DGW, OXW;        // words per entry, words of its LDS part, offset of its bit words
     // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
     // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
     unsigned long long *ex; int KB;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
     const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
     uint32_t *D = c.dig + (size_t)e * c.DW;
-    uint32_t *D_xw = D, *D_xl = D + B * NinW, *D_meta = D_xl + B * (LX / 2), *D_rm = D_meta + 40;
+    uint32_t *D_xl = D, *D_meta = D_xl + B * (LX / 2), *D_rm = D_meta + 40, *D_xw = D + c.OXW;   // (bit words last)
     uint16_t *D_ar = (uint16_t *)(D_rm + Nin), *D_rp = D_ar + 2 * ((Nin + 1) / 2);
     for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
     if (tid < 2) misc[tid] = 0;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     const int kst = bl * N + j;
     const int stepoff = t * B * Nin;                                   // < 2^31 (host check)
     const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
-    const uint32_t *Dg = c.dig + (size_t)t * c.DW + B * NinW;        // digest of step t-1 (entry t), past the bit words
+    const uint32_t *Dg = c.dig + (size_t)t * c.DW;                   // digest of step t-1 (entry t): the part staged in LDS comes first
     uint32_t r_dg[3];                                                  // DGW <= 3 * NT (host check)
 #pragma unroll
     for (int u = 0; u < 3; ++u) { const int k = tid + u * NT; r_dg[u] = k < c.DGW ? Dg[k] : 0u; }
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
             const uint16_t *rp = tile_full ? nullptr : rowpos;
             tile_currents<CascadeFlat>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wt, rp, jj, xb, j, curE, curI);
         } else {   // generic bit-scan path
-            const uint32_t *xw = c.dig + (size_t)t * c.DW + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
+            const uint32_t *xw = c.dig + (size_t)t * c.DW + c.OXW + bl * NinW, *iw = spI + bl * NW, *ew = finE + bl * NW;
             const uint64_t ax = ~0ull >> (64 - NinW), ar = ~0ull >> (64 - NW);
             if (tailcol) {
                 curE = 0.0f + ordered_dot<RowSum4>(c.Wxe, N, j, xw, ax, xb, Nin);
@@ -1165,13 +1165,13 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     }
     // digest of iteration e straight into LDS (global_load_lds: no register round trip); wave-uniform 256-byte chunks
     auto fetch_digest = [&](int e) {
-        const uint32_t *Dg = c.dig + (size_t)e * c.DW + B * NinW;
+        const uint32_t *Dg = c.dig + (size_t)e * c.DW;     // 16-byte aligned (DW % 4 == 0), LDS part first
         uint32_t *dst = dgbuf + (e & 1) * DGS;
-        for (int base = wave * 64; base < c.DGW; base += NT) {
+        for (int base = wave * 256; base < c.DGW; base += (NT / 64) * 256) {
             const int ub = __builtin_amdgcn_readfirstlane(base);
-            if (ub + lane < c.DGW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane),
-                                                 (__attribute__((address_space(3))) void *)(dst + ub), 4, 0, 0);
+            if (ub + lane * 4 < c.DGW)                     // DGW % 4 == 0: a lane's four words are all in or all out
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(dst + ub), 16, 0, 0);
         }
     };
     fetch_digest(0);
@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 }
                 tile_currents<CascadeFlat, CW>(c, lstX + bl * LX, nX, lstI + bl * LR, nI, lstE + bl * LR, nE, wi, we, wtile, nullptr, jj, xb, j, curE, curI);
             } else {   // generic bit-scan path
-                const Cur2 r = busy_currents(wtile, wieT, weiT, c.dig + (size_t)t * c.DW + bl * NinW, spI + bl * NW,
+                const Cur2 r = busy_currents(wtile, wieT, weiT, c.dig + (size_t)t * c.DW + c.OXW + bl * NinW, spI + bl * NW,
                                              finE + bl * NW, xb, NinW, NW, Nin, N, jj, tailcol, CW);
                 curE = r.e; curI = r.i;
             }
@@ -1611,8 +1611,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
 }
 
 // words of one digest entry / of its part that the step kernel copies into LDS
-int digest_words(int B, int Nin) { const int NinW = (Nin + 31) / 32; return ((B * NinW + B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + B) + 3) & ~3; }
-int digest_lds_words(int B, int Nin) { return digest_words(B, Nin) - B * ((Nin + 31) / 32); }
+// one digest entry: [part staged in LDS: lists | meta | row masks | active rows | row -> index | lane-grouped lists | group
+// sizes] padded to 4 words, then the [B][NinW] bit words (read from global memory by the bit-scan path only)
+int digest_lds_words(int B, int Nin) { return (B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + B + 3) & ~3; }
+int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin + 31) / 32) + 3) & ~3; }
 
 size_t lds_bytes(int B, int Nin, int N) {
     const int NW = (N + 31) / 32;
@@ -1721,7 +1723,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     float *xscratch = (float *)(ws + 4 * wb);
     snn_rng_state *rng2 = (snn_rng_state *)(ws + 4 * wb + al((size_t)B * Nin * 4));
     c.dig = (uint32_t *)(ws + fused_workspace(B, Nin, N));
-    c.DW = digest_words(B, Nin); c.DGW = digest_lds_words(B, Nin);
+    c.DW = digest_words(B, Nin); c.DGW = digest_lds_words(B, Nin); c.OXW = c.DGW;
     c.in = L[0].ext_spikes; c.sX0 = L[0].s;
     c.x_traces = L[0].p.lif.traces; c.x_decay = L[0].p.lif.trace_decay; c.x_scale = L[0].p.lif.trace_scale;
     c.x_additive = L[0].p.lif.traces_additive;
