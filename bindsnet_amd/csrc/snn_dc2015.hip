@@ -1095,7 +1095,7 @@ constexpr unsigned kPollLimit = 400000u;
 constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 98.2 k, 2 -> 96.6 k timesteps/s (same GPU box)
 constexpr size_t resident_fixed_lds(int cw) {
     return 3 * NT * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
-           2 * MAXB * cw * 4;
+           2 * MAXB * cw * 4 + 7 * MAXB * cw * 4;
 }     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
 // CWR = columns per workgroup (8, 4 or 2): the PostPre stage is ALU-throughput bound inside a CU, so narrower tiles on
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                      O_MT = O_XNU0 + MAXB * CW * 4, O_CAND = O_MT + 8 * 624 * 4, O_KEYS = O_CAND + NCAND * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
-                     O_CURB = O_MISC + 32, O_WT = O_CURB + 2 * MAXB * CW * 4;
+                     O_CURB = O_MISC + 32, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
     static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
@@ -1132,6 +1132,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     uint32_t *colmask = (uint32_t *)(smem + O_COLM);
     int *misc = (int *)(smem + O_MISC);
     float *curbuf = (float *)(smem + O_CURB);
+    // membrane state of the tile threads' (sample, column) pairs: [7][TT] = vE, rE, vI, rI, xE, xI, theta.  Each slot is
+    // touched by its own thread only; it lives in LDS rather than in registers because seven values that are used once
+    // per step are exactly what the register allocator spills to (much slower) scratch memory in this kernel.
+    float *stl = (float *)(smem + O_ST);
     float *wtile = (float *)(smem + O_WT);                 // [Nin][CW] the own weight slice, resident for the run
     float *wieT = wtile + (size_t)Nin * CW;                // [N][CW] own column slices of the recurrent weights
     float *weiT = wieT + (size_t)N * CW;
@@ -1175,12 +1179,12 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         }
     };
     fetch_digest(0);
-    float r_vE = 0.f, r_rE = 0.f, r_vI = 0.f, r_rI = 0.f, r_xE = 0.f, r_xI = 0.f, th = 0.f;
     bool last_sE = false, last_sI = false;
     if (mine) {
-        r_vE = c.vE[kst]; r_rE = c.rE[kst]; r_vI = c.vI[kst]; r_rI = c.rI[kst]; th = c.theta[j];
-        if (c.pI.traces) r_xI = c.xI[kst];
-        if (c.pE.lif.traces) r_xE = c.xE[kst];
+        stl[0 * TT + tid] = c.vE[kst]; stl[1 * TT + tid] = c.rE[kst]; stl[2 * TT + tid] = c.vI[kst]; stl[3 * TT + tid] = c.rI[kst];
+        stl[4 * TT + tid] = c.pE.lif.traces ? c.xE[kst] : 0.f;
+        stl[5 * TT + tid] = c.pI.traces ? c.xI[kst] : 0.f;
+        stl[6 * TT + tid] = c.theta[j];
         last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
     }
     int rng_pos = 0, mb = 0, ahead = 0; long long rng_consumed = 0;
@@ -1384,7 +1388,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 else sp = colv && bit_of(finE + bl * NW, j);
                 float xn = 0.f;
                 if (colv) {
-                    if (c.pE.lif.traces) { xn = trace_next(r_xE, sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); r_xE = xn; }
+                    if (c.pE.lif.traces) { xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); stl[4 * TT + tid] = xn; }
                     last_sE = sp;
                     if (c.rasE) (c.rasE + (size_t)(t - 1) * B * N)[kst] = sp;
                 }
@@ -1503,7 +1507,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         DBG_MARK(5);
         // ---- B2: membrane updates
         bool spE = false, spIn = false;
+        float r_vE = 0.f, r_vI = 0.f;
         if (mine) {
+            float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
+            r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
             // theta += theta_plus * (spikes of the previous step, summed over the batch), nodes.py:1094 -- applied
             // here, right before this step's decay, instead of behind a barrier of its own at the end of that step
             if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)cnt[((t - 1) & 1) * CW + jj];
@@ -1514,6 +1521,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             if (r_rI > 0.f) ci = 0.f;
             spIn = lif_update(r_vI, r_rI, ci, c.pI);
             last_sI = spIn;
+            stl[0 * TT + tid] = r_vE; stl[1 * TT + tid] = r_rE; stl[2 * TT + tid] = r_vI; stl[3 * TT + tid] = r_rI; stl[6 * TT + tid] = th;
+            if (c.pI.traces) stl[5 * TT + tid] = trace_next(stl[5 * TT + tid], spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
         }
         {   // publish crossing / spike bits of step t: epoch t+1.  A wave holds 64/CW samples x CW columns; SPG
             // consecutive samples share a granule
@@ -1529,7 +1538,6 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         }
         if (mine) {
             if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
-            if (c.pI.traces) r_xI = trace_next(r_xI, spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
             if (c.rasI) (c.rasI + (size_t)t * B * N)[kst] = spIn;
             if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
         }
@@ -1541,11 +1549,12 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
 
     // ---- epilogue: state and weights back to the tensors the caller owns
     if (mine) {
+        float th = stl[6 * TT + tid];
         if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[((T - 1) & 1) * CW + jj];   // the last step's spikes
-        c.vE[kst] = r_vE; c.rE[kst] = r_rE; c.vI[kst] = r_vI; c.rI[kst] = r_rI;
+        c.vE[kst] = stl[0 * TT + tid]; c.rE[kst] = stl[1 * TT + tid]; c.vI[kst] = stl[2 * TT + tid]; c.rI[kst] = stl[3 * TT + tid];
         if (bl == 0) c.theta[j] = th;
-        if (c.pI.traces) c.xI[kst] = r_xI;
-        if (c.pE.lif.traces) c.xE[kst] = r_xE;
+        if (c.pI.traces) c.xI[kst] = stl[5 * TT + tid];
+        if (c.pE.lif.traces) c.xE[kst] = stl[4 * TT + tid];
         c.sE[kst] = last_sE; c.sI[kst] = last_sI;
     }
     if (c.has_norm) {
@@ -1748,9 +1757,9 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
     if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
     int rcw = resident_cw(N);
-    while (rcw < 8 && (N + rcw - 1) / rcw > 224) rcw *= 2;          // one workgroup per CU, all co-resident
+    while (rcw < 8 && (N + rcw - 1) / rcw > 256) rcw *= 2;          // one workgroup per CU (256 CUs), all co-resident
     const int rG = (N + rcw - 1) / rcw, rKB = (B + 16 / rcw - 1) / (16 / rcw);
-    if (rG > 224 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N, rcw) > 150 * 1024 ||
+    if (rG > 256 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N, rcw) > 150 * 1024 ||
         resident_extra(B, Nin, N, R->T) > kResidentMaxExtra) resident = 0;
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
