@@ -1390,7 +1390,6 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                 if (colv) {
                     if (c.pE.lif.traces) { xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); stl[4 * TT + tid] = xn; }
                     last_sE = sp;
-                    if (c.rasE) (c.rasE + (size_t)(t - 1) * B * N)[kst] = sp;
                 }
                 xnu0[bl * CW + jj] = xn * c.nu0;
                 if (sp) atomicOr(&colmask[jj], 1u << bl);
@@ -1399,6 +1398,13 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         lds_barrier();
         if (phaseA) {
             DBG_MARK(3);
+            // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
+            // received Ai spikes), so whole [N]-byte rows are written by ONE workgroup each (sample b by workgroup b mod G)
+            // instead of CW-byte pieces by all of them: full coalesced lines instead of partial sectors
+            for (int b = g; b < B; b += c.G) {
+                if (c.rasE) { uint8_t *row = c.rasE + ((size_t)(t - 1) * B + b) * N; for (int jx = tid; jx < N; jx += NT) row[jx] = (uint8_t)bit_of(finE + b * NW, jx); }
+                if (c.rasI) { uint8_t *row = c.rasI + ((size_t)(t - 1) * B + b) * N; for (int jx = tid; jx < N; jx += NT) row[jx] = (uint8_t)bit_of(spI + b * NW, jx); }
+            }
             if (do_stdp) {
                 const float *xsrc = c.xtr + (size_t)t * B * Nin;          // X trace after step t-1
                 if (stdp_full) {
@@ -1538,7 +1544,6 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
         }
         if (mine) {
             if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
-            if (c.rasI) (c.rasI + (size_t)t * B * N)[kst] = spIn;
             if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
         }
         DBG_MARK(6);
