@@ -1103,8 +1103,7 @@ constexpr size_t resident_fixed_lds(int cw) {
 template <int CWR>
 __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     constexpr int CW = CWR, TT = MAXB * CWR;               // (shadow the per-step kernel's tile constants)
-    constexpr int FB = 2 * CW;                             // exchange: bits per (workgroup, sample) = CW crossings + CW Ai spikes
-    constexpr int SPG = 32 / FB;                           //           samples per granule
+    constexpr int SPG = 16 / CW;                           // exchange: samples per granule (CW crossing bits + CW Ai-spike bits each)
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1252,10 +1251,9 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                     if (b >= B) break;
                     uint32_t be = 0, bi = 0;
 #pragma unroll
-                    for (int w = 0; w < WPB; ++w) {
-                        const uint32_t f = (uint32_t)x[w] >> (sidx * FB);
-                        be |= (f & FM) << (w * CW);
-                        bi |= ((f >> CW) & FM) << (w * CW);
+                    for (int w = 0; w < WPB; ++w) {      // granule payload: crossings of its SPG samples | << 16: their Ai spikes
+                        be |= (((uint32_t)x[w] >> (sidx * CW)) & FM) << (w * CW);
+                        bi |= (((uint32_t)x[w] >> (16 + sidx * CW)) & FM) << (w * CW);
                     }
                     ((uint8_t *)crs)[(b * NW) * 4 + h] = (uint8_t)be;
                     ((uint8_t *)spI)[(b * NW) * 4 + h] = (uint8_t)bi;
@@ -1535,10 +1533,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
             constexpr int SPW = 64 / CW;
             const int sidx = lane / CW, b = wave * SPW + sidx;
-            const uint32_t fld = (uint32_t)((mE >> (sidx * CW)) & FM) | ((uint32_t)((mI >> (sidx * CW)) & FM) << CW);
-            uint32_t v = fld;
-#pragma unroll
-            for (int sn = 1; sn < SPG; ++sn) v |= (uint32_t)__shfl_down(fld, sn * CW) << (sn * FB);
+            // SPG consecutive samples x CW columns = 16 consecutive bits of each ballot: no cross-lane traffic needed
+            const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFFFull) << 16);
             if (tid < TT && (lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
                 granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
         }
