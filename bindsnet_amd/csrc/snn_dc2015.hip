@@ -914,12 +914,12 @@ __device__ __forceinline__ void granule_store(unsigned long long *p, unsigned lo
 }
 
 // PostPre on the LDS-resident slice: (row, column) items, rows listed in `arows` (all rows when FULL).
-template <class SUM, bool FULL, int CWL>
+template <class SUM, bool FULL, int CWL, int NTL>
 __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
                                               const uint32_t *colmask, const uint8_t *__restrict__ sbytes,
                                               const float *xnu0, const float *__restrict__ xsrc, float *wtile, int c0,
                                               int tid, int Emain) {
-    constexpr int CW = CWL;                                       // (tile width of the calling kernel)
+    constexpr int CW = CWL, NT = NTL;                             // (tile width / workgroup size of the calling kernel)
     const int B = c.B, Nin = c.Nin, N = c.N;
     const int nitems = nact * CW;
     const int q = tid % CW, jq = c0 + q;                          // NT % CW == 0: a thread keeps its column
@@ -973,11 +973,11 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
 }
 
 // Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike, on the LDS-resident slice.
-template <class SUM, int CWL>
+template <class SUM, int CWL, int NTL>
 __device__ __forceinline__ void stdp_cols_lds(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
                                               const uint32_t *colmask, const float *__restrict__ xsrc, float *wtile,
                                               int c0, int tid, int Emain) {
-    constexpr int CW = CWL;
+    constexpr int CW = CWL, NT = NTL;
     const int B = c.B, Nin = c.Nin, N = c.N;
     while (active_cols) {
         const int q = __ffs(active_cols) - 1; active_cols &= active_cols - 1;
@@ -1050,9 +1050,9 @@ __device__ __attribute__((noinline)) Cur2 busy_currents(const float *wtile, cons
 // on entry; everything beyond is (re)computed on the way.  Every thread of the workgroup must call it.
 __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uint32_t *crs, unsigned long long *keys,
                                                          int mb, int pos, int N, int ntw, int rows, int myrank,
-                                                         int wb, int wj, int BW, int tid) {
+                                                         int wb, int wj, int BW, int tid, int nthreads) {
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int NWV = NT / 64;
+    const int NWV = nthreads / 64;
     uint32_t parked = 0;
     int lo = 0, hi = min(ntw, 2);
     while (rows) {
@@ -1092,17 +1092,20 @@ __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uin
 }
 
 constexpr unsigned kPollLimit = 400000u;
+constexpr int kResidentDefaultNT = 1024;
 constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 98.2 k, 2 -> 96.6 k timesteps/s (same GPU box)
+constexpr int kBitWords = 1024;      // capacity of the [B][NW] bit-word arrays (independent of the workgroup size)
 constexpr size_t resident_fixed_lds(int cw) {
-    return 3 * NT * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
+    return 3 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
            2 * MAXB * cw * 4 + 7 * MAXB * cw * 4;
 }     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
 // CWR = columns per workgroup (8, 4 or 2): the PostPre stage is ALU-throughput bound inside a CU, so narrower tiles on
 // more CUs shorten it, while the stages every workgroup repeats (receive, lists, arbitration) stay as they are.
-template <int CWR>
-__global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
-    constexpr int CW = CWR, TT = MAXB * CWR;               // (shadow the per-step kernel's tile constants)
+// NTR = threads per workgroup: 1024, or 512 (twice the registers per thread: no spills; needs B*NW <= 512 and CW <= 4).
+template <int CWR, int NTR>
+__global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
+    constexpr int CW = CWR, TT = MAXB * CWR, NT = NTR;     // (shadow the per-step kernel's constants)
     constexpr int SPG = 16 / CW;                           // exchange: samples per granule (CW crossing bits + CW Ai-spike bits each)
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
@@ -1110,7 +1113,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
     //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.
-    constexpr size_t O_CRS = 0, O_FINE = O_CRS + NT * 4, O_SPI = O_FINE + NT * 4, O_XNU0 = O_SPI + NT * 4,
+    constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + kBitWords * 4,
                      O_MT = O_XNU0 + MAXB * CW * 4, O_CAND = O_MT + 8 * 624 * 4, O_KEYS = O_CAND + NCAND * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     }
     int rng_pos = 0, mb = 0, ahead = 0; long long rng_consumed = 0;
     if (c.pE.one_spike) {
-        if (tid < 624) mt[tid] = c.rng[0]->mt[tid];
+        for (int k = tid; k < 624; k += NT) mt[k] = c.rng[0]->mt[k];
         rng_pos = __builtin_amdgcn_readfirstlane(c.rng[0]->pos);
         const long long cons0 = c.rng[0]->consumed;
         rng_consumed = ((long long)__builtin_amdgcn_readfirstlane((int)(cons0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cons0);
@@ -1350,7 +1353,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                     atomicMax(&keys[b], key);
                 }
             } else {
-                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid);
+                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT);
                 ahead = ntw;            // blocks beyond ntw may have been overwritten by the walk
             }
             lds_barrier();
@@ -1406,8 +1409,8 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
             if (do_stdp) {
                 const float *xsrc = c.xtr + (size_t)t * B * Nin;          // X trace after step t-1
                 if (stdp_full) {
-                    if (anytail) stdp_rows_lds<OuterSum, true, CW>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                    else stdp_rows_lds<CascadeT, true, CW>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    if (anytail) stdp_rows_lds<OuterSum, true, CW, NT>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                    else stdp_rows_lds<CascadeT, true, CW, NT>(c, Nin, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
                 } else {
                     uint32_t acols = 0;
                     if (c.nu1 != 0.f) {
@@ -1415,11 +1418,11 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
                         for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
                     }
                     if (anytail) {
-                        stdp_rows_lds<OuterSum, false, CW>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                        stdp_cols_lds<OuterSum, CW>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                        stdp_rows_lds<OuterSum, false, CW, NT>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<OuterSum, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     } else {
-                        stdp_rows_lds<CascadeT, false, CW>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
-                        stdp_cols_lds<CascadeT, CW>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+                        stdp_rows_lds<CascadeT, false, CW, NT>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        stdp_cols_lds<CascadeT, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     }
                 }
             }
@@ -1615,7 +1618,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_run(const DcCtx c) {
     }
     if (g == 0 && c.pE.one_spike) {
         snn_rng_state *wr = c.rng[0];
-        if (tid < 624) wr->mt[tid] = mt[mb * 624 + tid];
+        for (int k = tid; k < 624; k += NT) wr->mt[k] = mt[mb * 624 + k];
         if (tid == 0) { wr->pos = rng_pos; wr->consumed = rng_consumed; }
     }
 }
@@ -1641,6 +1644,10 @@ size_t lds_bytes_resident(int B, int Nin, int N, int cw) {
 
 // tile width of the resident kernel: the narrowest of 8 / 4 / 2 columns whose grid still fits one workgroup per CU with
 // room to spare (SNN_DC_CW overrides)
+int resident_nt() {
+    if (const char *e = getenv("SNN_DC_NT")) { const int v = atoi(e); if (v == 512 || v == 1024) return v; }
+    return kResidentDefaultNT;
+}
 int resident_cw(int N) {
     if (const char *e = getenv("SNN_DC_CW")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) return v; }
     return kResidentDefaultCW;
@@ -1762,6 +1769,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     const int rG = (N + rcw - 1) / rcw, rKB = (B + 16 / rcw - 1) / (16 / rcw);
     if (rG > 256 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || lds_bytes_resident(B, Nin, N, rcw) > 150 * 1024 ||
         resident_extra(B, Nin, N, R->T) > kResidentMaxExtra) resident = 0;
+    int rnt = resident_nt();
+    if (rnt == 512 && (rcw > 4 || B * c.NW > 512)) rnt = 1024;       // single-pass stages of the 512-thread variant
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
     static int dbg_T = 0;
@@ -1775,9 +1784,10 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static bool lds_attr = false;
     if (!lds_attr) {   // the kernel may use more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_step, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
-        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
-        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
-        if (snn_check(hipFuncSetAttribute((const void *)k_dc2015_run<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
+        const void *rv[5] = {(const void *)k_dc2015_run<8, 1024>, (const void *)k_dc2015_run<4, 1024>, (const void *)k_dc2015_run<2, 1024>,
+                             (const void *)k_dc2015_run<4, 512>, (const void *)k_dc2015_run<2, 512>};
+        for (const void *f : rv)
+            if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         lds_attr = true;
     }
     // One run = memset of the exchange words (pad bytes for columns >= N are never written by a workgroup),
@@ -1792,9 +1802,11 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
             const size_t rl = lds_bytes_resident(B, Nin, N, rcw);
-            if (rcw == 8) hipLaunchKernelGGL(k_dc2015_run<8>, dim3(c.G), dim3(NT), rl, qs, c);
-            else if (rcw == 4) hipLaunchKernelGGL(k_dc2015_run<4>, dim3(c.G), dim3(NT), rl, qs, c);
-            else hipLaunchKernelGGL(k_dc2015_run<2>, dim3(c.G), dim3(NT), rl, qs, c);
+            if (rnt == 512 && rcw == 4) hipLaunchKernelGGL((k_dc2015_run<4, 512>), dim3(c.G), dim3(512), rl, qs, c);
+            else if (rnt == 512) hipLaunchKernelGGL((k_dc2015_run<2, 512>), dim3(c.G), dim3(512), rl, qs, c);
+            else if (rcw == 8) hipLaunchKernelGGL((k_dc2015_run<8, 1024>), dim3(c.G), dim3(1024), rl, qs, c);
+            else if (rcw == 4) hipLaunchKernelGGL((k_dc2015_run<4, 1024>), dim3(c.G), dim3(1024), rl, qs, c);
+            else hipLaunchKernelGGL((k_dc2015_run<2, 1024>), dim3(c.G), dim3(1024), rl, qs, c);
             if (prof) snn_prof_end(qs);
             return snn_check_launch();
         }
