@@ -1124,7 +1124,6 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     uint32_t *spI = (uint32_t *)(smem + O_SPI);            // ... Ai spikes
     float *xnu0 = (float *)(smem + O_XNU0);
     uint32_t *mt = (uint32_t *)(smem + O_MT);              // generator ring: block base+m in slot (mb + m) & 7
-    uint32_t *cand = (uint32_t *)(smem + O_CAND);
     unsigned long long *keys = (unsigned long long *)(smem + O_KEYS);
     uint16_t *lstI = (uint16_t *)(smem + O_LSTI);
     uint16_t *lstE = (uint16_t *)(smem + O_LSTE);
@@ -1260,6 +1259,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                     }
                     ((uint8_t *)crs)[(b * NW) * 4 + h] = (uint8_t)be;
                     ((uint8_t *)spI)[(b * NW) * 4 + h] = (uint8_t)bi;
+                    if (be && c.pE.one_spike) atomicOr((unsigned int *)&misc[3], 1u << b);   // samples with an Ae crossing: known at the barrier below
                 }
             }
         } else if (tid < BW) {   // t == 0: previous spikes come from the layers' `s` tensors (bytes -> bits)
@@ -1287,76 +1287,71 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         // ---- per sample (one wave each, in turns): event list of its Ai spikes; does it have an Ae crossing?
         if (NW <= 32) {                                    // two samples per wave, one per half
             const int hl = lane & 31;
-            const uint64_t halfmask = (lane & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
             for (int b2 = wave * 2; b2 < B; b2 += NWV * 2) {
                 const int b = b2 + (lane >> 5);
                 const bool bv = b < B;
                 const int ni = build_list_half(bv ? spI + b * NW : nullptr, NW, lane, lstI + (bv ? b : 0) * LR, LR);
-                const uint64_t mc = __ballot(use_rng && bv && hl < NW && crs[b * NW + hl] != 0) & halfmask;
                 if (hl == 0 && bv) {
                     cntI[b] = ni;
-                    if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
                     if (ni > 4) atomicOr((unsigned int *)&misc[2], 2u);
                 }
             }
         } else {
             for (int b = wave; b < B; b += NWV) {
                 const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
-                const uint64_t mc = __ballot(use_rng && lane < NW && crs[b * NW + lane] != 0);
                 if (lane == 0) {
                     cntI[b] = ni;
-                    if (mc) atomicOr((unsigned int *)&misc[3], 1u << b);
                     if (ni > 4) atomicOr((unsigned int *)&misc[2], 2u);
                 }
             }
         }
-        if (use_rng && tid < BW) {                         // threshold crossers of this (sample, word) -> compact candidate list
-            uint32_t bits = crs[tid];
-            if (bits) {
-                int at = atomicAdd(&misc[4], __popc(bits));
+        // ---- one_spike arbitration, identical in every workgroup (nodes.py:1097-1105): among the crossings of a sample
+        //      the winner is argmax(1 / q[j]), q = the generator's next Exp(1) draws, one per neuron of every sample that
+        //      has a crossing, in sample order.  Which samples crossed is known since the receive barrier, so each thread
+        //      scores the crossings of ITS (sample, word) right here, next to the list building: the barrier below
+        //      closes both.
+        uint32_t anym = 0;
+        int arb_rows = 0, arb_E = 0, arb_ntw = 0;
+        if (use_rng) {
+            anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
+            arb_rows = __popc(anym);
+            arb_E = rng_pos + 2 * arb_rows * N;
+            arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
+            if (arb_ntw <= 7 && tid < BW) {            // every block the step consumes is resident (ring run ahead at the top)
+                uint32_t bits = crs[tid];
+                const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
                 while (bits) {
                     const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
-                    if (at < NCAND) cand[at] = ((uint32_t)wb << 16) | (uint32_t)jx;
-                    ++at;
+                    const int d = myrank * N + jx;
+                    const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
+                    const int m0 = w0 / 624, m1 = w1 / 624;
+                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                    mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                    const float val = 1.0f / q;                             // p / q with p = 1
+                    const unsigned long long key =                          // max value, ties -> lowest index
+                        ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                    atomicMax(&keys[wb], key);
                 }
             }
         }
         DBG_MARK(1);
         lds_barrier();
+        if (tid == 35) misc[3] = 0;                        // crossing-sample mask: every thread has read it; next set by the next receive
         const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
         const int cjg = c0 + cj_;
         const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
 
         // ================================================================== phase A: finish step t-1
-        uint32_t anym = 0;                                 // samples with an Ae crossing at step t-1
         if (use_rng) {
             DBG_MARK(12);
-            anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
-            const int rows = __popc(anym);
-            const int pos = rng_pos;
-            const int E = pos + 2 * rows * N;
-            const int ntw = rows ? (E - 1) / 624 : 0;
-            const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
-            const int ncand = __builtin_amdgcn_readfirstlane(misc[4]);
-            if (ncand <= NCAND && ntw <= 7) {
-                for (int k = tid; k < ncand; k += NT) {
-                    const uint32_t cd = cand[k];
-                    const int b = (int)(cd >> 16), jx = (int)(cd & 0xFFFFu);
-                    const int d = __popc(anym & ((1u << b) - 1u)) * N + jx;
-                    const int w0 = pos + 2 * d, w1 = w0 + 1;
-                    const int m0 = w0 / 624, m1 = w1 / 624;
-                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
-                                                    mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
-                    const float val = 1.0f / q;
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
-                    atomicMax(&keys[b], key);
-                }
-            } else {
+            const int rows = arb_rows, pos = rng_pos, E = arb_E, ntw = arb_ntw;
+            if (ntw > 7) {
+                // more generator blocks than the ring holds: walk the stream block by block (out of line)
+                const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
                 arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT);
                 ahead = ntw;            // blocks beyond ntw may have been overwritten by the walk
+                lds_barrier();
             }
-            lds_barrier();
             DBG_MARK(13);
             if (tid < BW) {        // final spikes: the winner's bit, or nothing -- and with them the event lists (<= 1 entry)
                 uint32_t wbits = 0;
@@ -1433,7 +1428,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         if (!phaseB) break;
         // scratch of phase A: everyone is past its last read
         if (tid < 32) colmask[tid] = 0;
-        if (tid >= 34 && tid <= 36) misc[tid - 32] = 0;      // busy flag, crossing-sample mask, candidate count
+        if (tid == 34) misc[2] = 0;                          // busy flag (set in the list stage, read just above)
         if (tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;
 
         // ================================================================== phase B: start step t
