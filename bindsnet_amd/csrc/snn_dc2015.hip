@@ -1096,7 +1096,7 @@ constexpr int kResidentDefaultNT = 1024;
 constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 98.2 k, 2 -> 96.6 k timesteps/s (same GPU box)
 constexpr int kBitWords = 1024;      // capacity of the [B][NW] bit-word arrays (independent of the workgroup size)
 constexpr size_t resident_fixed_lds(int cw) {
-    return 3 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
+    return 4 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
            2 * MAXB * cw * 4 + 7 * MAXB * cw * 4;
 }     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
     //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.
-    constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + kBitWords * 4,
+    constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + 2 * kBitWords * 4,
                      O_MT = O_XNU0 + MAXB * CW * 4, O_CAND = O_MT + 8 * 624 * 4, O_KEYS = O_CAND + NCAND * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
-    uint32_t *spI = (uint32_t *)(smem + O_SPI);            // ... Ai spikes
+    uint32_t *spI2 = (uint32_t *)(smem + O_SPI);           // ... Ai spikes, two buffers by step parity (the raster rows of
+                                                           //     one step are written while the next receive may already run)
     float *xnu0 = (float *)(smem + O_XNU0);
     uint32_t *mt = (uint32_t *)(smem + O_MT);              // generator ring: block base+m in slot (mb + m) & 7
     unsigned long long *keys = (unsigned long long *)(smem + O_KEYS);
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
     if (tid < 8) misc[tid] = 0;
     if (tid < MAXB) keys[tid] = 0ull;
-    if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI[tid] = 0; }
+    if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
     bool failed = false;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 8] = (long long)clock64();
         if (c.dbg && threadIdx.x == 0) atomicMin((unsigned long long *)&c.dbg[(size_t)t * 24 + 20], (unsigned long long)wall_clock64());
         const int stepoff = t * B * Nin;
+        uint32_t *spI = spI2 + (t & 1) * kBitWords;
         const uint32_t *dg = dgbuf + (t & 1) * DGS;                       // digest of the X spikes of step t-1
         const uint16_t *lstX = (const uint16_t *)dg;
         const int *meta = (const int *)(dg + B * (LX / 2));
@@ -1394,13 +1396,6 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         lds_barrier();
         if (phaseA) {
             DBG_MARK(3);
-            // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
-            // received Ai spikes), so whole [N]-byte rows are written by ONE workgroup each (sample b by workgroup b mod G)
-            // instead of CW-byte pieces by all of them: full coalesced lines instead of partial sectors
-            for (int b = g; b < B; b += c.G) {
-                if (c.rasE) { uint8_t *row = c.rasE + ((size_t)(t - 1) * B + b) * N; for (int jx = tid; jx < N; jx += NT) row[jx] = (uint8_t)bit_of(finE + b * NW, jx); }
-                if (c.rasI) { uint8_t *row = c.rasI + ((size_t)(t - 1) * B + b) * N; for (int jx = tid; jx < N; jx += NT) row[jx] = (uint8_t)bit_of(spI + b * NW, jx); }
-            }
             if (do_stdp) {
                 const float *xsrc = c.xtr + (size_t)t * B * Nin;          // X trace after step t-1
                 if (stdp_full) {
@@ -1425,6 +1420,18 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const bool busy = (__builtin_amdgcn_readfirstlane(misc[2]) & 2) != 0;
         lds_barrier();
         DBG_MARK(4);
+        if (phaseA && tid >= TT) {
+            // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
+            // received Ai spikes), so whole [N]-byte rows are written by ONE workgroup each (row r of the 2*B rows by
+            // workgroup r mod G) instead of CW-byte pieces by all of them -- full coalesced lines instead of partial
+            // sectors -- and by the threads that have nothing to do while the tile threads compute currents
+            for (int r = g; r < 2 * B; r += c.G) {
+                const int b = r < B ? r : r - B;
+                uint8_t *ras = r < B ? c.rasE : c.rasI;
+                const uint32_t *bitsrc = (r < B ? finE : spI) + b * NW;
+                if (ras) { uint8_t *row = ras + ((size_t)(t - 1) * B + b) * N; for (int jx = tid - TT; jx < N; jx += NT - TT) row[jx] = (uint8_t)bit_of(bitsrc, jx); }
+            }
+        }
         if (!phaseB) break;
         // scratch of phase A: everyone is past its last read
         if (tid < 32) colmask[tid] = 0;
