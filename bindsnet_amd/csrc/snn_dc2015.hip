@@ -77,7 +77,7 @@ struct DcCtx {
     // per-step digest of the X spikes, produced once per run by k_dc2015_prep (entry e <-> spikes of step e-1):
     // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
     // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index | [B*LX/2] u16 event lists grouped by row_sum lane |
-    // [B] group sizes (5 bits each: lanes 0..3, leftover sources)
+    // [B] group sizes (5 bits each: lanes 0..3, leftover sources) | [B] events per 256-position group (5 bits each)
     uint32_t *dig; int DW, DGW, OXW;        // words per entry, words of its LDS part, offset of its bit words
     // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
     // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
@@ -438,6 +438,16 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
         if (in16) perm[my] = (uint16_t)i;
         if (lane < LX) D_l2[b * LX + lane] = perm[lane];
         if (lane == 0) D_gc[b] = gc;
+        // ... and how many of the (ascending) events fall into each 256-position group of the cascade order: a quad of
+        // threads of a multi_row_sum column sums one group each
+        {
+            uint32_t gq = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t mk = __ballot(in16 && min(i >> 8, 3) == k);
+                gq |= (uint32_t)__popcll(mk) << (5 * k);
+            }
+            if (lane == 0) D_gc[B + b] = gq;
+        }
     }
     for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
     for (int base = 0; base < Nin; base += NT) {       // compact the rows with a spike in any sample
@@ -1219,6 +1229,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
         const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);              // X events grouped by row_sum lane
         const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
+        const uint32_t *gqn = gcnt + B;                                   // X events per 256-position cascade group
         const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
         // ------------------------------------------------------------------ receive step t-1
         const bool use_rng = phaseA && c.pE.one_spike;
@@ -1420,7 +1431,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const bool busy = (__builtin_amdgcn_readfirstlane(misc[2]) & 2) != 0;
         lds_barrier();
         DBG_MARK(4);
-        if (phaseA && tid >= TT) {
+        auto write_raster_rows = [&]() {
+            if (phaseA && tid >= TT) {
             // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
             // received Ai spikes), so whole [N]-byte rows are written by ONE workgroup each (row r of the 2*B rows by
             // workgroup r mod G) instead of CW-byte pieces by all of them -- full coalesced lines instead of partial
@@ -1431,7 +1443,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 const uint32_t *bitsrc = (r < B ? finE : spI) + b * NW;
                 if (ras) { uint8_t *row = ras + ((size_t)(t - 1) * B + b) * N; for (int jx = tid - TT; jx < N; jx += NT - TT) row[jx] = (uint8_t)bit_of(bitsrc, jx); }
             }
-        }
+            }
+        };
+        if (!phaseB) write_raster_rows();                  // (last iteration: nothing to overlap with)
         if (!phaseB) break;
         // scratch of phase A: everyone is past its last read
         if (tid < 32) colmask[tid] = 0;
@@ -1440,6 +1454,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 
         // ================================================================== phase B: start step t
         float curE = 0.f, curI = 0.f;
+        const bool quadx = !tailcol && Nin <= 1024 && NT - TT >= B * CW * 4;
         if (!busy && tailcol) {
             if (cvalid) {
                 const int nX = cntX[cb_], nI = cntI[cb_], nE = cntE[cb_];
@@ -1495,6 +1510,65 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             }
             lds_barrier();
             if (mine) { curE = curbuf[(bl * CW + jj) * 2]; curI = curbuf[(bl * CW + jj) * 2 + 1]; }
+        } else if (!busy && quadx) {
+            // multi_row_sum columns, X -> Ae part: the cascade's 256-position groups are independent partial sums, so four
+            // threads (taken from the waves that are idle in this stage) sum one group of a (sample, column) pair each and
+            // lane 0 folds them in the cascade's order; meanwhile the pair's tile thread sums the recurrent parts.
+            const int qt = tid - TT;                           // spare threads <-> (sample, column, group)
+            if (phaseB && qt >= 0 && qt < (B * CW * 4)) {
+                const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+                const bool pv = c0 + pq < N;
+                const uint32_t gq = gqn[pb];
+                const int st = (pL > 0 ? (int)(gq & 31u) : 0) + (pL > 1 ? (int)((gq >> 5) & 31u) : 0) + (pL > 2 ? (int)((gq >> 10) & 31u) : 0);
+                const int nL = (int)((gq >> (5 * pL)) & 31u);
+                const uint16_t *lx = lstX + pb * LX;
+                const uint8_t *xb = sbytes ? sbytes + pb * Nin : nullptr;
+                int ix[8]; float wx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ix[u] = min((int)lx[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + pq];
+                CascadeFlat a; a.init();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u], wx[u] * (xb ? (float)xb[ix[u]] : 1.0f), Nin);
+                for (int u = 8; u < nL; ++u) {
+                    const int ii2 = (int)lx[st + u];
+                    a.add(ii2, wtile[ii2 * CW + pq] * (xb ? (float)xb[ii2] : 1.0f), Nin);
+                }
+                const float G = a.a1 + a.a0;                   // the group's sum as the cascade would carry it upward
+                const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
+                if (pL == 0 && pv) {
+                    const int GL = (Nin >> 4) >> 4;            // group holding the cascade's final (pseudo-)block
+                    const float Gs[4] = {G, G1, G2, G3};
+                    float A2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
+                    float Gl = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
+                    const float res = ((0.0f + Gl) + A2) + 0.0f;
+                    curbuf[(pb * CW + pq) * 2] = 0.0f + res;   // zeros + X->Ae (network.py:225-248)
+                }
+            }
+            float e2 = 0.f, e3 = 0.f;
+            if (mine) {
+                const int nI = cntI[bl], nE = cntE[bl];
+                int ii[4], ie[4]; float wi[4], we[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ii[u] = min((int)lstI[bl * LR + u], N - 1); ie[u] = min((int)lstE[bl * LR + u], N - 1); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { wi[u] = wieT[ii[u] * CW + jj]; we[u] = weiT[ie[u] * CW + jj]; }
+                CascadeFlat a; a.init();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (u < nI) a.add(ii[u], wi[u] * 1.0f, N);
+                e2 = a.finish(N);
+                a.init();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (u < nE) a.add(ie[u], we[u] * 1.0f, N);
+                e3 = a.finish(N);
+            }
+            lds_barrier();
+            if (mine) { curE = curbuf[(bl * CW + jj) * 2] + e2; curI = 0.0f + e3; }
         } else if (mine) {
             const int nX = cntX[bl], nI = cntI[bl], nE = cntE[bl];
             const uint8_t *xb = sbytes ? sbytes + bl * Nin : nullptr;
@@ -1512,6 +1586,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 curE = r.e; curI = r.i;
             }
         }
+        write_raster_rows();           // by the threads that idle while the tile threads update the membranes
         if (busy) lds_barrier();       // (uniform) the bit-scan path reads the exchanged words the next poll overwrites
         DBG_MARK(5);
         // ---- B2: membrane updates
@@ -1628,7 +1703,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 // words of one digest entry / of its part that the step kernel copies into LDS
 // one digest entry: [part staged in LDS: lists | meta | row masks | active rows | row -> index | lane-grouped lists | group
 // sizes] padded to 4 words, then the [B][NinW] bit words (read from global memory by the bit-scan path only)
-int digest_lds_words(int B, int Nin) { return (B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + B + 3) & ~3; }
+int digest_lds_words(int B, int Nin) { return (B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + 2 * B + 3) & ~3; }
 int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin + 31) / 32) + 3) & ~3; }
 
 size_t lds_bytes(int B, int Nin, int N) {
