@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     if (tid < MAXB) keys[tid] = 0ull;
     if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
     bool failed = false;
+    const bool early_fetch = tailcol || (Nin <= 1024 && NT - TT >= B * CW * 4);   // = the currents stage always has that barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1241,6 +1242,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
             ahead = 7;
         }
+        // next iteration's digest, issued before the wait for the exchange when nothing can still be reading the buffer
+        // it overwrites (the previous iteration's currents stage ended with a barrier behind its last digest read)
+        if (t < T && early_fetch) fetch_digest(t + 1);
         if (phaseA) {
             const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
             const int NH = (c.G + WPB - 1) / WPB;           // bytes per sample = groups of WPB workgroups
@@ -1289,7 +1293,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         lds_barrier();
         DBG_MARK(15);
         if (tid < CW) cnt[(t & 1) * CW + tid] = 0;         // this step's spike counts (buffer last read one iteration ago)
-        if (t < T) fetch_digest(t + 1);                    // next iteration's digest: in flight behind this one
+        if (t < T && !early_fetch) fetch_digest(t + 1);    // next iteration's digest: in flight behind this one
         DBG_MARK(16);
         const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
         const uint8_t *sbytes = (mflags & 1) ? sprev_g : nullptr;
