@@ -1,0 +1,262 @@
+// snn_dc2015.hpp -- shared by the two translation units of the DiehlAndCook2015 plans (snn_dc2015.hip: digest
+// pre-pass, one-launch-per-timestep kernel, host side; snn_dc2015_resident.hip: the resident whole-run kernel):
+// tile constants, the kernel context, bit / list / ordered-sum helpers, digest layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/snnhip.h"
+#include "snn_common.hpp"
+#include "snn_order.hpp"
+#include "snn_rng.hpp"
+
+// Kernel context of both plans (external linkage: it crosses the two translation units).
+struct DcCtx {
+    int B, Nin, N, T, NW, NinW, G, RS;     // NW = ceil(N/32), NinW = ceil(Nin/32), G workgroups, RS input rows per WG
+    float dt; int learning;
+    // X (Input)
+    const uint8_t *in;          // [T,B,Nin]
+    const uint8_t *sX0;         // [B,Nin] X.s at entry
+    float *xX[2];               // trace after step t lives in xX[t&1]; entry trace in xX[1]
+    int x_traces; float x_decay, x_scale; int x_additive;
+    // Ae (DiehlAndCookNodes)
+    float *vE, *rE, *xE, *theta; uint8_t *sE;
+    snn_dc_params pE;
+    uint8_t *rasE; float *rasVE;
+    // Ai (LIFNodes)
+    float *vI, *rI, *xI; uint8_t *sI;
+    snn_lif_params pI;
+    uint8_t *rasI; float *rasVI;
+    // weights
+    float *Wxe; const float *Wei; const float *Wie;
+    int rule; float nu0, nu1; int use_dt; int has_min; float wmin; int has_max; float wmax;
+    // exchange + generator
+    uint32_t *crossE[2], *spikeI[2];
+    snn_rng_state *rng[2];
+    float inv_hwps, inv_NW, inv_RS;   // reciprocals of Nin/16, NW, RS for the exact float-multiply divisions
+    // per-step digest of the X spikes, produced once per run by k_dc2015_prep (entry e <-> spikes of step e-1):
+    // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
+    // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index | [B*LX/2] u16 event lists grouped by row_sum lane |
+    // [B] group sizes (5 bits each: lanes 0..3, leftover sources) | [B] events per 256-position group (5 bits each)
+    uint32_t *dig; int DW, DGW, OXW;        // words per entry, words of its LDS part, offset of its bit words
+    // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
+    // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
+    unsigned long long *ex; int KB;
+    float *xtr;
+    int *status;
+    int has_norm; float norm; int norm_abs;   // post-run normalisation of Wxe, done in the resident kernel's epilogue
+    int dbg_wg;
+    long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
+};
+
+namespace {
+using namespace snn;
+
+// A single wave retires roughly one instruction every 4 cycles however idle the chip is, so the cost of a
+// launch is the instruction count on each thread's critical path.  Hence: MANY workgroups (8 columns each)
+// so the per-column work of a thread is small, each with MANY threads (1024) so the work every workgroup
+// repeats (staging the step's spikes, arbitration) and the STDP items are spread thin.
+constexpr int CW = 8;           // columns per workgroup
+constexpr int MAXB = 32;        // samples (batch) per workgroup
+constexpr int TT = MAXB * CW;   // "tile threads": thread tid < TT <-> (sample tid / CW, column tid % CW)
+constexpr int NT = 1024;        // threads per workgroup
+constexpr int NU = 2;           // staged 16-byte pieces per thread: B*Nin <= NU*NT*16 = 32 KiB
+
+// Barrier for LDS-only hand-offs: waits for this wave's LDS traffic but NOT for its outstanding global
+// stores (a plain __syncthreads() drains vmcnt and costs a full memory round trip every time).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+#define DBG_MARK(slot) do { if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + (slot)] = (long long)wall_clock64(); } while (0)
+
+__device__ __forceinline__ bool bit_of(const uint32_t *w, int j) { return (w[j >> 5] >> (j & 31)) & 1u; }
+
+// Input currents of neuron j of sample b from the previous step's spikes, in connection insertion
+// order (network.py:225-248): Ae <- (zeros + X->Ae) + Ai->Ae ; Ai <- zeros + Ae->Ai.  SUM selects the
+// ATen column class of j (multi_row_sum for j < 32*floor(N/32), row_sum otherwise).
+// ---- small helpers ----------------------------------------------------------------------------
+// 4-bit mask of the non-zero bytes of a 32-bit word (byte k -> bit k).
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {
+    const uint32_t t = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
+}
+
+// Ordered sum of W[i, j] * value(i) over the sources i whose bit is set in `words`, visited in
+// ascending i: `wmask` has one bit per NON-ZERO word, so silent stretches cost nothing.  Weight loads
+// are issued 8 at a time before the (order-constrained) adds.  vals == nullptr: all spikes are 1.
+template <class SUM>
+__device__ __forceinline__ float ordered_dot(const float *__restrict__ W, int N, int j, const uint32_t *words,
+                                             uint64_t wmask, const uint8_t *__restrict__ vals, int n_terms) {
+    SUM a; a.init();
+    int idx[8]; float wv[8];
+    int nq = 0;
+    while (wmask) {
+        const int w = __ffsll((unsigned long long)wmask) - 1; wmask &= wmask - 1;
+        uint32_t m = words[w];
+        while (m) {
+            idx[nq++] = w * 32 + __ffs(m) - 1; m &= m - 1;
+            if (nq == 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = W[idx[u] * N + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a.add(idx[u], wv[u] * (vals ? (float)vals[idx[u]] : 1.0f), n_terms);
+                nq = 0;
+            }
+        }
+    }
+    if (nq) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = W[idx[u < nq ? u : 0] * N + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < nq) a.add(idx[u], wv[u] * (vals ? (float)vals[idx[u]] : 1.0f), n_terms);
+    }
+    return a.finish(n_terms);
+}
+
+// Cascade taking (and ignoring) the `tail` flag at init, interface-compatible with OuterSum.
+struct CascadeT {
+    Cascade c;
+    __device__ __forceinline__ void init(bool) { c.init(); }
+    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
+    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+};
+
+constexpr int LX = 32, LR = 8;   // per-sample event-list capacities (X sources / recurrent sources)
+constexpr int NCAND = 2048;      // one_spike candidates evaluated one per thread (more: serial fallback)
+
+// One wave turns a row of spike bit words into the ascending list of set-bit indices (first `cap`
+// entries stored) and returns the total count.  nwords <= 64.
+__device__ __forceinline__ int build_list(const uint32_t *words, int nwords, int lane, uint16_t *out, int cap) {
+    uint32_t m = lane < nwords ? words[lane] : 0u;
+    const int cn = __popc(m);
+    // exclusive prefix of cn over lanes = sum_k popc(ballot(cn > k) & lanes_below): counts are tiny, so a
+    // few ballots beat a 6-step cross-lane scan
+    const uint64_t below = (1ull << lane) - 1ull;
+    int offp = 0, total = 0;
+    for (int k = 0; ; ++k) {
+        const uint64_t bm = __ballot(cn > k);
+        if (!bm) break;
+        offp += __popcll(bm & below);
+        total += __popcll(bm);
+    }
+    while (m) {
+        const int i = lane * 32 + __ffs(m) - 1; m &= m - 1;
+        if (offp < cap) out[offp] = (uint16_t)i;
+        ++offp;
+    }
+    return total;
+}
+
+// Two rows per wave: lanes 0..31 list row A, lanes 32..63 row B (nwords <= 32).  `words` / `out` are the calling
+// lane's own row; returns that row's total count.  Rows past the end: pass words == nullptr.
+__device__ __forceinline__ int build_list_half(const uint32_t *words, int nwords, int lane, uint16_t *out, int cap) {
+    const int hl = lane & 31;
+    const uint64_t halfmask = (lane & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+    uint32_t m = (words && hl < nwords) ? words[hl] : 0u;
+    const int cn = __popc(m);
+    const uint64_t below = ((1ull << lane) - 1ull) & halfmask;
+    int offp = 0, total = 0;
+    for (int k = 0; ; ++k) {
+        const uint64_t bm = __ballot(cn > k);
+        if (!bm) break;
+        offp += __popcll(bm & below);
+        total += __popcll(bm & halfmask);
+    }
+    while (m) {
+        const int i = hl * 32 + __ffs(m) - 1; m &= m - 1;
+        if (offp < cap) out[offp] = (uint16_t)i;
+        ++offp;
+    }
+    return total;
+}
+
+// Input currents of neuron j of sample b from the previous step's spikes, in connection insertion order
+// (network.py:225-248): Ae <- (zeros + X->Ae) + Ai->Ae ; Ai <- zeros + Ae->Ai, each summed in ascending source
+// order.  X->Ae weights come from the LDS tile the STDP pass just refreshed (wtile != nullptr: row `rowpos[i]`
+// of the compacted active rows, or row i itself when rowpos == nullptr) or from global memory; the recurrent
+// weights wi / we were prefetched by the caller.
+template <class SUM, int CWL = CW>
+__device__ __forceinline__ void tile_currents(const DcCtx &c, const uint16_t *lx, int nX, const uint16_t *li, int nI,
+                                              const uint16_t *le, int nE, const float *wi, const float *we,
+                                              const float *wtile, const uint16_t *rowpos, int jj,
+                                              const uint8_t *__restrict__ xb, int j, float &curE, float &curI) {
+    const int Nin = c.Nin, N = c.N;
+    int ix[16], ii[4], ie[4]; float wx[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ii[u] = (int)li[u]; ie[u] = (int)le[u]; }
+    // unconditional, clamped gathers (entries past nX are stale but in range): the 16 reads of each stage
+    // are independent, so the three dependent LDS stages cost three latencies, not forty-eight
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ix[u] = min((int)lx[u], Nin - 1);
+    if (wtile) {
+        int rr[16];
+        if (rowpos) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rr[u] = min((int)rowpos[ix[u]], Nin - 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rr[u] = ix[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wx[u] = wtile[rr[u] * CWL + jj];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wx[u] = c.Wxe[ix[u] * N + j];
+    }
+    SUM a; a.init();
+    if (xb) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nX) a.add(ix[u], wx[u] * (float)xb[ix[u]], Nin);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < nX) a.add(ix[u], wx[u] * 1.0f, Nin);
+    }
+    curE = 0.0f + a.finish(Nin);
+    a.init();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u < nI) a.add(ii[u], wi[u] * 1.0f, N);
+    curE = curE + a.finish(N);
+    a.init();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u < nE) a.add(ie[u], we[u] * 1.0f, N);
+    curI = 0.0f + a.finish(N);
+}
+
+// ATen "row_sum" columns (j >= 32*floor(N/32)): the reference sums the sources in four interleaved lanes
+// (source index mod 4), each lane a cascade over its n/4 sources, leftovers (n % 4) added to lane 0, lanes
+// combined ((l0+l1)+l2)+l3.  Four adjacent threads take one lane each of the same (sample, column) -- the
+// lanes really are independent -- and lane 0 combines them with quad shuffles.
+template <int NMAX>
+__device__ __forceinline__ float quad_lane_sum(const int *ix, int cnt, const float *wv, const uint8_t *vals, int n, int L) {
+    const int n4 = n >> 2;
+    CascadeFlat a; a.init();
+    float tailsum = 0.f;                 // lane 0 only: its combined cascade + leftovers, once the first leftover arrives
+    bool closed = false;
+#pragma unroll
+    for (int u = 0; u < NMAX; ++u) {
+        if (u < cnt) {
+            const int i = ix[u];
+            const float term = wv[u] * (vals ? (float)vals[i] : 1.0f);
+            if (i >= (n4 << 2)) {
+                if (L == 0) { if (!closed) { tailsum = a.finish(n4); closed = true; } tailsum += term; }
+            } else if ((i & 3) == L) {
+                a.add(i >> 2, term, n4);
+            }
+        }
+    }
+    float v = closed ? tailsum : a.finish(n4);
+    const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
+    return ((v + v1) + v2) + v3;         // meaningful in lane 0 of the quad
+}
+
+// one digest entry: [part staged in LDS: lists | meta | row masks | active rows | row -> index | lane-grouped lists | group
+// sizes] padded to 4 words, then the [B][NinW] bit words (read from global memory by the bit-scan path only)
+int digest_lds_words(int B, int Nin) { return (B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + 2 * B + 3) & ~3; }
+int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin + 31) / 32) + 3) & ~3; }
+
+}  // namespace
+
+// resident form (snn_dc2015_resident.hip)
+size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw);
+int snn_dc2015_resident_cw(int N);
+int snn_dc2015_resident_nt();
+int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, hipStream_t st);
