@@ -2,7 +2,7 @@
 // DiehlAndCook2015 graph (Input -X->Ae (PostPre)-> DiehlAndCookNodes <-> LIFNodes), i.e. the loop body
 // of bindsnet/network/network.py:380-461 for the wiring of bindsnet/models/models.py:156-244.
 //
-// Decomposition.  Workgroup g owns 32 consecutive target columns (neurons c0..c0+31 of BOTH Ae and
+// Decomposition.  Workgroup g owns 8 consecutive target columns (neurons c0..c0+7 of BOTH Ae and
 // Ai) for every sample of the batch: their membrane state, adaptive thresholds, post-synaptic
 // traces and the [Nin x 8] column slice of the learned weights.  Everything a step needs from
 // other columns is spikes, exchanged as bit masks through global memory across the kernel boundary:
@@ -16,6 +16,9 @@
 //                               X-trace update for an own slice of input rows
 // and launch T runs phase A only.  All arithmetic follows the reference's f32 operation order
 // (snn_order.hpp, snn_common.hpp, snn_rng.hpp); results are bit-identical to the generic plan.
+//
+// This file also holds the once-per-run input digest (k_dc2015_prep), the per-step X trace (k_dc2015_xtrace) and the host
+// side of BOTH D&C plans; the resident whole-run kernel (the default) lives in snn_dc2015_resident.hip.
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
