@@ -2,6 +2,8 @@
 seeded random shapes (column counts that do / do not leave ATen row_sum tail columns, batch 1..32, odd time lengths,
 sparse and busy inputs, multi-valued spike bytes).  The generic plan itself is pinned to the oracle and the reference
 fixtures by the other GPU tests."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -13,6 +15,7 @@ import test_gpu_twolayer as two
 
 pytestmark = pytest.mark.gpu
 u8 = np.uint8
+MORE = int(os.environ.get("SNN_FUZZ_MORE", "0"))      # extra seeds per family for a longer soak (default suite: 30 cases)
 
 
 def _same(a, b, what):
@@ -21,7 +24,7 @@ def _same(a, b, what):
             np.testing.assert_array_equal(x[k].view(u8), y[k].view(u8), err_msg=f"{what} input {r}: {k}")
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 + MORE))
 def test_fuzz_dc2015(seed):
     rs = np.random.RandomState(1000 + seed)
     N = int(rs.choice([8, 24, 32, 40, 64, 100, 200, 333, 400, 512, 600]))
@@ -48,7 +51,7 @@ def test_fuzz_dc2015(seed):
     _same(step, gen, f"per-step N={N} B={B} T={T} dens={dens}")
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 + MORE))
 def test_fuzz_twolayer(seed):
     rs = np.random.RandomState(2000 + seed)
     kind = str(rs.choice(["dense", "mcc"]))
@@ -66,7 +69,7 @@ def test_fuzz_twolayer(seed):
     _same(f, g, f"twolayer {kind} Nin={Nin} N={N} B={B} T={T} rule={rule} bias={bias}")
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + MORE))
 def test_fuzz_twolayer_mstdp(seed):
     rs = np.random.RandomState(3000 + seed)
     Nin = int(rs.choice([64, 256, 784, 1600]))
@@ -84,7 +87,7 @@ def test_fuzz_twolayer_mstdp(seed):
     _same(f, g, f"mstdp Nin={Nin} N={N} B={B} T={T} reward={reward} dens={dens}")
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + MORE))
 def test_fuzz_convlif(seed):
     rs = np.random.RandomState(4000 + seed)
     k = int(rs.choice([1, 3, 5, 4]))
