@@ -191,7 +191,7 @@ constexpr int kResidentDefaultNT = 1024;
 constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 98.2 k, 2 -> 96.6 k timesteps/s (same GPU box)
 constexpr int kBitWords = 1024;      // capacity of the [B][NW] bit-word arrays (independent of the workgroup size)
 constexpr size_t resident_fixed_lds(int cw) {
-    return 4 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + NCAND * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
+    return 4 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
            2 * MAXB * cw * 4 + 7 * MAXB * cw * 4;
 }     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
     //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.
     constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + 2 * kBitWords * 4,
-                     O_MT = O_XNU0 + MAXB * CW * 4, O_CAND = O_MT + 8 * 624 * 4, O_KEYS = O_CAND + NCAND * 4,
+                     O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + 8 * 624 * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
                      O_CURB = O_MISC + 32, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
