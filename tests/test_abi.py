@@ -129,3 +129,35 @@ def test_merge_deltas_single_process():
     a = [torch.full((3, 2), 1.5), torch.arange(4.0)]
     parallel.merge_deltas(b, a)
     assert torch.equal(a[0], torch.full((3, 2), 1.5)) and torch.equal(a[1], torch.arange(4.0))
+
+
+def test_scalar_parameter_cache_and_cpu_reset():
+    """Host logic that needs no GPU: the cached scalar reads follow in-place edits of the parameter tensors, and
+    Network.reset_state_variables() on CPU tensors takes the per-layer path with the reference's semantics
+    (s, x, refrac_count -> 0, v -> rest, theta untouched)."""
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.nodes import _f
+    t = torch.tensor(-52.0)
+    assert _f(t) == -52.0 and _f(t) == -52.0
+    t.fill_(-50.0)
+    assert _f(t) == -50.0
+    t.add_(1.5)
+    assert _f(t) == -48.5
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=16, n_neurons=4, exc=22.5, inh=120, dt=1.0, norm=1.6, theta_plus=0.05, inpt_shape=(1, 4, 4))
+    Ae, Ai, X = net.layers["Ae"], net.layers["Ai"], net.layers["X"]
+    for l in (Ae, Ai):
+        l.set_batch_size(3)
+    X.set_batch_size(3)
+    Ae.v.fill_(-40.0); Ae.refrac_count.fill_(3.0); Ae.s.fill_(1); Ae.x.fill_(0.7); Ae.theta.fill_(0.3)
+    Ai.v.fill_(-41.0); Ai.refrac_count.fill_(1.0)
+    X.s = torch.ones(3, 1, 4, 4, dtype=torch.uint8); X.x.fill_(0.5)
+    net.reset_state_variables()
+    assert float(Ae.v.min()) == float(Ae.v.max()) == float(Ae.rest)
+    assert float(Ai.v.min()) == float(Ai.v.max()) == float(Ai.rest)
+    assert not Ae.s.any() and not X.s.any() and float(Ae.x.abs().sum()) == 0.0 and float(X.x.abs().sum()) == 0.0
+    assert float(Ae.refrac_count.abs().sum()) == 0.0 and float(Ai.refrac_count.abs().sum()) == 0.0
+    assert torch.all(Ae.theta == 0.3)
+    from bindsnet_amd import _lib as lib_mod
+    with pytest.raises(lib_mod.SnnError):
+        net.run({"X": torch.zeros(5, 3, 1, 4, 4, dtype=torch.uint8)}, time=5)      # CPU tensors: no fallback
