@@ -176,7 +176,7 @@ def main():
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
                        "plan": net.last_plan, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
             "roofline": roof,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # N = 1 only
         }
         print(json.dumps(line))
     if dist is not None:
