@@ -10,16 +10,21 @@ namespace {
 // =====================================================================================================
 // Resident plan "dc2015-resident": the SAME decomposition and arithmetic as k_dc2015_step, but ONE launch for
 // the whole run.  What used to cross the kernel boundary now stays put or moves through tagged granules:
-//   * the [Nin x CW] weight slice lives in LDS for all T steps, membrane state / traces / theta in registers;
-//   * the X trace of every step is precomputed (k_dc2015_xtrace) -- it depends on the inputs alone;
+//   * the [Nin x CW] slice of the learned weights and the [N x CW] slices of both recurrent matrices live in LDS for
+//     all T steps; membrane state / traces / theta of a (sample, column) pair live in an LDS slot of its tile thread;
+//   * the X trace of every step is precomputed (k_dc2015_xtrace) -- it depends on the inputs alone; the digest of the
+//     next step streams into a second LDS buffer (global_load_lds) while the current one is in use;
 //   * each workgroup keeps its own copy of the generator (all copies advance identically);
 //   * the per-step spike exchange uses 8-byte {epoch, bits} granules written with ONE relaxed agent-scope
 //     (write-through) store and polled with relaxed agent-scope loads: the data is the flag, no fence
-//     (cdna_hip_programming.md Guideline 16, form R2).  Granule k of workgroup g carries samples 2k, 2k+1:
-//     crossing byte | Ai spike byte << 8 | (same for the odd sample) << 16.  Two buffers by epoch parity: a
-//     workgroup overwrites a buffer only after every other workgroup has published the epoch in between,
-//     which it does only after consuming the overwritten one.
-// All G <= 128 workgroups are co-resident (one 1024-thread workgroup per CU), polls are bounded (status word).
+//     (cdna_hip_programming.md Guideline 16, form R2).  Granule k of workgroup g carries 16/CW consecutive samples:
+//     their CW crossing bits each in the low half, their CW Ai-spike bits each in the high half (two 16-bit slices of
+//     the publishing wave's ballots).  Two buffers by epoch parity: a workgroup overwrites a buffer only after every
+//     other workgroup has published the epoch in between, which it does only after consuming the overwritten one.
+// Per step: receive (flags the samples with a crossing) | Ai event lists + scores of the crossings (one barrier closes
+// both) | winners | Ae trace | PostPre on the LDS slice | currents (X part: four spare threads per pair, recurrent part:
+// the tile thread) | membrane, publish -- while the spare threads write the step's raster rows.
+// All G <= 256 workgroups are co-resident (one workgroup per CU); polls are bounded (device status word).
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
