@@ -13,8 +13,15 @@ each input the weight and threshold deltas are all-reduced over RCCL and re-norm
 (bindsnet_amd.parallel.sharded_run; BASELINE.json north-star schedule -- DESIGN.md section
 "Multi-GPU" explains how it differs from a single global batch).
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak) and
-"cpu_baseline" (the C oracle -- a scalar port of the reference algorithm -- on one host core).
+`--gpus N` without a torch.distributed environment re-executes this script under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); the JSON line reports the
+ranks RCCL actually formed (`rccl_ranks`) and the device every rank ran on.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak),
+"cpu_baseline" (N = 1 only: oracle/torch_cpu_ref.py -- the reference's own ATen operator sequence on the
+host CPU -- at cpu_count()-1 threads [what eth_mnist.py:77 sets] and at 1 thread, plus the scalar C port)
+and "parity" (the first input re-run from a fresh network on the GPU and on the CPU restatement, same
+host, same run: rasters compared bit for bit, weights by max |dW|).
 """
 import argparse
 import json
@@ -53,7 +60,7 @@ def build_network(device):
     torch.manual_seed(0)
     net = DiehlAndCook2015(n_inpt=N_IN, n_neurons=N_EXC, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05,
                            inpt_shape=(1, 28, 28))
-    for l in ("Ae", "Ai"):                       # spike monitors, as eth_mnist.py registers
+    for l in ("X", "Ae", "Ai"):                  # the three spike monitors eth_mnist.py:143-148 registers
         net.add_monitor(Monitor(net.layers[l], ["s"], time=T), l + "_spikes")
     net.to(device)
     return net
@@ -70,17 +77,17 @@ def pmc_traffic(plan):
         return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")
 
 
-def cpu_baseline():
-    """Oracle (scalar C port of the reference algorithm) on one host core: one full input."""
+def c_port_baseline(steps=100):
+    """Scalar C port of the reference algorithm (oracle/snn_oracle.c) on one host core."""
     import cases
     import oracle
     import synth
     from test_oracle_golden import dc_params
     g = cases.gold("run_dc_n400_b32")
     P = dc_params(g)
-    P.T, P.B, P.N = T, BATCH, N_EXC
+    P.T, P.B, P.N = steps, BATCH, N_EXC
     st = cases.dc_state(N_EXC, BATCH)
-    sp = synth.spike_train(20, T, BATCH, N_IN)
+    sp = np.ascontiguousarray(synth.spike_train(20, T, BATCH, N_IN)[:steps])
     Q = cases.exp_noise(2, 400_000)
     cur = np.zeros(1, np.int64)
     t0 = time.perf_counter()
@@ -89,22 +96,98 @@ def cpu_baseline():
     except RuntimeError:
         return None
     dt = time.perf_counter() - t0
-    return {"value": round(T / dt, 2), "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": f"1 input: T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, oracle/snn_oracle.c ({dt:.1f} s)"}
+    return {"value": round(steps / dt, 2), "unit": "timesteps/s", "cores": 1,
+            "sample": f"{steps} timesteps of one input, oracle/snn_oracle.c ({dt:.1f} s)"}
+
+
+def cpu_baseline_and_parity(dev, seed_inputs):
+    """The reference's CPU path restated operator for operator (oracle/torch_cpu_ref.py), on this host's
+    cores, in this run -- timed, and its outputs compared with a fresh GPU run of the same input."""
+    import synth
+    from oracle.torch_cpu_ref import DcTorchRef
+    spikes = synth.spike_train(seed_inputs, T, BATCH, N_IN)
+    ncpu = os.cpu_count() or 2
+    many = max(1, ncpu - 1)                              # examples/mnist/eth_mnist.py:77
+    threads0 = torch.get_num_threads()
+    out = {}
+    # --- all threads but one: one whole input (also the parity witness)
+    torch.set_num_threads(many)
+    torch.manual_seed(0)
+    ref = DcTorchRef(n_inpt=N_IN, n_neurons=N_EXC)
+    ref.set_batch(BATCH)
+    torch.manual_seed(2)
+    t0 = time.perf_counter()
+    rec = ref.run(torch.from_numpy(spikes))
+    dt_many = time.perf_counter() - t0
+    # --- one thread: the first 100 timesteps of the same input from the same start
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    ref1 = DcTorchRef(n_inpt=N_IN, n_neurons=N_EXC)
+    ref1.set_batch(BATCH)
+    torch.manual_seed(2)
+    t0 = time.perf_counter()
+    ref1.run(torch.from_numpy(spikes[:100]), monitors=("X", "Ae", "Ai"))
+    dt_one = time.perf_counter() - t0
+    torch.set_num_threads(threads0)
+    cpu = {"value": round(T / dt_many, 2), "unit": "timesteps/s", "cores": many, "kind": "port",
+           "sample": f"1 input (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors) through oracle/torch_cpu_ref.py = the "
+                     f"reference's ATen operator sequence, {many} threads ({dt_many:.1f} s); /root/reference itself is absent on this box",
+           "one_thread": {"value": round(100 / dt_one, 2), "unit": "timesteps/s", "cores": 1,
+                          "sample": f"first 100 timesteps of the same input ({dt_one:.1f} s)"},
+           "c_port": c_port_baseline(), "host_cpus": ncpu}
+    # --- parity: the same input from the same seeds on the GPU
+    torch.manual_seed(0)
+    net = build_network(dev)
+    torch.manual_seed(2)
+    net.run({"X": torch.from_numpy(spikes).view(T, BATCH, 1, 28, 28).to(dev)}, time=T)
+    torch.cuda.synchronize()
+    ok = {}
+    for l in ("Ae", "Ai"):
+        got = net.monitors[l + "_spikes"].get("s").reshape(T, BATCH, N_EXC).cpu()
+        ok[l] = bool(torch.equal(got.bool(), rec[l].bool()))
+    W = net.connections[("X", "Ae")].pipeline[0].value.detach().cpu()
+    theta = net.layers["Ae"].theta.cpu()
+    probe_gpu = torch.rand(4)                             # host generator position after the GPU run ...
+    par = {"rasters_bit_exact": all(ok.values()), "exc_spikes": int(rec["Ae"].sum()), "inh_spikes": int(rec["Ai"].sum()),
+           "max_abs_dW": float((W - ref.W_xe).abs().max()), "weights_bit_exact": bool(torch.equal(W, ref.W_xe)),
+           "max_abs_dtheta": float((theta - ref.theta).abs().max()),
+           "against": "oracle/torch_cpu_ref.py on this host in this run, one input from identical seeds"}
+    return cpu, par
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: start N ranks ourselves."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", default="auto", choices=["auto", "generic", "per-step"])
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        respawn_under_launcher(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -113,8 +196,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -146,10 +227,15 @@ def main():
         one(args.warmup + k)
     fence()
     elapsed = time.perf_counter() - t0
+    ranks_seen, devices = 1, [f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}"]
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ranks_seen = dist.get_world_size()
+        ids = [None] * ranks_seen
+        dist.all_gather_object(ids, f"rank{rank}=cuda:{dev.index}")
+        devices = ids
 
     # ---- roofline of the dominant kernel: HIP events around single launches, after the timed region
     roof = None
@@ -164,20 +250,27 @@ def main():
                     "traffic": pmc_traffic(net.last_plan)}
 
     if rank == 0:
+        cpu = par = None
+        if not (args.no_cpu_baseline or world > 1):        # N = 1 only
+            cpu, par = cpu_baseline_and_parity(dev, 1000)
         steps_total = world * args.steps * T
         line = {
             "metric": "simulated timesteps/sec (whole node), DiehlAndCook2015 784->400 batch32",
             "value": round(steps_total / elapsed, 2), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": ranks_seen, "devices": devices,
             "config": {"workload": "configs[1]: DiehlAndCook2015 784->400 exc, batch 32/GPU, 250 timesteps per "
-                                   "network.run(), PostPre STDP on, 2 spike monitors, reset_state_variables() per input",
+                                   "network.run(), PostPre STDP on, 3 spike monitors (X, Ae, Ai), reset_state_variables() per input",
                        "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
                        "plan": net.last_plan, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # N = 1 only
+            "cpu_baseline": cpu,
+            "parity": par,
         }
+        if cpu is not None:
+            line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,7 +1,7 @@
 """BASELINE configs[1] at FULL size (D&C 784->400, batch 32, T = 250, PostPre on) on the GPU:
  * the fused plan and the generic per-operator plan are bit-identical (rasters, weights, theta, state,
    generator position) over three consecutive inputs -- two independent implementations of the same order;
- * the first 40 timesteps agree bit-for-bit with the CPU oracle (which is pinned to the reference);
+ * (the comparison with the reference itself at this size lives in tests/test_gpu_baseline_configs.py);
  * size-independent properties of the domain hold: at most one excitatory spike per sample per step
    (one_spike), weights stay in [wmin, wmax] before normalisation and every column sums to `norm` after it,
    theta only grows by multiples of theta_plus, refractory counters stay in range."""
@@ -75,27 +75,6 @@ def test_fused_equals_generic_and_properties_at_full_size():
         assert (a["theta"] >= 0).all() and a["theta"].max() > 0
     # theta grows monotonically across inputs (tc_theta_decay = 1e7)
     assert (fused[2]["theta"] >= fused[0]["theta"] * 0.999).all()
-
-
-def test_first_steps_match_oracle_at_full_size():
-    Ts = 40
-    from bindsnet_amd.network.monitors import Monitor
-    net, _ = build(False)
-    net.monitors.clear()
-    m = Monitor(net.layers["Ae"], ["s"], time=Ts)
-    net.add_monitor(m, "Ae")
-    spikes = synth.spike_train(50, Ts, B, 784)
-    torch.manual_seed(7)
-    net.run({"X": torch.from_numpy(spikes).view(Ts, B, 1, 28, 28).to(DEV)}, time=Ts)
-    g = cases.gold("run_dc_n400_b32")
-    P = dc_params(g); P.T = Ts
-    st = cases.dc_state(N, B)
-    cur = np.zeros(1, np.int64)
-    rasE, _ = oracle.run_dc2015(P, st, spikes, cases.exp_noise(7, 400_000), cur)
-    np.testing.assert_array_equal(m.get("s").cpu().numpy().reshape(Ts, B, N).astype(u8), rasE)
-    W = net.connections[("X", "Ae")].pipeline[0].value.cpu().numpy()
-    np.testing.assert_array_equal(W.view(np.uint32), st["W_xe"].view(np.uint32))
-    np.testing.assert_array_equal(net.layers["Ae"].theta.cpu().numpy().view(np.uint32), st["theta"].view(np.uint32))
 
 
 def _final_state(net, mons):

@@ -1,0 +1,174 @@
+"""Pin the CPU checkers at the FULL sizes of BASELINE.json's configs against fixtures the unmodified
+reference produced (tests/golden/make_golden_full.py):
+
+ * oracle/snn_oracle.c  -- cfg1 / cfg2 whole runs (3 inputs x 250 steps, reset between), bit for bit;
+   cfg3 (B = 16 / 32 / 128) and cfg5 on a column subset, teacher-forced with the reference's own MKL
+   currents (bit-exact) and free-running in the canonical ascending order (rasters identical, weights
+   <= 1e-5); cfg4 on two of the 64 samples (samples are independent without learning).
+ * oracle/torch_cpu_ref.py (bench.py's CPU baseline) -- cfg1 whole, cfg2 first input, bit for bit.
+
+The full-width / full-batch comparisons of cfg3-5 run on the GPU (tests/test_gpu_baseline_configs.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+import synth
+from cases import f32, u8, gold, check_packed, unpack
+from test_oracle_golden import dc_params, two_params
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def ref_init_weights(n_in, n, scale=0.3):
+    """The draw the reference constructors make right after torch.manual_seed(0) (models.py:73,184)."""
+    torch.manual_seed(0)
+    return (scale * torch.rand(n_in, n)).numpy() if scale != 1.0 else torch.rand(n_in, n).numpy()
+
+
+# --------------------------------------------------------------------------------------------- cfg1 / cfg2
+@pytest.mark.parametrize("name", ["full_cfg1_dc_n100_b1", "full_cfg2_dc_n400_b32"])
+def test_oracle_dc2015_full_size(name):
+    g = gold(name)
+    N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
+    P = dc_params(g)
+    st = cases.dc_state(N, B, inh=120.0)
+    st["W_xe"] = ref_init_weights(784, N)
+    assert cases.sha(st["W_xe"]) == str(g["W0_sha"])
+    total = sum(int(g[f"r{r}_consumed"]) for r in range(runs))
+    Q = cases.exp_noise(2, total + B * N)
+    cur = np.zeros(1, np.int64)
+    for r in range(runs):
+        spikes = synth.spike_train(1000 + r, T, B, 784)
+        before = int(cur[0])
+        rasE, rasI = oracle.run_dc2015(P, st, spikes, Q, cur)
+        np.testing.assert_array_equal(rasE, unpack(g[f"r{r}_sE"], (T, B, N)), err_msg=f"run {r} Ae raster")
+        np.testing.assert_array_equal(rasI, unpack(g[f"r{r}_sI"], (T, B, N)), err_msg=f"run {r} Ai raster")
+        assert int(cur[0]) - before == int(g[f"r{r}_consumed"])
+        assert cases.sha(st["W_xe"]) == str(g[f"r{r}_W_sha"]), f"run {r} weights"
+        np.testing.assert_array_equal(bits(st["theta"]), bits(g[f"r{r}_theta"]))
+        for key, a in (("vE", st["vE"]), ("rE", st["rE"]), ("xE", st["xE"]), ("xX", st["xX"]), ("vI", st["vI"]),
+                       ("rI", st["rI"])):
+            check_packed(g, f"r{r}_{key}", a)
+        cases.dc_reset(st)
+
+
+@pytest.mark.parametrize("name,runs", [("full_cfg1_dc_n100_b1", 3), ("full_cfg2_dc_n400_b32", 1)])
+def test_torch_cpu_restatement_full_size(name, runs):
+    from oracle.torch_cpu_ref import DcTorchRef
+    g = gold(name)
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    torch.manual_seed(0)
+    ref = DcTorchRef(n_inpt=784, n_neurons=N)
+    assert cases.sha(ref.W_xe.numpy()) == str(g["W0_sha"])
+    ref.set_batch(B)
+    torch.manual_seed(2)
+    for r in range(runs):
+        spikes = synth.spike_train(1000 + r, T, B, 784)
+        rec = ref.run(torch.from_numpy(spikes))
+        np.testing.assert_array_equal(rec["Ae"].numpy().astype(u8), unpack(g[f"r{r}_sE"], (T, B, N)))
+        np.testing.assert_array_equal(rec["Ai"].numpy().astype(u8), unpack(g[f"r{r}_sI"], (T, B, N)))
+        assert ref.consumed == int(g[f"r{r}_consumed"])
+        assert cases.sha(ref.W_xe.numpy()) == str(g[f"r{r}_W_sha"])
+        np.testing.assert_array_equal(bits(ref.theta.numpy()), bits(g[f"r{r}_theta"]))
+        check_packed(g, f"r{r}_vE", ref.vE.numpy())
+        ref.reset()
+
+
+def test_torch_cpu_restatement_small_fixture_with_carry_over():
+    """run_dc_n100_b3: second input continues from the first one's end state after a reset."""
+    from oracle.torch_cpu_ref import DcTorchRef
+    g = gold("run_dc_n100_b3")
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    ref = DcTorchRef(n_inpt=784, n_neurons=N, w=torch.from_numpy(synth.weights_q12(10, 784, N)))
+    ref.set_batch(B)
+    for r in range(int(g["runs"])):
+        torch.manual_seed(2 + r)
+        rec = ref.run(torch.from_numpy(synth.spike_train(20 + r, T, B, 784)))
+        np.testing.assert_array_equal(rec["Ae"].numpy().astype(u8), unpack(g[f"r{r}_sE"], (T, B, N)))
+        assert cases.sha(ref.W_xe.numpy()) == str(g[f"r{r}_W_sha"])
+        if r % 2 == 0:
+            ref.reset()
+
+
+# --------------------------------------------------------------------------------------------- cfg3 / cfg5
+def two_case(g, rule):
+    """Oracle parameters + inputs + reference start weights of a full-size dense-family fixture."""
+    P = two_params(g, rule)
+    Nin, N, B, T = P.Nin, P.N, P.B, P.T
+    if rule == "postpre":
+        P.norm = 78.4
+        spikes = synth.dense_spikes(2, (T, B, Nin), 0.012)
+        W0 = ref_init_weights(Nin, N)
+    else:
+        P.norm = 0.5 * Nin
+        frame = synth.dense_spikes(4, (B, Nin), 0.05)
+        spikes = np.ascontiguousarray(np.broadcast_to(frame, (T, B, Nin)))
+        W0 = ref_init_weights(Nin, N, scale=1.0)
+    return P, spikes, W0
+
+
+def two_state_cols(P, W0c):
+    B, Nin, n = P.B, P.Nin, W0c.shape[1]
+    st = dict(W=np.ascontiguousarray(W0c), sX=np.zeros((B, Nin), u8), xX=np.zeros((B, Nin), f32),
+              vY=np.full((B, n), -65.0, f32), rY=np.zeros((B, n), f32), sY=np.zeros((B, n), u8), xY=np.zeros((B, n), f32))
+    if P.rule == 2:
+        st.update(elig=np.zeros((B, Nin, n), f32), p_plus=np.zeros((B, Nin), f32), p_minus=np.zeros((B, n), f32))
+    return st
+
+
+@pytest.mark.parametrize("name,rule", [("full_cfg3_two_b16", "postpre"), ("full_cfg3_two_b32", "postpre"),
+                                       ("full_cfg3_two_b128", "postpre"), ("full_cfg5_mstdp_b16", "mstdp")])
+def test_oracle_dense_family_full_size_column_subset(name, rule):
+    g = gold(name)
+    P, spikes, W0 = two_case(g, rule)
+    assert cases.sha(W0) == str(g["W0_sha"])
+    cols = g["cols"].astype(np.int64)
+    N_full = P.N
+    ras_ref = unpack(g["sY"], (P.T, P.B, N_full))[:, :, cols]
+    P.N = len(cols)
+    # (1) teacher-forced with the reference's own currents: bit-exact
+    st = two_state_cols(P, W0[:, cols])
+    ras = oracle.run_two_layer(P, st, spikes, I_forced=np.ascontiguousarray(g["I_forced_cols"]))
+    np.testing.assert_array_equal(ras, ras_ref)
+    np.testing.assert_array_equal(bits(st["W"]), bits(g["W_cols"]))
+    if rule == "mstdp":
+        np.testing.assert_array_equal(bits(st["p_minus"]), bits(g["p_minus"][:, cols]))
+        check_packed(g, "p_plus", st["p_plus"])
+    check_packed(g, "xX", st["xX"])
+    # (2) canonical ascending-order propagation instead of MKL: rasters identical, weights <= 1e-5
+    st2 = two_state_cols(P, W0[:, cols])
+    ras2 = oracle.run_two_layer(P, st2, spikes)
+    assert ras2.sum() > 100
+    np.testing.assert_array_equal(ras2, ras_ref)
+    np.testing.assert_allclose(st2["W"], g["W_cols"], rtol=0, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------- cfg4
+def test_oracle_conv_lif_full_size_two_samples():
+    g = gold("full_cfg4_conv_b64")
+    B, T = int(g["B"]), int(g["T"])
+    torch.manual_seed(0)
+    W = (0.3 * torch.rand(32, 1, 5, 5)).numpy()
+    assert cases.sha(W) == str(g["W0_sha"])
+    spikes = synth.dense_spikes(3, (T, B, 1, 28, 28), 0.05)
+    pick = [0, B - 1]
+    sp = np.ascontiguousarray(spikes[:, pick])
+    n = 32 * 24 * 24
+    v = np.full((2, n), -65.0, f32); r = np.zeros((2, n), f32); s = np.zeros((2, n), u8)
+    prev = np.zeros((2, 1, 28, 28), u8)
+    ras = np.zeros((T, 2, n), u8)
+    bias = np.zeros(32, f32)
+    for t in range(T):
+        I = oracle.prop_conv2d(W, prev, bias=bias).reshape(2, n)
+        oracle.lif_step(v, r, s, None, I, decay=float(g["decay"]), rest=-65.0, reset=-65.0, thresh=-52.0, refrac0=5.0)
+        ras[t] = s
+        prev = sp[t]
+    ras = ras.reshape(T, 2, 32, 24, 24)
+    assert ras[:, 0].sum() == int(g["sY_per_sample"][0]) and ras[:, 1].sum() == int(g["sY_per_sample"][B - 1])
+    np.testing.assert_array_equal(np.packbits(ras[:, 0, 0]), g["sY_first"])
+    np.testing.assert_array_equal(np.packbits(ras[:, 1, 31]), g["sY_last"])
