@@ -69,7 +69,8 @@ def build_network(device):
 def pmc_traffic(plan):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
     command (profiles/r01_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
-    name = {"dc2015-resident": "r01_resident_pmc_hbm_traffic.json", "dc2015-fused": "r01_pmc_hbm_traffic.json"}.get(plan)
+    name = {"dc2015-resident-lean": "r02_lean_pmc_hbm_traffic.json", "dc2015-resident": "r01_resident_pmc_hbm_traffic.json",
+            "dc2015-fused": "r01_pmc_hbm_traffic.json"}.get(plan)
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
         return None
@@ -107,33 +108,44 @@ def cpu_baseline_and_parity(dev, seed_inputs):
     from oracle.torch_cpu_ref import DcTorchRef
     spikes = synth.spike_train(seed_inputs, T, BATCH, N_IN)
     ncpu = os.cpu_count() or 2
-    many = max(1, ncpu - 1)                              # examples/mnist/eth_mnist.py:77
     threads0 = torch.get_num_threads()
-    out = {}
-    # --- all threads but one: one whole input (also the parity witness)
-    torch.set_num_threads(many)
-    torch.manual_seed(0)
-    ref = DcTorchRef(n_inpt=N_IN, n_neurons=N_EXC)
-    ref.set_batch(BATCH)
-    torch.manual_seed(2)
+
+    def fresh():
+        torch.manual_seed(0)
+        r = DcTorchRef(n_inpt=N_IN, n_neurons=N_EXC)
+        r.set_batch(BATCH)
+        torch.manual_seed(2)
+        return r
+
+    # --- thread-count probe on a bounded sample (6 timesteps after 1 untimed one, same start every time).  The
+    # reference's own setting is cpu_count()-1 (examples/mnist/eth_mnist.py:77); on a many-core host that
+    # oversubscribes these small operators badly, so the baseline VALUE is the best setting found, not that one.
+    probe = {}
+    for nt in sorted({1, 4, 8, 16, 32, max(1, ncpu - 1)}):
+        if nt > max(1, ncpu - 1):
+            continue
+        torch.set_num_threads(nt)
+        r = fresh()
+        r.run(torch.from_numpy(spikes[:1]))
+        t0 = time.perf_counter()
+        r.run(torch.from_numpy(spikes[1:7]))
+        probe[nt] = round(6 / (time.perf_counter() - t0), 2)
+    best = max(probe, key=probe.get)
+    # --- one whole input at the best thread count (also the parity witness)
+    torch.set_num_threads(best)
+    ref = fresh()
     t0 = time.perf_counter()
     rec = ref.run(torch.from_numpy(spikes))
-    dt_many = time.perf_counter() - t0
-    # --- one thread: the first 100 timesteps of the same input from the same start
-    torch.set_num_threads(1)
-    torch.manual_seed(0)
-    ref1 = DcTorchRef(n_inpt=N_IN, n_neurons=N_EXC)
-    ref1.set_batch(BATCH)
-    torch.manual_seed(2)
-    t0 = time.perf_counter()
-    ref1.run(torch.from_numpy(spikes[:100]), monitors=("X", "Ae", "Ai"))
-    dt_one = time.perf_counter() - t0
+    dt_best = time.perf_counter() - t0
     torch.set_num_threads(threads0)
-    cpu = {"value": round(T / dt_many, 2), "unit": "timesteps/s", "cores": many, "kind": "port",
+    cpu = {"value": round(T / dt_best, 2), "unit": "timesteps/s", "cores": best, "kind": "port",
            "sample": f"1 input (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors) through oracle/torch_cpu_ref.py = the "
-                     f"reference's ATen operator sequence, {many} threads ({dt_many:.1f} s); /root/reference itself is absent on this box",
-           "one_thread": {"value": round(100 / dt_one, 2), "unit": "timesteps/s", "cores": 1,
-                          "sample": f"first 100 timesteps of the same input ({dt_one:.1f} s)"},
+                     f"reference's ATen operator sequence, {best} threads = the best of the probed settings ({dt_best:.1f} s); "
+                     "/root/reference itself is absent on this box",
+           "threads_probe_timesteps_per_s": {str(k): v for k, v in probe.items()},
+           "reference_default_threads": {"threads": max(1, ncpu - 1), "value": probe[max(1, ncpu - 1)],
+                                         "note": "torch.set_num_threads(os.cpu_count() - 1), eth_mnist.py:77; 6-timestep sample"},
+           "one_thread": {"value": probe[1], "unit": "timesteps/s", "cores": 1, "sample": "6-timestep sample"},
            "c_port": c_port_baseline(), "host_cpus": ncpu}
     # --- parity: the same input from the same seeds on the GPU
     torch.manual_seed(0)

@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
-SNN_OK, SNN_ERR_NOISE = 0, -4
-ABI_VERSION = 1
+SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
+ABI_VERSION = 2
 
 
 class SnnError(RuntimeError):
@@ -54,7 +54,7 @@ class RunDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
                 ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_ulonglong),
-                ("cursor", C.c_void_p), ("status", C.c_void_p)]
+                ("cursor", C.c_void_p), ("status", C.c_void_p), ("plan", C.c_int)]
 
 
 LAYER_INPUT, LAYER_LIF, LAYER_DC = 0, 1, 2
@@ -131,7 +131,7 @@ def profile_run(net, inputs, time, stride=4, repeats=5):
         for _ in range(max(1, repeats)):
             net.run(dict(inputs), time=time)
             net.reset_state_variables()
-            if net.last_plan != "dc2015-resident":
+            if not net.last_plan.startswith("dc2015-resident"):
                 break
         torch.cuda.synchronize()
         s, n = C.c_double(0), C.c_int(0)
@@ -141,8 +141,8 @@ def profile_run(net, inputs, time, stride=4, repeats=5):
     if n.value == 0:
         return None
     plan = net.last_plan
-    if plan == "dc2015-resident":
-        return {"kernel": "k_dc2015_run (one launch per network.run())", "avg_ms": s.value / n.value, "n": n.value,
+    if plan.startswith("dc2015-resident"):
+        return {"kernel": "k_dc2015_run%s (one launch per network.run())" % (" [lean form]" if plan.endswith("lean") else ""), "avg_ms": s.value / n.value, "n": n.value,
                 "timesteps_per_launch": int(round(time / net.dt))}
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}

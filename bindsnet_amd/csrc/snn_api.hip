@@ -24,6 +24,7 @@ extern "C" const char *snn_error_string(int code) {
         case SNN_ERR_NOISE: return "one_spike noise stream exhausted";
         case SNN_ERR_NO_DEVICE: return "no HIP device";
         case SNN_ERR_TIMEOUT: return "in-kernel workgroup hand-off timed out";
+        case SNN_ERR_RETRY: return "lean kernel form met an unsupported step (re-run with plan = 3)";
         default: return "unknown error";
     }
 }

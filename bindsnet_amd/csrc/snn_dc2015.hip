@@ -681,7 +681,8 @@ __global__ __launch_bounds__(256) void k_dc2015_xtrace(const DcCtx c) {
         for (int u = 0; u < 8; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
     }
     for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + 1) * n + k] = x; }
-    c.xX[1][k] = x;
+    // (the caller's trace tensor is NOT touched here: the resident kernel copies entry T into it in its epilogue, once
+    //  the run is known to have succeeded -- a refused or timed-out run must leave every state tensor as it found it)
 }
 
 size_t lds_bytes(int B, int Nin, int N) {
@@ -703,10 +704,13 @@ static size_t fused_workspace(int B, int Nin, int N) {
     return 4 * al((size_t)B * NW * 4) + al((size_t)B * Nin * 4) + al(sizeof(snn_rng_state));
 }
 
+// lean form: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2
+static size_t resident_summary_bytes(int N) { return (size_t)2 * ((N + 1) / 2) * 4 * 8; }
+
 static size_t resident_extra(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t gran = (size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8;      // >= 2 * G * KB * 8 for every tile width
-    return al(gran) + al((size_t)(T + 1) * B * Nin * 4);
+    return al(gran) + al(resident_summary_bytes(N)) + al((size_t)(T + 1) * B * Nin * 4);
 }
 
 // The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
@@ -760,7 +764,7 @@ extern "C" void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed) 
 }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int resident, int *handled, unsigned *normalized) {
+                         hipStream_t st, int resident, int allow_lean, int *handled, unsigned *normalized) {
     *handled = 0;
     *normalized = 0;
     if (!matches(L, nL, C, nC, R)) return SNN_OK;
@@ -797,19 +801,37 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         auto al2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
         unsigned char *p = (unsigned char *)c.dig + al2((size_t)(R->T + 1) * c.DW * 4);
         c.ex = (unsigned long long *)p;
-        c.xtr = (float *)(p + al2((size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8));
+        c.exs = (unsigned long long *)(p + al2((size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8));
+        c.xtr = (float *)((unsigned char *)c.exs + al2(resident_summary_bytes(N)));
         c.status = R->status;
+        c.stall_wg = getenv("SNN_DC_TEST_STALL") ? atoi(getenv("SNN_DC_TEST_STALL")) : -1;
         c.has_norm = C[0].has_norm; c.norm = C[0].norm; c.norm_abs = C[0].norm_abs;
     }
-    // resident plan needs every workgroup on its own CU at once and its first (clamp-everything) PostPre pass at t = 1
-    if (getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
+    // The resident plan hands spikes between workgroups INSIDE one launch, so every workgroup of the grid must be
+    // running at once: the grid is sized against what THIS device holds (CU count x occupancy of the chosen variant,
+    // snn_dc2015_resident_capacity), the tile is widened while the grid does not fit, and the launch itself is a
+    // cooperative one (the runtime refuses what it cannot make co-resident).  Whatever does not fit takes the
+    // one-launch-per-timestep form.  The first PostPre pass (clamp everything) needs the X trace at t = 1.
+    if (resident >= 0 && getenv("SNN_DC_RESIDENT")) resident = atoi(getenv("SNN_DC_RESIDENT"));
+    if (resident < 0) resident = 0;                                 // (-1: the cooperative launch was just refused)
     int rcw = snn_dc2015_resident_cw(N);
-    while (rcw < 8 && (N + rcw - 1) / rcw > 256) rcw *= 2;          // one workgroup per CU (256 CUs), all co-resident
+    int rnt0 = snn_dc2015_resident_nt();
+    if (!R->status) resident = 0;                                   // nowhere to report a failed hand-off
+    if (resident) {
+        auto cap = [&](int cw) { return snn_dc2015_resident_capacity(cw, (rnt0 == 512 && cw <= 4) ? 512 : 1024, snn_dc2015_resident_lds(B, Nin, N, cw)); };
+        while (rcw < 8 && ((N + rcw - 1) / rcw > cap(rcw) || snn_dc2015_resident_lds(B, Nin, N, rcw) > 150 * 1024)) rcw *= 2;
+        if ((N + rcw - 1) / rcw > cap(rcw)) resident = 0;
+    }
     const int rG = (N + rcw - 1) / rcw, rKB = (B + 16 / rcw - 1) / (16 / rcw);
-    if (rG > 256 || (c.rule == SNN_RULE_POSTPRE && !c.x_traces) || snn_dc2015_resident_lds(B, Nin, N, rcw) > 150 * 1024 ||
+    if ((c.rule == SNN_RULE_POSTPRE && !c.x_traces) || snn_dc2015_resident_lds(B, Nin, N, rcw) > 150 * 1024 ||
         resident_extra(B, Nin, N, R->T) > kResidentMaxExtra) resident = 0;
-    int rnt = snn_dc2015_resident_nt();
+    int rnt = rnt0;
     if (rnt == 512 && (rcw > 4 || B * c.NW > 512)) rnt = 1024;       // single-pass stages of the 512-thread variant
+    // lean form of the resident kernel (snn_dc2015_resident.hip): the common case compiled on its own.  Its receive stage
+    // relies on the barrier that closes the currents stage (row_sum workgroups, or X currents on the spare threads).
+    static const bool lean_on = !(getenv("SNN_DC_LEAN") && atoi(getenv("SNN_DC_LEAN")) == 0);
+    const bool lean = resident && allow_lean && lean_on && rcw == 4 && rnt == 1024 && L[1].p.one_spike && !getenv("SNN_DC_TIMING") &&
+                      ((size_t)Nin * N) % 32 == 0 && Nin <= 1024 && 1024 - MAXB * 4 >= B * 4 * 4;
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
     static int dbg_T = 0;
@@ -832,13 +854,13 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         int rc0;
         if (resident) {
             // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
-            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)2 * c.G * c.KB * 8, qs)))) return rc0;
+            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex), qs)))) return rc0;
             hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
-            const int rcl = snn_dc2015_resident_launch(c, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), qs);
+            const int rcl = snn_dc2015_resident_launch(c, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
             if (prof) snn_prof_end(qs);
-            return rcl;
+            return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
         rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
@@ -868,6 +890,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     int rc = SNN_OK;
     if (!graphs_on || resident || c.dbg || snn_prof_active()) {
         rc = enqueue(true); g_graph_stats[0]++;
+        if (rc == SNN_ERR_UNSUPPORTED && resident)          // grid refused by the runtime: the same run, one launch per timestep
+            return snn_try_fused_dc2015(L, nL, C, nC, R, st, -1, 0, handled, normalized);
     } else {
         // capture is not allowed on the legacy default stream torch usually runs on: fork to a private
         // non-blocking stream (event edge in, event edge out), so `st` still orders everything around the run
@@ -949,7 +973,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                 acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
     }
     if (resident && c.has_norm) *normalized |= 1u;          // connection 0 was normalised in the kernel's epilogue
-    snn_set_plan_name(resident ? "dc2015-resident" : "dc2015-fused");
+    snn_set_plan_name(resident ? (lean ? "dc2015-resident-lean" : "dc2015-resident") : "dc2015-fused");
     *handled = 1;
     return SNN_OK;
 }

@@ -41,9 +41,12 @@ struct DcCtx {
     // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
     // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
     unsigned long long *ex; int KB;
+    unsigned long long *exs;    // lean form: summary granules [2][G][tile waves]
     float *xtr;
     int *status;
     int has_norm; float norm; int norm_abs;   // post-run normalisation of Wxe, done in the resident kernel's epilogue
+    int stall_wg;               // test hook (SNN_DC_TEST_STALL=<workgroup>, -1 = none): that workgroup of the resident kernel
+                                // exits at once, as if it had never been scheduled -> every other one times out
     int dbg_wg;
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
 };
@@ -259,4 +262,5 @@ int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin 
 size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw);
 int snn_dc2015_resident_cw(int N);
 int snn_dc2015_resident_nt();
-int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, hipStream_t st);
+int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, int lean, hipStream_t st);
+int snn_dc2015_resident_capacity(int cw, int nt, size_t lds_bytes);

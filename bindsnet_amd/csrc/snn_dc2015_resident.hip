@@ -197,15 +197,25 @@ constexpr int kResidentDefaultCW = 4;   // measured at cfg2: 8 -> 93.8 k, 4 -> 9
 constexpr int kBitWords = 1024;      // capacity of the [B][NW] bit-word arrays (independent of the workgroup size)
 constexpr size_t resident_fixed_lds(int cw) {
     return 4 * kBitWords * 4 + MAXB * cw * 4 + 8 * 624 * 4 + MAXB * 8 + 2 * MAXB * LR * 2 + 2 * MAXB * 4 + 2 * 32 * 4 + 32 +
-           2 * MAXB * cw * 4 + 7 * MAXB * cw * 4;
+           2 * MAXB * cw * 4 + 7 * MAXB * cw * 4 + MAXB * LR * 2 + MAXB * 4;
 }     // bounded spin: ~0.5 s, then the run is flagged SNN_ERR_TIMEOUT
 
 // CWR = columns per workgroup (8, 4 or 2): the PostPre stage is ALU-throughput bound inside a CU, so narrower tiles on
 // more CUs shorten it, while the stages every workgroup repeats (receive, lists, arbitration) stay as they are.
 // NTR = threads per workgroup: 1024, or 512 (twice the registers per thread: no spills; needs B*NW <= 512 and CW <= 4).
-template <int CWR, int NTR>
+// LEAN = the common case compiled on its own (one_spike on, every input spike 0/1, no event-list overflow, Nin*N a
+// multiple of 32): cold branches are pruned at compile time, the spike exchange is ONE compact summary granule per tile
+// wave (up to three {type, sample, column} events inline; more -> the full bit granules of the general form, read on
+// demand), and ONE wave receives, decodes AND scores the one_spike candidates while the others wait at the barrier, so
+// the separate list-building and scoring stages (and their barrier) disappear.  A step it does not handle (multi-valued
+// spike bytes, a sample with more than four inhibitory spikes, > 32 input events in a sample) is detected identically
+// by every workgroup from the exchanged data: all of them leave the loop together with status SNN_ERR_RETRY, nothing
+// having been written back, and the host repeats the input on the general form.
+template <int CWR, int NTR, bool LEAN>
 __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     constexpr int CW = CWR, TT = MAXB * CWR, NT = NTR;     // (shadow the per-step kernel's constants)
+    constexpr int NTW = TT / 64, SPW = 64 / CW;            // tile waves; samples per tile wave
+    constexpr int MAXR = (256 * NTW + 63) / 64;            // lean receive: summary granules per lane of the receiving wave
     constexpr int SPG = 16 / CW;                           // exchange: samples per granule (CW crossing bits + CW Ai-spike bits each)
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
@@ -217,7 +227,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                      O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + 8 * 624 * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
-                     O_CURB = O_MISC + 32, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
+                     O_LSTIB = O_MISC + 32, O_CNTIB = O_LSTIB + MAXB * LR * 2,
+                     O_CURB = O_CNTIB + MAXB * 4, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
     static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
@@ -226,9 +237,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     float *xnu0 = (float *)(smem + O_XNU0);
     uint32_t *mt = (uint32_t *)(smem + O_MT);              // generator ring: block base+m in slot (mb + m) & 7
     unsigned long long *keys = (unsigned long long *)(smem + O_KEYS);
-    uint16_t *lstI = (uint16_t *)(smem + O_LSTI);
+    uint16_t *lstI0 = (uint16_t *)(smem + O_LSTI), *lstI1 = (uint16_t *)(smem + O_LSTIB);   // (second copy: lean form only)
     uint16_t *lstE = (uint16_t *)(smem + O_LSTE);
-    int *cntI = (int *)(smem + O_CNTI);
+    int *cntI0 = (int *)(smem + O_CNTI), *cntI1 = (int *)(smem + O_CNTIB);
     int *cntE = (int *)(smem + O_CNTE);
     int *cnt = (int *)(smem + O_CNT);
     uint32_t *colmask = (uint32_t *)(smem + O_COLM);
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, c0 = g * CW;
+    if (g == c.stall_wg) return;                           // test hook: a workgroup that never takes part
     const int jj = tid % CW, bl = tid / CW;
     const int j = c0 + jj;
     const bool colv = j < N;
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     const unsigned kst = (unsigned)(bl * N + j);
     const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;   // exchange word (sample wb, word wj)
     const int KB = c.KB, NG = c.G * KB;                    // granules per epoch
+    const int NGS = c.G * NTW;                             // lean form: summary granules per epoch
     const int Etot = Nin * N, Emain = (Etot / 32) * 32;
     const bool anytail = Etot != Emain;
     constexpr int NWV = NT / 64;
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     }
     if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
     if (tid < 8) misc[tid] = 0;
-    if (tid < MAXB) keys[tid] = 0ull;
+    if (tid < MAXB) { keys[tid] = 0ull; cntI0[tid] = 0; cntI1[tid] = 0; }
     if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
     bool failed = false;
     const bool early_fetch = tailcol || (Nin <= 1024 && NT - TT >= B * CW * 4);   // = the currents stage always has that barrier
@@ -322,9 +335,13 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
         const uint32_t *gqn = gcnt + B;                                   // X events per 256-position cascade group
         const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
+        uint16_t *lstI = (LEAN && (t & 1)) ? lstI1 : lstI0;               // Ai event lists of step t-1 (lean: by step parity)
+        int *cntI = (LEAN && (t & 1)) ? cntI1 : cntI0;
         // ------------------------------------------------------------------ receive step t-1
-        const bool use_rng = phaseA && c.pE.one_spike;
-        if (use_rng) {
+        const bool use_rng = phaseA && (LEAN || c.pE.one_spike);
+        uint32_t anym = 0;
+        bool heavy = !LEAN;                                               // lean: this step needs the all-thread scoring stage
+        if (!LEAN && use_rng) {
             // while the other waves wait for the exchange, the LAST wave runs the generator ahead (lockstep twists,
             // no barrier) until the ring is full: blocks base+1 .. base+7.  A step consumes 2 * N words per sample
             // with a crossing, i.e. a few blocks, so the arbitration below finds its blocks already there.
@@ -335,7 +352,106 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         // next iteration's digest, issued before the wait for the exchange when nothing can still be reading the buffer
         // it overwrites (the previous iteration's currents stage ended with a barrier behind its last digest read)
         if (t < T && early_fetch) fetch_digest(t + 1);
-        if (phaseA) {
+        if (LEAN && phaseA) {
+            if (wave == 0) {
+                // ---- ONE wave sweeps the G * NTW summary granules of epoch t, decodes them and scores the candidates
+                const unsigned long long *sums = c.exs + (size_t)(t & 1) * NGS;
+                const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
+                if (lane < MAXB) keys[lane] = 0ull;                  // (their readers of the previous iteration are all
+                if (lane == 0) { misc[3] = 0; misc[6] = 0; }          //  behind barriers this wave has passed since)
+                unsigned long long x[MAXR];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) {
+                        const int idx = lane + 64 * r;
+                        if (idx < NGS) { x[r] = granule_load(sums + idx); ok = ok && (uint32_t)(x[r] >> 32) == (uint32_t)t; }
+                        else x[r] = 0ull;
+                    }
+                    if (__all(ok) || failed) break;
+                    if (++spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                uint32_t my_any = 0;
+                bool hv = false;
+                auto event = [&](int bsm, int jx, bool inh) {           // one crossing / inhibitory spike of step t-1
+                    if (bsm >= B || jx >= N) return;
+                    if (!inh) { atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31)); my_any |= 1u << bsm; }
+                    else {
+                        atomicOr((unsigned int *)&spI[bsm * NW + (jx >> 5)], 1u << (jx & 31));
+                        const int slot = atomicAdd(&cntI[bsm], 1);
+                        if (slot < LR) lstI[bsm * LR + slot] = (uint16_t)jx;
+                        if (slot >= 4) atomicOr((unsigned int *)&misc[2], 2u);    // more than the four-entry fast path takes
+                    }
+                };
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int idx = lane + 64 * r;
+                    const uint32_t pay = (uint32_t)x[r];
+                    if (idx >= NGS || !pay) continue;
+                    const int gsrc = idx / NTW, w = idx - gsrc * NTW;
+                    if ((pay & 0xFFu) == 0xFFu) {                        // overflow: that wave's full bit granules
+                        hv = true;
+                        for (int q = 0; q < SPW / SPG; ++q) {
+                            const int k = w * (SPW / SPG) + q;
+                            if (k >= KB) break;
+                            unsigned long long d;
+                            for (unsigned sp2 = 0;; ++sp2) {
+                                d = granule_load(exr + gsrc * KB + k);
+                                if ((uint32_t)(d >> 32) == (uint32_t)t || failed) break;
+                                if (sp2 > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            uint32_t be = (uint32_t)d & 0xFFFFu, bi = ((uint32_t)d >> 16) & 0xFFFFu;
+                            while (be) { const int p_ = __ffs(be) - 1; be &= be - 1; event(k * SPG + p_ / CW, gsrc * CW + p_ % CW, false); }
+                            while (bi) { const int p_ = __ffs(bi) - 1; bi &= bi - 1; event(k * SPG + p_ / CW, gsrc * CW + p_ % CW, true); }
+                        }
+                    } else {
+                        const int ne = (int)(pay >> 30);
+                        for (int e = 0; e < ne; ++e) {
+                            const uint32_t ev = (pay >> (8 * e)) & 0xFFu;
+                            const int p_ = (int)(ev & 0x3Fu);
+                            event(w * SPW + p_ / CW, gsrc * CW + p_ % CW, (ev & 0x40u) != 0);
+                        }
+                    }
+                }
+                if (my_any) atomicOr((unsigned int *)&misc[3], my_any);
+                if (hv) misc[6] = 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t am = (uint32_t)__hip_atomic_load((unsigned int *)&misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool hvy = __hip_atomic_load(&misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+                const int rows = __popc(am), ntw_ = rows ? (rng_pos + 2 * rows * N - 1) / 624 : 0;
+                if (ntw_ > 7) { if (lane == 0) misc[6] = 1; }       // more generator blocks than the ring holds
+                else if (!hvy && rows) {
+                    // every block the step consumes is resident (ring run ahead in the previous iteration): score the
+                    // inline candidates right here -- argmax(1 / q[j]), ties to the lowest index (nodes.py:1097-1105)
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) {
+                        const int idx = lane + 64 * r;
+                        const uint32_t pay = (uint32_t)x[r];
+                        if (idx >= NGS || !pay) continue;
+                        const int gsrc = idx / NTW, w = idx - gsrc * NTW;
+                        const int ne = (int)(pay >> 30);
+                        for (int e = 0; e < ne; ++e) {
+                            const uint32_t ev = (pay >> (8 * e)) & 0xFFu;
+                            if (ev & 0x40u) continue;
+                            const int p_ = (int)(ev & 0x3Fu), bsm = w * SPW + p_ / CW, jx = gsrc * CW + p_ % CW;
+                            if (bsm >= B || jx >= N) continue;
+                            const int d = __popc(am & ((1u << bsm) - 1u)) * N + jx;
+                            const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
+                            const int m0 = w0 / 624, m1 = w1 / 624;
+                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                            mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                            const float val = 1.0f / q;
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                            atomicMax(&keys[bsm], key);
+                        }
+                    }
+                }
+            }
+        } else if (phaseA) {
             const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
             const int NH = (c.G + WPB - 1) / WPB;           // bytes per sample = groups of WPB workgroups
             for (int it = tid; it < NH * KB; it += NT) {
@@ -386,13 +502,23 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         if (t < T && !early_fetch) fetch_digest(t + 1);    // next iteration's digest: in flight behind this one
         DBG_MARK(16);
         const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
-        const uint8_t *sbytes = (mflags & 1) ? sprev_g : nullptr;
+        const uint8_t *sbytes = LEAN ? nullptr : ((mflags & 1) ? sprev_g : nullptr);   // lean: such a step ends the launch (below)
         if (tid == 0 && (mflags & 2)) atomicOr((unsigned int *)&misc[2], 2u);
+        if (LEAN) {
+            if (phaseA) { anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]); heavy = __builtin_amdgcn_readfirstlane(misc[6]) != 0; }
+            else heavy = true;                                            // t == 0: lists from the layers' spike bytes
+            if (phaseB) {   // what the NEXT decode accumulates into: its previous readers ended before the barrier above
+                for (int k = tid; k < BW; k += NT) spI2[((t + 1) & 1) * kBitWords + k] = 0;
+                if (tid < MAXB) ((t & 1) ? cntI0 : cntI1)[tid] = 0;
+            }
+        }
         const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
         const bool stdp_full = t == 1;
         const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
         // ---- per sample (one wave each, in turns): event list of its Ai spikes; does it have an Ae crossing?
-        if (NW <= 32) {                                    // two samples per wave, one per half
+        //      (lean form: the receiving wave has built them already, except at t == 0)
+        if (LEAN && phaseA) {
+        } else if (NW <= 32) {                                    // two samples per wave, one per half
             const int hl = lane & 31;
             for (int b2 = wave * 2; b2 < B; b2 += NWV * 2) {
                 const int b = b2 + (lane >> 5);
@@ -417,14 +543,13 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         //      has a crossing, in sample order.  Which samples crossed is known since the receive barrier, so each thread
         //      scores the crossings of ITS (sample, word) right here, next to the list building: the barrier below
         //      closes both.
-        uint32_t anym = 0;
         int arb_rows = 0, arb_E = 0, arb_ntw = 0;
         if (use_rng) {
-            anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
+            if (!LEAN) anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]);
             arb_rows = __popc(anym);
             arb_E = rng_pos + 2 * arb_rows * N;
             arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
-            if (arb_ntw <= 7 && tid < BW) {            // every block the step consumes is resident (ring run ahead at the top)
+            if (heavy && arb_ntw <= 7 && tid < BW) {            // every block the step consumes is resident (ring run ahead at the top)
                 uint32_t bits = crs[tid];
                 const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
                 while (bits) {
@@ -442,8 +567,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             }
         }
         DBG_MARK(1);
-        lds_barrier();
-        if (tid == 35) misc[3] = 0;                        // crossing-sample mask: every thread has read it; next set by the next receive
+        if (heavy) lds_barrier();                          // (lean, ordinary step: nothing happened since the receive barrier)
+        if (!LEAN && tid == 35) misc[3] = 0;               // crossing-sample mask: every thread has read it; next set by the next receive
         const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
         const int cjg = c0 + cj_;
         const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
@@ -460,6 +585,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 lds_barrier();
             }
             DBG_MARK(13);
+            if (LEAN) for (int k = tid; k < BW; k += NT) crs[k] = 0;     // (every reader of this step's crossings is done)
             if (tid < BW) {        // final spikes: the winner's bit, or nothing -- and with them the event lists (<= 1 entry)
                 uint32_t wbits = 0;
                 if ((anym >> wb) & 1u) {
@@ -525,6 +651,20 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const bool busy = (__builtin_amdgcn_readfirstlane(misc[2]) & 2) != 0;
         lds_barrier();
         DBG_MARK(4);
+        if (LEAN && (busy || (mflags & 1))) {
+            // a step the lean form does not handle.  Every workgroup derives this from the same exchanged data / input
+            // digest, so all of them leave here in the same iteration and nobody is left waiting for a granule.
+            if (tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            failed = true;
+            break;
+        }
+        if (LEAN && c.pE.one_spike && phaseB) {
+            // the LAST wave runs the generator ahead (lockstep twists, no barrier) until the ring is full -- blocks base+1 ..
+            // base+7 -- while the others compute currents: the next receive scores its candidates before any barrier
+            if (wave == NWV - 1)
+                for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
+            ahead = 7;
+        }
         auto write_raster_rows = [&]() {
             if (phaseA && tid >= TT) {
             // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
@@ -544,7 +684,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         // scratch of phase A: everyone is past its last read
         if (tid < 32) colmask[tid] = 0;
         if (tid == 34) misc[2] = 0;                          // busy flag (set in the list stage, read just above)
-        if (tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;
+        if (!LEAN && tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;   // (lean: zeroed by the receiving wave itself)
 
         // ================================================================== phase B: start step t
         float curE = 0.f, curI = 0.f;
@@ -702,7 +842,30 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             stl[0 * TT + tid] = r_vE; stl[1 * TT + tid] = r_rE; stl[2 * TT + tid] = r_vI; stl[3 * TT + tid] = r_rI; stl[6 * TT + tid] = th;
             if (c.pI.traces) stl[5 * TT + tid] = trace_next(stl[5 * TT + tid], spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
         }
-        {   // publish crossing / spike bits of step t: epoch t+1.  A wave holds 64/CW samples x CW columns; SPG
+        if constexpr (LEAN) {
+            // publish step t as epoch t+1: ONE summary granule per tile wave -- {count, up to three events} with event =
+            // type << 6 | lane (lane = sample-in-wave * CW + column); more than three: the wave's full bit granules first
+            // (general layout), drained, then the summary with the overflow mark
+            if (wave < NTW) {
+                const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
+                const int nev = __popcll(mE) + __popcll(mI);
+                uint32_t pay;
+                if (nev <= 3) {
+                    pay = (uint32_t)nev << 30;
+                    int sh = 0;
+                    for (uint64_t m = mE; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
+                    for (uint64_t m = mI; m; m &= m - 1) { pay |= (uint32_t)(0x40 | (__ffsll((unsigned long long)m) - 1)) << sh; sh += 8; }
+                } else {
+                    const int sidx = lane / CW, b = wave * SPW + sidx;
+                    const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFFFull) << 16);
+                    if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
+                        granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pay = 0xC0FFFFFFu;
+                }
+                if (lane == 0) granule_store(c.exs + (size_t)((t + 1) & 1) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            }
+        } else {   // publish crossing / spike bits of step t: epoch t+1.  A wave holds 64/CW samples x CW columns; SPG
             // consecutive samples share a granule
             const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
             constexpr int SPW = 64 / CW;
@@ -722,7 +885,18 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
     }
 
-    // ---- epilogue: state and weights back to the tensors the caller owns
+    // ---- epilogue: state and weights back to the tensors the caller owns.  Nothing the caller owns as STATE (membrane
+    //      state, traces, theta, weights, generator) has been written so far, so a run that gave up on a hand-off --
+    //      here or in any other workgroup (device status word) -- returns with all of it untouched and the host re-runs
+    //      the input on the one-launch-per-timestep plan (Network.run); only the monitor rasters hold garbage by then.
+    if (tid == 0) misc[4] = c.status ? __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (failed) misc[5] = 1;
+    __syncthreads();
+    if (misc[4] != 0 || misc[5] != 0) return;
+    if (c.x_traces) {                                  // X trace after the last step (k_dc2015_xtrace's entry T)
+        const float *src = c.xtr + (size_t)T * B * Nin;
+        for (int k = g * NT + tid; k < B * Nin; k += c.G * NT) c.xX[1][k] = src[k];
+    }
     if (mine) {
         float th = stl[6 * TT + tid];
         if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[((T - 1) & 1) * CW + jj];   // the last step's spikes
@@ -817,19 +991,51 @@ size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw) { return lds_bytes
 int snn_dc2015_resident_cw(int N) { return resident_cw(N); }
 int snn_dc2015_resident_nt() { return resident_nt(); }
 
-int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {   // the kernel uses more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        const void *rv[5] = {(const void *)k_dc2015_run<8, 1024>, (const void *)k_dc2015_run<4, 1024>, (const void *)k_dc2015_run<2, 1024>,
-                             (const void *)k_dc2015_run<4, 512>, (const void *)k_dc2015_run<2, 512>};
-        for (const void *f : rv)
-            if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
-        attr = true;
+static const void *resident_variant(int cw, int nt, bool lean = false) {
+    if (lean) return (const void *)k_dc2015_run<4, 1024, true>;         // the lean form exists for 4-column tiles only
+    if (nt == 512 && cw == 4) return (const void *)k_dc2015_run<4, 512, false>;
+    if (nt == 512) return (const void *)k_dc2015_run<2, 512, false>;
+    if (cw == 8) return (const void *)k_dc2015_run<8, 1024, false>;
+    if (cw == 4) return (const void *)k_dc2015_run<4, 1024, false>;
+    return (const void *)k_dc2015_run<2, 1024, false>;
+}
+
+static bool resident_attr_once() {
+    static int state = 0;          // 0 = not tried, 1 = ok, -1 = failed
+    if (!state) {   // the kernel uses more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        state = 1;
+        const int cws[6] = {8, 4, 2, 4, 2, 4}, nts[6] = {1024, 1024, 1024, 512, 512, 1024};
+        for (int k = 0; k < 6; ++k)
+            if (snn_check(hipFuncSetAttribute(resident_variant(cws[k], nts[k], k == 5), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) state = -1;
     }
-    if (nt == 512 && cw == 4) hipLaunchKernelGGL((k_dc2015_run<4, 512>), dim3(c.G), dim3(512), lds, st, c);
-    else if (nt == 512) hipLaunchKernelGGL((k_dc2015_run<2, 512>), dim3(c.G), dim3(512), lds, st, c);
-    else if (cw == 8) hipLaunchKernelGGL((k_dc2015_run<8, 1024>), dim3(c.G), dim3(1024), lds, st, c);
-    else if (cw == 4) hipLaunchKernelGGL((k_dc2015_run<4, 1024>), dim3(c.G), dim3(1024), lds, st, c);
-    else hipLaunchKernelGGL((k_dc2015_run<2, 1024>), dim3(c.G), dim3(1024), lds, st, c);
-    return snn_check_launch();
+    return state == 1;
+}
+
+// How many workgroups of this variant the current device is guaranteed to hold at once (CUs x workgroups per CU
+// from the occupancy calculator; 0 when the device cannot launch cooperatively).  The spin-wait hand-off between
+// workgroups is only correct when the whole grid is co-resident, so the plan is refused beyond this number.
+int snn_dc2015_resident_capacity(int cw, int nt, size_t lds) {
+    if (!resident_attr_once()) return 0;
+    int dev = 0, cus = 0, coop = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_variant(cw, nt), nt, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (getenv("SNN_DC_FAKE_CUS")) cus = atoi(getenv("SNN_DC_FAKE_CUS"));     // test hook: pretend to be a smaller device
+    return coop ? cus * per_cu : 0;
+}
+
+// Cooperative launch: the runtime itself refuses (hipErrorCooperativeLaunchTooLarge) a grid it cannot make co-resident.
+// Returns SNN_ERR_UNSUPPORTED in that case so that the caller takes the one-launch-per-timestep plan instead.
+int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, int lean, hipStream_t st) {
+    if (!resident_attr_once()) return SNN_ERR_LAUNCH;
+    static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    DcCtx arg = c;
+    void *args[1] = {(void *)&arg};
+    const void *fn = resident_variant(cw, nt, lean != 0);
+    if (!coop)         // developer switch: ordinary launch (co-residency then rests on snn_dc2015_resident_capacity alone)
+        return snn_check(hipLaunchKernel(fn, dim3(c.G), dim3(nt), args, lds, st));
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(c.G), dim3(nt), args, (unsigned)lds, st);
+    if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }
+    return snn_check(e);
 }

@@ -53,7 +53,7 @@ void snn_set_plan_name(const char *name) { g_plan = name; }
 extern "C" void snn_set_plan_mode(int mode) { g_plan_mode = mode; }
 
 int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
-                         hipStream_t st, int resident, int *handled, unsigned *normalized);
+                         hipStream_t st, int resident, int allow_lean, int *handled, unsigned *normalized);
 int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            hipStream_t st, int *handled, unsigned *normalized);
 int snn_try_fused_convlif(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
@@ -178,9 +178,10 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     hipStream_t st = (hipStream_t)stream;
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
-    if (g_plan_mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, g_plan_mode == 0, &handled, &normalized));
-    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
-    if (g_plan_mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));
+    const int mode = g_plan_mode ? g_plan_mode : R->plan;      // the process-wide test switch wins over the per-run request
+    if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
+    if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
+    if (mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));
     if (!handled) {
         g_plan = "generic";
         TRY(run_generic(L, nL, C, nC, R, st));

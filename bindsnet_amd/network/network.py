@@ -69,6 +69,20 @@ class Network(torch.nn.Module):
         f.seek(0)
         return torch.load(f, weights_only=False)
 
+    _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown")
+
+    def __getstate__(self):
+        """save() / clone() pickle the whole object like the reference (network.py:163-209); device scratch, the
+        workspace of the fused plans and the references that keep the last inputs alive are not model state."""
+        state = dict(self.__dict__)
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.last_plan = None
+
     def reset_state_variables(self) -> None:
         # Layers of the stock classes are reset together: a handful of multi-tensor launches instead of ~4 fills
         # per layer (same values: s, x, refrac_count -> 0, v -> rest; theta is NOT reset, nodes.py:1113-1120).
@@ -162,11 +176,14 @@ class Network(torch.nn.Module):
                 d.kind, d.ext_spikes, d.s = _lib.LAYER_INPUT, _dptr(x), _dptr(entry)
                 layer._trace_fields(d.p.lif)
                 d.x = _dptr(layer.x) if layer.traces else None
-                for m in self.monitors.values():   # the raster of an input layer IS its input (no copy)
-                    if isinstance(m, Monitor) and m.obj is layer:
-                        if list(m.state_vars) != ["s"]:
+                xcopy = None
+                for m in self.monitors.values():   # the raster of an input layer is a COPY of its input, like
+                    if isinstance(m, Monitor) and m.obj is layer:      # Monitor.record's clone (monitors.py:94-111):
+                        if list(m.state_vars) != ["s"]:                # the caller may refill its buffer in place
                             raise NotImplementedError("bindsnet_amd: Input layers can only be monitored for 's'")
-                        rasters.append((m, "s", x[:T].view(T, B, *layer.shape)))
+                        if xcopy is None:
+                            xcopy = x[:T].clone().view(T, B, *layer.shape)
+                        rasters.append((m, "s", xcopy))
                 inputs[name] = x
                 continue
             if name in inputs:
@@ -203,13 +220,37 @@ class Network(torch.nn.Module):
             R.workspace, R.workspace_bytes = _dptr(ws), need
         gen_bufs = (self._scratch("rng_block", (640,), torch.int32, dev),
                     self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev))
-        with DeviceGenerator(dev, max_draws, gen_bufs) as ns:      # host generator <-> device, exact (rng.py)
-            R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
-            R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
-            rc = _lib.lib().snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R),
-                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            _lib.check(rc, "snn_net_run")
-            self.last_plan = _lib.lib().snn_plan_name().decode()
+        lib = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # plan request of this run: automatic, unless the lean kernel form gave up on one of the last inputs (it is then
+        # left alone for a while: an input it cannot finish costs a whole second run)
+        cool = self.__dict__.get("_lean_cooldown", 0)
+        R.plan = 3 if cool > 0 else 0
+        if cool > 0:
+            self._lean_cooldown = cool - 1
+        for attempt in (0, 1, 2):
+            with DeviceGenerator(dev, max_draws, gen_bufs) as ns:  # host generator <-> device, exact (rng.py)
+                R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
+                R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
+                _lib.check(lib.snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R), stream), "snn_net_run")
+                self.last_plan = lib.snn_plan_name().decode()
+                # plans that hand spikes between workgroups report a failed hand-off (or a step the lean form does not
+                # handle) through the status word: it is read back after EVERY such run, with or without one_spike
+                ns.always_read = self.last_plan.startswith("dc2015-resident")
+                status = ns.finish(check_status=attempt == 2)
+            if status == 0:
+                break
+            # The kernel returned without touching any state tensor or the generator, so the same input is simply run
+            # again: SNN_ERR_RETRY (lean form, unsupported step) -> the general resident kernel; SNN_ERR_TIMEOUT (the GPU
+            # was shared and the grid was not co-resident in time) -> the one-launch-per-timestep plan, which cannot wait
+            # on another workgroup.
+            if status == _lib.SNN_ERR_RETRY:
+                self.lean_retries = getattr(self, "lean_retries", 0) + 1
+                self._lean_cooldown = 16
+                R.plan = 3
+            else:
+                self.resident_retries = getattr(self, "resident_retries", 0) + 1
+                R.plan = 2
         # Input.s aliases the last input slice, as in the reference (nodes.py:219)
         for name in names:
             if isinstance(self.layers[name], Input):
@@ -280,6 +321,11 @@ class Network(torch.nn.Module):
             feat = conn._weight()
             if feat.value.device != dev:
                 feat.to(dev)
+            val = feat.value
+            if val.dtype != torch.float32 or not val.is_contiguous() or tuple(val.shape) != (conn.source.n, conn.target.n):
+                raise NotImplementedError(f"bindsnet_amd: Weight.value must be a contiguous float32 [{conn.source.n}, "
+                                          f"{conn.target.n}] tensor (got {val.dtype}, shape {tuple(val.shape)}, "
+                                          f"contiguous={val.is_contiguous()})")
             d.kind, d.w = _lib.CONN_MCC, _dptr(feat.value.data)
             rule = feat.learning_rule
             if isinstance(rule, mcc_rules.PostPre) and not conn.manual_update:
@@ -341,6 +387,11 @@ class Network(torch.nn.Module):
                 d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
         elif not isinstance(rule, dense_rules.NoOp):
             raise NotImplementedError(f"bindsnet_amd: rule {type(rule).__name__} is not supported")
+        elif rule.weight_decay != 1.0 and self.learning:
+            # the reference's NoOp.update still decays w every step (learning.py:87-104); not on the accelerated path
+            raise NotImplementedError("bindsnet_amd: weight_decay on a connection without a learning rule is not supported")
+        if conn.w.dtype != torch.float32 or not conn.w.is_contiguous():
+            raise NotImplementedError("bindsnet_amd: connection weights must be contiguous float32")
         if conn.norm is not None:
             if isinstance(conn, Conv2dConnection):
                 raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not supported")

@@ -120,6 +120,7 @@ class DeviceGenerator:
         self.qbuf = buffers[1] if buffers is not None else None
         self.consumed = 0
         self._n = qbuf_floats
+        self.always_read = False       # set by Network.run for plans that report through the status word
 
     def __enter__(self):
         img = torch.zeros(_BLOCK_WORDS, dtype=torch.int32)
@@ -131,23 +132,30 @@ class DeviceGenerator:
         self._block.copy_(img)                             # state in, status = 0, cursor = 0
         return self
 
-    def finish(self) -> int:
-        if not self.enabled:
+    def finish(self, check_status: bool = True) -> int:
+        """Synchronise with the run, read the block back, leave the host generator where the reference would.
+        Returns the device status word: 0, or -- when `check_status` is False -- SNN_ERR_TIMEOUT (a resident run gave
+        up on a workgroup hand-off) / SNN_ERR_RETRY (the lean kernel form met a step it does not handle).  The caller
+        then repeats the run on another plan; the device left every state tensor and the generator state untouched
+        in that case, so the host generator is restored to its entry state."""
+        from ._lib import SNN_ERR_RETRY, SNN_ERR_TIMEOUT, SnnError
+        if not self.enabled and not check_status and not self.always_read:
             return 0
         blk = self._block.cpu().numpy()                    # synchronises with the run
         st = int(blk[_STATUS_AT])
         if st != 0:
-            from ._lib import SnnError
-            torch.set_rng_state(self._host0)
+            if self.enabled:
+                torch.set_rng_state(self._host0)
+            if st in (SNN_ERR_TIMEOUT, SNN_ERR_RETRY) and not check_status:
+                return st
             raise SnnError(f"device run reported status {st}")
-        img = blk[:RNG_STATE_BYTES // 4]
-        self.consumed = int(np.ascontiguousarray(img).view(np.int64)[(RNG_STATE_BYTES - 8) // 8])
-        torch.set_rng_state(words_to_torch_state(img, self._host0))
-        return self.consumed
+        if self.enabled:
+            img = blk[:RNG_STATE_BYTES // 4]
+            self.consumed = int(np.ascontiguousarray(img).view(np.int64)[(RNG_STATE_BYTES - 8) // 8])
+            torch.set_rng_state(words_to_torch_state(img, self._host0))
+        return 0
 
     def __exit__(self, exc_type, exc, tb):
-        if exc_type is None:
-            self.finish()
-        elif self.enabled:
+        if exc_type is not None and self.enabled:
             torch.set_rng_state(self._host0)
         return False

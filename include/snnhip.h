@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 1
+#define SNN_ABI_VERSION 2
 
 typedef void *snn_stream_t;
 
@@ -40,7 +40,9 @@ enum {
     SNN_ERR_LAUNCH = -3,       /* hip launch / runtime error (see snn_last_hip_error) */
     SNN_ERR_NOISE = -4,        /* one_spike noise stream exhausted (device status word) */
     SNN_ERR_NO_DEVICE = -5,
-    SNN_ERR_TIMEOUT = -6       /* an in-kernel workgroup hand-off gave up waiting (device status word) */
+    SNN_ERR_TIMEOUT = -6,      /* an in-kernel workgroup hand-off gave up waiting (device status word) */
+    SNN_ERR_RETRY = -7         /* the lean form of a plan met a step it does not handle (device status word): no state
+                                  was touched; run the same input again with snn_run_desc.plan = 3 */
 };
 
 int snn_abi_version(void);
@@ -222,7 +224,12 @@ typedef struct {
     void *workspace;            /* device scratch for fused plans (snn_net_workspace_bytes); nullable */
     unsigned long long workspace_bytes;
     long long *cursor;          /* device int64[2] */
-    int *status;                /* device int32[1]: 0 or SNN_ERR_NOISE after the run */
+    int *status;                /* device int32[1]: 0, SNN_ERR_NOISE or SNN_ERR_TIMEOUT after the run */
+    int plan;                   /* 0 = automatic, 1 = generic per-operator launches, 2 = fused plans in their
+                                   one-launch-per-timestep form (what a caller re-runs with after SNN_ERR_TIMEOUT),
+                                   3 = automatic, but never the lean form of a plan (what a caller re-runs with after
+                                   SNN_ERR_RETRY).  A run that reports either status has left every caller-owned STATE
+                                   tensor untouched. */
 } snn_run_desc;
 
 /* Runs T timesteps.  Asynchronous; the caller synchronises the stream before reading *status /
@@ -244,7 +251,7 @@ int snn_profile_collect(double *h_sum_ms, int *h_samples);
 /* Fused-plan bookkeeping: runs issued as plain launches / captured into a hipGraph / replayed from one. */
 void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed);
 /* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only,
- * 2 = fused plans in their one-launch-per-timestep form (no resident kernel). */
+ * 2 = fused plans in their one-launch-per-timestep form (no resident kernel), 3 = no lean forms. */
 void snn_set_plan_mode(int mode);
 
 #ifdef __cplusplus

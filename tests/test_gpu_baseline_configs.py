@@ -21,7 +21,7 @@ from test_oracle_fullsize import two_case, two_state_cols
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-PLAN_MODE = {"auto": 0, "generic": 1, "per-step": 2}
+PLAN_MODE = {"auto": 0, "generic": 1, "per-step": 2, "resident": 3}
 
 
 def bits(a):
@@ -32,7 +32,7 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("plan", ["auto", "per-step", "generic"])
+@pytest.mark.parametrize("plan", ["auto", "resident", "per-step", "generic"])
 @pytest.mark.parametrize("name", ["full_cfg1_dc_n100_b1", "full_cfg2_dc_n400_b32"])
 def test_dc2015_full_size_matches_reference(name, plan):
     from bindsnet_amd import _lib
@@ -69,7 +69,9 @@ def test_dc2015_full_size_matches_reference(name, plan):
                 check_packed(g, f"r{r}_{key}", host(a))
             net.reset_state_variables()
         np.testing.assert_array_equal(torch.rand(4).numpy(), g["probe_after"], err_msg="host generator position")
-        assert net.last_plan == {"auto": "dc2015-resident", "per-step": "dc2015-fused", "generic": "generic"}[plan]
+        assert net.last_plan == {"auto": "dc2015-resident-lean", "resident": "dc2015-resident", "per-step": "dc2015-fused",
+                                 "generic": "generic"}[plan]
+        assert getattr(net, "lean_retries", 0) == 0 and getattr(net, "resident_retries", 0) == 0
     finally:
         _lib.lib().snn_set_plan_mode(0)
 

@@ -36,7 +36,7 @@ def build(plan_generic):
 
 def run_plan(mode, n_inputs=3):
     from bindsnet_amd import _lib
-    _lib.lib().snn_set_plan_mode(mode)                # 0 resident kernel, 1 generic, 2 one launch per timestep
+    _lib.lib().snn_set_plan_mode(mode)                # 0 resident kernel (lean form), 1 generic, 2 one launch per timestep, 3 resident (general form)
     try:
         net, mons = build(mode)
         out = []
@@ -53,7 +53,7 @@ def run_plan(mode, n_inputs=3):
             st["sI"] = mons["Ai"].get("s").cpu().numpy().reshape(T, B, N).astype(u8)
             st["probe"] = probe.numpy()
             out.append(st)
-            assert net.last_plan == ("dc2015-resident", "generic", "dc2015-fused")[mode]
+            assert net.last_plan == ("dc2015-resident-lean", "generic", "dc2015-fused", "dc2015-resident")[mode]
             net.reset_state_variables()
         return out
     finally:
@@ -61,8 +61,8 @@ def run_plan(mode, n_inputs=3):
 
 
 def test_fused_equals_generic_and_properties_at_full_size():
-    fused, generic, stepped = run_plan(0), run_plan(1), run_plan(2)
-    for other in (generic, stepped):
+    fused, generic, stepped, general = run_plan(0), run_plan(1), run_plan(2), run_plan(3)
+    for other in (generic, stepped, general):
         for r, (a, b) in enumerate(zip(fused, other)):
             for k in a:
                 np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"input {r}: {k}")
@@ -93,7 +93,7 @@ def test_resident_kernel_soak_and_competing_load():
     from bindsnet_amd import _lib
     n_inputs = 12
     outs = {}
-    for mode in (2, 0):
+    for mode in (2, 0, 3):
         _lib.lib().snn_set_plan_mode(mode)
         try:
             net, mons = build(mode)
@@ -102,17 +102,18 @@ def test_resident_kernel_soak_and_competing_load():
             for r in range(n_inputs):
                 spikes = torch.from_numpy(synth.spike_train(300 + r, T, B, 784)).view(T, B, 1, 28, 28).to(DEV)
                 torch.manual_seed(40 + r)
-                if mode == 0:
+                if mode != 2:
                     with torch.cuda.stream(side):      # ~10 ms of GEMMs racing the resident kernel for CUs
                         for _ in range(40):
                             a = torch.tanh(a @ a * 1e-3)
                 net.run({"X": spikes}, time=T)
                 net.reset_state_variables() if r % 3 == 0 else None
             torch.cuda.synchronize()
-            assert net.last_plan == ("dc2015-resident", "generic", "dc2015-fused")[mode]
+            assert net.last_plan == ("dc2015-resident-lean", "generic", "dc2015-fused", "dc2015-resident")[mode]
             outs[mode] = _final_state(net, mons)
         finally:
             _lib.lib().snn_set_plan_mode(0)
     for k in outs[0]:
         np.testing.assert_array_equal(outs[0][k].view(np.uint8), outs[2][k].view(np.uint8), err_msg=k)
+        np.testing.assert_array_equal(outs[3][k].view(np.uint8), outs[2][k].view(np.uint8), err_msg=k)
     assert outs[0]["sE"].sum() > 20

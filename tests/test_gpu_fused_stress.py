@@ -78,12 +78,15 @@ def test_fused_equals_generic_under_stress(name):
             s = (s * rs.randint(1, vmax + 1, size=s.shape)).astype(np.uint8)
         spikes.append(s)
     fused, plan = run(0, N, B, T, spikes, w_scale=wsc)
-    assert plan == "dc2015-resident"
+    assert plan.startswith("dc2015-resident")           # lean form where it applies, else / after a give-up the general one
+    general, plan_r = run(3, N, B, T, spikes, w_scale=wsc)
+    assert plan_r == "dc2015-resident"
     stepped, plan_s = run(2, N, B, T, spikes, w_scale=wsc)
     assert plan_s == "dc2015-fused"
     generic, plan_g = run(1, N, B, T, spikes, w_scale=wsc)
     assert plan_g == "generic"
     same(fused, generic)
+    same(general, generic)
     same(stepped, generic)
     assert sum(int(x["sE"].sum()) for x in fused) > 0, "no excitatory spike at all: vacuous"
     assert all(x["sE"].reshape(T, B, N).sum(axis=2).max() <= 1 for x in fused)
@@ -92,9 +95,11 @@ def test_fused_equals_generic_under_stress(name):
 def test_learning_off_and_weak_inhibition():
     spikes = [synth.dense_spikes(80 + r, (30, 6, 784), 0.03) for r in range(2)]
     f, _ = run(0, 100, 6, 30, spikes, learning=False, inh=17.5)
+    r3, _ = run(3, 100, 6, 30, spikes, learning=False, inh=17.5)
     h, _ = run(2, 100, 6, 30, spikes, learning=False, inh=17.5)
     g, _ = run(1, 100, 6, 30, spikes, learning=False, inh=17.5)
     same(f, g)
+    same(r3, g)
     same(h, g)
 
 

@@ -49,7 +49,7 @@ def test_sharded_run_single_rank_rccl():
         for r in range(2):
             torch.manual_seed(3 + r)
             parallel.sharded_run(net, {"X": spikes[r]}, T)
-            assert net.last_plan == "dc2015-resident"
+            assert net.last_plan.startswith("dc2015-resident")
         dist.barrier()
         t = torch.ones(4, device=DEV)
         dist.all_reduce(t)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Developer aid: timeline of one bench step (network.run + reset_state_variables) on the host.
+
+Wraps the C-ABI call and the generator hand-over with perf_counter stamps (no profiler overhead) and prints the
+average microseconds spent in: python before the C call | snn_net_run (enqueue) | waiting for the device in the
+blocking read-back | python after it | reset_state_variables.
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from bindsnet_amd import _lib, rng  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    net = bench.build_network(dev)
+    pool = bench.make_inputs(1000, 2, dev)
+    L = _lib.lib()
+    stamps = {}
+    real_run = L.snn_net_run
+
+    class Wrapped:
+        argtypes, restype = real_run.argtypes, real_run.restype
+
+        def __call__(self, *a):
+            stamps["c0"] = time.perf_counter()
+            r = real_run(*a)
+            stamps["c1"] = time.perf_counter()
+            return r
+
+    L.snn_net_run = Wrapped()
+    real_finish = rng.DeviceGenerator.finish
+    real_cpu = torch.Tensor.cpu
+
+    def finish(self, *a, **k):
+        stamps["f0"] = time.perf_counter()
+        orig = self._block
+
+        class Probe:
+            def cpu(_):
+                out = real_cpu(orig)
+                stamps["f1"] = time.perf_counter()
+                return out
+        self._block = Probe()
+        try:
+            return real_finish(self, *a, **k)
+        finally:
+            self._block = orig
+
+    rng.DeviceGenerator.finish = finish
+    torch.manual_seed(2)
+    acc = {k: 0.0 for k in ("pre", "enqueue", "between", "wait", "post", "reset")}
+    n = 50
+    for k in range(n + 5):
+        t0 = time.perf_counter()
+        net.run({"X": pool[k % 2]}, time=bench.T)
+        t1 = time.perf_counter()
+        net.reset_state_variables()
+        t2 = time.perf_counter()
+        if k >= 5:
+            acc["pre"] += stamps["c0"] - t0
+            acc["enqueue"] += stamps["c1"] - stamps["c0"]
+            acc["between"] += stamps["f0"] - stamps["c1"]
+            acc["wait"] += stamps["f1"] - stamps["f0"]
+            acc["post"] += t1 - stamps["f1"]
+            acc["reset"] += t2 - t1
+    torch.cuda.synchronize()
+    total = sum(acc.values())
+    print("per bench step, us: " + " | ".join(f"{k} {v / n * 1e6:.1f}" for k, v in acc.items()) + f" | total {total / n * 1e6:.1f}")
+
+
+if __name__ == "__main__":
+    main()
