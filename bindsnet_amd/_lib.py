@@ -57,6 +57,11 @@ class RunDesc(C.Structure):
                 ("cursor", C.c_void_p), ("status", C.c_void_p), ("plan", C.c_int)]
 
 
+class FillSegment(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_ulonglong), ("pattern", C.c_uint32)]
+
+
+MAX_FILL_SEGMENTS = 32
 LAYER_INPUT, LAYER_LIF, LAYER_DC = 0, 1, 2
 CONN_MCC, CONN_DENSE, CONN_CONV2D = 0, 1, 2
 RULE_NONE, RULE_POSTPRE, RULE_MSTDP = 0, 1, 2
@@ -79,6 +84,7 @@ _SIGS = {
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
     "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "snn_fill_segments": ([C.POINTER(FillSegment), _i, _vp], _i),
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
     "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),
     "snn_plan_name": ([], C.c_char_p),

@@ -805,6 +805,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         c.xtr = (float *)((unsigned char *)c.exs + al2(resident_summary_bytes(N)));
         c.status = R->status;
         c.stall_wg = getenv("SNN_DC_TEST_STALL") ? atoi(getenv("SNN_DC_TEST_STALL")) : -1;
+        c.zone_shift = 19;
+        if (getenv("SNN_DC_TEST_ZONE")) { const int z = atoi(getenv("SNN_DC_TEST_ZONE")); if (z >= 0 && z <= 19) c.zone_shift = z; }
         c.has_norm = C[0].has_norm; c.norm = C[0].norm; c.norm_abs = C[0].norm_abs;
     }
     // The resident plan hands spikes between workgroups INSIDE one launch, so every workgroup of the grid must be
@@ -830,7 +832,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     // lean form of the resident kernel (snn_dc2015_resident.hip): the common case compiled on its own.  Its receive stage
     // relies on the barrier that closes the currents stage (row_sum workgroups, or X currents on the spare threads).
     static const bool lean_on = !(getenv("SNN_DC_LEAN") && atoi(getenv("SNN_DC_LEAN")) == 0);
-    const bool lean = resident && allow_lean && lean_on && rcw == 4 && rnt == 1024 && L[1].p.one_spike && !getenv("SNN_DC_TIMING") &&
+    const bool lean = resident && allow_lean && lean_on && rcw == 4 && rnt == 1024 && L[1].p.one_spike &&
                       ((size_t)Nin * N) % 32 == 0 && Nin <= 1024 && 1024 - MAXB * 4 >= B * 4 * 4;
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;

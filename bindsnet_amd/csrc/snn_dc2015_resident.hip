@@ -215,7 +215,6 @@ template <int CWR, int NTR, bool LEAN>
 __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     constexpr int CW = CWR, TT = MAXB * CWR, NT = NTR;     // (shadow the per-step kernel's constants)
     constexpr int NTW = TT / 64, SPW = 64 / CW;            // tile waves; samples per tile wave
-    constexpr int MAXR = (256 * NTW + 63) / 64;            // lean receive: summary granules per lane of the receiving wave
     constexpr int SPG = 16 / CW;                           // exchange: samples per granule (CW crossing bits + CW Ai-spike bits each)
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         const bool use_rng = phaseA && (LEAN || c.pE.one_spike);
         uint32_t anym = 0;
         bool heavy = !LEAN;                                               // lean: this step needs the all-thread scoring stage
-        if (!LEAN && use_rng) {
+        if (use_rng) {
             // while the other waves wait for the exchange, the LAST wave runs the generator ahead (lockstep twists,
             // no barrier) until the ring is full: blocks base+1 .. base+7.  A step consumes 2 * N words per sample
             // with a crossing, i.e. a few blocks, so the arbitration below finds its blocks already there.
@@ -352,47 +351,36 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         // next iteration's digest, issued before the wait for the exchange when nothing can still be reading the buffer
         // it overwrites (the previous iteration's currents stage ended with a barrier behind its last digest read)
         if (t < T && early_fetch) fetch_digest(t + 1);
+        uint32_t pay = 0;                                                  // lean: this thread's summary granule of epoch t
         if (LEAN && phaseA) {
-            if (wave == 0) {
-                // ---- ONE wave sweeps the G * NTW summary granules of epoch t, decodes them and scores the candidates
+            if (tid < NGS) {
+                // ---- one thread per summary granule (G * NTW of them): poll it, decode its events into the bit words /
+                //      Ai event lists / crossing-sample mask in LDS; the candidates are scored behind the barrier
                 const unsigned long long *sums = c.exs + (size_t)(t & 1) * NGS;
                 const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
-                if (lane < MAXB) keys[lane] = 0ull;                  // (their readers of the previous iteration are all
-                if (lane == 0) { misc[3] = 0; misc[6] = 0; }          //  behind barriers this wave has passed since)
-                unsigned long long x[MAXR];
-                unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int r = 0; r < MAXR; ++r) {
-                        const int idx = lane + 64 * r;
-                        if (idx < NGS) { x[r] = granule_load(sums + idx); ok = ok && (uint32_t)(x[r] >> 32) == (uint32_t)t; }
-                        else x[r] = 0ull;
-                    }
-                    if (__all(ok) || failed) break;
-                    if (++spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                unsigned long long x;
+                for (unsigned spins = 0;; ++spins) {
+                    x = granule_load(sums + tid);
+                    if ((uint32_t)(x >> 32) == (uint32_t)t || failed) break;
+                    if (spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                uint32_t my_any = 0;
-                bool hv = false;
-                auto event = [&](int bsm, int jx, bool inh) {           // one crossing / inhibitory spike of step t-1
-                    if (bsm >= B || jx >= N) return;
-                    if (!inh) { atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31)); my_any |= 1u << bsm; }
-                    else {
-                        atomicOr((unsigned int *)&spI[bsm * NW + (jx >> 5)], 1u << (jx & 31));
-                        const int slot = atomicAdd(&cntI[bsm], 1);
-                        if (slot < LR) lstI[bsm * LR + slot] = (uint16_t)jx;
-                        if (slot >= 4) atomicOr((unsigned int *)&misc[2], 2u);    // more than the four-entry fast path takes
-                    }
-                };
-#pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
-                    const int idx = lane + 64 * r;
-                    const uint32_t pay = (uint32_t)x[r];
-                    if (idx >= NGS || !pay) continue;
-                    const int gsrc = idx / NTW, w = idx - gsrc * NTW;
+                pay = (uint32_t)x;
+                if (pay) {
+                    uint32_t my_any = 0;
+                    auto event = [&](int bsm, int jx, bool inh) {       // one crossing / inhibitory spike of step t-1
+                        if (bsm >= B || jx >= N) return;
+                        if (!inh) { atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31)); my_any |= 1u << bsm; }
+                        else {
+                            atomicOr((unsigned int *)&spI[bsm * NW + (jx >> 5)], 1u << (jx & 31));
+                            const int slot = atomicAdd(&cntI[bsm], 1);
+                            if (slot < LR) lstI[bsm * LR + slot] = (uint16_t)jx;
+                            if (slot >= 4) atomicOr((unsigned int *)&misc[2], 2u);   // more than the four-entry fast path takes
+                        }
+                    };
+                    const int gsrc = tid / NTW, w = tid - gsrc * NTW;
                     if ((pay & 0xFFu) == 0xFFu) {                        // overflow: that wave's full bit granules
-                        hv = true;
+                        misc[6] = 1;
                         for (int q = 0; q < SPW / SPG; ++q) {
                             const int k = w * (SPW / SPG) + q;
                             if (k >= KB) break;
@@ -415,40 +403,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                             event(w * SPW + p_ / CW, gsrc * CW + p_ % CW, (ev & 0x40u) != 0);
                         }
                     }
-                }
-                if (my_any) atomicOr((unsigned int *)&misc[3], my_any);
-                if (hv) misc[6] = 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const uint32_t am = (uint32_t)__hip_atomic_load((unsigned int *)&misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const bool hvy = __hip_atomic_load(&misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-                const int rows = __popc(am), ntw_ = rows ? (rng_pos + 2 * rows * N - 1) / 624 : 0;
-                if (ntw_ > 7) { if (lane == 0) misc[6] = 1; }       // more generator blocks than the ring holds
-                else if (!hvy && rows) {
-                    // every block the step consumes is resident (ring run ahead in the previous iteration): score the
-                    // inline candidates right here -- argmax(1 / q[j]), ties to the lowest index (nodes.py:1097-1105)
-#pragma unroll
-                    for (int r = 0; r < MAXR; ++r) {
-                        const int idx = lane + 64 * r;
-                        const uint32_t pay = (uint32_t)x[r];
-                        if (idx >= NGS || !pay) continue;
-                        const int gsrc = idx / NTW, w = idx - gsrc * NTW;
-                        const int ne = (int)(pay >> 30);
-                        for (int e = 0; e < ne; ++e) {
-                            const uint32_t ev = (pay >> (8 * e)) & 0xFFu;
-                            if (ev & 0x40u) continue;
-                            const int p_ = (int)(ev & 0x3Fu), bsm = w * SPW + p_ / CW, jx = gsrc * CW + p_ % CW;
-                            if (bsm >= B || jx >= N) continue;
-                            const int d = __popc(am & ((1u << bsm) - 1u)) * N + jx;
-                            const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
-                            const int m0 = w0 / 624, m1 = w1 / 624;
-                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
-                                                            mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
-                            const float val = 1.0f / q;
-                            const unsigned long long key =
-                                ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
-                            atomicMax(&keys[bsm], key);
-                        }
-                    }
+                    if (my_any) atomicOr((unsigned int *)&misc[3], my_any);
                 }
             }
         } else if (phaseA) {
@@ -549,6 +504,56 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             arb_rows = __popc(anym);
             arb_E = rng_pos + 2 * arb_rows * N;
             arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
+            if (LEAN && arb_ntw > 7) heavy = true;         // more generator blocks than the ring holds: the block-by-block walk
+            if (LEAN && !heavy && arb_rows) {
+                // ---- one wave per sample with a crossing (rank r = its position among them), lane = bit word of the sample.
+                // The winner is argmax over the candidates j of fl32(1 / q_j), q_j = fl32(-log1p(-u_j)), u_j = m_j * 2^-53 the
+                // j-th draw, ties to the lowest j (nodes.py:1097-1105).  u -> fl32(1/q) is monotone non-increasing, and for
+                // m2 > m1 + (m1 >> 19) strictly decreasing: -log1p(-u) grows by at least the relative step of u (its
+                // derivative 1/(1-u) >= f(u)/u), i.e. by more than 2^-19, which the three roundings on the way (f64 log1p,
+                // f32 cast, f32 division: < 2^-22 together) cannot close.  So the candidate with the smallest 53-bit draw wins
+                // outright unless another one lies inside that margin -- only then (probability ~ candidates * 2^-19) are
+                // the logarithms evaluated.  No log1p on the common path.
+                int r = 0;
+                for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
+                    if ((r % NWV) != wave) continue;
+                    const int bsm = __ffs(rem) - 1;
+                    const uint32_t bits = lane < NW ? crs[bsm * NW + lane] : 0u;
+                    unsigned long long k1 = ~0ull, k2 = ~0ull;            // this lane's two smallest keys (m << 10 | j)
+                    for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                        const int jx = lane * 32 + __ffs(bb) - 1;
+                        const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
+                        const int m0 = w0 / 624, m1 = w1 / 624;
+                        const uint32_t hi = mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]);
+                        const uint32_t lo = mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]);
+                        const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
+                        const unsigned long long key = (m << 10) | (unsigned long long)jx;
+                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                    }
+                    if (lane == 0) keys[bsm] = ~0ull;                      // (LDS operations of one wave execute in order)
+                    if (bits) atomicMin(&keys[bsm], k1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long kmin = *(volatile unsigned long long *)&keys[bsm];
+                    const unsigned long long mmin = kmin >> 10, zone = mmin + (mmin >> c.zone_shift) + 1ull;   // zone_shift = 19 (test hook: smaller)
+                    const bool close = (k1 != ~0ull && k1 != kmin && (k1 >> 10) <= zone) || (k2 != ~0ull && (k2 >> 10) <= zone);
+                    int win = (int)(kmin & 1023ull);
+                    if (__any(close)) {                                    // rare: exact evaluation of every candidate
+                        if (lane == 0) keys[bsm] = 0ull;
+                        for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                            const int jx = lane * 32 + __ffs(bb) - 1;
+                            const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
+                            const int m0 = w0 / 624, m1 = w1 / 624;
+                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                            mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                            const float val = 1.0f / q;
+                            atomicMax(&keys[bsm], ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        win = (int)(0xFFFFFFFFu - (uint32_t)(*(volatile unsigned long long *)&keys[bsm] & 0xFFFFFFFFull));
+                    }
+                    if (lane == 0) keys[bsm] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)win);   // (what the stages below decode)
+                }
+            }
             if (heavy && arb_ntw <= 7 && tid < BW) {            // every block the step consumes is resident (ring run ahead at the top)
                 uint32_t bits = crs[tid];
                 const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
@@ -567,8 +572,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             }
         }
         DBG_MARK(1);
-        if (heavy) lds_barrier();                          // (lean, ordinary step: nothing happened since the receive barrier)
-        if (!LEAN && tid == 35) misc[3] = 0;               // crossing-sample mask: every thread has read it; next set by the next receive
+        if (heavy || arb_rows > 0) lds_barrier();          // (lean, step without a crossing: nothing happened since the receive barrier)
+        if (tid == 35) { misc[3] = 0; misc[6] = 0; }       // crossing-sample mask / overflow mark: every thread has read them; next set by the next receive
         const int cb_ = tailcol ? tid / (CW * 4) : bl, cj_ = tailcol ? (tid >> 2) % CW : jj, cL = tid & 3;
         const int cjg = c0 + cj_;
         const bool cvalid = phaseB && cb_ < B && cjg < N && (tailcol || tid < TT);
@@ -658,13 +663,6 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
             failed = true;
             break;
         }
-        if (LEAN && c.pE.one_spike && phaseB) {
-            // the LAST wave runs the generator ahead (lockstep twists, no barrier) until the ring is full -- blocks base+1 ..
-            // base+7 -- while the others compute currents: the next receive scores its candidates before any barrier
-            if (wave == NWV - 1)
-                for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
-            ahead = 7;
-        }
         auto write_raster_rows = [&]() {
             if (phaseA && tid >= TT) {
             // spike rasters of step t-1: every workgroup holds the complete bit strings of the step (final Ae spikes,
@@ -684,7 +682,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         // scratch of phase A: everyone is past its last read
         if (tid < 32) colmask[tid] = 0;
         if (tid == 34) misc[2] = 0;                          // busy flag (set in the list stage, read just above)
-        if (!LEAN && tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;   // (lean: zeroed by the receiving wave itself)
+        if (tid >= 64 && tid < 64 + MAXB) keys[tid - 64] = 0ull;
 
         // ================================================================== phase B: start step t
         float curE = 0.f, curI = 0.f;

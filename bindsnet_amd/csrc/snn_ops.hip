@@ -725,3 +725,49 @@ extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, 
     hipLaunchKernelGGL(k_scale_cols, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, E, N, colsum_ws);
     return snn_check_launch();
 }
+
+
+// =============================================================================================
+// Network.reset_state_variables(): every state tensor of every layer filled in ONE launch
+// (bindsnet/network/network.py:467-481 -> nodes.py:109-120, 531-538, 1113-1120: s, x, refrac_count <- 0, v <- rest).
+// =============================================================================================
+namespace {
+struct FillArgs { snn_fill_segment seg[SNN_MAX_FILL_SEGMENTS]; unsigned first_block[SNN_MAX_FILL_SEGMENTS + 1]; int n; };
+
+__global__ __launch_bounds__(256) void k_fill_segments(const FillArgs a) {
+    int k = 0;
+    while (k + 1 < a.n && blockIdx.x >= a.first_block[k + 1]) ++k;          // (n <= 32: a short uniform scan)
+    const snn_fill_segment sg = a.seg[k];
+    const size_t off = ((size_t)(blockIdx.x - a.first_block[k]) * 256 + threadIdx.x) * 16;
+    if (off >= sg.bytes) return;
+    unsigned char *p = (unsigned char *)sg.ptr + off;
+    if (off + 16 <= sg.bytes && (((uintptr_t)p) & 15) == 0) {
+        *(uint4 *)p = make_uint4(sg.pattern, sg.pattern, sg.pattern, sg.pattern);
+    } else {
+        const size_t n = sg.bytes - off < 16 ? sg.bytes - off : 16;
+        for (size_t b = 0; b < n; ++b) p[b] = (unsigned char)(sg.pattern >> (8 * ((off + b) & 3)));
+    }
+}
+}  // namespace
+
+extern "C" int snn_fill_segments(const snn_fill_segment *h_segs, int n, snn_stream_t stream) {
+    if (n < 0 || (n > 0 && !h_segs)) return SNN_ERR_INVALID;
+    if (n > SNN_MAX_FILL_SEGMENTS) return SNN_ERR_UNSUPPORTED;
+    FillArgs a;
+    a.n = 0;
+    unsigned blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!h_segs[k].bytes) continue;
+        if (!h_segs[k].ptr) return SNN_ERR_INVALID;
+        // a non-zero pattern is a 32-bit value: the buffer must then be a whole number of aligned words
+        if (h_segs[k].pattern && ((h_segs[k].bytes & 3) || (((uintptr_t)h_segs[k].ptr) & 3))) return SNN_ERR_INVALID;
+        a.seg[a.n] = h_segs[k];
+        a.first_block[a.n] = blocks;
+        blocks += (unsigned)((h_segs[k].bytes + 4095) / 4096);
+        ++a.n;
+    }
+    if (!a.n) return SNN_OK;
+    a.first_block[a.n] = blocks;
+    hipLaunchKernelGGL(k_fill_segments, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return snn_check_launch();
+}

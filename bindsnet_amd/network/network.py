@@ -84,24 +84,29 @@ class Network(torch.nn.Module):
         self.last_plan = None
 
     def reset_state_variables(self) -> None:
-        # Layers of the stock classes are reset together: a handful of multi-tensor launches instead of ~4 fills
-        # per layer (same values: s, x, refrac_count -> 0, v -> rest; theta is NOT reset, nodes.py:1113-1120).
-        zero, vs, rests = [], [], []
+        """Reference: network.py:467-481.  The state tensors of the stock layer classes (s, x, refrac_count <- 0,
+        v <- rest; theta is NOT reset, nodes.py:1113-1120) are filled by ONE launch (snn_fill_segments) instead of
+        four small fills per layer."""
+        import struct
+        segs = []
         for l in self.layers.values():
-            if type(l) in (Input, LIFNodes, DiehlAndCookNodes) and l.s.is_cuda:
-                zero.append(l.s)
+            if type(l) in (Input, LIFNodes, DiehlAndCookNodes) and l.s.is_cuda and l.s.is_contiguous():
+                segs.append((l.s, 0))
                 if l.traces:
-                    zero.append(l.x)
+                    segs.append((l.x, 0))
                 if type(l) is not Input:
-                    zero += [l.refrac_count, l.v]
-                    vs.append(l.v)
-                    rests.append(_f(l.rest))
+                    segs += [(l.refrac_count, 0), (l.v, struct.unpack("<I", struct.pack("<f", _f(l.rest)))[0])]
             else:
                 l.reset_state_variables()
-        if zero:
-            torch._foreach_zero_(zero)
-        if vs:
-            torch._foreach_add_(vs, rests)             # 0 + rest == rest exactly
+        if segs and all(t.is_contiguous() for t, _ in segs) and len(segs) <= _lib.MAX_FILL_SEGMENTS:
+            arr = (_lib.FillSegment * len(segs))()
+            for k, (t, pat) in enumerate(segs):
+                arr[k].ptr, arr[k].bytes, arr[k].pattern = t.data_ptr(), t.numel() * t.element_size(), pat
+            _lib.check(_lib.lib().snn_fill_segments(arr, len(segs), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "snn_fill_segments")
+        else:
+            for t, pat in segs:
+                t.zero_() if pat == 0 else t.view(torch.int32).fill_(pat - (1 << 32) if pat >> 31 else pat)
         for c in self.connections.values():
             c.reset_state_variables()
         for m in self.monitors.values():
@@ -218,8 +223,11 @@ class Network(torch.nn.Module):
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             R.workspace, R.workspace_bytes = _dptr(ws), need
+        pool = self.__dict__.setdefault("_scratch_pool", {})
+        if "rng_host" not in pool:
+            pool["rng_host"] = torch.zeros(640, dtype=torch.int32).pin_memory()
         gen_bufs = (self._scratch("rng_block", (640,), torch.int32, dev),
-                    self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev))
+                    self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev), pool["rng_host"])
         lib = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         # plan request of this run: automatic, unless the lean kernel form gave up on one of the last inputs (it is then

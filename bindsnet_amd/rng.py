@@ -109,7 +109,7 @@ class DeviceGenerator:
     (which also zeroes status and cursor) and one blocking device->host copy at exit."""
 
     def __init__(self, device, qbuf_floats: int, buffers=None):
-        """buffers: optional persistent (block int32[640], qbuf f32[n]) tensors."""
+        """buffers: optional persistent (block int32[640], qbuf f32[n], pinned host int32[640]) tensors."""
         self.device = torch.device(device)
         self.enabled = qbuf_floats > 0
         block = buffers[0] if buffers is not None else torch.zeros(_BLOCK_WORDS, dtype=torch.int32, device=self.device)
@@ -118,18 +118,22 @@ class DeviceGenerator:
         self.status = block[_STATUS_AT:_STATUS_AT + 1]
         self.cursor = block[_CURSOR_AT:_CURSOR_AT + 4].view(torch.int64)
         self.qbuf = buffers[1] if buffers is not None else None
+        # page-locked staging block: the upload is an asynchronous copy and the read-back lands without a bounce
+        # buffer (a pageable copy costs a blocking driver round trip each way, every run)
+        self._host = buffers[2] if buffers is not None and len(buffers) > 2 else torch.zeros(_BLOCK_WORDS, dtype=torch.int32).pin_memory()
         self.consumed = 0
         self._n = qbuf_floats
         self.always_read = False       # set by Network.run for plans that report through the status word
 
     def __enter__(self):
-        img = torch.zeros(_BLOCK_WORDS, dtype=torch.int32)
+        img = self._host.numpy()
+        img[:] = 0                                         # status = 0, cursor = 0
         if self.enabled:
             self._host0 = torch.get_rng_state()
-            img[:RNG_STATE_BYTES // 4] = torch.from_numpy(torch_state_to_words(self._host0).copy())
+            img[:RNG_STATE_BYTES // 4] = torch_state_to_words(self._host0)
             if self.qbuf is None:
                 self.qbuf = torch.empty(self._n, dtype=torch.float32, device=self.device)
-        self._block.copy_(img)                             # state in, status = 0, cursor = 0
+        self._block.copy_(self._host, non_blocking=True)   # (the previous run's blocking read-back ordered us behind it)
         return self
 
     def finish(self, check_status: bool = True) -> int:
@@ -141,7 +145,8 @@ class DeviceGenerator:
         from ._lib import SNN_ERR_RETRY, SNN_ERR_TIMEOUT, SnnError
         if not self.enabled and not check_status and not self.always_read:
             return 0
-        blk = self._block.cpu().numpy()                    # synchronises with the run
+        self._host.copy_(self._block)                      # blocking: synchronises with the run
+        blk = self._host.numpy()
         st = int(blk[_STATUS_AT])
         if st != 0:
             if self.enabled:

@@ -173,6 +173,15 @@ int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *cols
                   snn_stream_t stream);
 
 
+/* ---- Network.reset_state_variables ----------------------------------------------------------
+ * bindsnet/network/network.py:467-481 (-> nodes.py:109-120, :531-538, :1113-1120): spikes, traces and
+ * refractory counters <- 0, voltages <- rest.  One launch fills up to SNN_MAX_FILL_SEGMENTS device buffers:
+ * `pattern` is the 32-bit word every aligned word of the buffer receives (0, or the bit pattern of the f32
+ * rest potential; a non-zero pattern needs a 4-byte aligned buffer of a multiple of 4 bytes).         */
+#define SNN_MAX_FILL_SEGMENTS 32
+typedef struct { void *ptr; unsigned long long bytes; uint32_t pattern; } snn_fill_segment;
+int snn_fill_segments(const snn_fill_segment *h_segs, int n, snn_stream_t stream);
+
 /* ---- a1: Network.run ------------------------------------------------------------------------
  * bindsnet/network/network.py:380-465 (the per-timestep loop and the post-loop normalisation),
  * for graphs built from {Input, LIFNodes, DiehlAndCookNodes} x {MulticompartmentConnection+

@@ -72,6 +72,15 @@ def test_missing_workgroup_times_out_state_untouched_and_run_is_repeated(monkeyp
     assert plans == ["dc2015-resident-lean"] and getattr(net, "resident_retries", 0) == 0
 
 
+def test_lean_arbitration_exact_branch(monkeypatch):
+    """The lean kernel picks the one_spike winner by comparing the raw 53-bit draws and evaluates the logarithms only
+    when two draws are within 2^-19 of each other (practically never).  SNN_DC_TEST_ZONE=0 widens that margin to a factor
+    of two, so the exact branch runs for most arbitrations -- and must give the same (reference) results."""
+    monkeypatch.setenv("SNN_DC_TEST_ZONE", "0")
+    net, plans = run_cfg2_inputs(2)
+    assert plans == ["dc2015-resident-lean"] * 2 and getattr(net, "lean_retries", 0) == 0
+
+
 def test_ordinary_launch_switch_still_matches(monkeypatch):
     """SNN_DC_COOP is read once per process; the non-cooperative launch is exercised in a child process."""
     code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_resident_safety as t; _, p = t.run_cfg2_inputs(2); "
