@@ -84,6 +84,8 @@ _SIGS = {
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
     "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "snn_encode_bernoulli": ([_vp, _vp, _i, _i, _f, _vp, _vp], _i),
+    "snn_encode_poisson": ([_vp, _i, _i, _f, C.c_ulonglong, _vp, _vp], _i),
     "snn_fill_segments": ([C.POINTER(FillSegment), _i, _vp], _i),
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
     "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),

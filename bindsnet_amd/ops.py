@@ -125,3 +125,27 @@ def rng_fill_exponential(rng_state, crossings, qbuf, cursor):
     N = crossings.numel() // B
     check(lib().snn_rng_fill_exponential(_ptr(rng_state, torch.int32), _ptr(crossings, "spike"), B, N, _ptr(qbuf, F32),
                                          _ptr(cursor, torch.int64), _stream()), "rng_fill_exponential")
+
+
+def encode_bernoulli(datum_flat, steps, max_prob, device):
+    """encodings.bernoulli on the device, drawing from the HOST generator's stream (left advanced by steps * n outputs,
+    exactly as torch.bernoulli on the CPU would leave it).  datum_flat: 1-D float tensor on any device."""
+    from .rng import DeviceGenerator
+    x = datum_flat.to(device=device, dtype=F32).contiguous()
+    n = x.numel()
+    out = torch.empty(steps * n, dtype=torch.uint8, device=x.device)
+    with DeviceGenerator(x.device, 1) as g:
+        check(lib().snn_encode_bernoulli(_ptr(g.state, torch.int32), _ptr(x, F32), n, steps, float(max_prob), _ptr(out, torch.uint8),
+                                         _stream()), "encode_bernoulli")
+        g.finish()
+    return out
+
+
+def encode_poisson(datum_flat, steps, dt, seed, device):
+    """encodings.poisson_device: Poisson spike trains from a Philox stream keyed by (seed, element)."""
+    x = datum_flat.to(device=device, dtype=F32).contiguous()
+    n = x.numel()
+    out = torch.empty(steps * n, dtype=torch.uint8, device=x.device)
+    check(lib().snn_encode_poisson(_ptr(x, F32), n, steps, float(dt), C.c_ulonglong(seed & ((1 << 64) - 1)), _ptr(out, torch.uint8),
+                                   _stream()), "encode_poisson")
+    return out

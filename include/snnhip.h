@@ -173,6 +173,18 @@ int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *cols
                   snn_stream_t stream);
 
 
+/* ---- f2: spike encoders on the device ---------------------------------------------------------
+ * bindsnet/encoding/encodings.py:51-98 (bernoulli): out [steps, n] u8 = what torch.bernoulli(max_prob *
+ * datum.repeat([steps, 1])) draws from the HOST generator whose state is in *rng -- one 32-bit mt19937 output
+ * per element, u = (r & 0xFFFFFF) * 2^-24 < p -- bit for bit; *rng is advanced by steps * n outputs.
+ * bindsnet/encoding/encodings.py:101-152 (poisson): same construction (intervals ~ Poisson(1000 / (x dt)), zeros
+ * bumped to one, cumulated) from a Philox stream keyed by (seed, element): same distribution, NOT the reference's
+ * stream (ATen's sampler draws a data-dependent number of outputs per element).                       */
+int snn_encode_bernoulli(snn_rng_state *rng, const float *datum, int n, int steps, float max_prob, uint8_t *out,
+                         snn_stream_t stream);
+int snn_encode_poisson(const float *datum, int n, int steps, float dt, unsigned long long seed, uint8_t *out,
+                       snn_stream_t stream);
+
 /* ---- Network.reset_state_variables ----------------------------------------------------------
  * bindsnet/network/network.py:467-481 (-> nodes.py:109-120, :531-538, :1113-1120): spikes, traces and
  * refractory counters <- 0, voltages <- rest.  One launch fills up to SNN_MAX_FILL_SEGMENTS device buffers:

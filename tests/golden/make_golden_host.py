@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Fixtures for the host-side plumbing that examples/mnist/eth_mnist.py needs around the hot path (build container only):
+the reference's encoders (spike trains AND the state they leave the global CPU generator in), its evaluation read-outs
+and its weight / assignment reshaping helpers, all on tests/synth.py inputs.
+
+    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import synth  # noqa: E402
+import make_golden as mg  # noqa: E402  (reference import recipe)
+from make_golden import T_, save  # noqa: E402
+from bindsnet.encoding import bernoulli, poisson, rank_order, repeat, single  # noqa: E402
+from bindsnet.encoding import BernoulliEncoder, PoissonEncoder  # noqa: E402
+from bindsnet.evaluation import all_activity, assign_labels, ngram, proportion_weighting, update_ngram_scores  # noqa: E402
+from bindsnet.utils import get_square_assignments, get_square_weights, reshape_conv2d_weights  # noqa: E402
+
+from make_golden_host_cases import ENC_CASES, datum_for  # noqa: E402
+
+
+def gen_encoding():
+    fns = dict(poisson=poisson, bernoulli=bernoulli, rank_order=rank_order, single=single, repeat=repeat)
+    out = {}
+    for k, (name, shape, scale, time, dt, kw) in enumerate(ENC_CASES):
+        torch.manual_seed(100 + k)
+        x = T_(datum_for(k, shape, scale)).clone()
+        y = fns[name](x, time=time, dt=dt, **kw)
+        out[f"y{k}"] = np.packbits(y.numpy().astype(np.uint8)) if name != "repeat" else y.numpy()
+        out[f"shape{k}"] = np.array(y.shape)
+        out[f"dtype{k}"] = str(y.dtype)
+        out[f"probe{k}"] = torch.rand(3).numpy()               # where the encoder left the generator
+        out[f"x_after{k}"] = x.numpy().copy()                  # (bernoulli / rank_order normalise their argument in place)
+    # encoder objects as dataset transforms
+    torch.manual_seed(5)
+    e = PoissonEncoder(time=30, dt=1.0)(T_(datum_for(0, (1, 28, 28), 128.0)))
+    b = BernoulliEncoder(time=12, dt=1.0, max_prob=0.7)(T_(datum_for(3, (1, 28, 28), 1.0)))
+    out.update(enc_poisson=np.packbits(e.numpy()), enc_bernoulli=np.packbits(b.numpy()), enc_probe=torch.rand(2).numpy())
+    save("op_encoding", **out)
+
+
+def gen_evaluation():
+    rs = np.random.RandomState(9)
+    n, T, N, L = 24, 30, 40, 10
+    spikes = (rs.uniform(size=(n, T, N)) < 0.06).astype(np.float32)
+    labels = rs.randint(0, L, size=n)
+    a, p, r = assign_labels(T_(spikes), T_(labels), L)
+    a2, p2, r2 = assign_labels(T_(spikes[:12]), T_(labels[:12]), L, rates=r.clone(), alpha=0.9)
+    out = dict(assign=a.numpy(), prop=p.numpy(), rates=r.numpy(), assign2=a2.numpy(), prop2=p2.numpy(), rates2=r2.numpy(),
+               all_act=all_activity(T_(spikes), a, L).numpy(), prop_w=proportion_weighting(T_(spikes), a, p, L).numpy())
+    sparse = (rs.uniform(size=(6, 12, 8)) < 0.05).astype(np.float32)
+    scores = update_ngram_scores(T_(sparse), T_(labels[:6]), L, 2, {})
+    keys = sorted(scores)
+    out.update(ngram_keys=np.array(keys), ngram_vals=np.array([scores[k].numpy() for k in keys]),
+               ngram_pred=ngram(T_(sparse), scores, L, 2).numpy())
+    W = synth.uniform_f32(77, (784, 90), 0.0, 1.0)
+    out.update(sq_w=get_square_weights(T_(W), 10, 28).numpy(), sq_w_rect=get_square_weights(T_(W[:600]), 10, (20, 30)).numpy(),
+               sq_a=get_square_assignments(T_(labels[:20].astype(np.float32)), 5).numpy(),
+               conv=reshape_conv2d_weights(T_(synth.uniform_f32(78, (6, 3, 4, 5), 0.0, 1.0))).numpy())
+    save("op_evaluation", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)
+    gen_encoding()
+    gen_evaluation()

@@ -1,0 +1,135 @@
+"""Host-side plumbing around the hot path (what examples/mnist/eth_mnist.py imports besides the network classes) against
+fixtures from the unmodified reference (tests/golden/make_golden_host.py): encoders -- spike trains bit for bit AND the
+state they leave the global CPU generator in --, evaluation read-outs, reshaping helpers, the `bindsnet` import alias and
+the dataset wrapper.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+from cases import gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_encodings_match_reference_stream_for_stream():
+    from make_golden_host_cases import ENC_CASES, datum_for
+    from bindsnet_amd.encoding import bernoulli, poisson, rank_order, repeat, single
+    fns = dict(poisson=poisson, bernoulli=bernoulli, rank_order=rank_order, single=single, repeat=repeat)
+    g = gold("op_encoding")
+    for k, (name, shape, scale, time, dt, kw) in enumerate(ENC_CASES):
+        torch.manual_seed(100 + k)
+        x = T_(datum_for(k, shape, scale)).clone()
+        y = fns[name](x, time=time, dt=dt, **kw)
+        assert list(y.shape) == list(g[f"shape{k}"]) and str(y.dtype) == str(g[f"dtype{k}"]), (name, k)
+        got = np.packbits(y.numpy().astype(np.uint8)) if name != "repeat" else y.numpy()
+        np.testing.assert_array_equal(got, g[f"y{k}"], err_msg=f"{name} case {k}")
+        np.testing.assert_array_equal(torch.rand(3).numpy(), g[f"probe{k}"], err_msg=f"{name} case {k}: generator position")
+        np.testing.assert_array_equal(x.numpy(), g[f"x_after{k}"], err_msg=f"{name} case {k}: in-place normalisation")
+
+
+def test_encoder_objects():
+    from make_golden_host_cases import datum_for
+    from bindsnet_amd.encoding import BernoulliEncoder, NullEncoder, PoissonEncoder
+    g = gold("op_encoding")
+    torch.manual_seed(5)
+    e = PoissonEncoder(time=30, dt=1.0)(T_(datum_for(0, (1, 28, 28), 128.0)))
+    b = BernoulliEncoder(time=12, dt=1.0, max_prob=0.7)(T_(datum_for(3, (1, 28, 28), 1.0)))
+    np.testing.assert_array_equal(np.packbits(e.numpy()), g["enc_poisson"])
+    np.testing.assert_array_equal(np.packbits(b.numpy()), g["enc_bernoulli"])
+    np.testing.assert_array_equal(torch.rand(2).numpy(), g["enc_probe"])
+    assert NullEncoder()(7) == 7
+
+
+def test_evaluation_and_reshaping_match_reference():
+    from bindsnet_amd.evaluation import all_activity, assign_labels, ngram, proportion_weighting, update_ngram_scores
+    from bindsnet_amd.utils import get_square_assignments, get_square_weights, reshape_conv2d_weights
+    g = gold("op_evaluation")
+    rs = np.random.RandomState(9)
+    n, T, N, L = 24, 30, 40, 10
+    spikes = (rs.uniform(size=(n, T, N)) < 0.06).astype(np.float32)
+    labels = rs.randint(0, L, size=n)
+    a, p, r = assign_labels(T_(spikes), T_(labels), L)
+    for got, key in ((a, "assign"), (p, "prop"), (r, "rates")):
+        np.testing.assert_array_equal(got.numpy(), g[key], err_msg=key)
+    a2, p2, r2 = assign_labels(T_(spikes[:12]), T_(labels[:12]), L, rates=r.clone(), alpha=0.9)
+    for got, key in ((a2, "assign2"), (p2, "prop2"), (r2, "rates2")):
+        np.testing.assert_array_equal(got.numpy(), g[key], err_msg=key)
+    np.testing.assert_array_equal(all_activity(T_(spikes), a, L).numpy(), g["all_act"])
+    np.testing.assert_array_equal(proportion_weighting(T_(spikes), a, p, L).numpy(), g["prop_w"])
+    sparse = (rs.uniform(size=(6, 12, 8)) < 0.05).astype(np.float32)
+    scores = update_ngram_scores(T_(sparse), T_(labels[:6]), L, 2, {})
+    keys = sorted(scores)
+    np.testing.assert_array_equal(np.array(keys), g["ngram_keys"])
+    np.testing.assert_array_equal(np.array([scores[k].numpy() for k in keys]), g["ngram_vals"])
+    np.testing.assert_array_equal(ngram(T_(sparse), scores, L, 2).numpy(), g["ngram_pred"])
+    W = synth.uniform_f32(77, (784, 90), 0.0, 1.0)
+    np.testing.assert_array_equal(get_square_weights(T_(W), 10, 28).numpy(), g["sq_w"])
+    np.testing.assert_array_equal(get_square_weights(T_(W[:600]), 10, (20, 30)).numpy(), g["sq_w_rect"])
+    np.testing.assert_array_equal(get_square_assignments(T_(labels[:20].astype(np.float32)), 5).numpy(), g["sq_a"])
+    np.testing.assert_array_equal(reshape_conv2d_weights(T_(synth.uniform_f32(78, (6, 3, 4, 5), 0.0, 1.0))).numpy(), g["conv"])
+
+
+def test_bindsnet_alias_resolves_to_the_same_module_objects():
+    import bindsnet
+    import bindsnet.network.monitors as m_alias
+    import bindsnet_amd.network.monitors as m_real
+    from bindsnet.learning.MCC_learning import PostPre as A
+    from bindsnet_amd.learning.MCC_learning import PostPre as B
+    assert m_alias is m_real and A is B
+    from bindsnet.models import DiehlAndCook2015
+    from bindsnet.network import Network
+    assert issubclass(DiehlAndCook2015, Network)
+    assert bindsnet.encoding.PoissonEncoder is bindsnet.encoding.encoders.PoissonEncoder
+    with pytest.raises(ImportError):
+        import bindsnet.pipeline  # noqa: F401  (control plane outside the hot path: not provided)
+
+
+def test_dataset_wrapper_and_plotting_with_the_torchvision_stand_in():
+    os.environ["MPLBACKEND"] = "Agg"
+    import matplotlib
+    matplotlib.use("Agg", force=True)
+    import tv_shim
+    tv_shim.install()
+    from torchvision import transforms
+    from bindsnet.analysis.plotting import (plot_assignments, plot_input, plot_performance, plot_spikes, plot_voltages,
+                                            plot_weights)
+    from bindsnet.datasets import MNIST
+    from bindsnet.encoding import PoissonEncoder
+    ds = MNIST(PoissonEncoder(time=40, dt=1.0), None, root="x", download=True, train=True,
+               transform=transforms.Compose([transforms.ToTensor(), transforms.Lambda(lambda x: x * 128)]))
+    torch.manual_seed(0)
+    item = ds[3]
+    assert set(item) == {"image", "label", "encoded_image", "encoded_label"}
+    assert tuple(item["encoded_image"].shape) == (40, 1, 28, 28) and item["encoded_image"].dtype == torch.uint8
+    assert item["encoded_label"] == item["label"]
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=1, shuffle=True)))
+    assert tuple(batch["encoded_image"].shape) == (1, 40, 1, 28, 28)
+    # the six live views, first call and redraw
+    s = {"Ae": torch.rand(40, 1, 25) < 0.05, "X": item["encoded_image"]}
+    v = {"Ae": torch.randn(40, 1, 25), "Ai": torch.randn(40, 1, 25)}
+    axes, ims = plot_input(item["image"].view(28, 28), item["encoded_image"].sum(0).view(28, 28), label=torch.tensor([3]))
+    plot_input(item["image"].view(28, 28), item["encoded_image"].sum(0).view(28, 28), label=torch.tensor([4]), axes=axes, ims=ims)
+    ims, axes = plot_spikes(s)
+    plot_spikes(s, ims=ims, axes=axes)
+    im = plot_weights(torch.rand(50, 50))
+    plot_weights(torch.rand(50, 50), im=im)
+    im = plot_assignments(-torch.ones(5, 5))
+    plot_assignments(torch.zeros(5, 5), im=im)
+    ax = plot_performance({"all": [], "proportion": []}, x_scale=4)
+    plot_performance({"all": [10.0, 50.0], "proportion": [20.0, 60.0]}, x_scale=4, ax=ax)
+    ims, axes = plot_voltages(v, plot_type="line")
+    plot_voltages(v, ims=ims, axes=axes, plot_type="line")
+    plot_voltages(v, plot_type="color")
+    import matplotlib.pyplot as plt
+    plt.close("all")
