@@ -696,7 +696,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (C[0].src != 0 || C[0].dst != 1) return false;
     if (C[0].kind != SNN_CONN_MCC && C[0].kind != SNN_CONN_DENSE) return false;
     if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE && C[0].rule != SNN_RULE_MSTDP) return false;
-    if (C[0].rule == SNN_RULE_MSTDP && (C[0].kind != SNN_CONN_DENSE || !C[0].p_plus || !C[0].p_minus || !C[0].s_src_prev ||
+    if (C[0].rule == SNN_RULE_MSTDP && (!C[0].p_plus || !C[0].p_minus || !C[0].s_src_prev ||
                                         !C[0].s_tgt_prev || !(C[0].a_plus >= 0.f))) return false;
     if (C[0].rule == SNN_RULE_POSTPRE && (!L[0].x || !L[1].x || !L[0].p.lif.traces || !L[1].p.lif.traces)) return false;
     if (C[0].kind == SNN_CONN_MCC && C[0].bias) return false;
@@ -778,9 +778,9 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
     static bool attr = false;
     if (!attr) {
-        const void *variants[5] = {(const void *)k_two_run<true, SNN_RULE_NONE>, (const void *)k_two_run<true, SNN_RULE_POSTPRE>,
+        const void *variants[6] = {(const void *)k_two_run<true, SNN_RULE_NONE>, (const void *)k_two_run<true, SNN_RULE_POSTPRE>,
                                    (const void *)k_two_run<false, SNN_RULE_NONE>, (const void *)k_two_run<false, SNN_RULE_POSTPRE>,
-                                   (const void *)k_two_run<false, SNN_RULE_MSTDP>};
+                                   (const void *)k_two_run<false, SNN_RULE_MSTDP>, (const void *)k_two_run<true, SNN_RULE_MSTDP>};
         for (const void *f : variants)
             if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         if (snn_check(hipFuncSetAttribute((const void *)k_two_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
@@ -800,6 +800,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         const dim3 grid(c.G), blk(NT);
         const size_t lds = run_lds(c);
         if (c.cascade && c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
+        else if (c.cascade && c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_MSTDP>), grid, blk, lds, st, c);
         else if (c.cascade) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_NONE>), grid, blk, lds, st, c);
         else if (c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
         else if (c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_MSTDP>), grid, blk, lds, st, c);

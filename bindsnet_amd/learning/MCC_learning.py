@@ -1,6 +1,6 @@
 """Learning rules for MulticompartmentConnection features: API mirror of
-bindsnet/learning/MCC_learning.py for `MCC_LearningRule`, `NoOp`, `PostPre`.
-The update itself is snn_stdp_postpre (use_dt = 1)."""
+bindsnet/learning/MCC_learning.py for `MCC_LearningRule`, `NoOp`, `PostPre`, `MSTDP`.
+The updates themselves are snn_stdp_postpre (use_dt = 1) / snn_mstdp_step."""
 import warnings
 from typing import Optional, Sequence, Union
 
@@ -100,8 +100,60 @@ class PostPre(MCC_LearningRule):
 
 
 class MSTDP(MCC_LearningRule):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("bindsnet_amd: MCC MSTDP is not on the accelerated path yet (SURVEY.md 8(f)-3)")
+    """Reward-modulated STDP on a MulticompartmentConnection's Weight (reference: MCC_learning.py:392-551).  Same
+    arithmetic as the dense rule (learning.py:1504-1574); the dense eligibility tensor of the reference is kept factored
+    on the device (snn_mstdp_step), `p_plus` / `p_minus` keep their reference meaning."""
+
+    def __init__(self, connection, feature_value, range=None, nu=None, reduction=None, decay: float = 0.0,
+                 enforce_polarity: bool = False, **kwargs) -> None:
+        super().__init__(connection=connection, feature_value=feature_value,
+                         range=[-1, +1] if range is None else range, nu=nu, reduction=reduction, decay=decay,
+                         enforce_polarity=enforce_polarity, **kwargs)
+        from ..network.topology import MulticompartmentConnection
+        if not isinstance(connection, MulticompartmentConnection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        if kwargs.get("average_update", 0):
+            raise NotImplementedError("bindsnet_amd: average_update buffers are outside the accelerated path")
+        if self.reduction not in (torch.sum, torch.squeeze):
+            raise NotImplementedError("bindsnet_amd: only reduction=torch.sum (or squeeze at batch 1) is supported")
+        self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
+        self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
+
+    def _ensure_state(self):
+        B, dev = self.source.batch_size, self.feature_value.device
+        if not hasattr(self, "p_plus") or self.p_plus.shape[0] != B or self.p_plus.device != dev:
+            self.p_plus = torch.zeros(B, self.source.n, device=dev)
+            self.p_minus = torch.zeros(B, self.target.n, device=dev)
+            self._s_src_prev = torch.zeros(B, self.source.n, dtype=torch.uint8, device=dev)
+            self._s_tgt_prev = torch.zeros(B, self.target.n, dtype=torch.uint8, device=dev)
+
+    def _decays(self):
+        dt = self.connection.dt
+        return float(torch.exp(-dt / self.tc_plus)), float(torch.exp(-dt / self.tc_minus))   # MCC_learning.py:538,540
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        B = self.source.batch_size
+        if self.reduction is torch.squeeze and B != 1:
+            raise RuntimeError("reduction=torch.squeeze requires batch size 1 (as in the reference)")
+        self._ensure_state()
+        reward = kwargs["reward"]
+        rvec = None
+        if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+            rvec, reward = reward.to(self.feature_value.device, torch.float32).reshape(-1).contiguous(), 0.0
+        dp, dm = self._decays()
+        lo, hi = self._bounds()
+        ops.mstdp_step(self.feature_value.data, self.p_plus, self.p_minus, self._s_src_prev, self._s_tgt_prev,
+                       self.source.s.reshape(B, -1).contiguous(), self.target.s.reshape(B, -1), float(reward),
+                       float(self.nu[0]), float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0)), dp, dm,
+                       wdecay=float(self.decay), wmin=lo, wmax=hi, reward_vec=rvec)
+
+    @property
+    def eligibility(self) -> torch.Tensor:
+        """Dense view of the factored eligibility (for inspection only)."""
+        self._ensure_state()
+        return (self.p_plus.unsqueeze(2) * self._s_tgt_prev.float().unsqueeze(1)
+                + self._s_src_prev.float().unsqueeze(2) * self.p_minus.unsqueeze(1))
 
 
 class MSTDPET(MCC_LearningRule):

@@ -3,8 +3,13 @@
 The reference allocates and copies every monitored tensor once per timestep
 (monitors.py:94-111).  Here Network.run hands the node kernels a [T, B, *shape] buffer and they
 write the raster directly, so `get()` returns a tensor with the reference's shape and contents
-without any per-step host work.  Supported variables: `s` of any layer, `v` of LIF / D&C layers.
+without any per-step host work.  Supported variables: `s` of any layer, `v` of LIF / D&C layers.  `Monitor(sparse=True)` hands the recording back as a
+sparse COO tensor like the reference; `NetworkMonitor` keeps float recordings of `s` / `v` of the chosen layers in a
+rolling window (per-step snapshots of connection weights are not kept by the resident kernels and are rejected).
 """
+import os
+
+import numpy as np
 from typing import Iterable, Optional
 
 import torch
@@ -17,8 +22,6 @@ class AbstractMonitor:
 class Monitor(AbstractMonitor):
     def __init__(self, obj, state_vars: Iterable[str], time: Optional[int] = None, batch_size: int = 1,
                  device: str = "cpu", sparse: Optional[bool] = False):
-        if sparse:
-            raise NotImplementedError("bindsnet_amd: sparse monitors are not supported")
         self.obj, self.state_vars, self.time = obj, list(state_vars), time
         self.batch_size, self.device, self.sparse = batch_size, device, sparse
         if self.time is None:
@@ -34,7 +37,7 @@ class Monitor(AbstractMonitor):
         out = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
         if self.time is None:
             self.recording[var] = []
-        return out
+        return out.to_sparse() if self.sparse else out       # (monitors.py:105-107: sparse records concatenate to a sparse tensor)
 
     def record(self) -> None:
         """Single-step recording for code that steps layers by hand (reference: monitors.py:94-111)."""
@@ -59,3 +62,69 @@ class Monitor(AbstractMonitor):
                 total -= rec.pop(0).shape[0]
             if total > self.time:
                 rec[0] = rec[0][total - self.time:]
+
+
+class NetworkMonitor(AbstractMonitor):
+    """State variables of several layers at once (reference: monitors.py:127-329): `get()` returns
+    {layer: {var: float tensor [time, batch, *shape]}}; with `time` set the recording is a rolling window that starts
+    out as zeros, without it the recording grows.  Supported: `s` and `v` of layers."""
+
+    def __init__(self, network, layers: Optional[Iterable[str]] = None, connections: Optional[Iterable] = None,
+                 state_vars: Optional[Iterable[str]] = None, time: Optional[int] = None):
+        self.network = network
+        self.layers = list(layers) if layers is not None else list(network.layers.keys())
+        self.connections = list(connections) if connections is not None else list(network.connections.keys())
+        self.state_vars = tuple(state_vars) if state_vars is not None else ("v", "s", "w")
+        self.time = time
+        for c in self.connections:
+            for v in self.state_vars:
+                if hasattr(network.connections[c], v):
+                    raise NotImplementedError(f"bindsnet_amd: NetworkMonitor cannot record '{v}' of connection {c} every "
+                                              "timestep (the resident kernels keep weights on chip for the whole run)")
+        self.reset_state_variables()
+
+    def _wanted(self):
+        """(layer name, var) pairs this monitor records."""
+        return [(l, v) for v in self.state_vars for l in self.layers if hasattr(self.network.layers[l], v)]
+
+    def get(self):
+        return self.recording
+
+    def _append(self, layer: str, var: str, chunk: torch.Tensor) -> None:
+        data = chunk.float()
+        old = self.recording[layer][var]
+        if self.time is None:
+            self.recording[layer][var] = data if old.numel() == 0 else torch.cat((old.to(data.device), data), 0)
+        else:
+            keep = torch.cat((old.to(data.device), data), 0) if old.shape[1:] == data.shape[1:] else data
+            self.recording[layer][var] = keep[-self.time:]
+
+    def record(self) -> None:
+        """Single-step recording for code that steps layers by hand (monitors.py:222-262)."""
+        for l, v in self._wanted():
+            self._append(l, v, getattr(self.network.layers[l], v).unsqueeze(0))
+        if self.time is not None:
+            self.i += 1
+
+    def save(self, path: str, fmt: str = "npz") -> None:
+        """monitors.py:264-299."""
+        d = os.path.dirname(path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        if fmt == "npz":
+            arrays = {}
+            for o, rec in self.recording.items():
+                key = "-".join(o) if isinstance(o, tuple) else o
+                arrays.update({"_".join([key, v]): rec[v].cpu().numpy() for v in rec})
+            np.savez_compressed(path, **arrays)
+        elif fmt == "pickle":
+            with open(path, "wb") as f:
+                torch.save(self.recording, f)
+
+    def reset_state_variables(self) -> None:
+        self.recording = {k: {} for k in self.layers + self.connections}
+        if self.time is not None:
+            self.i = 0
+        for l, v in self._wanted():
+            t = getattr(self.network.layers[l], v)
+            self.recording[l][v] = torch.Tensor() if self.time is None else torch.zeros(self.time, *t.size(), device=t.device)

@@ -14,7 +14,7 @@ import torch
 
 from .. import _lib
 from ..rng import DeviceGenerator
-from .monitors import AbstractMonitor, Monitor
+from .monitors import AbstractMonitor, Monitor, NetworkMonitor
 from .nodes import DiehlAndCookNodes, Input, LIFNodes, Nodes, _f
 from .topology import AbstractConnection, Connection, Conv2dConnection, MulticompartmentConnection
 
@@ -189,13 +189,17 @@ class Network(torch.nn.Module):
                         if xcopy is None:
                             xcopy = x[:T].clone().view(T, B, *layer.shape)
                         rasters.append((m, "s", xcopy))
+                    elif isinstance(m, NetworkMonitor) and (name, "s") in m._wanted():
+                        if xcopy is None:
+                            xcopy = x[:T].clone().view(T, B, *layer.shape)
+                        rasters.append((m, (name, "s"), xcopy))
                 inputs[name] = x
                 continue
             if name in inputs:
                 raise NotImplementedError("bindsnet_amd: external input currents into non-Input layers are "
                                           "outside the accelerated path")
             self._check_state(layer, B, dev)
-            mon_s, mon_v = self._monitor_buffers(layer, T, B, dev, rasters)
+            mon_s, mon_v = self._monitor_buffers(layer, name, T, B, dev, rasters)
             cur = self._scratch("cur_" + name, (B, layer.n), torch.float32, dev)
             d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
             d.x = _dptr(layer.x) if layer.traces else None
@@ -263,8 +267,11 @@ class Network(torch.nn.Module):
         for name in names:
             if isinstance(self.layers[name], Input):
                 self.layers[name].s = inputs[name][T - 1]
-        for mon, var, buf in rasters:
-            mon._append(var, buf)
+        for mon, key, buf in rasters:
+            if isinstance(key, tuple):
+                mon._append(key[0], key[1], buf)       # NetworkMonitor: (layer name, variable)
+            else:
+                mon._append(key, buf)
         self._keep = keep
 
     # ------------------------------------------------------------------ helpers
@@ -299,27 +306,48 @@ class Network(torch.nn.Module):
                 or not layer.s.is_contiguous():
             layer.s = torch.zeros(B, *layer.shape, dtype=torch.bool, device=dev)
 
-    def _monitor_buffers(self, layer, T, B, dev, rasters):
+    def _monitor_buffers(self, layer, name, T, B, dev, rasters):
         mon_s = mon_v = None
+        requests = []                                  # (monitor, key handed back to its _append, variable)
         for m in self.monitors.values():
-            if not isinstance(m, Monitor) or m.obj is not layer:
-                if isinstance(m, Monitor) and not isinstance(m.obj, Nodes):
+            if isinstance(m, NetworkMonitor):
+                requests += [(m, (l, v), v) for l, v in m._wanted() if l == name]
+            elif isinstance(m, Monitor):
+                if m.obj is layer:
+                    requests += [(m, v, v) for v in m.state_vars]
+                elif not isinstance(m.obj, Nodes):
                     raise NotImplementedError("bindsnet_amd: monitors on connections/features are not supported")
-                continue
-            for var in m.state_vars:
-                if var == "s":
-                    if mon_s is None:          # bool like layer.s; the node kernels store a 0/1 byte for EVERY
-                        # (step, sample, neuron), so the buffer needs no initialisation
-                        mon_s = torch.empty(T, B, *layer.shape, dtype=torch.bool, device=dev)
-                    rasters.append((m, "s", mon_s))
-                elif var == "v" and hasattr(layer, "v"):
-                    if mon_v is None:
-                        mon_v = torch.empty(T, B, *layer.shape, device=dev)
-                    rasters.append((m, "v", mon_v))
-                else:
-                    raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "
-                                              "outside the accelerated path (supported: 's', 'v')")
+        for m, key, var in requests:
+            if var == "s":
+                if mon_s is None:              # bool like layer.s; the node kernels store a 0/1 byte for EVERY
+                    # (step, sample, neuron), so the buffer needs no initialisation
+                    mon_s = torch.empty(T, B, *layer.shape, dtype=torch.bool, device=dev)
+                rasters.append((m, key, mon_s))
+            elif var == "v" and hasattr(layer, "v"):
+                if mon_v is None:
+                    mon_v = torch.empty(T, B, *layer.shape, device=dev)
+                rasters.append((m, key, mon_v))
+            else:
+                raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "
+                                          "outside the accelerated path (supported: 's', 'v')")
         return mon_s, mon_v
+
+    @staticmethod
+    def _fill_mstdp(d, rule, kwargs, dev, keep):
+        """Reward / a_plus / a_minus keyword arguments and the rule's device state (learning.py:1504-1574,
+        MCC_learning.py:468-551)."""
+        reward = kwargs["reward"]
+        if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+            rv = reward.to(dev, torch.float32).reshape(-1).contiguous()
+            keep.append(rv)
+            d.reward_vec, reward = _dptr(rv), 0.0
+        a_plus, a_minus = kwargs.get("a_plus", 1.0), kwargs.get("a_minus", -1.0)
+        if isinstance(a_plus, dict) or isinstance(a_minus, dict):
+            raise NotImplementedError("bindsnet_amd: per-connection a_plus/a_minus dicts are not supported")
+        d.rule, d.reward, d.a_plus, d.a_minus = _lib.RULE_MSTDP, float(reward), float(a_plus), float(a_minus)
+        d.decay_plus, d.decay_minus = rule._decays()
+        d.p_plus, d.p_minus = _dptr(rule.p_plus), _dptr(rule.p_minus)
+        d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
 
     def _fill_conn(self, d, conn, src, dst, B, dev, keep, kwargs):
         from ..learning import learning as dense_rules
@@ -344,6 +372,18 @@ class Network(torch.nn.Module):
                 d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
                 d.has_min, d.wmin = int(lo is not None), lo or 0.0
                 d.has_max, d.wmax = int(hi is not None), hi or 0.0
+            elif isinstance(rule, mcc_rules.MSTDP) and not conn.manual_update:
+                if rule.reduction is torch.squeeze and B != 1:
+                    raise RuntimeError("reduction=torch.squeeze requires batch size 1")
+                if "reward" not in kwargs:
+                    raise KeyError("reward")
+                rule._ensure_state()
+                lo, hi = rule._bounds()
+                d.wdecay = float(rule.decay)
+                d.has_min, d.wmin = int(lo is not None), lo or 0.0
+                d.has_max, d.wmax = int(hi is not None), hi or 0.0
+                d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+                self._fill_mstdp(d, rule, kwargs, dev, keep)
             elif not isinstance(rule, mcc_rules.NoOp):
                 raise NotImplementedError(f"bindsnet_amd: MCC rule {type(rule).__name__} is not supported")
             if feat.norm is not None:
@@ -381,18 +421,7 @@ class Network(torch.nn.Module):
                 if "reward" not in kwargs:
                     raise KeyError("reward")
                 rule._ensure_state()
-                reward = kwargs["reward"]
-                if isinstance(reward, torch.Tensor) and reward.numel() > 1:
-                    rv = reward.to(dev, torch.float32).reshape(-1).contiguous()
-                    keep.append(rv)
-                    d.reward_vec, reward = _dptr(rv), 0.0
-                a_plus, a_minus = kwargs.get("a_plus", 1.0), kwargs.get("a_minus", -1.0)
-                if isinstance(a_plus, dict) or isinstance(a_minus, dict):
-                    raise NotImplementedError("bindsnet_amd: per-connection a_plus/a_minus dicts are not supported")
-                d.rule, d.reward, d.a_plus, d.a_minus = _lib.RULE_MSTDP, float(reward), float(a_plus), float(a_minus)
-                d.decay_plus, d.decay_minus = rule._decays()
-                d.p_plus, d.p_minus = _dptr(rule.p_plus), _dptr(rule.p_minus)
-                d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
+                self._fill_mstdp(d, rule, kwargs, dev, keep)
         elif not isinstance(rule, dense_rules.NoOp):
             raise NotImplementedError(f"bindsnet_amd: rule {type(rule).__name__} is not supported")
         elif rule.weight_decay != 1.0 and self.learning:

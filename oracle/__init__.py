@@ -49,7 +49,7 @@ class TwoParams(C.Structure):
         ("wmin", C.c_float), ("wmax", C.c_float), ("has_norm", C.c_int), ("norm", C.c_float),
         ("reward", C.c_float), ("a_plus", C.c_float), ("a_minus", C.c_float),
         ("decay_plus", C.c_float), ("decay_minus", C.c_float),
-        ("learning", C.c_int),
+        ("learning", C.c_int), ("mcc", C.c_int),
     ]
 
 

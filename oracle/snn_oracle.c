@@ -452,6 +452,10 @@ typedef struct {
     float nu0, nu1; int has_min, has_max; float wmin, wmax; int has_norm; float norm;
     float reward, a_plus, a_minus, decay_plus, decay_minus;
     int learning;
+    int mcc;    /* 1: MulticompartmentConnection + Weight instead of a dense Connection: propagation in ATen's sum(dim=1)
+                   order (topology.py:437-479), PostPre scaled by dt (MCC_learning.py:224-302), MSTDP as
+                   MCC_learning.py:468-551 (same arithmetic as learning.py:1504-1574), signed column sums in normalize
+                   (topology_features.py:250-266) */
 } orc_two_params;
 
 ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *bias,
@@ -466,6 +470,7 @@ ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *b
     const uint8_t *sX = sX_prev;
     for (int t = 0; t < P->T; ++t) {
         if (I_forced) memcpy(I, I_forced + (long)t * B * N, sizeof(float) * (size_t)B * N);
+        else if (P->mcc) orc_prop_mcc(W, sX, I, B, Nin, N, 0);
         else orc_prop_dense(W, bias, sX, I, B, Nin, N, 0);
         sX = inputs + (long)t * B * Nin;
         orc_input_step(sX, xX, (long)B * Nin, P->x_traces, P->x_trace_decay, P->x_trace_scale, 0);
@@ -473,7 +478,7 @@ ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *b
                      P->refrac, P->dt, 0, 0.f, P->y_traces, P->y_trace_decay,
                      P->y_trace_scale, 0);
         if (P->learning && P->rule == 1)
-            orc_postpre(W, sX, xX, sY, xY, B, Nin, N, P->nu0, P->nu1, 0, P->dt, 1.0f,
+            orc_postpre(W, sX, xX, sY, xY, B, Nin, N, P->nu0, P->nu1, P->mcc, P->dt, 1.0f,
                         P->has_min, P->wmin, P->has_max, P->wmax);
         else if (P->learning && P->rule == 2)
             orc_mstdp(W, elig, p_plus, p_minus, sX, sY, B, Nin, N, P->reward, NULL, P->nu0,
@@ -481,7 +486,7 @@ ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *b
                       P->has_min, P->wmin, P->has_max, P->wmax);
         if (rasterY) memcpy(rasterY + (long)t * B * N, sY, (size_t)B * N);
     }
-    if (P->has_norm) orc_normalize(W, Nin, N, P->norm, 1);
+    if (P->has_norm) orc_normalize(W, Nin, N, P->norm, P->mcc ? 0 : 1);
     if (P->T > 0) memcpy(sX_prev, inputs + (long)(P->T - 1) * B * Nin, (size_t)B * Nin);
     free(I);
 }

@@ -203,3 +203,48 @@ def test_unsupported_features_fail_loudly():
         net.run({"X": torch.zeros(5, 1, 10, dtype=torch.uint8, device=DEV)}, time=5, clamp={"Y": torch.zeros(5).bool()})
     with pytest.raises(NotImplementedError):
         net.run({"X": torch.zeros(5, 1, 10, device=DEV)}, time=5)   # float inputs
+
+
+def test_sparse_monitor_and_network_monitor_match_reference():
+    """monitors.py:30-329: `Monitor(sparse=True)` hands back a sparse COO recording; `NetworkMonitor` keeps float
+    recordings of s / v for several layers in a rolling window.  Fixtures: tests/golden/make_golden_r2.py."""
+    from bindsnet_amd.network.monitors import Monitor, NetworkMonitor
+    g = gold("net_monitor")
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    net = build_dc(N, B, 120.0)
+    sp = Monitor(net.layers["Ae"], ["s"], time=T, sparse=True, batch_size=B)
+    dn = Monitor(net.layers["Ae"], ["s", "v"], time=T, batch_size=B)
+    net.add_monitor(sp, "Ae_sparse"); net.add_monitor(dn, "Ae_dense")
+    net.to(DEV)
+    spikes = synth.spike_train(20, T, B, 784)
+    torch.manual_seed(2)
+    net.run({"X": torch.from_numpy(spikes).view(T, B, 1, 28, 28).to(DEV)}, time=T)
+    s = sp.get("s")
+    assert s.is_sparse == bool(g["sparse_is_sparse"]) and list(s.shape) == list(g["sparse_shape"])
+    np.testing.assert_array_equal(np.packbits(host(s.to_dense()).astype(u8)), g["sparse_dense"])
+    np.testing.assert_array_equal(np.packbits(host(dn.get("s")).astype(u8)), g["dense_s"])
+    np.testing.assert_array_equal(bits(host(dn.get("v"))), bits(g["dense_v"]))
+    # NetworkMonitor, batch 1 (the reference sizes its buffers from the layers' current state tensors)
+    g = gold("net_monitor_b1")
+    N, T = int(g["N"]), int(g["T"])
+    net = build_dc(N, 1, 120.0)
+    net.to(DEV)
+    nm = NetworkMonitor(net, layers=["Ae", "Ai"], connections=[], state_vars=["s", "v"], time=T)
+    net.add_monitor(nm, "all")
+    spikes = synth.spike_train(21, T, 1, 784, max_rate=0.2)
+    torch.manual_seed(3)
+    net.run({"X": torch.from_numpy(spikes).view(T, 1, 1, 28, 28).to(DEV)}, time=T)
+    rec = nm.get()
+    for l in ("Ae", "Ai"):
+        assert rec[l]["s"].dtype == torch.float32 and list(rec[l]["s"].shape) == list(g[f"{l}_s_shape"])
+        np.testing.assert_array_equal(np.packbits(host(rec[l]["s"]).astype(u8)), g[f"{l}_s"], err_msg=l)
+        np.testing.assert_array_equal(bits(host(rec[l]["v"])), bits(g[f"{l}_v"]), err_msg=l)
+    # rolling window: a shorter second run shifts the first one's tail in front of it
+    first_tail = rec["Ae"]["v"][10:].clone()
+    net.run({"X": torch.from_numpy(spikes[:10]).view(10, 1, 1, 28, 28).to(DEV)}, time=10)
+    rec = nm.get()
+    assert rec["Ae"]["v"].shape[0] == T and torch.equal(rec["Ae"]["v"][:T - 10], first_tail)
+    with pytest.raises(NotImplementedError):
+        from bindsnet_amd.models import TwoLayerNetwork
+        two = TwoLayerNetwork(n_inpt=16, n_neurons=4, reduction=torch.sum)
+        NetworkMonitor(two, state_vars=["w"])

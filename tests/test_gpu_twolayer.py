@@ -179,3 +179,48 @@ def test_twolayer_mstdp_learning_off():
     for a, b in zip(f, g):
         for k in a:
             np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ MCC MSTDP
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("name", ["run_two_mcc_mstdp_b4", "run_two_mcc_mstdp_b20"])
+def test_mcc_mstdp_matches_reference(name, generic):
+    """MulticompartmentConnection + Weight with MCC_learning.MSTDP (MCC_learning.py:392-551): two consecutive runs
+    (scalar reward, then per-sample rewards) bit for bit against the reference fixture, on both plans."""
+    import cases
+    from cases import gold, unpack
+    from bindsnet_amd import _lib
+    from bindsnet_amd.learning.MCC_learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    g = gold(name)
+    Nin, N, B, T = int(g["Nin"]), int(g["N"]), int(g["B"]), int(g["T"])
+    _lib.lib().snn_set_plan_mode(1 if generic else 0)
+    try:
+        net = Network(dt=1.0)
+        X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+        feat = Weight("weight", torch.from_numpy(synth.weights_q12(11, Nin, N)), range=[0.0, 1.0], norm=0.1 * Nin, nu=(1e-1, 1e-1),
+                      learning_rule=MSTDP)
+        conn = MulticompartmentConnection(X_, Y_, device="cpu", pipeline=[feat])
+        net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+        net.add_connection(conn, "X", "Y")
+        mon = Monitor(net.layers["Y"], ["s"], time=T)
+        net.add_monitor(mon, "Y_s")
+        net.to(DEV)
+        for r in range(2):
+            spikes = synth.spike_train(30 + r, T, B, Nin, active=0.3, max_rate=0.12)
+            reward = 1.0 if r == 0 else torch.from_numpy(synth.uniform_f32(17, (B,), -1.0, 1.0)).view(B, 1, 1)
+            net.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T, reward=reward)
+            assert net.last_plan == ("generic" if generic else "twolayer-fused")
+            rule = feat.learning_rule
+            np.testing.assert_array_equal(mon.get("s").cpu().numpy().reshape(T, B, N).astype(np.uint8), unpack(g[f"r{r}_sY"], (T, B, N)))
+            for got, key in ((feat.value, "W"), (net.layers["Y"].v, "vY"), (rule.p_plus, "p_plus"), (rule.p_minus, "p_minus")):
+                np.testing.assert_array_equal(got.detach().cpu().numpy().view(np.uint32), g[f"r{r}_{key}"].view(np.uint32),
+                                              err_msg=f"run {r} {key}")
+            assert cases.sha(rule.eligibility.cpu().numpy()) == str(g[f"r{r}_elig_sha"])
+            net.reset_state_variables()
+    finally:
+        _lib.lib().snn_set_plan_mode(0)

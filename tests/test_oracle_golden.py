@@ -238,3 +238,38 @@ def test_dense_family_run_matches_reference(name, rule):
     ras2 = oracle.run_two_layer(P, st2, spikes)
     np.testing.assert_array_equal(ras2, unpack(g["sY"], (P.T, P.B, P.N)))
     np.testing.assert_allclose(st2["W"], g["W"], rtol=0, atol=1e-5)
+
+
+# --------------------------------------------------------------------------- MCC MSTDP
+def mcc_mstdp_params(g):
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T = int(g["B"]), int(g["Nin"]), int(g["N"]), int(g["T"])
+    P.rule, P.mcc, P.dt = 2, 1, 1.0
+    P.x_trace_decay = float(g["x_trace_decay"]); P.x_trace_scale = 1.0; P.x_traces = 1
+    P.decay = float(g["decay"]); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.y_traces = 1; P.y_trace_decay = float(g["y_trace_decay"]); P.y_trace_scale = 1.0
+    P.has_min = P.has_max = 1; P.wmin, P.wmax = 0.0, 1.0; P.has_norm = 1; P.norm = 0.1 * P.Nin
+    P.nu0 = P.nu1 = 1e-1
+    P.a_plus, P.a_minus = 1.0, -1.0
+    P.decay_plus, P.decay_minus = float(g["decay_plus"]), float(g["decay_minus"])
+    P.learning = 1
+    return P
+
+
+@pytest.mark.parametrize("name", ["run_two_mcc_mstdp_b4", "run_two_mcc_mstdp_b20"])
+def test_mcc_mstdp_run_matches_reference(name):
+    """Input -> MulticompartmentConnection[Weight, MCC MSTDP] -> LIF (MCC_learning.py:392-551): ATen-ordered
+    throughout, so everything is bit-exact.  Run 0: scalar reward; run 1 (after a reset): the scalar the oracle driver
+    takes cannot express the per-sample reward vector of the fixture's second run -- that one is covered on the GPU."""
+    g = gold(name)
+    P = mcc_mstdp_params(g)
+    st = two_state(P)
+    spikes = synth.spike_train(30, P.T, P.B, P.Nin, active=0.3, max_rate=0.12)
+    P.reward = 1.0
+    ras = oracle.run_two_layer(P, st, spikes)
+    np.testing.assert_array_equal(ras, unpack(g["r0_sY"], (P.T, P.B, P.N)))
+    np.testing.assert_array_equal(bits(st["W"]), bits(g["r0_W"]))
+    np.testing.assert_array_equal(bits(st["vY"]), bits(g["r0_vY"]))
+    np.testing.assert_array_equal(bits(st["p_plus"]), bits(g["r0_p_plus"]))
+    np.testing.assert_array_equal(bits(st["p_minus"]), bits(g["r0_p_minus"]))
+    assert cases.sha(st["elig"]) == str(g["r0_elig_sha"])
