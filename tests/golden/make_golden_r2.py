@@ -106,6 +106,7 @@ if __name__ == "__main__":
     if "mstdp" in jobs:
         mcc_mstdp_case("run_two_mcc_mstdp_b4", 196, 48, 4, 40)
         mcc_mstdp_case("run_two_mcc_mstdp_b20", 196, 37, 20, 30)
+        mcc_mstdp_case("run_two_mcc_mstdp_n208", 208, 40, 16, 30)      # Nin % 16 == 0: the fused plan's shape
     if "monitor" in jobs:
         net_monitor_case()
         net_monitor_b1_case()

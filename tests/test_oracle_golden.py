@@ -256,7 +256,7 @@ def mcc_mstdp_params(g):
     return P
 
 
-@pytest.mark.parametrize("name", ["run_two_mcc_mstdp_b4", "run_two_mcc_mstdp_b20"])
+@pytest.mark.parametrize("name", ["run_two_mcc_mstdp_b4", "run_two_mcc_mstdp_b20", "run_two_mcc_mstdp_n208"])
 def test_mcc_mstdp_run_matches_reference(name):
     """Input -> MulticompartmentConnection[Weight, MCC MSTDP] -> LIF (MCC_learning.py:392-551): ATen-ordered
     throughout, so everything is bit-exact.  Run 0: scalar reward; run 1 (after a reset): the scalar the oracle driver
