@@ -76,6 +76,7 @@ _SIGS = {
     "snn_device_count": ([], _i),
     "snn_prop_cascade_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "snn_prop_dense_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "snn_prop_dense_mfma_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "snn_prop_conv2d_f32": ([_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "snn_input_step": ([_vp, _vp, _l, _f, _f, _i, _vp, _vp], _i),
     "snn_lif_step": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp], _i),
@@ -87,6 +88,12 @@ _SIGS = {
     "snn_encode_bernoulli": ([_vp, _vp, _i, _i, _f, _vp, _vp], _i),
     "snn_encode_poisson": ([_vp, _i, _i, _f, C.c_ulonglong, _vp, _vp], _i),
     "snn_fill_segments": ([C.POINTER(FillSegment), _i, _vp], _i),
+    "snn_dist_unique_id": ([_vp], _i),
+    "snn_dist_init": ([_i, _i, _vp, C.POINTER(_vp)], _i),
+    "snn_dist_world": ([_vp, C.POINTER(_i), C.POINTER(_i)], _i),
+    "snn_dist_allreduce_dw": ([_vp, _vp, _ll, _vp], _i),
+    "snn_dist_allgather_step": ([_vp, _vp, _vp, _ll, _vp], _i),
+    "snn_dist_destroy": ([_vp], _i),
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
     "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),
     "snn_plan_name": ([], C.c_char_p),

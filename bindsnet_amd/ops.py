@@ -56,6 +56,16 @@ def prop_dense(W, s, out, bias=None, accumulate=False):
     return out
 
 
+def prop_dense_mfma(W, s, out, bias=None, accumulate=False):
+    """a6 on the f32 matrix cores: bit-identical to prop_dense for 0/1 spikes (one k-ordered MFMA chain per tile)."""
+    B = s.shape[0]
+    Nin, N = W.shape
+    assert s.numel() == B * Nin and out.numel() == B * N
+    check(lib().snn_prop_dense_mfma_f32(_ptr(W, F32), _ptr(bias, F32, True), _ptr(s, "spike"), _ptr(out, F32), B, Nin, N,
+                                        int(accumulate), _stream()), "prop_dense_mfma")
+    return out
+
+
 def prop_conv2d(W, s, out, bias=None, stride=1, pad=0, accumulate=False):
     """a7: F.conv2d on spikes; s [B,Cin,H,W], W [Cout,Cin,KH,KW], out [B,Cout,OH,OW]."""
     B, Cin, H, Wd = s.shape

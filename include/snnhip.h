@@ -68,6 +68,13 @@ int snn_prop_cascade_f32(const float *W, const uint8_t *s, float *out,
 int snn_prop_dense_f32(const float *W, const float *bias, const uint8_t *s, float *out,
                        int B, int Nin, int N, int accumulate, snn_stream_t stream);
 
+/* The same product on the f32 matrix cores (v_mfma_f32_16x16x4_f32): ONE k-ordered accumulator chain per output
+ * tile, bit-identical to snn_prop_dense_f32 when every spike byte is 0 or 1 (products are then exact and gfx950's
+ * f32 MFMA is a k-ordered fmaf chain).  Cost is Nin / 4 dependent MFMAs per tile regardless of sparsity; kept as an
+ * operator for dense inputs and as the measured alternative to the event-driven kernel (profiles/).   */
+int snn_prop_dense_mfma_f32(const float *W, const float *bias, const uint8_t *s, float *out,
+                            int B, int Nin, int N, int accumulate, snn_stream_t stream);
+
 /* ---- a7: Conv2dConnection.compute ---------------------------------------------------------
  * bindsnet/network/topology.py:799-815 (F.conv2d).  s [B,Cin,H,W] u8, W [Cout,Cin,KH,KW],
  * out [B,Cout,OH,OW]; taps accumulated sequentially in (cin,kh,kw) row-major order, then bias.*/
@@ -274,6 +281,20 @@ void snn_graph_stats(int *h_plain, int *h_captured, int *h_replayed);
 /* Force a plan for testing: 0 = automatic, 1 = generic per-operator launches only,
  * 2 = fused plans in their one-launch-per-timestep form (no resident kernel), 3 = no lean forms. */
 void snn_set_plan_mode(int mode);
+
+/* ---- (e) multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
+ * SURVEY.md 8(e).  Rank 0 calls snn_dist_unique_id and distributes the 128 bytes; every rank then calls snn_dist_init
+ * with the HIP device it will use already current.  snn_dist_allreduce_dw = the north-star schedule (sum the
+ * per-input weight / threshold deltas over ranks, in place); snn_dist_allgather_step = the exact per-timestep mode
+ * (every rank's packed step factors, concatenated in rank order).  Both are stream-ordered and asynchronous.
+ * SNN_ERR_UNSUPPORTED: no RCCL library could be opened on this machine.                               */
+typedef struct snn_dist snn_dist;
+int snn_dist_unique_id(void *h_id128);
+int snn_dist_init(int rank, int world, const void *h_id128, snn_dist **h_out);
+int snn_dist_world(const snn_dist *d, int *h_rank, int *h_world);
+int snn_dist_allreduce_dw(snn_dist *d, float *buf, long long count, snn_stream_t stream);
+int snn_dist_allgather_step(snn_dist *d, const void *send, void *recv, long long bytes_per_rank, snn_stream_t stream);
+int snn_dist_destroy(snn_dist *d);
 
 #ifdef __cplusplus
 }

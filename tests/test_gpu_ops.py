@@ -270,3 +270,26 @@ def test_device_generator_matches_torch_stream(B, N, p_row, seed, warm):
     img = host(state)
     assert int(img.view(np.int64)[(rng.RNG_STATE_BYTES - 8) // 8]) == total
     assert torch.equal(rng.words_to_torch_state(img, st0), torch.get_rng_state())
+
+
+@pytest.mark.parametrize("B,Nin,N,dens,bias,acc", [(16, 784, 1600, 0.012, False, False), (128, 784, 1600, 0.012, False, False),
+                                                    (16, 6400, 500, 0.05, False, False), (5, 37, 21, 0.5, True, True),
+                                                    (33, 130, 70, 0.3, True, False), (1, 784, 100, 0.02, False, True)])
+def test_prop_dense_mfma_is_bit_identical_to_the_ordered_sum(B, Nin, N, dens, bias, acc):
+    """snn_prop_dense_mfma_f32 (v_mfma_f32_16x16x4_f32, one k-ordered chain per tile) vs the oracle's ascending-source
+    sequential sum and vs the event-driven kernel: bit for bit, for 0/1 spikes."""
+    from bindsnet_amd import ops
+    W = synth.uniform_f32(31, (Nin, N), -1.0, 1.0)
+    s = synth.dense_spikes(32, (B, Nin), dens)
+    b = synth.uniform_f32(33, (N,), -0.5, 0.5) if bias else None
+    out0 = synth.uniform_f32(34, (B, N), -1.0, 1.0) if acc else np.zeros((B, N), np.float32)
+    ref = out0.copy()
+    oracle.prop_dense(W, s, bias=b, out=ref, accumulate=acc)
+    dW, ds = torch.from_numpy(W).to(DEV), torch.from_numpy(s).to(DEV)
+    db = None if b is None else torch.from_numpy(b).to(DEV)
+    got = torch.from_numpy(out0.copy()).to(DEV)
+    ops.prop_dense_mfma(dW, ds, got, bias=db, accumulate=acc)
+    ev = torch.from_numpy(out0.copy()).to(DEV)
+    ops.prop_dense(dW, ds, ev, bias=db, accumulate=acc)
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_array_equal(ev.cpu().numpy().view(np.uint32), ref.view(np.uint32))

@@ -67,3 +67,74 @@ def test_sharded_run_single_rank_rccl():
     np.testing.assert_allclose(Ws.sum(0), 78.4, rtol=1e-5)
     np.testing.assert_allclose(net.layers["Ae"].theta.cpu().numpy(), ref.layers["Ae"].theta.cpu().numpy(), rtol=0, atol=1e-6)
     assert net.connections[("X", "Ae")].pipeline[0].norm == 78.4
+
+
+@pytest.mark.parametrize("kind", ["postpre", "mstdp"])
+def test_column_shards_on_the_device_equal_the_full_network(kind):
+    """The exact multi-GPU mode, executed for real on the one GPU there is: the column slices `column_shard` builds are
+    run one after the other (each on the whole batch, two consecutive inputs) and put side by side -- weights after
+    normalisation, rasters and membrane state must equal the unsharded network's, bit for bit."""
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.models import TwoLayerNetwork
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    from bindsnet_amd.parallel import column_shard
+    T, B, Nin, N = 40, 24, 784, 352                 # 11 blocks of 32 columns over 3 ranks: slices of 128, 128, 96
+
+    def make():
+        torch.manual_seed(0)
+        if kind == "postpre":
+            net = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum)
+        else:
+            net = Network(dt=1.0)
+            net.add_layer(Input(n=Nin, traces=True), "X")
+            net.add_layer(LIFNodes(n=N, traces=True), "Y")
+            net.add_connection(Connection(net.layers["X"], net.layers["Y"], w=0.3 * torch.rand(Nin, N), wmin=0, wmax=1, update_rule=MSTDP,
+                                          nu=1e-1, norm=0.1 * Nin, reduction=torch.sum), "X", "Y")
+        return net
+
+    kw = {"reward": 1.0} if kind == "mstdp" else {}
+    inputs = [torch.from_numpy(synth.dense_spikes(40 + r, (T, B, Nin), 0.03)).to(DEV) for r in range(2)]
+
+    def run(net):
+        mon = Monitor(net.layers["Y"], ["s"], time=T)
+        net.add_monitor(mon, "Y_s")
+        net.to(DEV)
+        out = []
+        for x in inputs:
+            net.run({"X": x}, time=T, **kw)
+            out.append((mon.get("s").reshape(T, B, -1).clone(), net.connections[("X", "Y")].w.detach().clone(), net.layers["Y"].v.clone()))
+        return out
+
+    full = run(make())
+    world = 3
+    parts = []
+    for r in range(world):
+        shard, lo, hi = column_shard(make(), r, world)
+        parts.append(run(shard))
+    for k in range(2):
+        for idx, name in ((0, "raster"), (1, "weights"), (2, "membrane")):
+            got = torch.cat([p[k][idx] for p in parts], dim=-1)
+            assert torch.equal(got, full[k][idx]), f"input {k}: {name}"
+    assert int(full[1][0].sum()) > 100
+
+
+def test_native_rccl_communicator_single_rank():
+    """include/snnhip.h snn_dist_*: the C ABI's own RCCL collectives (no torch.distributed), world size 1."""
+    from bindsnet_amd.parallel import NativeComm
+    from bindsnet_amd._lib import SnnError
+    try:
+        comm = NativeComm(0, 1)
+    except SnnError as e:
+        pytest.skip(f"RCCL communicator could not be created on this box: {e}")
+    try:
+        t = torch.arange(1000, dtype=torch.float32, device=DEV)
+        comm.allreduce_(t)
+        g = comm.allgather(torch.arange(64, dtype=torch.uint8, device=DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32)) and tuple(g.shape) == (1, 64)
+        assert torch.equal(g[0].cpu(), torch.arange(64, dtype=torch.uint8))
+    finally:
+        comm.close()

@@ -12,6 +12,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -77,3 +80,109 @@ def test_sharded_merge_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res[0] == res[1], "replicas diverged after the merge"
+
+
+# ------------------------------------------------------------------------------------------------ exact mode
+def _column_worker(rank, world, port, q):
+    """One rank of the exact multi-GPU mode, with the CPU oracle standing in for the device: it runs ITS column slice of
+    cfg3's graph (all samples), nothing is exchanged during the run, and the slices are gathered at the end."""
+    import os, sys
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import synth
+    from bindsnet_amd.parallel import column_shard_bounds, gather_columns
+    from test_oracle_fullsize import two_state_cols
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    P, spikes, W0 = _column_case()
+    lo, hi = column_shard_bounds(P.N, world, rank)
+    N_full = P.N
+    P.N = hi - lo
+    st = two_state_cols(P, W0[:, lo:hi])
+    ras = oracle.run_two_layer(P, st, spikes)
+    W = gather_columns(torch.from_numpy(st["W"]), N_full)
+    R = gather_columns(torch.from_numpy(ras), N_full)
+    V = gather_columns(torch.from_numpy(st["vY"]), N_full)
+    if rank == 0:
+        q.put((W.numpy(), R.numpy(), V.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _column_case():
+    import numpy as np
+    import oracle
+    import synth
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T, P.rule, P.dt = 48, 784, 160, 40, 1, 1.0           # B > 32: three 16-sample cascade blocks
+    P.x_trace_decay = P.y_trace_decay = float(np.exp(np.float32(-1.0 / 20.0))); P.x_trace_scale = P.y_trace_scale = 1.0
+    P.x_traces = P.y_traces = 1
+    P.decay = float(np.exp(np.float32(-1.0 / 100.0))); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.nu0, P.nu1, P.has_min, P.has_max, P.wmin, P.wmax, P.has_norm, P.norm, P.learning = 1e-4, 1e-2, 1, 1, 0.0, 1.0, 1, 78.4, 1
+    spikes = synth.dense_spikes(2, (P.T, P.B, P.Nin), 0.02)
+    return P, spikes, synth.weights_q12(11, P.Nin, P.N)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_column_sharded_exact_mode_equals_the_unsharded_run(world):
+    """SURVEY 8(e) "exact": column slices (32-aligned) of a coupling-free graph computed independently by `world`
+    processes and gathered == the single-process result for the global batch, bit for bit -- weights (after the
+    per-column normalisation), rasters, membrane state."""
+    import torch.multiprocessing as mp
+    import oracle
+    from test_oracle_fullsize import two_state_cols
+    P, spikes, W0 = _column_case()
+    st = two_state_cols(P, W0)
+    ras = oracle.run_two_layer(P, st, spikes)
+    assert ras.sum() > 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_column_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        W, R, V = q.get(timeout=120)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    np.testing.assert_array_equal(W.view(np.uint32), st["W"].view(np.uint32))
+    np.testing.assert_array_equal(R, ras)
+    np.testing.assert_array_equal(V.view(np.uint32), st["vY"].view(np.uint32))
+
+
+def test_column_shard_builds_the_slice_network():
+    import torch
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.models import TwoLayerNetwork
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    from bindsnet_amd.parallel import column_shard, column_shard_bounds
+    assert [column_shard_bounds(1600, 8, r) for r in range(8)][-1] == (1408, 1600)
+    assert column_shard_bounds(100, 4, 2) == (64, 100) and column_shard_bounds(100, 4, 3) == (100, 100)
+    torch.manual_seed(0)
+    net = TwoLayerNetwork(n_inpt=784, n_neurons=256, reduction=torch.sum)
+    covered = []
+    for r in range(3):
+        s, lo, hi = column_shard(net, r, 3)
+        c = s.connections[("X", "Y")]
+        assert torch.equal(c.w, net.connections[("X", "Y")].w[:, lo:hi]) and s.layers["Y"].n == hi - lo
+        assert type(c.update_rule).__name__ == "PostPre" and c.norm == 78.4 and float(c.wmax) == 1.0
+        covered += list(range(lo, hi))
+    assert covered == list(range(256))
+    net2 = Network(dt=1.0)
+    net2.add_layer(Input(n=6400, shape=(1, 80, 80), traces=True), "X")
+    net2.add_layer(LIFNodes(n=500, traces=True), "Y")
+    net2.add_connection(Connection(net2.layers["X"], net2.layers["Y"], wmin=0, wmax=1, update_rule=MSTDP, nu=1e-1, norm=3200.0,
+                                   reduction=torch.sum), "X", "Y")
+    s, lo, hi = column_shard(net2, 1, 2)
+    assert (lo, hi) == (256, 500) and type(s.connections[("X", "Y")].update_rule).__name__ == "MSTDP"
+    from bindsnet_amd.models import DiehlAndCook2015
+    with pytest.raises(NotImplementedError):
+        column_shard(DiehlAndCook2015(784, n_neurons=64), 0, 2)
