@@ -147,11 +147,11 @@ __global__ __launch_bounds__(NTC) void k_convlif_run(const ConvCtx c) {
                     }
                 }
             } else {
-                int tap = 0;
-                for (int ci = 0; ci < c.Cin; ++ci)
-                    for (int ky = 0; ky < c.KH; ++ky) {
-                        const int iy = oy * c.stride - c.pad + ky;
-                        for (int kx = 0; kx < c.KW; ++kx, ++tap) {
+                for (int ky = 0; ky < c.KH; ++ky) {       // reference order: taps row-major, input channels innermost
+                    const int iy = oy * c.stride - c.pad + ky;
+                    for (int kx = 0; kx < c.KW; ++kx)
+                        for (int ci = 0; ci < c.Cin; ++ci) {
+                            const int tap = (ci * c.KH + ky) * c.KW + kx;
                             const int ix = ox * c.stride - c.pad + kx;
                             if (iy < 0 || iy >= c.H || ix < 0 || ix >= c.Wd) continue;
                             const uint8_t sv = ib[(ci * c.H + iy) * c.Wd + ix];
@@ -226,8 +226,10 @@ int snn_try_fused_convlif(const snn_layer_desc *L, int nL, const snn_conn_desc *
         const long n = (long)c.B * img;
         hipLaunchKernelGGL(k_conv_xtrace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c);
     }
-    if (c.KH == 5 && c.KW == 5) hipLaunchKernelGGL((k_convlif_run<5, 5>), dim3((unsigned)grid), dim3(NTC), lds, st, c);
-    else if (c.KH == 3 && c.KW == 3) hipLaunchKernelGGL((k_convlif_run<3, 3>), dim3((unsigned)grid), dim3(NTC), lds, st, c);
+    // (the window-mask forms walk one input channel at a time; with several channels the reference's order interleaves
+    //  them tap by tap, which the general form follows)
+    if (c.Cin == 1 && c.KH == 5 && c.KW == 5) hipLaunchKernelGGL((k_convlif_run<5, 5>), dim3((unsigned)grid), dim3(NTC), lds, st, c);
+    else if (c.Cin == 1 && c.KH == 3 && c.KW == 3) hipLaunchKernelGGL((k_convlif_run<3, 3>), dim3((unsigned)grid), dim3(NTC), lds, st, c);
     else hipLaunchKernelGGL((k_convlif_run<0, 0>), dim3((unsigned)grid), dim3(NTC), lds, st, c);
     const int rc = snn_check_launch();
     if (rc) return rc;

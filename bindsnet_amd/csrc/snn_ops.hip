@@ -92,7 +92,7 @@ extern "C" int snn_prop_dense_f32(const float *W, const float *bias, const uint8
 // =============================================================================================
 // a7: conv2d propagation.  thread <-> (b, oy, ox); all Cout channels accumulated in registers in
 // chunks of 8 so the u8 input window is read once per chunk; weights broadcast from LDS.
-// Tap order (cin, kh, kw) row-major, sequential, then + bias.
+// Tap order (kh, kw, cin): taps row-major, input channels innermost (what oneDNN does for C_in <= 16), sequential, + bias.
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_conv2d(const float *__restrict__ W, const float *__restrict__ bias,
                                                 const uint8_t *__restrict__ s, float *__restrict__ out, int B,
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void k_conv2d(const float *__restrict__ W, con
         float acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-        int tap = 0;
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int ky = 0; ky < KH; ++ky)
-                for (int kx = 0; kx < KW; ++kx, ++tap) {
+        for (int ky = 0; ky < KH; ++ky)               // reference order: taps row-major, input channels innermost
+            for (int kx = 0; kx < KW; ++kx)
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const int tap = (ci * KH + ky) * KW + kx;
                     const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
                     if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
                     const uint8_t sv = s[(((size_t)b * Cin + ci) * H + iy) * Wd + ix];
@@ -142,6 +142,7 @@ extern "C" int snn_prop_conv2d_f32(const float *W, const float *bias, const uint
         return SNN_ERR_INVALID;
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
+    if (Cin > 16) return SNN_ERR_UNSUPPORTED;      // the reference's accumulation order is only characterised up to 16 channels
     const size_t lds = sizeof(float) * (size_t)Cout * Cin * KH * KW;
     if (lds > 64 * 1024) return SNN_ERR_UNSUPPORTED;
     const long npix = (long)B * OH * OW;

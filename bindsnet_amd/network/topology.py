@@ -106,6 +106,9 @@ class Conv2dConnection(AbstractConnection):
             raise NotImplementedError("bindsnet_amd: learning on Conv2dConnection is not on the accelerated path "
                                       "(SURVEY.md 8(f)-4)")
         self.in_channels, ih, iw = source.shape[0], source.shape[1], source.shape[2]
+        if self.in_channels > 16:
+            raise NotImplementedError("bindsnet_amd: Conv2dConnection with more than 16 input channels is not supported (the "
+                                      "reference's oneDNN accumulation order is only characterised up to 16)")
         self.out_channels = target.shape[0]
         oh = int((ih - self.kernel_size[0] + 2 * self.padding[0]) / self.stride[0] + 1)
         ow = int((iw - self.kernel_size[1] + 2 * self.padding[1]) / self.stride[1] + 1)

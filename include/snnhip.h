@@ -77,7 +77,9 @@ int snn_prop_dense_mfma_f32(const float *W, const float *bias, const uint8_t *s,
 
 /* ---- a7: Conv2dConnection.compute ---------------------------------------------------------
  * bindsnet/network/topology.py:799-815 (F.conv2d).  s [B,Cin,H,W] u8, W [Cout,Cin,KH,KW],
- * out [B,Cout,OH,OW]; taps accumulated sequentially in (cin,kh,kw) row-major order, then bias.*/
+ * out [B,Cout,OH,OW]; accumulated sequentially in (kh,kw,cin) order -- taps row-major, input channels
+ * innermost: what the reference's oneDNN kernel does for Cin <= 16 (bit-exact against reference fixtures for Cin =
+ * 1, 3, 8, 16) --, then bias.  Cin > 16: SNN_ERR_UNSUPPORTED (oneDNN switches kernels, order not characterised). */
 int snn_prop_conv2d_f32(const float *W, const float *bias, const uint8_t *s, float *out,
                         int B, int Cin, int H, int Wd, int Cout, int KH, int KW,
                         int stride, int pad, int accumulate, snn_stream_t stream);

@@ -119,8 +119,8 @@ ORC_API void orc_prop_dense(const float *W, const float *bias, const uint8_t *s,
 }
 
 /* a7: Conv2dConnection.compute, bindsnet/network/topology.py:799-815 (F.conv2d, oneDNN).
- * Order per SURVEY.md finding 5 / probe P8: bias-free sequential accumulation over
- * (c_in, kh, kw) row-major, then + bias. */
+ * Order per SURVEY.md finding 5 / probe P8 and the round-2 probe below: bias-free sequential
+ * accumulation over (kh, kw, c_in) -- taps row-major, channels innermost --, then + bias. */
 ORC_API void orc_prop_conv2d(const float *W, const float *bias, const uint8_t *s, float *out,
                              int B, int Cin, int H, int Wd, int Cout, int KH, int KW,
                              int stride, int pad, int accumulate)
@@ -131,9 +131,13 @@ ORC_API void orc_prop_conv2d(const float *W, const float *bias, const uint8_t *s
             for (int oy = 0; oy < OH; ++oy)
                 for (int ox = 0; ox < OW; ++ox) {
                     float acc = 0.f;
-                    for (int ci = 0; ci < Cin; ++ci)
-                        for (int ky = 0; ky < KH; ++ky)
-                            for (int kx = 0; kx < KW; ++kx) {
+                    /* probe (round 2, torch 2.10 / oneDNN 3.7.1, threads 1 and 8, strides / paddings / batch sizes):
+                     * for C_in <= 16 the reference accumulates taps in (kh, kw) row-major order with the input
+                     * channels INNERMOST; for C_in = 1 that is the plain row-major tap order.  Wider inputs take
+                     * other oneDNN kernels (C_in = 32: channel-major; 64: blocked) and are rejected by the library. */
+                    for (int ky = 0; ky < KH; ++ky)
+                        for (int kx = 0; kx < KW; ++kx)
+                            for (int ci = 0; ci < Cin; ++ci) {
                                 const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
                                 if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
                                 acc += (float)s[(((long)b * Cin + ci) * H + iy) * Wd + ix] *

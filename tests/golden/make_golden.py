@@ -196,12 +196,14 @@ def gen_nodes():
 
 def gen_conv():
     out = {}
-    cases = [(4, 1, 28, 28, 32, 5, 1, 0), (2, 1, 12, 12, 4, 3, 2, 1), (2, 3, 10, 10, 5, 3, 1, 0)]
+    cases = [(4, 1, 28, 28, 32, 5, 1, 0), (2, 1, 12, 12, 4, 3, 2, 1), (2, 3, 10, 10, 5, 3, 1, 0),
+             (2, 8, 8, 8, 16, 3, 1, 1), (2, 16, 8, 8, 32, 5, 1, 2), (3, 4, 9, 11, 7, 3, 2, 1)]
     for k, (B, Cin, H, Wd, Cout, K, stride, pad) in enumerate(cases):
         W = synth.uniform_f32(1000 + k, (Cout, Cin, K, K), 0.0, 0.3)
         s = synth.dense_spikes(1100 + k, (B, Cin, H, Wd), 0.2)
         OH = (H + 2 * pad - K) // stride + 1
-        src, tgt = Input(shape=(Cin, H, Wd)), LIFNodes(shape=(Cout, OH, OH))
+        OW = (Wd + 2 * pad - K) // stride + 1
+        src, tgt = Input(shape=(Cin, H, Wd)), LIFNodes(shape=(Cout, OH, OW))
         conn = Conv2dConnection(src, tgt, kernel_size=K, stride=stride, padding=pad, w=T_(W).clone())
         pack(out, f"out{k}", conn.compute(T_(s)).numpy())
     save("op_conv2d", cases=np.array(cases), **out)
