@@ -34,14 +34,14 @@ void snn_set_plan_name(const char *name);
 namespace {
 
 constexpr int NT = 1024;
-constexpr int MAXB = 32;
-constexpr int META = 40;        // [0] list entries, [1] active rows, [2] flags (1: spike byte > 1, 2: list overflow), [4..36] CSR offsets
+constexpr int MAXB = 128;       // samples per run: sample masks are MW = ceil(B / 32) words wide (one word up to batch 32)
+constexpr int META = 136;       // [0] list entries, [1] active rows, [2] flags (1: spike byte > 1, 2: list overflow), [4..4+B] CSR offsets
 constexpr int PF = 16;          // digest words prefetched per thread per step
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct TwoCtx {
-    int B, Nin, N, T, NinW, CW, G;
+    int B, Nin, N, T, NinW, CW, G, MW, BC;               // MW mask words per sample set, BC = 32 * MW (array capacity)
     float dt; int learning;
     const uint8_t *in; const uint8_t *sX0;
     const float *xX0; float *xXout; float *xall;       // entry trace, exit trace, [T][B][Nin] trace after each step
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, NinW = c.NinW;
     uint32_t *sXw = (uint32_t *)smem;                    // [B][NinW] bit words
-    uint32_t *rowmask = sXw + B * NinW;                  // [Nin]
-    int *cntb = (int *)(rowmask + Nin);                  // [B+1] per-sample counts -> offsets
+    uint32_t *rowmask = sXw + B * NinW;                  // [Nin][MW] samples in which the row spiked
+    const int mw = c.MW;
+    int *cntb = (int *)(rowmask + Nin * mw);             // [B+1] per-sample counts -> offsets
     int *misc = cntb + MAXB + 1;                         // [0] nact, [1] flags
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
     // (MSTDP: one more entry, T+1 = the source spikes the rule remembers from its last update before this run)
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     uint32_t *D = c.dig + (size_t)e * c.DW;
     uint16_t *D_ent = (uint16_t *)(D + c.o_ent), *D_ar = (uint16_t *)(D + c.o_ar);
     uint32_t *D_am = D + c.o_am, *D_ab = D + c.o_ab, *D_xw = D + c.o_xw;
-    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
+    for (int k = tid; k < Nin * mw; k += NT) rowmask[k] = 0;
     for (int k = tid; k < NinW; k += NT) D_ab[k] = 0;    // (own entry; finished before the atomics below by the barrier)
     if (tid < 2) misc[tid] = 0;
     __syncthreads();
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
             if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
             while (m16) {
                 const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
-                atomicOr(&rowmask[i], 1u << b);
+                atomicOr(&rowmask[i * mw + (b >> 5)], 1u << (b & 31));
             }
         }
         if (big) atomicOr((unsigned int *)&misc[1], 1u);
@@ -194,14 +195,16 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
     for (int base = 0; base < Nin; base += NT) {          // rows with a spike in any sample, with their sample masks
         const int i = base + tid;
-        const bool o = i < Nin && rowmask[i] != 0;
+        bool o = false;
+        if (i < Nin) for (int w = 0; w < mw; ++w) o = o || rowmask[i * mw + w] != 0;
         const uint64_t m = __ballot(o);
         int wbase = 0;
         if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
         wbase = __shfl(wbase, 0);
         if (o) {
             const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull));
-            D_ar[cp] = (uint16_t)i; D_am[cp] = rowmask[i];
+            D_ar[cp] = (uint16_t)i;
+            for (int w = 0; w < mw; ++w) D_am[cp * mw + w] = rowmask[i * mw + w];
             atomicOr(&D_ab[i >> 5], 1u << (i & 31));
         }
     }
@@ -257,28 +260,33 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
                                          const uint32_t *ab, const float *xnu0, const uint32_t *cm,
                                          const float *__restrict__ xs, const float *xsl, const uint8_t *__restrict__ sbytes,
                                          int nact, bool full, int c0, int tid, int cwl, int Emain) {
-    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW;
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = c.MW;
+    auto first_of = [&](const uint32_t *m) -> int { for (int w = 0; w < mw; ++w) if (m[w]) return w * 32 + __ffs(m[w]) - 1; return -1; };
+    auto any_of = [&](const uint32_t *m) -> bool { uint32_t o = 0; for (int w = 0; w < mw; ++w) o |= m[w]; return o != 0; };
     // source trace of sample b at row i, for the post-synaptic term of column q: the first spiking sample of q is
     // staged in LDS (xsl), any further one comes from global memory
-    auto xsrc = [&](int q, int b, int i, uint32_t colmask_q) -> float {
-        return (xsl && b == __ffs(colmask_q) - 1) ? xsl[q * Nin + i] : xs[b * Nin + i];
+    auto xsrc = [&](int q, int b, int i, int first_b) -> float {
+        return (xsl && b == first_b) ? xsl[q * Nin + i] : xs[b * Nin + i];
     };
     // ---- pass 1: rows with a pre-synaptic spike x own columns
     for (int item = tid; item < (nact << cwl); item += NT) {
         const int kq = item >> cwl, q = item & (CW - 1);
         const int i = (int)ar[kq];
-        const uint32_t m = am[kq];
-        const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
+        const uint32_t *m = am + kq * mw;                 // samples in which row i spiked
+        const uint32_t *cq = cm + q * mw;                 // samples in which column q spiked
+        const bool cany = c.nu1 != 0.f && any_of(cq);
         if (c0 + q >= N) continue;
         const bool tl = i * N + c0 + q >= Emain;
         float w = wt[i * CW + q];
         if (c.nu0 != 0.f) {                               // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
             SUM acc; acc.init(tl);
-            uint32_t mm = m;
-            while (mm) {
-                const int b = __ffs(mm) - 1; mm &= mm - 1;
-                const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
-                acc.add(b, sv * xnu0[b * 8 + q], B);
+            for (int wd = 0; wd < mw; ++wd) {             // ascending sample index = the reference's batch-sum order
+                uint32_t mm = m[wd];
+                while (mm) {
+                    const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1;
+                    const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                    acc.add(b, sv * xnu0[b * 8 + q], B);
+                }
             }
             float uu = acc.finish(B);
             if (c.use_dt) uu = uu * c.dt;
@@ -286,10 +294,13 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
         }
         if (c.nu1 != 0.f) {                               // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
             float uu = 0.f;
-            if (cq) {
+            if (cany) {
                 SUM acc; acc.init(tl);
-                uint32_t mm = cq;
-                while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, cq) * (1.0f * c.nu1), B); }
+                const int fb = first_of(cq);
+                for (int wd = 0; wd < mw; ++wd) {
+                    uint32_t mm = cq[wd];
+                    while (mm) { const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, fb) * (1.0f * c.nu1), B); }
+                }
                 uu = acc.finish(B);
             }
             if (c.use_dt) uu = uu * c.dt;
@@ -302,22 +313,26 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
     }
     // ---- pass 2: rows WITHOUT a pre-synaptic spike: the columns that spiked (every column when `full`)
     uint32_t todo = 0;                                    // columns to visit, as a bit mask
-    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || (c.nu1 != 0.f && cm[q]))) todo |= 1u << q;
+    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || (c.nu1 != 0.f && any_of(cm + q * mw)))) todo |= 1u << q;
     if (!todo) return;
     for (int i = tid; i < Nin; i += NT) {
         if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
         uint32_t td = todo;
         while (td) {
             const int q = __ffs(td) - 1; td &= td - 1;
-            const uint32_t cq = c.nu1 != 0.f ? cm[q] : 0u;
+            const uint32_t *cq = cm + q * mw;
+            const bool cany = c.nu1 != 0.f && any_of(cq);
             float w = wt[i * CW + q];
             if (c.nu0 != 0.f) w = w - (c.use_dt ? 0.0f * c.dt : 0.0f);
             if (c.nu1 != 0.f) {
                 float uu = 0.f;
-                if (cq) {
+                if (cany) {
                     SUM acc; acc.init(i * N + c0 + q >= Emain);
-                    uint32_t mm = cq;
-                    while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, cq) * (1.0f * c.nu1), B); }
+                    const int fb = first_of(cq);
+                    for (int wd = 0; wd < mw; ++wd) {
+                        uint32_t mm = cq[wd];
+                        while (mm) { const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, fb) * (1.0f * c.nu1), B); }
+                    }
                     uu = acc.finish(B);
                 }
                 if (c.use_dt) uu = uu * c.dt;
@@ -340,19 +355,26 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
                                           const uint32_t *ab, const float *pml, const float *zl, const uint32_t *cm,
                                           const float *rvl, const float *__restrict__ pp, const uint8_t *__restrict__ sbytes,
                                           int nact, bool full, int c0, int tid, int cwl, int Emain) {
-    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW;
-    auto elem = [&](int i, int q, uint32_t m, uint32_t cq, float w) -> float {
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = c.MW;
+    const uint32_t zeros[4] = {0u, 0u, 0u, 0u};
+    auto any_of = [&](const uint32_t *m) -> bool { uint32_t o = 0; for (int w = 0; w < mw; ++w) o |= m[w]; return o != 0; };
+    // m: samples in which row i spiked (nullptr-safe: `zeros`), cq: samples in which column q spiked
+    auto elem = [&](int i, int q, const uint32_t *m, const uint32_t *cq, float w) -> float {
         SUM acc; acc.init(i * N + c0 + q >= Emain);
-        uint32_t mm = m | cq;
-        if (!cq && !sbytes) {      // no target spike in this column, 0/1 source spikes: the term is zl[b][q], staged by the caller
-            while (mm) { const int b = __ffs(mm) - 1; mm &= mm - 1; acc.add(b, zl[b * 8 + q], B); }
-        } else
-        while (mm) {
-            const int b = __ffs(mm) - 1; mm &= mm - 1;
-            const float e1 = ((cq >> b) & 1u) ? pp[b * Nin + i] * 1.0f : 0.0f;                          // p_plus (x) s_tgt
-            const float sv = ((m >> b) & 1u) ? (sbytes ? (float)sbytes[b * Nin + i] : 1.0f) : 0.0f;
-            const float e2 = sv * pml[b * 8 + q];                                                       // s_src (x) p_minus
-            acc.add(b, rvl[b] * (e1 + e2), B);
+        const bool cany = any_of(cq);
+        for (int wd = 0; wd < mw; ++wd) {                 // ascending sample index = the reference's batch-sum order
+            const uint32_t mr = m[wd], mc = cq[wd];
+            uint32_t mm = mr | mc;
+            if (!cany && !sbytes) {   // no target spike in this column, 0/1 source spikes: the term is zl[b][q], staged by the caller
+                while (mm) { const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; acc.add(b, zl[b * 8 + q], B); }
+            } else
+            while (mm) {
+                const int bb = __ffs(mm) - 1, b = wd * 32 + bb; mm &= mm - 1;
+                const float e1 = ((mc >> bb) & 1u) ? pp[b * Nin + i] * 1.0f : 0.0f;                        // p_plus (x) s_tgt
+                const float sv = ((mr >> bb) & 1u) ? (sbytes ? (float)sbytes[b * Nin + i] : 1.0f) : 0.0f;
+                const float e2 = sv * pml[b * 8 + q];                                                     // s_src (x) p_minus
+                acc.add(b, rvl[b] * (e1 + e2), B);
+            }
         }
         const float u = acc.finish(B);
         w = w + c.nu0 * u;                                // learning.py:1561
@@ -366,18 +388,18 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
         const int kq = item >> cwl, q = item & (CW - 1);
         if (c0 + q >= N) continue;
         const int i = (int)ar[kq];
-        wt[i * CW + q] = elem(i, q, am[kq], cm[q], wt[i * CW + q]);
+        wt[i * CW + q] = elem(i, q, am + kq * mw, cm + q * mw, wt[i * CW + q]);
     }
     // ---- pass 2: the other rows: the columns whose target spiked (every column when `full`)
     uint32_t todo = 0;
-    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || cm[q])) todo |= 1u << q;
+    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || any_of(cm + q * mw))) todo |= 1u << q;
     if (!todo) return;
     for (int i = tid; i < Nin; i += NT) {
         if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
         uint32_t td = todo;
         while (td) {
             const int q = __ffs(td) - 1; td &= td - 1;
-            wt[i * CW + q] = elem(i, q, 0u, cm[q], wt[i * CW + q]);
+            wt[i * CW + q] = elem(i, q, zeros, cm + q * mw, wt[i * CW + q]);
         }
     }
 }
@@ -387,18 +409,18 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
 template <bool CASC, int RULE>
 __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW;
+    const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW, mw = c.MW, BC = c.BC, CMS = 8 * c.MW;
     size_t off = 0;
     float *wt = (float *)(smem + off); off += (size_t)Nin * CW * 4;                       // own weight slice [Nin][CW]
     int *meta = (int *)(smem + off); off += META * 4;
     uint16_t *ent = (uint16_t *)(smem + off); off += ((size_t)c.LCAP * 2 + 15) & ~(size_t)15;
-    uint32_t *am = (uint32_t *)(smem + off); off += (size_t)Nin * 4;
+    uint32_t *am = (uint32_t *)(smem + off); off += (size_t)Nin * mw * 4;                 // [active rows][MW] sample masks
     uint16_t *ar = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;
     uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
-    float *xnu0 = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                     // [B][CW] x_tgt * nu0
-    uint32_t *colmask = (uint32_t *)(smem + off); off += 16 * 4;                          // [2][8]: samples whose neuron (column q) spiked
-    float *rvl = (float *)(smem + off); off += (size_t)MAXB * 4;                          // MSTDP: reward per sample
-    float *zl = (float *)(smem + off); off += (size_t)MAXB * 8 * 4;                       // MSTDP: reward * p_minus per (sample, column)
+    float *xnu0 = (float *)(smem + off); off += (size_t)BC * 8 * 4;                       // [B][CW] x_tgt * nu0
+    uint32_t *colmask = (uint32_t *)(smem + off); off += (size_t)2 * CMS * 4;             // [2][8][MW]: samples whose neuron (column q) spiked
+    float *rvl = (float *)(smem + off); off += (size_t)BC * 4;                            // MSTDP: reward per sample
+    float *zl = (float *)(smem + off); off += (size_t)BC * 8 * 4;                         // MSTDP: reward * p_minus per (sample, column)
     float *prod = (float *)(smem + off); off += c.prodw ? (size_t)c.prodw * 4 : 0;        // dense dot: staged products
     int *szt = (int *)(smem + off); off += (size_t)(c.T + 2) * 8;                         // (events, active rows) of every digest entry
     float *xsl = (float *)(smem + off); off += c.use_xsl ? (size_t)Nin * CW * 4 : 0;      // source trace of the first spiking sample of each column
@@ -424,11 +446,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (c.bias) bias = c.bias[j];
         if (do_mstdp) pm = c.p_minus[kst];
     }
-    if (tid < 16) colmask[tid] = 0;
-    if (tid < MAXB) rvl[tid] = (do_mstdp && tid < B) ? (c.reward_vec ? c.reward_vec[tid] : c.reward) : 0.f;
+    if (tid < 2 * CMS) colmask[tid] = 0;
+    if (tid < BC) rvl[tid] = (do_mstdp && tid < B) ? (c.reward_vec ? c.reward_vec[tid] : c.reward) : 0.f;
     if (do_mstdp) {      // the target spikes the rule remembers from its last update: "previous step" of iteration 0
         __syncthreads();
-        if (mine && c.s_tgt_prev[kst]) atomicOr(&colmask[8 + jj], 1u << bl);
+        if (mine && c.s_tgt_prev[kst]) atomicOr(&colmask[CMS + jj * mw + (bl >> 5)], 1u << (bl & 31));
     }
     // digest words copied into LDS each step: [meta | entries | row masks | active rows | row bitmap]
     const int region4 = NinW;
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     auto issue = [&](int e) {     // loads of digest entry e; lengths from the LDS size table, so no dependent global read
         const uint32_t *D = c.dig + (size_t)e * c.DW;
         const int tot = min(szt[2 * e], c.LCAP), nact = szt[2 * e + 1];
-        const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+        const int n1 = (tot + 1) / 2, n2 = nact * mw, n3 = (nact + 1) / 2, n4 = region4;
         const int nw = META + n1 + n2 + n3 + n4;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -465,7 +487,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         // sizes first (they sit in the first META words = thread tid < META, u = 0)
         {
             const int tot = min(szt[2 * t], c.LCAP), nact = szt[2 * t + 1];
-            const int n1 = (tot + 1) / 2, n2 = nact, n3 = (nact + 1) / 2, n4 = region4;
+            const int n1 = (tot + 1) / 2, n2 = nact * mw, n3 = (nact + 1) / 2, n4 = region4;
             const int nw = META + n1 + n2 + n3 + n4;
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -479,11 +501,15 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             }
             // traces prefetched at the end of the previous iteration, and the spike masks this iteration will fill
             if (c.use_xsl && t >= 1 && tid < Nin) {
-                const uint32_t *cmp = colmask + ((t + 1) & 1) * 8;
+                const uint32_t *cmp = colmask + ((t + 1) & 1) * CMS;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if (q < CW && cmp[q]) xsl[q * Nin + tid] = x_pf[q];
+                for (int q = 0; q < 8; ++q) {
+                    uint32_t anyq = 0;
+                    if (q < CW) for (int w = 0; w < mw; ++w) anyq |= cmp[q * mw + w];
+                    if (anyq) xsl[q * Nin + tid] = x_pf[q];
+                }
             }
-            if (tid < 8) colmask[(t & 1) * 8 + tid] = 0;
+            if (tid < CMS) colmask[(t & 1) * CMS + tid] = 0;
         }
         lds_barrier();
         TMARK(1);
@@ -492,7 +518,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         const int tot = meta[0], nact = meta[1], flags = meta[2];
         const bool overflow = (flags & 2) != 0;          // more events than the LDS list holds: walk bit words from global
         const uint8_t *sbytes = (flags & 1) ? ((t == 0) ? c.sX0 : c.in + (size_t)(t - 1) * B * Nin) : nullptr;
-        const uint32_t *cm = colmask + ((t + 1) & 1) * 8;   // spikes of step t-1 (written in iteration t-1)
+        const uint32_t *cm = colmask + ((t + 1) & 1) * CMS;   // spikes of step t-1 (written in iteration t-1)
 
         // ================================================== phase A: PostPre of step t-1 on the LDS weight tile
         if (t >= 1 && do_stdp) {
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (t == c.T) break;
 
         // ================================================== phase B: step t
-        uint32_t *cmn = colmask + (t & 1) * 8;
+        uint32_t *cmn = colmask + (t & 1) * CMS;
         uint8_t sp = 0;
         float cur = 0.f;
         // dense Connection with long event lists (wide inputs): one thread per (sample, column) would chase ~hundreds of
@@ -583,7 +609,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 pm = p + c.a_minus * (float)sp;
             } else
             xnu0[bl * 8 + jj] = xy * c.nu0;               // target_x * nu[0]
-            if (sp) atomicOr(&cmn[jj], 1u << bl);
+            if (sp) atomicOr(&cmn[jj * mw + (bl >> 5)], 1u << (bl & 31));
             if (c.rasY) c.rasY[(size_t)t * B * N + kst] = sp;
             if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
         }
@@ -591,7 +617,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (c.use_xsl && do_stdp && tid < Nin) {         // source traces the next PostPre needs: in flight across the loop edge
             const float *xs = c.xall + (size_t)t * B * Nin;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const uint32_t m = q < CW ? cmn[q] : 0u; x_pf[q] = m ? xs[(__ffs(m) - 1) * Nin + tid] : 0.f; }
+            for (int q = 0; q < 8; ++q) {
+                int fb = -1;
+                if (q < CW) for (int w = 0; w < mw && fb < 0; ++w) if (cmn[q * mw + w]) fb = w * 32 + __ffs(cmn[q * mw + w]) - 1;
+                x_pf[q] = fb >= 0 ? xs[fb * Nin + tid] : 0.f;
+            }
         }
         if (do_mstdp) {
             // ---- MSTDP update of step t (applied before step t+1 propagates): factors of step t-1 = this iteration's
@@ -604,7 +634,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 // layer's entry spikes: digest entry T+1 replaces the row tables (the event list is not needed)
                 const uint32_t *D = c.dig + (size_t)(c.T + 1) * c.DW;
                 na = szt[2 * (c.T + 1) + 1];
-                for (int k = tid; k < na; k += NT) am[k] = D[c.o_am + k];
+                for (int k = tid; k < na * mw; k += NT) am[k] = D[c.o_am + k];
                 for (int k = tid; k < (na + 1) / 2; k += NT) ((uint32_t *)ar)[k] = D[c.o_ar + k];
                 for (int k = tid; k < NinW; k += NT) ab[k] = D[c.o_ab + k];
                 sb = (D[2] & 1u) ? c.s_src_prev : nullptr;
@@ -676,7 +706,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
 int digest_layout(TwoCtx &c) {
     c.o_ent = META;
     c.o_am = c.o_ent + c.LCAP / 2;
-    c.o_ar = c.o_am + c.Nin;
+    c.o_ar = c.o_am + c.Nin * c.MW;
     c.o_ab = c.o_ar + (c.Nin + 1) / 2;
     c.o_xw = c.o_ab + c.NinW;
     return (c.o_xw + c.B * c.NinW + 3) & ~3;
@@ -685,7 +715,8 @@ int digest_layout(TwoCtx &c) {
 size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
-           al((size_t)c.NinW * 4) + (size_t)MAXB * 8 * 4 + 16 * 4 + (size_t)MAXB * 4 + (size_t)MAXB * 8 * 4 + (size_t)c.prodw * 4 +
+           (size_t)c.Nin * (c.MW - 1) * 4 +
+           al((size_t)c.NinW * 4) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
            (size_t)(c.T + 2) * 8 +
            (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
@@ -705,6 +736,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if ((double)Nin * N >= 2147483648.0 || (double)(R->T + 1) * B * Nin >= 2147483648.0) return false;
     memset(&c, 0, sizeof(c));
     c.B = B; c.Nin = Nin; c.N = N; c.T = R->T; c.NinW = (Nin + 31) / 32;
+    c.MW = (B + 31) / 32; c.BC = 32 * c.MW;
     c.dt = R->dt; c.learning = R->learning;
     c.rule = C[0].rule;
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
@@ -725,7 +757,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.use_xsl = 0;
     if (Nin <= NT && c.rule == SNN_RULE_POSTPRE) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
-    if (META + c.LCAP / 2 + Nin + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
+    if (META + c.LCAP / 2 + Nin * c.MW + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
     return true;
 }
 
@@ -786,7 +818,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         if (snn_check(hipFuncSetAttribute((const void *)k_two_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         attr = true;
     }
-    const size_t prep_lds = (size_t)(B * c.NinW + Nin + MAXB + 1 + 4) * 4;
+    const size_t prep_lds = (size_t)(B * c.NinW + Nin * c.MW + MAXB + 1 + 4) * 4;
     if (prep_lds > 150 * 1024) return SNN_OK;
     if (c.x_traces) hipLaunchKernelGGL(k_two_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);
     if (mstdp) hipLaunchKernelGGL(k_two_pplus, dim3((B * Nin + 255) / 256), dim3(256), 0, st, c);

@@ -130,6 +130,7 @@ def test_dense_family_full_size_matches_reference(name, rule):
     np.testing.assert_array_equal(ras[:, :, cols], ras_o)
     np.testing.assert_array_equal(bits(W[:, cols]), bits(st["W"]))
     np.testing.assert_array_equal(bits(host(net.layers["Y"].v)[:, cols]), bits(st["vY"]))
+    assert net.last_plan == "twolayer-fused", "every BASELINE dense-family config runs as one fused launch (batch <= 128)"
     print(f"{name}: plan {net.last_plan}; weights bit-identical to the reference: {cases.sha(W) == str(g['W_sha'])}")
 
 

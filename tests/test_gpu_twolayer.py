@@ -72,6 +72,13 @@ CASES = {
     "mcc_postpre_b32_n37": ("mcc", 400, 37, 32, 25, True, False),
     "mcc_norule_b3": ("mcc", 784, 50, 3, 30, False, False),
     "dense_wide_input_b16": ("dense", 6400, 64, 16, 12, True, False),
+    # batch > 32: sample masks several words wide (the reference's batch sums cross 16-sample cascade blocks)
+    "dense_postpre_b48": ("dense", 784, 96, 48, 25, True, False),
+    "dense_postpre_b128_cfg3_slice": ("dense", 784, 160, 128, 20, True, False),
+    "dense_postpre_b33_bias": ("dense", 256, 40, 33, 30, True, True),
+    "mcc_postpre_b64_tailcols": ("mcc", 784, 100, 64, 20, True, False),
+    "mcc_postpre_b100_n37": ("mcc", 400, 37, 100, 15, True, False),
+    "dense_norule_b96": ("dense", 784, 64, 96, 15, False, True),
 }
 
 
@@ -96,7 +103,7 @@ def test_twolayer_learning_off_and_big_batch_fallback():
     for a, b in zip(f, g):
         for k in a:
             np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8))
-    _, plan = run(False, "dense", 784, 64, 48, 5)       # batch > 32: generic plan
+    _, plan = run(False, "dense", 784, 64, 130, 5)      # batch > 128: generic plan
     assert plan == "generic"
 
 
@@ -155,6 +162,8 @@ MSTDP_CASES = {
     "b1": (256, 40, 1, 50, 1.0, 0.08, 1),
     "multivalued_source_bytes": (784, 48, 8, 30, 1.0, 0.05, 3),
     "cfg5_shape_short": (6400, 500, 16, 8, 1.0, 0.05, 1),
+    "b48_scalar_reward": (784, 64, 48, 25, 1.0, 0.05, 1),
+    "b100_reward_vector": (400, 40, 100, 20, "vec", 0.06, 1),
 }
 
 
