@@ -255,12 +255,12 @@ struct CascT {             // batch sums have at most 32 terms: the branch-free 
     __device__ __forceinline__ float finish(int n) { return c.finish(n); }
 };
 
-template <class SUM>
+template <class SUM, int MWT>
 __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
                                          const uint32_t *ab, const float *xnu0, const uint32_t *cm,
                                          const float *__restrict__ xs, const float *xsl, const uint8_t *__restrict__ sbytes,
                                          int nact, bool full, int c0, int tid, int cwl, int Emain) {
-    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = c.MW;
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;   // (one mask word: the loops fold away)
     auto first_of = [&](const uint32_t *m) -> int { for (int w = 0; w < mw; ++w) if (m[w]) return w * 32 + __ffs(m[w]) - 1; return -1; };
     auto any_of = [&](const uint32_t *m) -> bool { uint32_t o = 0; for (int w = 0; w < mw; ++w) o |= m[w]; return o != 0; };
     // source trace of sample b at row i, for the post-synaptic term of column q: the first spiking sample of q is
@@ -350,12 +350,12 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
 // snn_mstdp_step): w += nu0 * sum_b reward[b] * (p_plus[b,i] * s_tgt[b,j] + s_src[b,i] * p_minus[b,j]), decay, clamp,
 // all four factors being those of the PREVIOUS step.  Samples in which neither side spiked contribute +0.0 and are
 // skipped; p_plus >= +0 (a_plus >= 0, host check) so a silent target contributes exactly +0.0 without loading it.
-template <class SUM>
+template <class SUM, int MWT>
 __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
                                           const uint32_t *ab, const float *pml, const float *zl, const uint32_t *cm,
                                           const float *rvl, const float *__restrict__ pp, const uint8_t *__restrict__ sbytes,
                                           int nact, bool full, int c0, int tid, int cwl, int Emain) {
-    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = c.MW;
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;
     const uint32_t zeros[4] = {0u, 0u, 0u, 0u};
     auto any_of = [&](const uint32_t *m) -> bool { uint32_t o = 0; for (int w = 0; w < mw; ++w) o |= m[w]; return o != 0; };
     // m: samples in which row i spiked (nullptr-safe: `zeros`), cq: samples in which column q spiked
@@ -406,10 +406,11 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
 
 // CASC: MulticompartmentConnection (ATen cascade order) vs dense Connection (ascending sequential order);
 // RULE: the connection's learning rule.  Compile-time so that each variant carries only its own code (and registers).
-template <bool CASC, int RULE>
+// MWT: 1 = batch <= 32 (one sample-mask word, compiled without the word loops), 4 = up to 128 samples.
+template <bool CASC, int RULE, int MWT>
 __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW, mw = c.MW, BC = c.BC, CMS = 8 * c.MW;
+    const int B = c.B, Nin = c.Nin, N = c.N, NinW = c.NinW, CW = c.CW, mw = MWT == 1 ? 1 : c.MW, BC = 32 * mw, CMS = 8 * mw;
     size_t off = 0;
     float *wt = (float *)(smem + off); off += (size_t)Nin * CW * 4;                       // own weight slice [Nin][CW]
     int *meta = (int *)(smem + off); off += META * 4;
@@ -524,8 +525,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (t >= 1 && do_stdp) {
             const bool full = (t == 1) || c.wdecay != 1.0f;   // first update of a run (or a real decay) touches every element
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
-            if (Etot != Emain) two_stdp<OuterSum>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
-            else two_stdp<CascT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            if (Etot != Emain) two_stdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            else two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
         }
         TMARK(3);
         lds_barrier();
@@ -641,8 +642,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 __syncthreads();
             }
             const bool full = (t == 0) || c.wdecay != 1.0f;
-            if (Etot != Emain) two_mstdp<OuterSum>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
-            else two_mstdp<CascT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            if (Etot != Emain) two_mstdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
+            else two_mstdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
             lds_barrier();                               // tile and row tables are free for the next iteration
         }
         (void)tot;
@@ -810,9 +811,13 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
     static bool attr = false;
     if (!attr) {
-        const void *variants[6] = {(const void *)k_two_run<true, SNN_RULE_NONE>, (const void *)k_two_run<true, SNN_RULE_POSTPRE>,
-                                   (const void *)k_two_run<false, SNN_RULE_NONE>, (const void *)k_two_run<false, SNN_RULE_POSTPRE>,
-                                   (const void *)k_two_run<false, SNN_RULE_MSTDP>, (const void *)k_two_run<true, SNN_RULE_MSTDP>};
+        const void *variants[12] = {
+            (const void *)k_two_run<true, SNN_RULE_NONE, 1>, (const void *)k_two_run<true, SNN_RULE_POSTPRE, 1>,
+            (const void *)k_two_run<false, SNN_RULE_NONE, 1>, (const void *)k_two_run<false, SNN_RULE_POSTPRE, 1>,
+            (const void *)k_two_run<false, SNN_RULE_MSTDP, 1>, (const void *)k_two_run<true, SNN_RULE_MSTDP, 1>,
+            (const void *)k_two_run<true, SNN_RULE_NONE, 4>, (const void *)k_two_run<true, SNN_RULE_POSTPRE, 4>,
+            (const void *)k_two_run<false, SNN_RULE_NONE, 4>, (const void *)k_two_run<false, SNN_RULE_POSTPRE, 4>,
+            (const void *)k_two_run<false, SNN_RULE_MSTDP, 4>, (const void *)k_two_run<true, SNN_RULE_MSTDP, 4>};
         for (const void *f : variants)
             if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
         if (snn_check(hipFuncSetAttribute((const void *)k_two_prep, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
@@ -831,12 +836,15 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     {
         const dim3 grid(c.G), blk(NT);
         const size_t lds = run_lds(c);
-        if (c.cascade && c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
-        else if (c.cascade && c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_MSTDP>), grid, blk, lds, st, c);
-        else if (c.cascade) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_NONE>), grid, blk, lds, st, c);
-        else if (c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_POSTPRE>), grid, blk, lds, st, c);
-        else if (c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_MSTDP>), grid, blk, lds, st, c);
-        else hipLaunchKernelGGL((k_two_run<false, SNN_RULE_NONE>), grid, blk, lds, st, c);
+#define TWO_LAUNCH(MWV) do { \
+        if (c.cascade && c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_POSTPRE, MWV>), grid, blk, lds, st, c); \
+        else if (c.cascade && c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_MSTDP, MWV>), grid, blk, lds, st, c); \
+        else if (c.cascade) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_NONE, MWV>), grid, blk, lds, st, c); \
+        else if (c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_POSTPRE, MWV>), grid, blk, lds, st, c); \
+        else if (c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_MSTDP, MWV>), grid, blk, lds, st, c); \
+        else hipLaunchKernelGGL((k_two_run<false, SNN_RULE_NONE, MWV>), grid, blk, lds, st, c); } while (0)
+        if (c.MW == 1) TWO_LAUNCH(1); else TWO_LAUNCH(4);
+#undef TWO_LAUNCH
     }
     int rc = snn_check_launch();
     if (rc) return rc;

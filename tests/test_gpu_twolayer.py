@@ -162,7 +162,7 @@ MSTDP_CASES = {
     "b1": (256, 40, 1, 50, 1.0, 0.08, 1),
     "multivalued_source_bytes": (784, 48, 8, 30, 1.0, 0.05, 3),
     "cfg5_shape_short": (6400, 500, 16, 8, 1.0, 0.05, 1),
-    "b48_scalar_reward": (784, 64, 48, 25, 1.0, 0.05, 1),
+    "b48_negative_reward": (784, 64, 48, 25, -0.5, 0.05, 1),
     "b100_reward_vector": (400, 40, 100, 20, "vec", 0.06, 1),
 }
 
