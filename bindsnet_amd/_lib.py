@@ -47,7 +47,8 @@ class ConnDesc(C.Structure):
                 ("s_tgt_prev", C.c_void_p), ("reward", C.c_float), ("reward_vec", C.c_void_p),
                 ("a_plus", C.c_float), ("a_minus", C.c_float), ("decay_plus", C.c_float),
                 ("decay_minus", C.c_float),
-                ("has_norm", C.c_int), ("norm", C.c_float), ("norm_abs", C.c_int), ("norm_ws", C.c_void_p)]
+                ("has_norm", C.c_int), ("norm", C.c_float), ("norm_abs", C.c_int), ("norm_ws", C.c_void_p),
+                ("e_trace", C.c_void_p), ("decay_e", C.c_float), ("tc_e", C.c_float)]
 
 
 class RunDesc(C.Structure):
@@ -64,7 +65,7 @@ class FillSegment(C.Structure):
 MAX_FILL_SEGMENTS = 32
 LAYER_INPUT, LAYER_LIF, LAYER_DC = 0, 1, 2
 CONN_MCC, CONN_DENSE, CONN_CONV2D = 0, 1, 2
-RULE_NONE, RULE_POSTPRE, RULE_MSTDP = 0, 1, 2
+RULE_NONE, RULE_POSTPRE, RULE_MSTDP, RULE_HEBBIAN, RULE_WDPOSTPRE, RULE_MSTDPET = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -82,6 +83,8 @@ _SIGS = {
     "snn_lif_step": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp], _i),
     "snn_dc_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp, _vp], _i),
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
+    "snn_stdp_hebbian": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _i, _f, _i, _f, _vp], _i),
+    "snn_mstdpet_step": ([_vp] * 8 + [_i, _i] + [_f] * 11 + [_i, _f, _i, _f, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
     "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),

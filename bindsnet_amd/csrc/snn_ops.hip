@@ -411,6 +411,8 @@ struct StdpArgs {
     int has_min; float wmin; int has_max; float wmax;
     int assume_clamped;
     // MSTDP (mode 1): x_src = p_plus, x_tgt = p_minus, s_* = previous-step spikes
+    // mode 2: Hebbian (learning.py:1110-1135), mode 3: WeightDependentPostPre (learning.py:626-653): raw outer products
+    // reduced over the batch first, learning rates (and the weight-dependent factors) applied to the sums
     int mode; float reward; const float *reward_vec;
 };
 
@@ -507,6 +509,33 @@ __global__ __launch_bounds__(256) void k_plasticity(StdpArgs a) {
                 if (a.use_dt) u = u * a.dt;
                 w_ = w_ + u;
             }
+        } else if (a.mode == 2 || a.mode == 3) {
+            float u1 = 0.f, u2 = 0.f;
+            {   // U1 = sum_b s_src[b,i] * x_tgt[b,j]
+                OuterSum acc; acc.init(tail);
+                for (int w = 0; w < MW; ++w) {
+                    uint32_t m = mS[ii * MW + w];
+                    while (m) { const int b = w * 32 + __ffs(m) - 1; m &= m - 1; acc.add(b, (float)vS[(size_t)b * kTI + ii] * xt[(size_t)b * TJ + jj], B); }
+                }
+                u1 = acc.finish(B);
+            }
+            {   // U2 = sum_b x_src[b,i] * s_tgt[b,j]
+                OuterSum acc; acc.init(tail);
+                for (int w = 0; w < MW; ++w) {
+                    uint32_t m = mT[jj * MW + w];
+                    while (m) { const int b = w * 32 + __ffs(m) - 1; m &= m - 1; acc.add(b, xs[(size_t)b * kTI + ii] * (float)vT[(size_t)b * TJ + jj], B); }
+                }
+                u2 = acc.finish(B);
+            }
+            if (a.mode == 2) {                          // w += nu0 * U1; w += nu1 * U2
+                w_ = w_ + a.nu0 * u1;
+                w_ = w_ + a.nu1 * u2;
+            } else {                                    // update = 0 - (nu0 U1)(w - wmin) + (nu1 U2)(wmax - w); w += update
+                float upd = 0.f; bool have = false;
+                if (a.nu0 != 0.f) { upd = 0.0f - (a.nu0 * u1) * (w_ - a.wmin); have = true; }
+                if (a.nu1 != 0.f) { const float y = (a.nu1 * u2) * (a.wmax - w_); upd = have ? upd + y : y; have = true; }
+                if (have) w_ = w_ + upd;
+            }
         } else {                                        // MSTDP: sum_b reward * elig[b][i,j]
             OuterSum acc; acc.init(tail);
             for (int w = 0; w < MW; ++w) {
@@ -591,6 +620,56 @@ __global__ __launch_bounds__(256) void k_mstdp_traces(float *__restrict__ p_plus
             s_tgt_prev[q] = sv;
         }
     }
+}
+
+extern "C" int snn_stdp_hebbian(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                                int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay, int has_min,
+                                float wmin, int has_max, float wmax, snn_stream_t stream) {
+    if (!W || !s_src || !x_src || !s_tgt || !x_tgt || B <= 0 || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (weight_dependent && !(has_min && has_max)) return SNN_ERR_INVALID;      // learning.py:600-602: finite wmin and wmax
+    if (B > 256) return SNN_ERR_UNSUPPORTED;
+    StdpArgs a{W, s_src, x_src, s_tgt, x_tgt, B, Nin, N, nu0, nu1, 0, 1.f, decay, has_min, wmin, has_max, wmax, 0,
+               weight_dependent ? 3 : 2, 0.f, nullptr};
+    return launch_plasticity(a, (hipStream_t)stream);
+}
+
+// MSTDPET (learning.py:2187-2248, batch 1): the eligibility TRACE is genuinely dense state; the point eligibility is the
+// rank-2 expression of the previous step's factors and is formed on the fly.
+__global__ __launch_bounds__(256) void k_mstdpet(float *__restrict__ W, float *__restrict__ e_trace, const float *__restrict__ p_plus,
+                                                 const float *__restrict__ p_minus, const uint8_t *__restrict__ s_src_prev,
+                                                 const uint8_t *__restrict__ s_tgt_prev, int Nin, int N, float scale, float decay_e,
+                                                 float tc_e, float wdecay, int has_min, float wmin, int has_max, float wmax) {
+    const long E = (long)Nin * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / N), j = (int)(e - (long)i * N);
+        const float el = p_plus[i] * (float)s_tgt_prev[j] + (float)s_src_prev[i] * p_minus[j];    // :2241-2243
+        float et = e_trace[e] * decay_e;                // :2223
+        et = et + el / tc_e;                            // :2224
+        e_trace[e] = et;
+        float w = W[e] + scale * et;                    // :2226-2230
+        w = w * wdecay;
+        if (has_min && w < wmin) w = wmin;
+        if (has_max && w > wmax) w = wmax;
+        W[e] = w;
+    }
+}
+
+extern "C" int snn_mstdpet_step(float *W, float *e_trace, float *p_plus, float *p_minus, uint8_t *s_src_prev, uint8_t *s_tgt_prev,
+                                const uint8_t *s_src, const uint8_t *s_tgt, int Nin, int N, float reward, float nu0, float dt,
+                                float a_plus, float a_minus, float decay_plus, float decay_minus, float decay_e, float tc_e,
+                                float wdecay, int has_min, float wmin, int has_max, float wmax, snn_stream_t stream) {
+    if (!W || !e_trace || !p_plus || !p_minus || !s_src_prev || !s_tgt_prev || !s_src || !s_tgt || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
+    const long E = (long)Nin * N;
+    const unsigned grid = (unsigned)((E + 255) / 256 < 4096 ? (E + 255) / 256 : 4096);
+    const float scale = (nu0 * dt) * reward;            // ((nu[0] * dt) * reward) * eligibility_trace
+    hipLaunchKernelGGL(k_mstdpet, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, e_trace, p_plus, p_minus, s_src_prev, s_tgt_prev,
+                       Nin, N, scale, decay_e, tc_e, wdecay, has_min, wmin, has_max, wmax);
+    int rc = snn_check_launch();
+    if (rc) return rc;
+    const long n = (long)Nin + N;
+    hipLaunchKernelGGL(k_mstdp_traces, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_plus, p_minus, s_src_prev,
+                       s_tgt_prev, s_src, s_tgt, (long)Nin, (long)N, a_plus, a_minus, decay_plus, decay_minus);
+    return snn_check_launch();
 }
 
 extern "C" int snn_mstdp_step(float *W, float *p_plus, float *p_minus, uint8_t *s_src_prev, uint8_t *s_tgt_prev,

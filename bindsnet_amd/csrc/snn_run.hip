@@ -97,7 +97,10 @@ static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
         if (L[d.dst].kind == SNN_LAYER_INPUT) return SNN_ERR_UNSUPPORTED;
         if (d.rule != SNN_RULE_NONE && d.kind == SNN_CONN_CONV2D) return SNN_ERR_UNSUPPORTED;
         if (d.rule == SNN_RULE_POSTPRE && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
-        if (d.rule == SNN_RULE_MSTDP && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
+        if ((d.rule == SNN_RULE_MSTDP || d.rule == SNN_RULE_MSTDPET) && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
+        if ((d.rule == SNN_RULE_HEBBIAN || d.rule == SNN_RULE_WDPOSTPRE) && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
+        if (d.rule == SNN_RULE_MSTDPET && (!d.e_trace || R->B != 1)) return SNN_ERR_INVALID;
+        if (d.rule < SNN_RULE_NONE || d.rule > SNN_RULE_MSTDPET) return SNN_ERR_INVALID;
         if (d.has_norm && (!d.norm_ws || d.kind == SNN_CONN_CONV2D)) return SNN_ERR_INVALID;
     }
     return SNN_OK;
@@ -162,6 +165,13 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 if (d.rule == SNN_RULE_POSTPRE)
                     TRY(snn_stdp_postpre(d.w, ss, S.x, D.s, D.x, B, S.n, D.n, d.nu0, d.nu1, d.use_dt, R->dt, d.wdecay,
                                          d.has_min, d.wmin, d.has_max, d.wmax, /*assume_clamped=*/t > 0, st));
+                else if (d.rule == SNN_RULE_HEBBIAN || d.rule == SNN_RULE_WDPOSTPRE)
+                    TRY(snn_stdp_hebbian(d.w, ss, S.x, D.s, D.x, B, S.n, D.n, d.nu0, d.nu1, d.rule == SNN_RULE_WDPOSTPRE, d.wdecay,
+                                         d.has_min, d.wmin, d.has_max, d.wmax, st));
+                else if (d.rule == SNN_RULE_MSTDPET)
+                    TRY(snn_mstdpet_step(d.w, d.e_trace, d.p_plus, d.p_minus, d.s_src_prev, d.s_tgt_prev, ss, D.s, S.n, D.n, d.reward,
+                                         d.nu0, R->dt, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus, d.decay_e, d.tc_e, d.wdecay,
+                                         d.has_min, d.wmin, d.has_max, d.wmax, st));
                 else
                     TRY(snn_mstdp_step(d.w, d.p_plus, d.p_minus, d.s_src_prev, d.s_tgt_prev, ss, D.s, B, S.n, D.n,
                                        d.reward, d.reward_vec, d.nu0, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus,

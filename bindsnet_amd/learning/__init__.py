@@ -1,3 +1,3 @@
-from .learning import LearningRule, MSTDP, NoOp, PostPre
+from .learning import Hebbian, LearningRule, MSTDP, MSTDPET, NoOp, PostPre, WeightDependentPostPre
 
-__all__ = ["LearningRule", "NoOp", "PostPre", "MSTDP"]
+__all__ = ["LearningRule", "NoOp", "PostPre", "WeightDependentPostPre", "Hebbian", "MSTDP", "MSTDPET"]

@@ -1,5 +1,6 @@
-"""Learning rules for dense `Connection`s: API mirror of bindsnet/learning/learning.py for
-`LearningRule`, `NoOp`, `PostPre`, `MSTDP`.  Updates run in snn_stdp_postpre / snn_mstdp_step."""
+"""Learning rules for dense `Connection`s: API mirror of bindsnet/learning/learning.py for `LearningRule`, `NoOp`,
+`PostPre`, `WeightDependentPostPre`, `Hebbian`, `MSTDP`, `MSTDPET`.  Updates run in snn_stdp_postpre /
+snn_stdp_hebbian / snn_mstdp_step / snn_mstdpet_step."""
 import warnings
 from typing import Optional, Sequence, Union
 
@@ -131,3 +132,91 @@ class MSTDP(LearningRule):
         self._ensure_state()
         return (self.p_plus.unsqueeze(2) * self._s_tgt_prev.float().unsqueeze(1)
                 + self._s_src_prev.float().unsqueeze(2) * self.p_minus.unsqueeze(1))
+
+
+class _OuterProductRule(LearningRule):
+    """Shared part of Hebbian / WeightDependentPostPre: raw outer products reduced over the batch, then scaled."""
+    _weight_dependent = False
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        from ..network.topology import Connection
+        if not isinstance(connection, Connection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        self._check_reduction()
+        B = self.source.batch_size
+        lo, hi = self._bounds()
+        ops.stdp_hebbian(self.connection.w.data, self.source.s.reshape(B, -1).contiguous(), self.source.x.reshape(B, -1),
+                         self.target.s.reshape(B, -1), self.target.x.reshape(B, -1), float(self.nu[0]), float(self.nu[1]),
+                         weight_dependent=self._weight_dependent, decay=float(self.weight_decay), wmin=lo, wmax=hi)
+
+
+class Hebbian(_OuterProductRule):
+    """Both the pre- and the post-synaptic term potentiate (reference: learning.py:1052-1135)."""
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        assert self.source.traces and self.target.traces, "Both pre- and post-synaptic nodes must record spike traces."
+
+
+class WeightDependentPostPre(_OuterProductRule):
+    """PostPre whose depression scales with (w - wmin) and potentiation with (wmax - w) (reference: learning.py:562-653)."""
+    _weight_dependent = True
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        assert self.source.traces, "Pre-synaptic nodes must record spike traces."
+        assert (connection.wmin != -np.inf).any() and (connection.wmax != np.inf).any(), \
+            "Connection must define finite wmin and wmax."
+        if not self.target.traces:
+            raise NotImplementedError("bindsnet_amd: WeightDependentPostPre needs spike traces on the target layer too "
+                                      "(the update reads target.x)")
+
+
+class MSTDPET(LearningRule):
+    """Reward-modulated STDP with an eligibility trace (reference: learning.py:2124-2248); like the reference's dense
+    form it is defined for batch size 1.  `eligibility_trace` is the rule's dense [Nin, N] state on the device."""
+
+    def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
+        super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
+        from ..network.topology import Connection
+        if not isinstance(connection, Connection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
+        self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
+        self.tc_e_trace = torch.tensor(kwargs.get("tc_e_trace", 25.0))
+
+    def _ensure_state(self):
+        dev = self.connection.w.device
+        if not hasattr(self, "p_plus") or self.p_plus.device != dev:
+            self.p_plus = torch.zeros(self.source.n, device=dev)
+            self.p_minus = torch.zeros(self.target.n, device=dev)
+            self.eligibility_trace = torch.zeros(*self.connection.w.shape, device=dev)
+            self._s_src_prev = torch.zeros(self.source.n, dtype=torch.uint8, device=dev)
+            self._s_tgt_prev = torch.zeros(self.target.n, dtype=torch.uint8, device=dev)
+
+    def _decays(self):
+        dt = torch.tensor(self.connection.dt)
+        return (float(torch.exp(-dt / self.tc_plus)), float(torch.exp(-dt / self.tc_minus)),
+                float(torch.exp(-dt / self.tc_e_trace)))
+
+    @property
+    def eligibility(self) -> torch.Tensor:
+        self._ensure_state()
+        return torch.outer(self.p_plus, self._s_tgt_prev.float()) + torch.outer(self._s_src_prev.float(), self.p_minus)
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        if self.source.batch_size != 1:
+            raise NotImplementedError("MSTDPET on a dense Connection is defined for batch size 1 (learning.py:2211-2212)")
+        self._ensure_state()
+        dp, dm, de = self._decays()
+        lo, hi = self._bounds()
+        ops.mstdpet_step(self.connection.w.data, self.eligibility_trace, self.p_plus, self.p_minus, self._s_src_prev,
+                         self._s_tgt_prev, self.source.s.reshape(-1).contiguous(), self.target.s.reshape(-1), float(kwargs["reward"]),
+                         float(self.nu[0]), float(self.connection.dt), float(kwargs.get("a_plus", 1.0)),
+                         float(kwargs.get("a_minus", -1.0)), dp, dm, de, float(self.tc_e_trace),
+                         wdecay=float(self.weight_decay), wmin=lo, wmax=hi)

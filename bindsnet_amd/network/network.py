@@ -422,6 +422,31 @@ class Network(torch.nn.Module):
                     raise KeyError("reward")
                 rule._ensure_state()
                 self._fill_mstdp(d, rule, kwargs, dev, keep)
+        elif isinstance(rule, (dense_rules.Hebbian, dense_rules.WeightDependentPostPre)):
+            rule._check_reduction()
+            lo, hi = rule._bounds()
+            d.rule = _lib.RULE_WDPOSTPRE if isinstance(rule, dense_rules.WeightDependentPostPre) else _lib.RULE_HEBBIAN
+            d.wdecay = float(rule.weight_decay)
+            d.has_min, d.wmin = int(lo is not None), lo or 0.0
+            d.has_max, d.wmax = int(hi is not None), hi or 0.0
+            d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+        elif isinstance(rule, dense_rules.MSTDPET):
+            if B != 1:
+                raise NotImplementedError("MSTDPET on a dense Connection is defined for batch size 1 (learning.py:2211-2212)")
+            if "reward" not in kwargs:
+                raise KeyError("reward")
+            rule._ensure_state()
+            lo, hi = rule._bounds()
+            d.wdecay = float(rule.weight_decay)
+            d.has_min, d.wmin = int(lo is not None), lo or 0.0
+            d.has_max, d.wmax = int(hi is not None), hi or 0.0
+            d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+            dp, dm, de = rule._decays()
+            d.rule, d.reward = _lib.RULE_MSTDPET, float(kwargs["reward"])
+            d.a_plus, d.a_minus = float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0))
+            d.decay_plus, d.decay_minus, d.decay_e, d.tc_e = dp, dm, de, float(rule.tc_e_trace)
+            d.p_plus, d.p_minus, d.e_trace = _dptr(rule.p_plus), _dptr(rule.p_minus), _dptr(rule.eligibility_trace)
+            d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
         elif not isinstance(rule, dense_rules.NoOp):
             raise NotImplementedError(f"bindsnet_amd: rule {type(rule).__name__} is not supported")
         elif rule.weight_decay != 1.0 and self.learning:

@@ -122,6 +122,26 @@ def mstdp_step(W, p_plus, p_minus, s_src_prev, s_tgt_prev, s_src, s_tgt, reward,
                                int(wmax is not None), 0.0 if wmax is None else wmax, _stream()), "mstdp_step")
 
 
+def stdp_hebbian(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, weight_dependent=False, decay=1.0, wmin=None, wmax=None):
+    """f3: Hebbian (weight_dependent=False) / WeightDependentPostPre (True) on a dense weight matrix."""
+    B = s_src.shape[0]
+    Nin, N = W.shape
+    check(lib().snn_stdp_hebbian(_ptr(W, F32), _ptr(s_src, "spike"), _ptr(x_src, F32), _ptr(s_tgt, "spike"), _ptr(x_tgt, F32),
+                                 B, Nin, N, nu0, nu1, int(weight_dependent), decay, int(wmin is not None),
+                                 0.0 if wmin is None else wmin, int(wmax is not None), 0.0 if wmax is None else wmax, _stream()),
+          "stdp_hebbian")
+
+
+def mstdpet_step(W, e_trace, p_plus, p_minus, s_src_prev, s_tgt_prev, s_src, s_tgt, reward, nu0, dt, a_plus, a_minus,
+                 decay_plus, decay_minus, decay_e, tc_e, wdecay=1.0, wmin=None, wmax=None):
+    Nin, N = W.shape
+    check(lib().snn_mstdpet_step(_ptr(W, F32), _ptr(e_trace, F32), _ptr(p_plus, F32), _ptr(p_minus, F32), _ptr(s_src_prev, "spike"),
+                                 _ptr(s_tgt_prev, "spike"), _ptr(s_src, "spike"), _ptr(s_tgt, "spike"), Nin, N, reward, nu0, dt,
+                                 a_plus, a_minus, decay_plus, decay_minus, decay_e, tc_e, wdecay, int(wmin is not None),
+                                 0.0 if wmin is None else wmin, int(wmax is not None), 0.0 if wmax is None else wmax, _stream()),
+          "mstdpet_step")
+
+
 def normalize(W, norm, use_abs, ws=None):
     Nin, N = W.shape
     if ws is None:

@@ -29,7 +29,7 @@ def _learned(network):
             if type(rule).__name__ == "PostPre":
                 lo, hi = rule._bounds()
                 out.append((feat.value.data, lo, hi, feat))
-        elif type(conn.update_rule).__name__ in ("PostPre", "MSTDP"):
+        elif type(conn.update_rule).__name__ in ("PostPre", "MSTDP", "Hebbian", "WeightDependentPostPre", "MSTDPET"):
             lo, hi = conn.update_rule._bounds()
             out.append((conn.w.data, lo, hi, conn))
     return out

@@ -173,6 +173,26 @@ int snn_mstdp_step(float *W, float *p_plus, float *p_minus,
                    float decay_plus, float decay_minus, float wdecay,
                    int has_min, float wmin, int has_max, float wmax, snn_stream_t stream);
 
+/* ---- f3: Hebbian / WeightDependentPostPre (dense Connection) --------------------------------------
+ * bindsnet/learning/learning.py:1110-1135 and :626-653 (+ LearningRule.update :87-104).  U1 = sum_b s_src (x) x_tgt,
+ * U2 = sum_b x_src (x) s_tgt (ATen batch-sum order), then
+ *   weight_dependent = 0:  W += nu0 * U1;  W += nu1 * U2
+ *   weight_dependent = 1:  update = 0 - (nu0 U1)(W - wmin) + (nu1 U2)(wmax - W);  W += update   (needs both bounds)
+ * followed by W *= decay and the clamp.  Limits: B <= 256.                                              */
+int snn_stdp_hebbian(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                     int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay,
+                     int has_min, float wmin, int has_max, float wmax, snn_stream_t stream);
+
+/* ---- f3: MSTDPET (dense Connection, batch 1) -----------------------------------------------------------
+ * bindsnet/learning/learning.py:2187-2248.  e_trace [Nin,N] is the rule's dense eligibility trace (in/out); the point
+ * eligibility is p_plus (x) s_tgt_prev + s_src_prev (x) p_minus of the previous call's factors, formed on the fly.
+ * Order: e_trace = e_trace * decay_e + elig / tc_e;  W += ((nu0 * dt) * reward) * e_trace;  W *= wdecay; clamp;
+ * then p_plus / p_minus / *_prev advance as in snn_mstdp_step.                                           */
+int snn_mstdpet_step(float *W, float *e_trace, float *p_plus, float *p_minus, uint8_t *s_src_prev, uint8_t *s_tgt_prev,
+                     const uint8_t *s_src, const uint8_t *s_tgt, int Nin, int N, float reward, float nu0, float dt,
+                     float a_plus, float a_minus, float decay_plus, float decay_minus, float decay_e, float tc_e,
+                     float wdecay, int has_min, float wmin, int has_max, float wmax, snn_stream_t stream);
+
 /* ---- a11: normalize -------------------------------------------------------------------------
  * AbstractFeature.normalize, bindsnet/network/topology_features.py:250-266 (use_abs = 0) and
  * Connection.normalize, bindsnet/network/topology.py:383-392 (use_abs = 1).
@@ -211,7 +231,8 @@ int snn_fill_segments(const snn_fill_segment *h_segs, int n, snn_stream_t stream
  * order, which fixes the evaluation order exactly as the reference's dict iteration does.   */
 enum { SNN_LAYER_INPUT = 0, SNN_LAYER_LIF = 1, SNN_LAYER_DC = 2 };
 enum { SNN_CONN_MCC = 0, SNN_CONN_DENSE = 1, SNN_CONN_CONV2D = 2 };
-enum { SNN_RULE_NONE = 0, SNN_RULE_POSTPRE = 1, SNN_RULE_MSTDP = 2 };
+enum { SNN_RULE_NONE = 0, SNN_RULE_POSTPRE = 1, SNN_RULE_MSTDP = 2, SNN_RULE_HEBBIAN = 3, SNN_RULE_WDPOSTPRE = 4,
+       SNN_RULE_MSTDPET = 5 };
 
 typedef struct {
     int kind;                   /* SNN_LAYER_* */
@@ -241,6 +262,8 @@ typedef struct {
     float reward; const float *reward_vec; float a_plus, a_minus, decay_plus, decay_minus;
     int has_norm; float norm; int norm_abs;   /* post-run normalisation (norm_abs: Connection) */
     float *norm_ws;             /* [N] scratch when has_norm */
+    float *e_trace;             /* MSTDPET: dense eligibility trace [Nin,N] */
+    float decay_e, tc_e;        /* MSTDPET: exp(-dt / tc_e_trace), tc_e_trace */
 } snn_conn_desc;
 
 typedef struct {

@@ -49,7 +49,7 @@ class TwoParams(C.Structure):
         ("wmin", C.c_float), ("wmax", C.c_float), ("has_norm", C.c_int), ("norm", C.c_float),
         ("reward", C.c_float), ("a_plus", C.c_float), ("a_minus", C.c_float),
         ("decay_plus", C.c_float), ("decay_minus", C.c_float),
-        ("learning", C.c_int), ("mcc", C.c_int),
+        ("learning", C.c_int), ("decay_e", C.c_float), ("tc_e", C.c_float), ("mcc", C.c_int),
     ]
 
 
@@ -155,6 +155,22 @@ def mstdp(W, elig, p_plus, p_minus, s_src, s_tgt, *, reward, nu0, a_plus=1.0, a_
                     ci(wmin is not None), cf(wmin or 0.0), ci(wmax is not None), cf(wmax or 0.0))
 
 
+def hebbian_wdpp(W, s_src, x_src, s_tgt, x_tgt, *, nu0, nu1, weight_dependent, decay=1.0, wmin=None, wmax=None):
+    B, Nin = s_src.shape
+    N = s_tgt.shape[1]
+    lib().orc_hebbian_wdpp(_p(W, f32), _p(s_src, u8), _p(x_src, f32), _p(s_tgt, u8), _p(x_tgt, f32), ci(B), ci(Nin), ci(N),
+                           cf(nu0), cf(nu1), ci(int(weight_dependent)), cf(decay), ci(wmin is not None), cf(wmin or 0.0),
+                           ci(wmax is not None), cf(wmax or 0.0))
+
+
+def mstdpet(W, elig, e_trace, p_plus, p_minus, s_src, s_tgt, *, reward, nu0, dt=1.0, a_plus=1.0, a_minus=-1.0, decay_plus,
+            decay_minus, decay_e, tc_e, wdecay=1.0, wmin=None, wmax=None):
+    Nin, N = W.shape
+    lib().orc_mstdpet(_p(W, f32), _p(elig, f32), _p(e_trace, f32), _p(p_plus, f32), _p(p_minus, f32), _p(s_src, u8), _p(s_tgt, u8),
+                      ci(Nin), ci(N), cf(reward), cf(nu0), cf(dt), cf(a_plus), cf(a_minus), cf(decay_plus), cf(decay_minus),
+                      cf(decay_e), cf(tc_e), cf(wdecay), ci(wmin is not None), cf(wmin or 0.0), ci(wmax is not None), cf(wmax or 0.0))
+
+
 def normalize(W, norm, use_abs):
     Nin, N = W.shape
     lib().orc_normalize(_p(W, f32), ci(Nin), ci(N), cf(norm), ci(int(use_abs)))
@@ -185,7 +201,7 @@ def run_two_layer(P: TwoParams, st: dict, inputs, I_forced=None, bias=None):
     lib().orc_run_two_layer(C.byref(P), _p(st["W"], f32), _p(bias, f32), _p(inputs, u8), _p(st["sX"], u8),
                             _p(st["xX"], f32), _p(st["vY"], f32), _p(st["rY"], f32), _p(st["sY"], u8),
                             _p(st.get("xY"), f32), _p(st.get("elig"), f32), _p(st.get("p_plus"), f32),
-                            _p(st.get("p_minus"), f32), _p(I_forced, f32), _p(ras, u8))
+                            _p(st.get("p_minus"), f32), _p(I_forced, f32), _p(ras, u8), _p(st.get("e_trace"), f32))
     return ras
 
 

@@ -303,6 +303,75 @@ ORC_API void orc_postpre(float *W, const uint8_t *s_src, const float *x_src,
         }
 }
 
+/* f3: Hebbian._connection_update (learning.py:1110-1135) and WeightDependentPostPre._connection_update
+ * (learning.py:626-653) on a dense Connection, then LearningRule.update (:87-104: *= weight_decay, clamp).
+ * Both reduce the raw outer products s_src (x) x_tgt and x_src (x) s_tgt over the batch first (bmm with K = 1 is one
+ * exact multiply per element; torch.sum(dim=0) order) and scale afterwards:
+ *   Hebbian:  w += nu0 * U1;  w += nu1 * U2
+ *   WDPP:     update = 0 - (nu0 * U1) * (w - wmin)   [if nu0];  update += (nu1 * U2) * (wmax - w)   [if nu1];  w += update */
+static float raw_term(const void *c, long b)
+{
+    const pp_ctx *p = (const pp_ctx *)c;
+    return !p->spike_is_tgt ? (float)p->sp[b * p->ns + p->is] * p->tr[b * p->nt + p->it]
+                            : p->tr[b * p->nt + p->it] * (float)p->sp[b * p->ns + p->is];
+}
+
+ORC_API void orc_hebbian_wdpp(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                              int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay,
+                              int has_min, float wmin, int has_max, float wmax)
+{
+    const long E = (long)Nin * N;
+    for (int i = 0; i < Nin; ++i)
+        for (int j = 0; j < N; ++j) {
+            const long e = (long)i * N + j;
+            float w = W[e];
+            pp_ctx c1 = { s_src, x_tgt, Nin, N, i, j, 1.0f, 0 }, c2 = { s_tgt, x_src, N, Nin, j, i, 1.0f, 1 };
+            if (!weight_dependent) {
+                const float u1 = outer_sum(raw_term, &c1, B, e, E);
+                w = w + nu0 * u1;
+                const float u2 = outer_sum(raw_term, &c2, B, e, E);
+                w = w + nu1 * u2;
+            } else {
+                float upd = 0.f; int have = 0;
+                if (nu0 != 0.f) { const float u1 = outer_sum(raw_term, &c1, B, e, E); upd = 0.0f - (nu0 * u1) * (w - wmin); have = 1; }
+                if (nu1 != 0.f) { const float u2 = outer_sum(raw_term, &c2, B, e, E); const float y = (nu1 * u2) * (wmax - w); upd = have ? upd + y : y; have = 1; }
+                if (have) w = w + upd;
+            }
+            w = w * decay;
+            if (has_min && w < wmin) w = wmin;
+            if (has_max && w > wmax) w = wmax;
+            W[e] = w;
+        }
+}
+
+/* f3: MSTDPET._connection_update, learning.py:2187-2248 (batch size 1: the reference flattens the spikes).
+ * elig / e_trace are the reference's dense [Nin,N] tensors.  Order: e_trace *= exp(-dt/tc_e); e_trace += elig / tc_e;
+ * w += ((nu0 * dt) * reward) * e_trace; p_plus / p_minus; elig = p_plus (x) s_tgt + s_src (x) p_minus; decay; clamp. */
+ORC_API void orc_mstdpet(float *W, float *elig, float *e_trace, float *p_plus, float *p_minus,
+                         const uint8_t *s_src, const uint8_t *s_tgt, int Nin, int N, float reward, float nu0, float dt,
+                         float a_plus, float a_minus, float decay_plus, float decay_minus, float decay_e, float tc_e,
+                         float wdecay, int has_min, float wmin, int has_max, float wmax)
+{
+    const float scale = (nu0 * dt) * reward;
+    for (long e = 0; e < (long)Nin * N; ++e) {
+        float et = e_trace[e] * decay_e;
+        et = et + elig[e] / tc_e;
+        e_trace[e] = et;
+        W[e] = W[e] + scale * et;
+    }
+    for (int i = 0; i < Nin; ++i) { const float p = p_plus[i] * decay_plus; p_plus[i] = p + a_plus * (float)s_src[i]; }
+    for (int j = 0; j < N; ++j) { const float p = p_minus[j] * decay_minus; p_minus[j] = p + a_minus * (float)s_tgt[j]; }
+    for (int i = 0; i < Nin; ++i)
+        for (int j = 0; j < N; ++j)
+            elig[(long)i * N + j] = p_plus[i] * (float)s_tgt[j] + (float)s_src[i] * p_minus[j];
+    for (long e = 0; e < (long)Nin * N; ++e) {
+        float w = W[e] * wdecay;
+        if (has_min && w < wmin) w = wmin;
+        if (has_max && w > wmax) w = wmax;
+        W[e] = w;
+    }
+}
+
 /* a10: MSTDP._connection_update, bindsnet/learning/learning.py:1504-1574.
  * elig is the dense [B,Nin,N] eligibility of the reference (kept dense here on purpose). */
 typedef struct { const float *elig; long E; long e; float reward; const float *reward_vec; } ms_ctx;
@@ -447,7 +516,8 @@ ORC_API int orc_run_dc2015(const orc_dc_params *P,
 
 /* a1 (dense family): Input -> Connection -> LIFNodes with PostPre or MSTDP, the graph of
  * TwoLayerNetwork (bindsnet/models/models.py:21-91) and of cfg5.
- * rule: 0 none, 1 PostPre (learning.py:390-420), 2 MSTDP (learning.py:1504-1574). */
+ * rule: 0 none, 1 PostPre (learning.py:390-420), 2 MSTDP (learning.py:1504-1574), 3 Hebbian (:1110-1135),
+ *       4 WeightDependentPostPre (:626-653), 5 MSTDPET (:2187-2248, batch 1; `elig` / `e_trace` are [Nin,N]). */
 typedef struct {
     int B, Nin, N, T, rule;
     float dt;
@@ -456,6 +526,7 @@ typedef struct {
     float nu0, nu1; int has_min, has_max; float wmin, wmax; int has_norm; float norm;
     float reward, a_plus, a_minus, decay_plus, decay_minus;
     int learning;
+    float decay_e, tc_e;   /* MSTDPET: exp(-dt / tc_e_trace), tc_e_trace */
     int mcc;    /* 1: MulticompartmentConnection + Weight instead of a dense Connection: propagation in ATen's sum(dim=1)
                    order (topology.py:437-479), PostPre scaled by dt (MCC_learning.py:224-302), MSTDP as
                    MCC_learning.py:468-551 (same arithmetic as learning.py:1504-1574), signed column sums in normalize
@@ -467,7 +538,7 @@ ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *b
                                float *vY, float *rY, uint8_t *sY, float *xY,
                                float *elig, float *p_plus, float *p_minus,
                                const float *I_forced,   /* optional [T,B,N] teacher-forced currents */
-                               uint8_t *rasterY)
+                               uint8_t *rasterY, float *e_trace)
 {
     const int B = P->B, Nin = P->Nin, N = P->N;
     float *I = (float *)malloc(sizeof(float) * (size_t)B * N);
@@ -488,6 +559,12 @@ ORC_API void orc_run_two_layer(const orc_two_params *P, float *W, const float *b
             orc_mstdp(W, elig, p_plus, p_minus, sX, sY, B, Nin, N, P->reward, NULL, P->nu0,
                       P->a_plus, P->a_minus, P->decay_plus, P->decay_minus, 1.0f,
                       P->has_min, P->wmin, P->has_max, P->wmax);
+        else if (P->learning && (P->rule == 3 || P->rule == 4))
+            orc_hebbian_wdpp(W, sX, xX, sY, xY, B, Nin, N, P->nu0, P->nu1, P->rule == 4, 1.0f,
+                             P->has_min, P->wmin, P->has_max, P->wmax);
+        else if (P->learning && P->rule == 5)
+            orc_mstdpet(W, elig, e_trace, p_plus, p_minus, sX, sY, Nin, N, P->reward, P->nu0, P->dt, P->a_plus, P->a_minus,
+                        P->decay_plus, P->decay_minus, P->decay_e, P->tc_e, 1.0f, P->has_min, P->wmin, P->has_max, P->wmax);
         if (rasterY) memcpy(rasterY + (long)t * B * N, sY, (size_t)B * N);
     }
     if (P->has_norm) orc_normalize(W, Nin, N, P->norm, P->mcc ? 0 : 1);

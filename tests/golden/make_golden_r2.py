@@ -101,8 +101,56 @@ def net_monitor_b1_case():
     save("net_monitor_b1", N=N, T=T, **out)
 
 
+RULE_CASES = [(1, 40, 24), (3, 40, 24), (16, 40, 24), (32, 40, 24), (48, 40, 24), (5, 33, 31)]     # (B, Nin, N)
+
+
+def rule_inputs(k, B, Nin, N):
+    return (synth.uniform_f32(300 + k, (Nin, N), 0.0, 1.0), synth.dense_spikes(400 + k, (B, Nin), 0.3),
+            synth.dense_spikes(500 + k, (B, N), 0.2), synth.uniform_f32(600 + k, (B, Nin), 0.0, 1.0),
+            synth.uniform_f32(700 + k, (B, N), 0.0, 1.0))
+
+
+def rules_case():
+    """Single update() calls of the dense rules beyond PostPre / MSTDP (learning.py:562-653 WeightDependentPostPre,
+    :1052-1135 Hebbian) and a 12-step sequence of MSTDPET (:2124-2248, batch 1)."""
+    from bindsnet.learning import Hebbian, MSTDPET, WeightDependentPostPre
+    from make_golden import Connection, _set_layer
+    out = {}
+    for k, (B, Nin, N) in enumerate(RULE_CASES):
+        W0, s_src, s_tgt, x_src, x_tgt = rule_inputs(k, B, Nin, N)
+        for tag, rule, kw in (("hebb", Hebbian, dict(wmin=0.0, wmax=1.0)), ("hebb_free", Hebbian, dict()),
+                              ("wdpp", WeightDependentPostPre, dict(wmin=0.0, wmax=1.0)),
+                              ("wdpp_decay", WeightDependentPostPre, dict(wmin=-0.5, wmax=1.5, weight_decay=0.01))):
+            src, tgt = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+            conn = Connection(src, tgt, w=T_(W0).clone(), update_rule=rule, nu=(1e-2, 3e-2), reduction=torch.sum, **kw)
+            _set_layer(src, B, s_src, x_src)
+            _set_layer(tgt, B, s_tgt.astype(bool), x_tgt)
+            conn.update(learning=True)
+            out[f"{tag}{k}"] = conn.w.detach().numpy().copy()
+    # MSTDPET: batch 1, a sequence of updates (the eligibility trace integrates over steps)
+    Nin, N, T = 36, 20, 12
+    src, tgt = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    conn = Connection(src, tgt, w=T_(synth.uniform_f32(900, (Nin, N), 0.0, 1.0)).clone(), update_rule=MSTDPET, nu=(1e-1, 1e-1),
+                      wmin=0.0, wmax=1.0, tc_e_trace=25.0)
+    conn.dt = 1.0
+    for t in range(T):
+        _set_layer(src, 1, synth.dense_spikes(910 + t, (1, Nin), 0.2), None)
+        _set_layer(tgt, 1, synth.dense_spikes(940 + t, (1, N), 0.2).astype(bool), None)
+        conn.update(learning=True, reward=0.7 if t % 3 else -0.4)
+    ur = conn.update_rule
+    out.update(et_w=conn.w.detach().numpy().copy(), et_trace=ur.eligibility_trace.numpy().copy(), et_elig=ur.eligibility.numpy().copy(),
+               et_p_plus=ur.p_plus.numpy().copy(), et_p_minus=ur.p_minus.numpy().copy(),
+               et_decay_plus=torch.exp(-torch.tensor(1.0) / ur.tc_plus).numpy(), et_decay_minus=torch.exp(-torch.tensor(1.0) / ur.tc_minus).numpy(),
+               et_decay_e=torch.exp(-torch.tensor(1.0) / ur.tc_e_trace).numpy(), et_tc_e=ur.tc_e_trace.numpy())
+    save("op_rules", cases=np.array(RULE_CASES), **out)
+
+
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "monitor"]
+    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules"]
+    if "rules" in jobs:
+        torch.set_num_threads(1)
+        rules_case()
+        torch.set_num_threads(8)
     if "mstdp" in jobs:
         mcc_mstdp_case("run_two_mcc_mstdp_b4", 196, 48, 4, 40)
         mcc_mstdp_case("run_two_mcc_mstdp_b20", 196, 37, 20, 30)

@@ -1,0 +1,124 @@
+"""Dense learning rules beyond PostPre / MSTDP: Hebbian, WeightDependentPostPre, MSTDPET.
+ * single update() calls through the rule classes against the reference's own results (tests/golden/op_rules.npz);
+ * whole Network.run() calls (generic plan: snn_stdp_hebbian / snn_mstdpet_step every timestep) against the oracle's
+   run driver, which tests/test_oracle_golden.py pins to the same fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from cases import f32, u8, gold
+from test_oracle_golden import RULE_VARIANTS, rule_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def layers(B, Nin, N, s_src, x_src, s_tgt, x_tgt):
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    src, tgt = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    for l, s, x in ((src, s_src, x_src), (tgt, s_tgt, x_tgt)):
+        l.batch_size = B
+        l.s = dev(s)
+        if x is not None:
+            l.x = dev(x)
+    return src, tgt
+
+
+@pytest.mark.parametrize("tag", list(RULE_VARIANTS))
+def test_hebbian_and_weight_dependent_postpre_update_vs_reference(tag):
+    from bindsnet_amd.learning import Hebbian, WeightDependentPostPre
+    from bindsnet_amd.network.topology import Connection
+    g = gold("op_rules")
+    wd, decay, lo, hi = RULE_VARIANTS[tag]
+    for k, (B, Nin, N) in enumerate(g["cases"]):
+        B, Nin, N = int(B), int(Nin), int(N)
+        W0, s_src, s_tgt, x_src, x_tgt = rule_inputs(k, B, Nin, N)
+        src, tgt = layers(B, Nin, N, s_src, x_src, s_tgt, x_tgt)
+        kw = {} if lo is None else dict(wmin=lo, wmax=hi)
+        if decay != 1.0:
+            kw["weight_decay"] = 0.01
+        conn = Connection(src, tgt, w=torch.from_numpy(W0).clone(), update_rule=WeightDependentPostPre if wd else Hebbian,
+                          nu=(1e-2, 3e-2), reduction=torch.sum, **kw).to(DEV)
+        conn.update(learning=True)
+        np.testing.assert_array_equal(bits(host(conn.w)), bits(g[f"{tag}{k}"]), err_msg=f"{tag} case {k}")
+
+
+def test_mstdpet_update_sequence_vs_reference():
+    from bindsnet_amd.learning import MSTDPET
+    from bindsnet_amd.network.topology import Connection
+    g = gold("op_rules")
+    Nin, N, T = 36, 20, 12
+    src, tgt = layers(1, Nin, N, np.zeros((1, Nin), u8), None, np.zeros((1, N), u8), None)
+    conn = Connection(src, tgt, w=torch.from_numpy(synth.uniform_f32(900, (Nin, N), 0.0, 1.0)), update_rule=MSTDPET, nu=(1e-1, 1e-1),
+                      wmin=0.0, wmax=1.0, tc_e_trace=25.0).to(DEV)
+    conn.dt = 1.0
+    for t in range(T):
+        src.s = dev(synth.dense_spikes(910 + t, (1, Nin), 0.2))
+        tgt.s = dev(synth.dense_spikes(940 + t, (1, N), 0.2))
+        conn.update(learning=True, reward=0.7 if t % 3 else -0.4)
+    ur = conn.update_rule
+    for got, key in ((conn.w, "et_w"), (ur.eligibility_trace, "et_trace"), (ur.eligibility, "et_elig"), (ur.p_plus, "et_p_plus"),
+                     (ur.p_minus, "et_p_minus")):
+        np.testing.assert_array_equal(bits(host(got)), bits(g[key]), err_msg=key)
+
+
+@pytest.mark.parametrize("rule", ["hebbian", "wdpp", "mstdpet"])
+def test_network_run_with_the_rule_vs_oracle(rule):
+    from bindsnet_amd.learning import Hebbian, MSTDPET, WeightDependentPostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    Nin, N, T = 196, 48, 40
+    B = 1 if rule == "mstdpet" else 6
+    W0 = synth.weights_q12(11, Nin, N)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True), "Y")
+    cls = {"hebbian": Hebbian, "wdpp": WeightDependentPostPre, "mstdpet": MSTDPET}[rule]
+    nu = (1e-1, 1e-1) if rule == "mstdpet" else (1e-4, 1e-3)
+    conn = Connection(net.layers["X"], net.layers["Y"], w=torch.from_numpy(W0).clone(), wmin=0.0, wmax=1.0, update_rule=cls, nu=nu,
+                      norm=0.1 * Nin, reduction=torch.sum)
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    net.to(DEV)
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    kw = {"reward": 0.8} if rule == "mstdpet" else {}
+    net.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T, **kw)
+    assert net.last_plan == "generic"
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T, P.dt = B, Nin, N, T, 1.0
+    P.rule = {"hebbian": 3, "wdpp": 4, "mstdpet": 5}[rule]
+    P.x_trace_decay = float(net.layers["X"].trace_decay); P.x_trace_scale = 1.0; P.x_traces = 1
+    P.decay = float(net.layers["Y"].decay); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.y_traces = 1; P.y_trace_decay = float(net.layers["Y"].trace_decay); P.y_trace_scale = 1.0
+    P.nu0, P.nu1 = nu
+    P.has_min = P.has_max = 1; P.wmin, P.wmax = 0.0, 1.0; P.has_norm = 1; P.norm = 0.1 * Nin; P.learning = 1
+    st = dict(W=W0.copy(), sX=np.zeros((B, Nin), u8), xX=np.zeros((B, Nin), f32), vY=np.full((B, N), -65.0, f32),
+              rY=np.zeros((B, N), f32), sY=np.zeros((B, N), u8), xY=np.zeros((B, N), f32))
+    if rule == "mstdpet":
+        ur = conn.update_rule
+        dp, dm, de = ur._decays()
+        P.reward, P.a_plus, P.a_minus, P.decay_plus, P.decay_minus, P.decay_e, P.tc_e = 0.8, 1.0, -1.0, dp, dm, de, 25.0
+        st.update(elig=np.zeros((Nin, N), f32), e_trace=np.zeros((Nin, N), f32), p_plus=np.zeros(Nin, f32), p_minus=np.zeros(N, f32))
+    ras = oracle.run_two_layer(P, st, spikes)
+    assert ras.sum() > 20
+    np.testing.assert_array_equal(host(mon.get("s")).reshape(T, B, N).astype(u8), ras)
+    np.testing.assert_array_equal(bits(host(conn.w)), bits(st["W"]))
+    if rule == "mstdpet":
+        np.testing.assert_array_equal(bits(host(conn.update_rule.eligibility_trace)), bits(st["e_trace"]))

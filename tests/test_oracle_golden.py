@@ -268,3 +268,41 @@ def test_mcc_mstdp_run_matches_reference(name):
     np.testing.assert_array_equal(bits(st["p_plus"]), bits(g["r0_p_plus"]))
     np.testing.assert_array_equal(bits(st["p_minus"]), bits(g["r0_p_minus"]))
     assert cases.sha(st["elig"]) == str(g["r0_elig_sha"])
+
+
+# --------------------------------------------------------------------------- Hebbian / WeightDependentPostPre / MSTDPET
+RULE_VARIANTS = {"hebb": (False, 1.0, 0.0, 1.0), "hebb_free": (False, 1.0, None, None), "wdpp": (True, 1.0, 0.0, 1.0),
+                 "wdpp_decay": (True, 1.0 - 0.01, -0.5, 1.5)}      # tag -> (weight dependent, decay factor, wmin, wmax)
+
+
+def rule_inputs(k, B, Nin, N):
+    return (synth.uniform_f32(300 + k, (Nin, N), 0.0, 1.0), synth.dense_spikes(400 + k, (B, Nin), 0.3),
+            synth.dense_spikes(500 + k, (B, N), 0.2), synth.uniform_f32(600 + k, (B, Nin), 0.0, 1.0),
+            synth.uniform_f32(700 + k, (B, N), 0.0, 1.0))
+
+
+@pytest.mark.parametrize("tag", list(RULE_VARIANTS))
+def test_hebbian_and_weight_dependent_postpre_match_reference(tag):
+    g = gold("op_rules")
+    wd, decay, lo, hi = RULE_VARIANTS[tag]
+    for k, (B, Nin, N) in enumerate(g["cases"]):
+        W, s_src, s_tgt, x_src, x_tgt = rule_inputs(k, int(B), int(Nin), int(N))
+        if lo is None and wd:
+            continue
+        oracle.hebbian_wdpp(W, s_src, x_src, s_tgt, x_tgt, nu0=np.float32(1e-2), nu1=np.float32(3e-2), weight_dependent=wd,
+                            decay=np.float32(decay), wmin=lo, wmax=hi)
+        np.testing.assert_array_equal(bits(W), bits(g[f"{tag}{k}"]), err_msg=f"{tag} case {k}")
+
+
+def test_mstdpet_sequence_matches_reference():
+    g = gold("op_rules")
+    Nin, N, T = 36, 20, 12
+    W = synth.uniform_f32(900, (Nin, N), 0.0, 1.0)
+    elig = np.zeros((Nin, N), f32); et = np.zeros((Nin, N), f32); pp = np.zeros(Nin, f32); pm = np.zeros(N, f32)
+    for t in range(T):
+        oracle.mstdpet(W, elig, et, pp, pm, synth.dense_spikes(910 + t, (1, Nin), 0.2).reshape(-1),
+                       synth.dense_spikes(940 + t, (1, N), 0.2).reshape(-1), reward=np.float32(0.7 if t % 3 else -0.4), nu0=np.float32(1e-1),
+                       decay_plus=g["et_decay_plus"], decay_minus=g["et_decay_minus"], decay_e=g["et_decay_e"], tc_e=g["et_tc_e"],
+                       wmin=0.0, wmax=1.0)
+    for got, key in ((W, "et_w"), (et, "et_trace"), (elig, "et_elig"), (pp, "et_p_plus"), (pm, "et_p_minus")):
+        np.testing.assert_array_equal(bits(got), bits(g[key]), err_msg=key)
