@@ -33,7 +33,9 @@ class LayerDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("n", C.c_int), ("p", DcParams),
                 ("v", C.c_void_p), ("refrac", C.c_void_p), ("x", C.c_void_p), ("theta", C.c_void_p),
                 ("s", C.c_void_p), ("ext_spikes", C.c_void_p), ("raster_s", C.c_void_p),
-                ("raster_v", C.c_void_p), ("current", C.c_void_p)]
+                ("raster_v", C.c_void_p), ("current", C.c_void_p),
+                ("clamp", C.c_void_p), ("unclamp", C.c_void_p), ("clamp_per_step", C.c_int), ("unclamp_per_step", C.c_int),
+                ("inject_v", C.c_void_p), ("inject_per_step", C.c_int), ("inject_len", C.c_int)]
 
 
 class ConnDesc(C.Structure):
@@ -48,7 +50,8 @@ class ConnDesc(C.Structure):
                 ("a_plus", C.c_float), ("a_minus", C.c_float), ("decay_plus", C.c_float),
                 ("decay_minus", C.c_float),
                 ("has_norm", C.c_int), ("norm", C.c_float), ("norm_abs", C.c_int), ("norm_ws", C.c_void_p),
-                ("e_trace", C.c_void_p), ("decay_e", C.c_float), ("tc_e", C.c_float)]
+                ("e_trace", C.c_void_p), ("decay_e", C.c_float), ("tc_e", C.c_float), ("rule_ws", C.c_void_p),
+                ("mask", C.c_void_p)]
 
 
 class RunDesc(C.Structure):
@@ -83,6 +86,7 @@ _SIGS = {
     "snn_lif_step": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp], _i),
     "snn_dc_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp, _vp], _i),
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
+    "snn_conv2d_postpre": ([_vp] * 5 + [_i] * 9 + [_f, _f, _f, _i, _f, _i, _f, _vp, _vp], _i),
     "snn_stdp_hebbian": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _i, _f, _i, _f, _vp], _i),
     "snn_mstdpet_step": ([_vp] * 8 + [_i, _i] + [_f] * 10 + [_i, _f, _i, _f, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),

@@ -622,6 +622,72 @@ __global__ __launch_bounds__(256) void k_mstdp_traces(float *__restrict__ p_plus
     }
 }
 
+// f4: PostPre on a Conv2dConnection (learning.py:457-497).  Phase 1: one thread per (sample, weight element) sums its
+// products over the output positions l in ascending order; phase 2: one thread per weight element reduces the samples in
+// ATen's sum(dim=0) order, applies the learning rates, decay and clamp.
+__global__ __launch_bounds__(256) void k_conv_pp_partial(const uint8_t *__restrict__ s_src, const float *__restrict__ x_src,
+                                                         const uint8_t *__restrict__ s_tgt, const float *__restrict__ x_tgt,
+                                                         float *__restrict__ part, int B, int Cin, int H, int Wd, int Cout, int KH,
+                                                         int KW, int stride, int pad, int OH, int OW) {
+    const long K = (long)Cin * KH * KW, E = (long)Cout * K;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)B * E) return;
+    const int b = (int)(id / E);
+    const long e = id - (long)b * E;
+    const int co = (int)(e / K), k = (int)(e - (long)co * K);
+    const int ci = k / (KH * KW), ky = (k / KW) % KH, kx = k % KW;
+    const int L = OH * OW;
+    float a = 0.f, p = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int oy = l / OW, ox = l - oy * OW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+        const size_t si = (((size_t)b * Cin + ci) * H + (in ? iy : 0)) * Wd + (in ? ix : 0);
+        const size_t ti = ((size_t)b * Cout + co) * L + l;
+        a += x_tgt[ti] * (in ? (float)s_src[si] : 0.0f);
+        p += (float)s_tgt[ti] * (in ? x_src[si] : 0.0f);
+    }
+    part[id] = a;
+    part[(size_t)B * E + id] = p;
+}
+
+__global__ __launch_bounds__(256) void k_conv_pp_apply(float *__restrict__ W, const float *__restrict__ part, int B, long E, float nu0,
+                                                       float nu1, float decay, int has_min, float wmin, int has_max, float wmax) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const bool tail = e >= (E / 32) * 32;
+    float w = W[e];
+    if (nu0 != 0.f) {
+        OuterSum acc; acc.init(tail);
+        for (int b = 0; b < B; ++b) acc.add(b, part[(size_t)b * E + e], B);
+        w = w - nu0 * acc.finish(B);
+    }
+    if (nu1 != 0.f) {
+        OuterSum acc; acc.init(tail);
+        for (int b = 0; b < B; ++b) acc.add(b, part[(size_t)(B + b) * E + e], B);
+        w = w + nu1 * acc.finish(B);
+    }
+    w = w * decay;
+    if (has_min && w < wmin) w = wmin;
+    if (has_max && w > wmax) w = wmax;
+    W[e] = w;
+}
+
+extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                                  int B, int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad, float nu0, float nu1,
+                                  float decay, int has_min, float wmin, int has_max, float wmax, float *ws, snn_stream_t stream) {
+    if (!W || !s_src || !x_src || !s_tgt || !x_tgt || !ws || B <= 0 || Cin <= 0 || H <= 0 || Wd <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
+        stride <= 0 || pad < 0) return SNN_ERR_INVALID;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
+    const long E = (long)Cout * Cin * KH * KW, n = (long)B * E;
+    hipLaunchKernelGGL(k_conv_pp_partial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws,
+                       B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW);
+    hipLaunchKernelGGL(k_conv_pp_apply, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ws, B, E, nu0, nu1, decay,
+                       has_min, wmin, has_max, wmax);
+    return snn_check_launch();
+}
+
 extern "C" int snn_stdp_hebbian(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
                                 int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay, int has_min,
                                 float wmin, int has_max, float wmax, snn_stream_t stream) {

@@ -68,6 +68,26 @@ int snn_launch_rng_fill(snn_rng_state *rng, const uint8_t *s, int B, int N, floa
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// ---- run(..., clamp / unclamp / injects_v / masks): small elementwise helpers of the generic plan (network.py:395-449)
+__global__ __launch_bounds__(256) void k_clamp(uint8_t *__restrict__ s, uint8_t *__restrict__ raster, const uint8_t *__restrict__ clamp,
+                                               const uint8_t *__restrict__ unclamp, long total, int n) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
+        const int j = (int)(k % n);
+        uint8_t v = s[k];
+        if (clamp && clamp[j]) v = 1;                  // :416-421
+        if (unclamp && unclamp[j]) v = 0;              // :424-429
+        s[k] = v;
+        if (raster) raster[k] = v;                     // monitors record after the clamps
+    }
+}
+__global__ __launch_bounds__(256) void k_inject(float *__restrict__ v, const float *__restrict__ inj, long total, int len) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) v[k] = v[k] + inj[k % len];   // :399-404
+}
+__global__ __launch_bounds__(256) void k_mask_fill(float *__restrict__ W, const uint8_t *__restrict__ mask, long total) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) if (mask[k]) W[k] = 0.f;     // topology.py:129-133
+}
+static unsigned grid_for(long n) { const long g = (n + 255) / 256; return (unsigned)(g < 4096 ? (g > 0 ? g : 1) : 4096); }
+
 static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R) {
     if (!L || nL <= 0 || (nC > 0 && !C) || !R || R->B <= 0 || R->T < 0) return SNN_ERR_INVALID;
     for (int l = 0; l < nL; ++l) {
@@ -95,7 +115,7 @@ static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
         const snn_conn_desc &d = C[c];
         if (d.src < 0 || d.src >= nL || d.dst < 0 || d.dst >= nL || !d.w) return SNN_ERR_INVALID;
         if (L[d.dst].kind == SNN_LAYER_INPUT) return SNN_ERR_UNSUPPORTED;
-        if (d.rule != SNN_RULE_NONE && d.kind == SNN_CONN_CONV2D) return SNN_ERR_UNSUPPORTED;
+        if (d.kind == SNN_CONN_CONV2D && d.rule != SNN_RULE_NONE && (d.rule != SNN_RULE_POSTPRE || !d.rule_ws)) return SNN_ERR_UNSUPPORTED;
         if (d.rule == SNN_RULE_POSTPRE && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
         if ((d.rule == SNN_RULE_MSTDP || d.rule == SNN_RULE_MSTDPET) && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
         if ((d.rule == SNN_RULE_HEBBIAN || d.rule == SNN_RULE_WDPOSTPRE) && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
@@ -146,6 +166,11 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 continue;
             }
             if (!fed[l]) TRY(snn_check(hipMemsetAsync(d.current, 0, sizeof(float) * (size_t)B * d.n, st)));  // :409-413
+            if (d.inject_v) {
+                const int len = d.inject_len > 0 ? d.inject_len : d.n;
+                hipLaunchKernelGGL(k_inject, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.v,
+                                   d.inject_v + (d.inject_per_step ? (size_t)t * len : 0), (long)B * d.n, len);
+            }
             if (d.kind == SNN_LAYER_LIF) TRY(snn_lif_step(d.v, d.refrac, d.s, d.x, d.current, B, d.n, &d.p.lif, rs, rv, st));
             else if (R->rng && d.p.one_spike) {   // device generator: membrane -> draws for this step -> arbitration
                 TRY(snn_launch_dc_membrane(d.v, d.refrac, d.s, d.theta, d.current, B, d.n, d.p, R->cursor, rv, st));
@@ -155,6 +180,14 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
             } else TRY(snn_dc_step(d.v, d.refrac, d.s, d.x, d.theta, d.current, B, d.n, &d.p, R->noise_q, R->q_len,
                                    R->cursor, R->status, rs, rv, st));
         }
+        for (int l = 0; l < nL; ++l) {        // clamps, after every layer has stepped (each layer's own `s` only: order-free)
+            const snn_layer_desc &d = L[l];
+            if (d.kind == SNN_LAYER_INPUT || (!d.clamp && !d.unclamp)) continue;
+            const size_t off = (size_t)t * B * d.n;
+            hipLaunchKernelGGL(k_clamp, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.s, d.raster_s ? d.raster_s + off : nullptr,
+                               d.clamp ? d.clamp + (d.clamp_per_step ? (size_t)t * d.n : 0) : nullptr,
+                               d.unclamp ? d.unclamp + (d.unclamp_per_step ? (size_t)t * d.n : 0) : nullptr, (long)B * d.n, d.n);
+        }
         // (3) network.py:431-454 learning rules, connection order
         if (R->learning)
             for (int c = 0; c < nC; ++c) {
@@ -162,7 +195,10 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 if (d.rule == SNN_RULE_NONE) continue;
                 const snn_layer_desc &S = L[d.src], &D = L[d.dst];
                 const uint8_t *ss = layer_spikes(S, B, t, true);
-                if (d.rule == SNN_RULE_POSTPRE)
+                if (d.rule == SNN_RULE_POSTPRE && d.kind == SNN_CONN_CONV2D)
+                    TRY(snn_conv2d_postpre(d.w, ss, S.x, D.s, D.x, B, d.cin, d.h, d.wd, d.cout, d.kh, d.kw, d.stride, d.pad, d.nu0, d.nu1,
+                                           d.wdecay, d.has_min, d.wmin, d.has_max, d.wmax, d.rule_ws, st));
+                else if (d.rule == SNN_RULE_POSTPRE)
                     TRY(snn_stdp_postpre(d.w, ss, S.x, D.s, D.x, B, S.n, D.n, d.nu0, d.nu1, d.use_dt, R->dt, d.wdecay,
                                          d.has_min, d.wmin, d.has_max, d.wmax, /*assume_clamped=*/t > 0, st));
                 else if (d.rule == SNN_RULE_HEBBIAN || d.rule == SNN_RULE_WDPOSTPRE)
@@ -177,9 +213,13 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                                        d.reward, d.reward_vec, d.nu0, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus,
                                        d.wdecay, d.has_min, d.wmin, d.has_max, d.wmax, st));
             }
+        for (int c = 0; c < nC; ++c)          // masks apply every step, learning or not (topology.py:124-133)
+            if (C[c].mask && C[c].kind != SNN_CONN_CONV2D)
+                hipLaunchKernelGGL(k_mask_fill, dim3(grid_for((long)L[C[c].src].n * L[C[c].dst].n)), dim3(256), 0, st, C[c].w, C[c].mask,
+                                   (long)L[C[c].src].n * L[C[c].dst].n);
         if (prof) snn_prof_end(st);
     }
-    return SNN_OK;
+    return snn_check_launch();
 }
 
 extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
@@ -188,7 +228,9 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     hipStream_t st = (hipStream_t)stream;
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
-    const int mode = g_plan_mode ? g_plan_mode : R->plan;      // the process-wide test switch wins over the per-run request
+    int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request
+    for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v) mode = 1;   // only the generic plan implements these
+    for (int c = 0; c < nC; ++c) if (C[c].mask || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
     if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));

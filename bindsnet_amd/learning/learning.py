@@ -70,15 +70,23 @@ class PostPre(LearningRule):
     def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
         super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
         assert self.source.traces and self.target.traces, "Both pre- and post-synaptic nodes must record spike traces."
-        from ..network.topology import Connection
-        if not isinstance(connection, Connection):
+        from ..network.topology import Connection, Conv2dConnection, LocalConnection
+        if not isinstance(connection, (Connection, LocalConnection, Conv2dConnection)):
             raise NotImplementedError("This learning rule is not supported for this Connection type.")
 
     def update(self, **kwargs) -> None:
         from .. import ops
+        from ..network.topology import Conv2dConnection
         self._check_reduction()
         B = self.source.batch_size
         lo, hi = self._bounds()
+        if isinstance(self.connection, Conv2dConnection):         # learning.py:457-497
+            c = self.connection
+            ops.conv2d_postpre(c.w.data, self.source.s.reshape(B, *self.source.shape).contiguous(),
+                               self.source.x.reshape(B, *self.source.shape), self.target.s.reshape(B, *self.target.shape),
+                               self.target.x.reshape(B, *self.target.shape), float(self.nu[0]), float(self.nu[1]),
+                               stride=c.stride[0], pad=c.padding[0], decay=float(self.weight_decay), wmin=lo, wmax=hi)
+            return
         ops.stdp_postpre(self.connection.w.data, self.source.s.reshape(B, -1).contiguous(),
                          self.source.x.reshape(B, -1), self.target.s.reshape(B, -1), self.target.x.reshape(B, -1),
                          float(self.nu[0]), float(self.nu[1]), use_dt=False, decay=float(self.weight_decay),
@@ -92,8 +100,8 @@ class MSTDP(LearningRule):
 
     def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
         super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
-        from ..network.topology import Connection
-        if not isinstance(connection, Connection):
+        from ..network.topology import Connection, LocalConnection
+        if not isinstance(connection, (Connection, LocalConnection)):
             raise NotImplementedError("This learning rule is not supported for this Connection type.")
         self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
         self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
@@ -140,8 +148,8 @@ class _OuterProductRule(LearningRule):
 
     def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
         super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
-        from ..network.topology import Connection
-        if not isinstance(connection, Connection):
+        from ..network.topology import Connection, LocalConnection
+        if not isinstance(connection, (Connection, LocalConnection)):
             raise NotImplementedError("This learning rule is not supported for this Connection type.")
 
     def update(self, **kwargs) -> None:
@@ -182,8 +190,8 @@ class MSTDPET(LearningRule):
 
     def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
         super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
-        from ..network.topology import Connection
-        if not isinstance(connection, Connection):
+        from ..network.topology import Connection, LocalConnection
+        if not isinstance(connection, (Connection, LocalConnection)):
             raise NotImplementedError("This learning rule is not supported for this Connection type.")
         self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
         self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))

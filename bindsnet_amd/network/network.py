@@ -16,7 +16,7 @@ from .. import _lib
 from ..rng import DeviceGenerator
 from .monitors import AbstractMonitor, Monitor, NetworkMonitor
 from .nodes import DiehlAndCookNodes, Input, LIFNodes, Nodes, _f
-from .topology import AbstractConnection, Connection, Conv2dConnection, MulticompartmentConnection
+from .topology import AbstractConnection, Connection, Conv2dConnection, LocalConnection, MulticompartmentConnection
 
 
 def load(file_name: str, map_location: str = "cpu", learning: bool = None) -> "Network":
@@ -121,9 +121,8 @@ class Network(torch.nn.Module):
         assert type(inputs) == dict, (
             "'inputs' must be a dict of names of layers (str) and relevant input tensors. "
             f"Got {type(inputs).__name__} instead.")
-        for k in ("clamp", "unclamp", "masks", "injects_v"):
-            if kwargs.get(k):
-                raise NotImplementedError(f"bindsnet_amd: run(..., {k}=...) is outside the accelerated path")
+        clamps, unclamps = kwargs.get("clamp", {}) or {}, kwargs.get("unclamp", {}) or {}
+        injects_v, masks = kwargs.get("injects_v", {}) or {}, kwargs.get("masks", {}) or {}
         if one_step:
             raise NotImplementedError("bindsnet_amd: one_step mode is outside the accelerated path")
         if self.reward_fn is not None:
@@ -204,6 +203,28 @@ class Network(torch.nn.Module):
             d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
             d.x = _dptr(layer.x) if layer.traces else None
             d.raster_s, d.raster_v = _dptr(mon_s), _dptr(mon_v)
+            # clamp / unclamp / injects_v (network.py:395-429): [n] masks or values, or one slice per timestep
+            for key, table in (("clamp", clamps), ("unclamp", unclamps)):
+                m = table.get(name)
+                if m is not None:
+                    m = torch.as_tensor(m).to(dev)
+                    per_step = m.dim() >= 2
+                    if m.numel() != (T if per_step else 1) * layer.n and not (per_step and m.shape[0] >= T and m[0].numel() == layer.n):
+                        raise ValueError(f"{key}['{name}'] must have {layer.n} entries (optionally one row per timestep)")
+                    m = (m[:T] if per_step else m).ne(0).to(torch.uint8).contiguous()
+                    keep.append(m)
+                    setattr(d, key, _dptr(m))
+                    setattr(d, key + "_per_step", int(per_step))
+            inj = injects_v.get(name)
+            if inj is not None:
+                inj = torch.as_tensor(inj).to(dev, torch.float32)
+                per_step = inj.dim() >= 2
+                one = inj[0] if per_step else inj
+                if one.numel() not in (layer.n, B * layer.n) or (per_step and inj.shape[0] < T):
+                    raise ValueError(f"injects_v['{name}'] must have {layer.n} (or batch x {layer.n}) entries, optionally per timestep")
+                inj = (inj[:T] if per_step else inj).contiguous()
+                keep.append(inj)
+                d.inject_v, d.inject_per_step, d.inject_len = _dptr(inj), int(per_step), one.numel()
             if isinstance(layer, DiehlAndCookNodes):
                 d.kind, d.p, d.theta = _lib.LAYER_DC, layer._dc_params(), _dptr(layer.theta)
                 if layer.one_spike:
@@ -215,9 +236,24 @@ class Network(torch.nn.Module):
                 raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
                                           "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
 
+        for table, what in ((clamps, "clamp"), (unclamps, "unclamp"), (injects_v, "injects_v")):
+            for lname in table:
+                if lname not in self.layers or isinstance(self.layers[lname], Input):
+                    raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
         Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
         for k, ((src, dst), conn) in enumerate(self.connections.items()):
             self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+            mask = masks.get((src, dst))
+            if mask is None:
+                mask = getattr(conn, "mask", None)         # LocalConnection's structural mask (topology.py:1468-1470)
+            if mask is not None:
+                if not hasattr(conn, "w") or isinstance(conn, Conv2dConnection):
+                    raise NotImplementedError("bindsnet_amd: weight masks are supported on dense connections")
+                m = torch.as_tensor(mask).to(dev).ne(0).to(torch.uint8).contiguous()
+                if m.numel() != conn.w.numel():
+                    raise ValueError(f"mask of connection {(src, dst)} must have the shape of its weights")
+                keep.append(m)
+                Cn[k].mask = _dptr(m)
 
         R = _lib.RunDesc()
         R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
@@ -403,7 +439,7 @@ class Network(torch.nn.Module):
             d.cin, d.h, d.wd = conn.in_channels, conn.source.shape[1], conn.source.shape[2]
             d.cout, d.kh, d.kw = conn.out_channels, conn.kernel_size[0], conn.kernel_size[1]
             d.stride, d.pad = conn.stride[0], conn.padding[0]
-        elif isinstance(conn, Connection):
+        elif isinstance(conn, (Connection, LocalConnection)):
             d.kind = _lib.CONN_DENSE
         else:
             raise NotImplementedError(f"bindsnet_amd: connection type {type(conn).__name__} is not supported")
@@ -417,6 +453,9 @@ class Network(torch.nn.Module):
             d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
             if isinstance(rule, dense_rules.PostPre):
                 d.rule, d.use_dt = _lib.RULE_POSTPRE, 0
+                if isinstance(conn, Conv2dConnection):       # learning.py:457-497: per-sample partial sums live in scratch
+                    ws = self._scratch(f"convpp_{src}_{dst}", (2 * B * conn.w.numel(),), torch.float32, dev)
+                    d.rule_ws = _dptr(ws)
             else:
                 if "reward" not in kwargs:
                     raise KeyError("reward")
@@ -458,4 +497,5 @@ class Network(torch.nn.Module):
             if isinstance(conn, Conv2dConnection):
                 raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not supported")
             ws = self._scratch(f"norm_{src}_{dst}", (conn.target.n,), torch.float32, dev)
-            d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(conn.norm), 1, _dptr(ws)
+            # Connection.normalize sums |w| (topology.py:383-392), LocalConnection.normalize the signed weights (:1475-1482)
+            d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(conn.norm), int(not isinstance(conn, LocalConnection)), _dptr(ws)

@@ -39,8 +39,9 @@ class AbstractConnection(Module):
         """Reference: topology.py:112-139."""
         if kwargs.get("learning", True):
             self.update_rule.update(**kwargs)
-        if kwargs.get("mask", None) is not None:
-            raise NotImplementedError("bindsnet_amd: weight masks are outside the accelerated path")
+        mask = kwargs.get("mask", None)
+        if mask is not None:                       # topology.py:129-133
+            self.w.masked_fill_(torch.as_tensor(mask, device=self.w.device).bool(), 0)
 
     def reset_state_variables(self) -> None:
         pass
@@ -90,6 +91,75 @@ class Connection(AbstractConnection):
             ops.normalize(self.w.data, float(self.norm), use_abs=True)
 
 
+class LocalConnection(AbstractConnection):
+    """Locally connected synapses (reference: topology.py:1304-1485): a dense [source.n, target.n] matrix that is zero
+    outside each target neuron's receptive field (`mask`), propagated like `Connection` (+ bias), learned with the dense
+    rules, masked again after every update, normalised by the SIGNED column sums (norm scaled by the kernel size).  Like
+    the reference it draws its initial weights from numpy's global generator, and its `compute` output carries no batch
+    dimension, i.e. it is meant for batch size 1."""
+
+    def __init__(self, source: Nodes, target: Nodes, kernel_size: Union[int, Tuple[int, int]],
+                 stride: Union[int, Tuple[int, int]], n_filters: int, nu=None, reduction=None, weight_decay: float = 0.0,
+                 w_dtype: torch.dtype = torch.float32, **kwargs) -> None:
+        super().__init__(source, target, nu, reduction, weight_decay, **kwargs)
+        if w_dtype != torch.float32:
+            raise NotImplementedError("bindsnet_amd computes in float32 only")
+        self.kernel_size, self.stride, self.n_filters = _pair(kernel_size), _pair(stride), n_filters
+        shape = kwargs.get("input_shape", None)
+        if shape is None:
+            shape = _pair(int(np.sqrt(source.n)))
+        kh, kw = self.kernel_size
+        if self.kernel_size == tuple(shape):
+            conv_size = [1, 1]
+        else:
+            conv_size = (int((shape[0] - kh) / self.stride[0]) + 1, int((shape[1] - kw) / self.stride[1]) + 1)
+        self.conv_size = conv_size
+        conv_prod, kernel_prod = int(np.prod(conv_size)), int(np.prod(self.kernel_size))
+        assert target.n == n_filters * conv_prod, (
+            f"Total neurons in target layer must be {n_filters * conv_prod}. Got {target.n}.")
+        # source index of tap (k1, k2) of receptive field (c1, c2) -- with the reference's own row stride for k1
+        # (shape[0], topology.py:1420-1427)
+        c1, c2 = torch.arange(conv_size[0]).view(1, 1, -1, 1), torch.arange(conv_size[1]).view(1, 1, 1, -1)
+        k1, k2 = torch.arange(kh).view(-1, 1, 1, 1), torch.arange(kw).view(1, -1, 1, 1)
+        locations = (c1 * self.stride[0] * shape[1] + c2 * self.stride[1] + k1 * shape[0] + k2).long()
+        self.register_buffer("locations", locations.reshape(kernel_prod, conv_prod))
+        w = kwargs.get("w", None)
+        unbounded = bool((self.wmin == -np.inf).any() or (self.wmax == np.inf).any())
+        if w is None:
+            w = torch.zeros(source.n, target.n)
+            for f in range(n_filters):                       # same visiting order as the reference: the draws come
+                for c in range(conv_prod):                   # from numpy's global generator one at a time
+                    for k in range(kernel_prod):
+                        w[self.locations[k, c], f * conv_prod + c] = np.random.rand()
+            w = torch.clamp(w, self.wmin, self.wmax) if unbounded else self.wmin + w * (self.wmax - self.wmin)
+            w = w.to(dtype=w_dtype)
+        else:
+            if not unbounded or bool((self.wmin != -np.inf).any() or (self.wmax != np.inf).any()):
+                w = torch.clamp(torch.as_tensor(w), self.wmin, self.wmax)
+            w = self.cast_dtype_if_needed(w, w_dtype)
+        self.w = Parameter(w, requires_grad=False)
+        self.register_buffer("mask", self.w == 0)
+        self.b = Parameter(kwargs.get("b", torch.zeros(target.n)), requires_grad=False)
+        if self.norm is not None:
+            self.norm *= kernel_prod
+
+    def compute(self, s: torch.Tensor) -> torch.Tensor:
+        B = s.size(0)
+        out = torch.empty(B, self.target.n, device=self.w.device)
+        ops.prop_dense(self.w.data, s.reshape(B, -1).contiguous(), out, bias=self.b.data)
+        return out.view(*self.target.shape) if B == 1 else out.view(B, *self.target.shape)
+
+    def update(self, **kwargs) -> None:
+        if kwargs.get("mask", None) is None:
+            kwargs["mask"] = self.mask
+        super().update(**kwargs)
+
+    def normalize(self) -> None:
+        """Signed column sums (topology.py:1475-1482)."""
+        if self.norm is not None:
+            ops.normalize(self.w.data.view(self.source.n, self.target.n), float(self.norm), use_abs=False)
+
+
 class Conv2dConnection(AbstractConnection):
     """2-D convolutional synapses (reference: topology.py:686-844); propagation only."""
 
@@ -102,9 +172,9 @@ class Conv2dConnection(AbstractConnection):
         self.padding, self.dilation = _pair(padding), _pair(dilation)
         if self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
             raise NotImplementedError("bindsnet_amd: conv2d supports dilation 1 and symmetric stride/padding only")
-        if kwargs.get("update_rule", None) is not None:
-            raise NotImplementedError("bindsnet_amd: learning on Conv2dConnection is not on the accelerated path "
-                                      "(SURVEY.md 8(f)-4)")
+        rule = kwargs.get("update_rule", None)
+        if rule is not None and rule.__name__ not in ("PostPre", "NoOp"):
+            raise NotImplementedError(f"bindsnet_amd: {rule.__name__} on Conv2dConnection is not supported (PostPre is)")
         self.in_channels, ih, iw = source.shape[0], source.shape[1], source.shape[2]
         if self.in_channels > 16:
             raise NotImplementedError("bindsnet_amd: Conv2dConnection with more than 16 input channels is not supported (the "

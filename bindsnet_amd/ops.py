@@ -122,6 +122,18 @@ def mstdp_step(W, p_plus, p_minus, s_src_prev, s_tgt_prev, s_src, s_tgt, reward,
                                int(wmax is not None), 0.0 if wmax is None else wmax, _stream()), "mstdp_step")
 
 
+def conv2d_postpre(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, stride=1, pad=0, decay=1.0, wmin=None, wmax=None, ws=None):
+    """f4: PostPre on Conv2dConnection weights [Cout,Cin,KH,KW]; s_src / x_src [B,Cin,H,W], s_tgt / x_tgt [B,Cout,OH,OW]."""
+    B, Cin, H, Wd = s_src.shape
+    Cout, _, KH, KW = W.shape
+    if ws is None:
+        ws = torch.empty(2 * B * W.numel(), dtype=F32, device=W.device)
+    check(lib().snn_conv2d_postpre(_ptr(W, F32), _ptr(s_src, "spike"), _ptr(x_src, F32), _ptr(s_tgt, "spike"), _ptr(x_tgt, F32),
+                                   B, Cin, H, Wd, Cout, KH, KW, stride, pad, nu0, nu1, decay, int(wmin is not None),
+                                   0.0 if wmin is None else wmin, int(wmax is not None), 0.0 if wmax is None else wmax,
+                                   _ptr(ws, F32), _stream()), "conv2d_postpre")
+
+
 def stdp_hebbian(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, weight_dependent=False, decay=1.0, wmin=None, wmax=None):
     """f3: Hebbian (weight_dependent=False) / WeightDependentPostPre (True) on a dense weight matrix."""
     B = s_src.shape[0]

@@ -183,6 +183,16 @@ int snn_stdp_hebbian(float *W, const uint8_t *s_src, const float *x_src, const u
                      int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay,
                      int has_min, float wmin, int has_max, float wmax, snn_stream_t stream);
 
+/* ---- f4: PostPre on a Conv2dConnection -----------------------------------------------------------------
+ * bindsnet/learning/learning.py:457-497 (+ :87-104).  With k = (cin,kh,kw), l = (oy,ox) and unfold = im2col:
+ *   W[co,k] -= nu0 * sum_b sum_l x_tgt[b,co,l] * unfold(s_src)[b,k,l];  W[co,k] += nu1 * sum_b sum_l s_tgt[b,co,l] *
+ *   unfold(x_src)[b,k,l];  W *= decay; clamp.  The sum over l is sequential in ascending l (the reference's runs inside
+ * torch.bmm: BLAS order, compared within tolerance), the batch sum in ATen's sum(dim=0) order.
+ * ws: device scratch of 2 * B * Cout*Cin*KH*KW floats.                                                       */
+int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                       int B, int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad, float nu0, float nu1,
+                       float decay, int has_min, float wmin, int has_max, float wmax, float *ws, snn_stream_t stream);
+
 /* ---- f3: MSTDPET (dense Connection, batch 1) -----------------------------------------------------------
  * bindsnet/learning/learning.py:2187-2248.  e_trace [Nin,N] is the rule's dense eligibility trace (in/out); the point
  * eligibility is p_plus (x) s_tgt_prev + s_src_prev (x) p_minus of the previous call's factors, formed on the fly.
@@ -244,6 +254,12 @@ typedef struct {
     uint8_t *raster_s;          /* nullable [T,B,n] spike monitor */
     float *raster_v;            /* nullable [T,B,n] voltage monitor */
     float *current;             /* [B,n] scratch for the summed input current (non-INPUT layers) */
+    /* run(..., clamp= / unclamp= / injects_v=), network.py:395-429 (nullable; handled by the generic plan):
+     * after the layer's step  s[:, clamp] = 1, then s[:, unclamp] = 0  (u8 masks [n], or [T,n] when *_per_step);
+     * before it               v += inject_v  (f32 [n] broadcast over the batch, or [T,...] when inject_per_step, each
+     *                         slice [inject_len] with inject_len = n or B*n) */
+    const uint8_t *clamp, *unclamp; int clamp_per_step, unclamp_per_step;
+    const float *inject_v; int inject_per_step; int inject_len;
 } snn_layer_desc;
 
 typedef struct {
@@ -264,6 +280,9 @@ typedef struct {
     float *norm_ws;             /* [N] scratch when has_norm */
     float *e_trace;             /* MSTDPET: dense eligibility trace [Nin,N] */
     float decay_e, tc_e;        /* MSTDPET: exp(-dt / tc_e_trace), tc_e_trace */
+    float *rule_ws;             /* CONV2D + PostPre: scratch of 2 * B * Cout*Cin*KH*KW floats */
+    const uint8_t *mask;        /* nullable [Nin,N] (same layout as w): weights forced to zero after every step's update --
+                                   run(..., masks=) / LocalConnection.mask, topology.py:129-133 (generic plan) */
 } snn_conn_desc;
 
 typedef struct {

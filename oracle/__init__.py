@@ -171,6 +171,14 @@ def mstdpet(W, elig, e_trace, p_plus, p_minus, s_src, s_tgt, *, reward, nu0, dt=
                       cf(decay_e), cf(tc_e), cf(wdecay), ci(wmin is not None), cf(wmin or 0.0), ci(wmax is not None), cf(wmax or 0.0))
 
 
+def conv2d_postpre(W, s_src, x_src, s_tgt, x_tgt, *, stride=1, pad=0, nu0, nu1, decay=1.0, wmin=None, wmax=None):
+    B, Cin, H, Wd = s_src.shape
+    Cout, _, KH, KW = W.shape
+    lib().orc_conv2d_postpre(_p(W, f32), _p(s_src, u8), _p(x_src, f32), _p(s_tgt, u8), _p(x_tgt, f32), ci(B), ci(Cin), ci(H), ci(Wd),
+                             ci(Cout), ci(KH), ci(KW), ci(stride), ci(pad), cf(nu0), cf(nu1), cf(decay), ci(wmin is not None),
+                             cf(wmin or 0.0), ci(wmax is not None), cf(wmax or 0.0))
+
+
 def normalize(W, norm, use_abs):
     Nin, N = W.shape
     lib().orc_normalize(_p(W, f32), ci(Nin), ci(N), cf(norm), ci(int(use_abs)))

@@ -344,6 +344,51 @@ ORC_API void orc_hebbian_wdpp(float *W, const uint8_t *s_src, const float *x_src
         }
 }
 
+/* f4: PostPre._conv2d_connection_update, learning.py:457-497 (+ LearningRule.update :87-104).
+ * pre[co,k]  = sum_b sum_l x_tgt[b,co,l] * unfold(s_src)[b,k,l];  w -= nu0 * pre
+ * post[co,k] = sum_b sum_l s_tgt[b,co,l] * unfold(x_src)[b,k,l];  w += nu1 * post       (k = (ci,kh,kw), l = (oy,ox))
+ * The reference's inner sum over l runs inside torch.bmm (BLAS order, not reproducible: SURVEY.md finding 5); the
+ * canonical order pinned here is ascending l, sequential f32, then torch.sum(dim=0) order over the batch.            */
+typedef struct { const float *part; long E, e; } cp_ctx;
+static float cp_term(const void *c, long b) { const cp_ctx *p = (const cp_ctx *)c; return p->part[b * p->E + p->e]; }
+
+ORC_API void orc_conv2d_postpre(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
+                                int B, int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad,
+                                float nu0, float nu1, float decay, int has_min, float wmin, int has_max, float wmax)
+{
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1, L = OH * OW;
+    const long K = (long)Cin * KH * KW, E = (long)Cout * K;
+    float *pre = (float *)calloc((size_t)B * E, sizeof(float)), *post = (float *)calloc((size_t)B * E, sizeof(float));
+    for (int b = 0; b < B; ++b)
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int ky = 0; ky < KH; ++ky)
+                    for (int kx = 0; kx < KW; ++kx) {
+                        float a = 0.f, p = 0.f;
+                        for (int l = 0; l < L; ++l) {
+                            const int oy = l / OW, ox = l - oy * OW;
+                            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                            const int in = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+                            const long si = (((long)b * Cin + ci) * H + (in ? iy : 0)) * Wd + (in ? ix : 0);
+                            const long ti = ((long)b * Cout + co) * L + l;
+                            a += x_tgt[ti] * (in ? (float)s_src[si] : 0.0f);
+                            p += (float)s_tgt[ti] * (in ? x_src[si] : 0.0f);
+                        }
+                        const long e = (long)co * K + ((long)ci * KH + ky) * KW + kx;
+                        pre[b * E + e] = a; post[b * E + e] = p;
+                    }
+    for (long e = 0; e < E; ++e) {
+        float w = W[e];
+        if (nu0 != 0.f) { cp_ctx c = { pre, E, e }; w = w - nu0 * outer_sum(cp_term, &c, B, e, E); }
+        if (nu1 != 0.f) { cp_ctx c = { post, E, e }; w = w + nu1 * outer_sum(cp_term, &c, B, e, E); }
+        w = w * decay;
+        if (has_min && w < wmin) w = wmin;
+        if (has_max && w > wmax) w = wmax;
+        W[e] = w;
+    }
+    free(pre); free(post);
+}
+
 /* f3: MSTDPET._connection_update, learning.py:2187-2248 (batch size 1: the reference flattens the spikes).
  * elig / e_trace are the reference's dense [Nin,N] tensors.  Order: e_trace *= exp(-dt/tc_e); e_trace += elig / tc_e;
  * w += ((nu0 * dt) * reward) * e_trace; p_plus / p_minus; elig = p_plus (x) s_tgt + s_src (x) p_minus; decay; clamp. */

@@ -145,8 +145,78 @@ def rules_case():
     save("op_rules", cases=np.array(RULE_CASES), **out)
 
 
+def extras_case():
+    """run() keyword arguments clamp / unclamp / injects_v / masks (network.py:395-449) on a dense two-layer network;
+    LocalConnection with PostPre (topology.py:1304-1485; batch 1 like its compute()); PostPre on a Conv2dConnection
+    (learning.py:457-497): single updates and a short run."""
+    from bindsnet.learning import PostPre
+    from make_golden import Connection, Conv2dConnection, TwoLayerNetwork, _set_layer
+    from bindsnet.network.topology import LocalConnection
+    out = {}
+    # ---- kwargs
+    Nin, N, B, T = 196, 48, 3, 40
+    torch.manual_seed(0)
+    net = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum, norm=78.4 * Nin / 784)
+    conn = net.connections[("X", "Y")]
+    conn.w.data.copy_(T_(synth.weights_q12(11, Nin, N)))
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    mv = Monitor(net.layers["Y"], ["v"], time=T)
+    net.add_monitor(mon, "s"); net.add_monitor(mv, "v")
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    clamp = T_(synth.dense_spikes(51, (T, N), 0.03)).bool()          # per-step clamp rows
+    unclamp = T_(synth.dense_spikes(52, (N,), 0.2)).bool()           # fixed unclamp mask
+    inject = T_(synth.uniform_f32(53, (N,), 0.0, 0.6))
+    mask = T_(synth.dense_spikes(54, (Nin, N), 0.3)).bool()
+    net.run({"X": T_(spikes)}, time=T, clamp={"Y": clamp}, unclamp={"Y": unclamp}, injects_v={"Y": inject}, masks={("X", "Y"): mask})
+    out.update(kw_sY=np.packbits(mon.get("s").numpy().astype(np.uint8)), kw_v=mv.get("v").numpy().copy(), kw_W=conn.w.detach().numpy().copy())
+    # ---- LocalConnection + PostPre, batch 1
+    np.random.seed(7)
+    T2 = 50
+    net = Network(dt=1.0)
+    X, Y = Input(n=144, traces=True), LIFNodes(n=4 * 16, traces=True)
+    lc = LocalConnection(X, Y, kernel_size=6, stride=2, n_filters=4, update_rule=PostPre, nu=(1e-4, 1e-2), wmin=0.0, wmax=1.0, norm=0.2)
+    net.add_layer(X, "X"); net.add_layer(Y, "Y"); net.add_connection(lc, "X", "Y")
+    out["lc_W0"] = lc.w.detach().numpy().copy()
+    mon = Monitor(Y, ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    sp = synth.spike_train(31, T2, 1, 144, active=0.5, max_rate=0.25)
+    net.run({"X": T_(sp)}, time=T2)
+    out.update(lc_sY=np.packbits(mon.get("s").numpy().astype(np.uint8)), lc_W=lc.w.detach().numpy().copy(), lc_norm=np.float64(lc.norm),
+               lc_mask=np.packbits(lc.mask.numpy()))
+    # ---- Conv2d PostPre: single updates
+    cases = [(3, 1, 12, 12, 4, 3, 1, 0), (2, 3, 10, 10, 5, 3, 2, 1), (17, 2, 8, 8, 6, 5, 1, 2)]
+    for k, (B, Cin, H, Wd, Cout, K, stride, pad) in enumerate(cases):
+        OH = (H + 2 * pad - K) // stride + 1
+        src, tgt = Input(shape=(Cin, H, Wd), traces=True), LIFNodes(shape=(Cout, OH, OH), traces=True)
+        c = Conv2dConnection(src, tgt, kernel_size=K, stride=stride, padding=pad, w=T_(synth.uniform_f32(1200 + k, (Cout, Cin, K, K), 0.0, 0.5)).clone(),
+                             update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=1.0)
+        _set_layer(src, B, synth.dense_spikes(1300 + k, (B, Cin, H, Wd), 0.15), synth.uniform_f32(1400 + k, (B, Cin, H, Wd), 0.0, 1.0))
+        _set_layer(tgt, B, synth.dense_spikes(1500 + k, (B, Cout, OH, OH), 0.1).astype(bool), synth.uniform_f32(1600 + k, (B, Cout, OH, OH), 0.0, 1.0))
+        c.update(learning=True)
+        out[f"cpp{k}"] = c.w.detach().numpy().copy()
+    out["cpp_cases"] = np.array(cases)
+    # ---- Conv2d PostPre: a run
+    B, T3 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(1700, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T3)
+    net.add_monitor(mon, "s")
+    sp = synth.dense_spikes(1701, (T3, B, 1, 12, 12), 0.2)
+    net.run({"X": T_(sp)}, time=T3)
+    out.update(crun_sY=np.packbits(mon.get("s").numpy().astype(np.uint8)), crun_W=cc.w.detach().numpy().copy())
+    print("  extras: kwargs run spikes", int(np.unpackbits(out["kw_sY"]).sum()), "| local", int(np.unpackbits(out["lc_sY"]).sum()),
+          "| conv run", int(np.unpackbits(out["crun_sY"]).sum()))
+    save("run_extras", **out)
+
+
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules"]
+    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules", "extras"]
+    if "extras" in jobs:
+        extras_case()
     if "rules" in jobs:
         torch.set_num_threads(1)
         rules_case()

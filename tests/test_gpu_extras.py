@@ -1,0 +1,118 @@
+"""What widens the boundary beyond the BASELINE graphs (SURVEY 8(f)-4 and the run() keyword arguments of row a1), each
+against fixtures from the unmodified reference (tests/golden/make_golden_r2.py: run_extras.npz):
+ * run(..., clamp=, unclamp=, injects_v=, masks=) on a dense two-layer network (network.py:395-449);
+ * LocalConnection with PostPre (topology.py:1304-1485);
+ * PostPre on a Conv2dConnection (learning.py:457-497): single updates (bit-exact vs the oracle's canonical order, 1e-5
+   vs the reference's BLAS order) and a run."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from cases import gold, u8, unpack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_run_keyword_arguments_match_reference():
+    from bindsnet_amd.models import TwoLayerNetwork
+    from bindsnet_amd.network.monitors import Monitor
+    g = gold("run_extras")
+    Nin, N, B, T = 196, 48, 3, 40
+    torch.manual_seed(0)
+    net = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum, norm=78.4 * Nin / 784)
+    conn = net.connections[("X", "Y")]
+    conn.w.data.copy_(T_(synth.weights_q12(11, Nin, N)))
+    mon, mv = Monitor(net.layers["Y"], ["s"], time=T), Monitor(net.layers["Y"], ["v"], time=T)
+    net.add_monitor(mon, "s"); net.add_monitor(mv, "v")
+    net.to(DEV)
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    clamp = T_(synth.dense_spikes(51, (T, N), 0.03)).bool()
+    unclamp = T_(synth.dense_spikes(52, (N,), 0.2)).bool()
+    inject = T_(synth.uniform_f32(53, (N,), 0.0, 0.6))
+    mask = T_(synth.dense_spikes(54, (Nin, N), 0.3)).bool()
+    net.run({"X": T_(spikes).to(DEV)}, time=T, clamp={"Y": clamp}, unclamp={"Y": unclamp}, injects_v={"Y": inject},
+            masks={("X", "Y"): mask})
+    assert net.last_plan == "generic"
+    np.testing.assert_array_equal(host(mon.get("s")).reshape(T, B, N).astype(u8), unpack(g["kw_sY"], (T, B, N)))
+    np.testing.assert_allclose(host(mv.get("v")), g["kw_v"], rtol=0, atol=2e-4)       # (MKL order in the reference's `@`)
+    W = host(conn.w)
+    np.testing.assert_allclose(W, g["kw_W"], rtol=0, atol=1e-5)
+    assert (W[mask.numpy()] == 0).all()
+
+
+def test_local_connection_postpre_matches_reference():
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import LocalConnection
+    g = gold("run_extras")
+    np.random.seed(7)
+    T2 = 50
+    net = Network(dt=1.0)
+    X, Y = Input(n=144, traces=True), LIFNodes(n=4 * 16, traces=True)
+    lc = LocalConnection(X, Y, kernel_size=6, stride=2, n_filters=4, update_rule=PostPre, nu=(1e-4, 1e-2), wmin=0.0, wmax=1.0, norm=0.2)
+    net.add_layer(X, "X"); net.add_layer(Y, "Y"); net.add_connection(lc, "X", "Y")
+    np.testing.assert_array_equal(host(lc.w).view(np.uint32), g["lc_W0"].view(np.uint32))          # numpy-generator initialisation
+    np.testing.assert_array_equal(np.packbits(host(lc.mask)), g["lc_mask"])
+    assert lc.norm == float(g["lc_norm"])
+    mon = Monitor(Y, ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    net.to(DEV)
+    sp = synth.spike_train(31, T2, 1, 144, active=0.5, max_rate=0.25)
+    net.run({"X": T_(sp).to(DEV)}, time=T2)
+    np.testing.assert_array_equal(host(mon.get("s")).reshape(T2, 1, 64).astype(u8), unpack(g["lc_sY"], (T2, 1, 64)))
+    np.testing.assert_allclose(host(lc.w), g["lc_W"], rtol=0, atol=1e-5)
+    assert (host(lc.w)[host(lc.mask)] == 0).all()
+
+
+def test_conv2d_postpre_updates_and_run():
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    g = gold("run_extras")
+    for k, (B, Cin, H, Wd, Cout, K, stride, pad) in enumerate(g["cpp_cases"]):
+        B, Cin, H, Wd, Cout, K, stride, pad = (int(v) for v in (B, Cin, H, Wd, Cout, K, stride, pad))
+        OH = (H + 2 * pad - K) // stride + 1
+        W0 = synth.uniform_f32(1200 + k, (Cout, Cin, K, K), 0.0, 0.5)
+        s_src, x_src = synth.dense_spikes(1300 + k, (B, Cin, H, Wd), 0.15), synth.uniform_f32(1400 + k, (B, Cin, H, Wd), 0.0, 1.0)
+        s_tgt, x_tgt = synth.dense_spikes(1500 + k, (B, Cout, OH, OH), 0.1), synth.uniform_f32(1600 + k, (B, Cout, OH, OH), 0.0, 1.0)
+        src, tgt = Input(shape=(Cin, H, Wd), traces=True), LIFNodes(shape=(Cout, OH, OH), traces=True)
+        c = Conv2dConnection(src, tgt, kernel_size=K, stride=stride, padding=pad, w=T_(W0).clone(), update_rule=PostPre, nu=(1e-3, 1e-2),
+                             reduction=torch.sum, wmin=0.0, wmax=1.0).to(DEV)
+        for l, s, x in ((src, s_src, x_src), (tgt, s_tgt, x_tgt)):
+            l.batch_size = B
+            l.s, l.x = T_(s).to(DEV), T_(x).to(DEV)
+        c.update(learning=True)
+        Wo = W0.copy()
+        oracle.conv2d_postpre(Wo, s_src, x_src, s_tgt, x_tgt, stride=stride, pad=pad, nu0=np.float32(1e-3), nu1=np.float32(1e-2), wmin=0.0, wmax=1.0)
+        np.testing.assert_array_equal(host(c.w).view(np.uint32), Wo.view(np.uint32), err_msg=f"case {k} vs oracle")
+        np.testing.assert_allclose(host(c.w), g[f"cpp{k}"], rtol=0, atol=1e-5, err_msg=f"case {k} vs reference")
+    B, T3 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(1700, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T3)
+    net.add_monitor(mon, "s")
+    net.to(DEV)
+    sp = synth.dense_spikes(1701, (T3, B, 1, 12, 12), 0.2)
+    net.run({"X": T_(sp).to(DEV)}, time=T3)
+    assert net.last_plan == "generic"
+    np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
+    np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-4)

@@ -306,3 +306,17 @@ def test_mstdpet_sequence_matches_reference():
                        wmin=0.0, wmax=1.0)
     for got, key in ((W, "et_w"), (et, "et_trace"), (elig, "et_elig"), (pp, "et_p_plus"), (pm, "et_p_minus")):
         np.testing.assert_array_equal(bits(got), bits(g[key]), err_msg=key)
+
+
+def test_conv2d_postpre_matches_reference_within_blas_tolerance():
+    """learning.py:457-497: the reference sums over output positions inside torch.bmm (BLAS order), the oracle in
+    ascending order -- same mathematics, compared at 1e-5."""
+    g = gold("run_extras")
+    for k, (B, Cin, H, Wd, Cout, K, stride, pad) in enumerate(g["cpp_cases"]):
+        B, Cin, H, Wd, Cout, K, stride, pad = (int(v) for v in (B, Cin, H, Wd, Cout, K, stride, pad))
+        OH = (H + 2 * pad - K) // stride + 1
+        W = synth.uniform_f32(1200 + k, (Cout, Cin, K, K), 0.0, 0.5)
+        oracle.conv2d_postpre(W, synth.dense_spikes(1300 + k, (B, Cin, H, Wd), 0.15), synth.uniform_f32(1400 + k, (B, Cin, H, Wd), 0.0, 1.0),
+                              synth.dense_spikes(1500 + k, (B, Cout, OH, OH), 0.1), synth.uniform_f32(1600 + k, (B, Cout, OH, OH), 0.0, 1.0),
+                              stride=stride, pad=pad, nu0=np.float32(1e-3), nu1=np.float32(1e-2), wmin=0.0, wmax=1.0)
+        np.testing.assert_allclose(W, g[f"cpp{k}"], rtol=0, atol=1e-5, err_msg=f"case {k}")
