@@ -58,7 +58,7 @@ class RunDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
                 ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_ulonglong),
-                ("cursor", C.c_void_p), ("status", C.c_void_p), ("plan", C.c_int)]
+                ("cursor", C.c_void_p), ("status", C.c_void_p), ("one_step", C.c_int), ("plan", C.c_int)]
 
 
 class FillSegment(C.Structure):

@@ -141,22 +141,30 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
     if (nL > 64) return SNN_ERR_UNSUPPORTED;
     for (int t = 0; t < R->T; ++t) {
         const bool prof = snn_prof_begin(t, st);
-        // (1) network.py:384 _get_inputs(): previous-step spikes through every connection, in order
+        // (1) network.py:384 _get_inputs(): previous-step spikes through every connection, in order.  one_step
+        //     (network.py:388-393): the same per target layer, right before that layer steps, from the sources' CURRENT
+        //     spikes -- a source that has already stepped in this timestep (lower layer index) contributes its new ones.
         for (int l = 0; l < nL; ++l) fed[l] = false;
-        for (int c = 0; c < nC; ++c) {
-            const snn_conn_desc &d = C[c];
-            const snn_layer_desc &S = L[d.src], &D = L[d.dst];
-            const uint8_t *sp = layer_spikes(S, B, t, false);
-            const int acc = fed[d.dst] ? 1 : 0;
-            if (d.kind == SNN_CONN_MCC) TRY(snn_prop_cascade_f32(d.w, sp, D.current, B, S.n, D.n, acc, st));
-            else if (d.kind == SNN_CONN_DENSE) TRY(snn_prop_dense_f32(d.w, d.bias, sp, D.current, B, S.n, D.n, acc, st));
-            else TRY(snn_prop_conv2d_f32(d.w, d.bias, sp, D.current, B, d.cin, d.h, d.wd, d.cout, d.kh, d.kw,
-                                         d.stride, d.pad, acc, st));
-            fed[d.dst] = true;
-        }
+        auto feed = [&](int only_dst) -> int {
+            for (int c = 0; c < nC; ++c) {
+                const snn_conn_desc &d = C[c];
+                if (only_dst >= 0 && d.dst != only_dst) continue;
+                const snn_layer_desc &S = L[d.src], &D = L[d.dst];
+                const uint8_t *sp = layer_spikes(S, B, t, only_dst >= 0 && d.src < only_dst);
+                const int acc = fed[d.dst] ? 1 : 0;
+                if (d.kind == SNN_CONN_MCC) TRY(snn_prop_cascade_f32(d.w, sp, D.current, B, S.n, D.n, acc, st));
+                else if (d.kind == SNN_CONN_DENSE) TRY(snn_prop_dense_f32(d.w, d.bias, sp, D.current, B, S.n, D.n, acc, st));
+                else TRY(snn_prop_conv2d_f32(d.w, d.bias, sp, D.current, B, d.cin, d.h, d.wd, d.cout, d.kh, d.kw,
+                                             d.stride, d.pad, acc, st));
+                fed[d.dst] = true;
+            }
+            return SNN_OK;
+        };
+        if (!R->one_step) TRY(feed(-1));
         // (2) network.py:386-413 layers in insertion order
         for (int l = 0; l < nL; ++l) {
             const snn_layer_desc &d = L[l];
+            if (R->one_step && d.kind != SNN_LAYER_INPUT) TRY(feed(l));
             const size_t off = (size_t)t * B * d.n;
             uint8_t *rs = d.raster_s ? d.raster_s + off : nullptr;
             float *rv = d.raster_v ? d.raster_v + off : nullptr;
@@ -231,6 +239,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request
     for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v) mode = 1;   // only the generic plan implements these
     for (int c = 0; c < nC; ++c) if (C[c].mask || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
+    if (R->one_step) mode = 1;
     if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));

@@ -123,8 +123,6 @@ class Network(torch.nn.Module):
             f"Got {type(inputs).__name__} instead.")
         clamps, unclamps = kwargs.get("clamp", {}) or {}, kwargs.get("unclamp", {}) or {}
         injects_v, masks = kwargs.get("injects_v", {}) or {}, kwargs.get("masks", {}) or {}
-        if one_step:
-            raise NotImplementedError("bindsnet_amd: one_step mode is outside the accelerated path")
         if self.reward_fn is not None:
             kwargs["reward"] = self.reward_fn.compute(**kwargs)
 
@@ -257,6 +255,7 @@ class Network(torch.nn.Module):
 
         R = _lib.RunDesc()
         R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
+        R.one_step = int(bool(one_step))                  # network.py:388-393 (generic plan)
         need = int(_lib.lib().snn_net_workspace_bytes(L, len(names), Cn, len(self.connections), C.byref(R)))
         if need:
             ws = getattr(self, "_workspace", None)

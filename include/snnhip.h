@@ -297,6 +297,9 @@ typedef struct {
     unsigned long long workspace_bytes;
     long long *cursor;          /* device int64[2] */
     int *status;                /* device int32[1]: 0, SNN_ERR_NOISE or SNN_ERR_TIMEOUT after the run */
+    int one_step;               /* network.py:388-393 one_step=True: every layer's input is computed right before its own step
+                                   from the CURRENT spikes of its sources (those already stepped in this timestep contribute
+                                   their new spikes) -- a feed-forward pass per timestep.  Generic plan only. */
     int plan;                   /* 0 = automatic, 1 = generic per-operator launches, 2 = fused plans in their
                                    one-launch-per-timestep form (what a caller re-runs with after SNN_ERR_TIMEOUT),
                                    3 = automatic, but never the lean form of a plan (what a caller re-runs with after

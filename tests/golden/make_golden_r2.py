@@ -213,8 +213,34 @@ def extras_case():
     save("run_extras", **out)
 
 
+def one_step_case():
+    """run(..., one_step=True) (network.py:388-393) on Input -> A -> B (+ a feedback B -> A), MulticompartmentConnections."""
+    nX, nA, nB, B, T = 64, 40, 24, 2, 30
+    net = Network(dt=1.0, learning=False)
+    X, A, Bl = Input(n=nX), LIFNodes(n=nA, thresh=-60.0), LIFNodes(n=nB, thresh=-61.0)
+    net.add_layer(X, "X"); net.add_layer(A, "A"); net.add_layer(Bl, "B")
+    for k, (src, dst, ns, nd, sc) in enumerate((("X", "A", nX, nA, 2.0), ("A", "B", nA, nB, 3.0), ("B", "A", nB, nA, -1.0))):
+        w = synth.uniform_f32(2200 + k, (ns, nd), 0.0, abs(sc)) * np.sign(sc)
+        c = MulticompartmentConnection(net.layers[src], net.layers[dst], device="cpu", pipeline=[Weight("weight", T_(w.astype(np.float32)).clone())])
+        net.add_connection(c, src, dst)
+    mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("A", "B")}
+    for l, m in mons.items():
+        net.add_monitor(m, l)
+    sp = synth.dense_spikes(2210, (T, B, nX), 0.15)
+    out = {}
+    for tag, flag in (("one", True), ("sync", False)):
+        net.reset_state_variables()
+        net.run({"X": T_(sp)}, time=T, one_step=flag)
+        for l in ("A", "B"):
+            out[f"{tag}_{l}"] = np.packbits(mons[l].get("s").numpy().astype(np.uint8))
+        print(f"  one_step={flag}: A spikes {int(mons['A'].get('s').sum())}, B spikes {int(mons['B'].get('s').sum())}")
+    save("run_one_step", **out)
+
+
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules", "extras"]
+    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules", "extras", "one_step"]
+    if "one_step" in jobs:
+        one_step_case()
     if "extras" in jobs:
         extras_case()
     if "rules" in jobs:

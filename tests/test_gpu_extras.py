@@ -116,3 +116,31 @@ def test_conv2d_postpre_updates_and_run():
     assert net.last_plan == "generic"
     np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
     np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-4)
+
+
+def test_one_step_mode_matches_reference():
+    """run(..., one_step=True): every layer's input comes from the CURRENT spikes of its sources (network.py:388-393);
+    Input -> A -> B with a feedback B -> A.  Both modes against the reference, bit for bit (MCC path: ATen order)."""
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    g = gold("run_one_step")
+    nX, nA, nB, B, T = 64, 40, 24, 2, 30
+    net = Network(dt=1.0, learning=False)
+    net.add_layer(Input(n=nX), "X"); net.add_layer(LIFNodes(n=nA, thresh=-60.0), "A"); net.add_layer(LIFNodes(n=nB, thresh=-61.0), "B")
+    for k, (src, dst, ns, nd, sc) in enumerate((("X", "A", nX, nA, 2.0), ("A", "B", nA, nB, 3.0), ("B", "A", nB, nA, -1.0))):
+        w = (synth.uniform_f32(2200 + k, (ns, nd), 0.0, abs(sc)) * np.sign(sc)).astype(np.float32)
+        net.add_connection(MulticompartmentConnection(net.layers[src], net.layers[dst], device="cpu", pipeline=[Weight("weight", T_(w).clone())]), src, dst)
+    mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("A", "B")}
+    for l, m in mons.items():
+        net.add_monitor(m, l)
+    net.to(DEV)
+    sp = synth.dense_spikes(2210, (T, B, nX), 0.15)
+    for tag, flag in (("one", True), ("sync", False)):
+        net.reset_state_variables()
+        net.run({"X": T_(sp).to(DEV)}, time=T, one_step=flag)
+        for l, n in (("A", nA), ("B", nB)):
+            np.testing.assert_array_equal(host(mons[l].get("s")).reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
+    assert not np.array_equal(g["one_A"], g["sync_A"])
