@@ -200,8 +200,6 @@ def test_unsupported_features_fail_loudly():
     net.add_layer(LIFNodes(n=5), "Y")
     net.to(DEV)
     with pytest.raises(NotImplementedError):
-        net.run({"X": torch.zeros(5, 1, 10, dtype=torch.uint8, device=DEV)}, time=5, one_step=True)
-    with pytest.raises(NotImplementedError):
         net.run({"X": torch.zeros(5, 1, 10, dtype=torch.uint8, device=DEV)}, time=5, clamp={"X": torch.zeros(10).bool()})   # Input layers
     with pytest.raises(NotImplementedError):
         net.run({"X": torch.zeros(5, 1, 10, device=DEV)}, time=5)   # float inputs
