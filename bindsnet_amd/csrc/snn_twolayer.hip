@@ -55,6 +55,7 @@ struct TwoCtx {
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
     float inv_hwps;
     int prodw;                                           // floats of LDS for the staged products of the dense dot (0: off)
+    int rowmajor;                                        // PostPre in its row-major form (developer switch SNN_TWO_ROWMAJOR=0: off)
     int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= NT)
     // MSTDP (learning.py:1504-1574), factored eligibility: p_plus / p_minus traces, previous-step spike factors
     float *p_plus, *p_minus; uint8_t *s_src_prev, *s_tgt_prev;
@@ -346,6 +347,154 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
     }
 }
 
+// PostPre, row-major form (used whenever no element can fall into ATen's <32-element tail, i.e. Nin*N % 32 == 0): thread <->
+// source row i, all CW columns of the tile in registers.  The pre-synaptic term walks the row's own sample mask; the
+// post-synaptic term walks the SAMPLES (union over the tile's columns of the samples whose neuron spiked, ascending) in
+// the outer loop -- coalesced loads of x_src[b, :] for the whole workgroup, eight samples in flight at a time -- and
+// feeds each column's own accumulator only for the samples of that column, so every element still sees its terms in
+// ascending sample order.  Same arithmetic per element as two_stdp: w -= pre * dt; w += post * dt; w *= decay; clamp.
+//
+// Batch sums here have B <= 128 terms, for which ATen's cascade (snn_order.hpp CascadeFlat) is: one partial per block of
+// 16 samples, the partials of the full blocks added up in ascending order, and the partial of the trailing short block
+// (B % 16 samples) added in front: ((tail + sum_blocks) + 0) + 0.  Samples that contribute nothing add +0.0, which never
+// changes a partial (partials start at +0.0 and so are never -0.0); the loops below skip them.
+template <int MWT>
+__device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, const uint32_t *am, const uint32_t *ab,
+                                                  const uint16_t *ridx, const float *xnu0, const uint32_t *cm,
+                                                  const float *__restrict__ xs, bool full, int c0, int tid) {
+    const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;
+    const int nfull = B >> 4;                              // blocks 0 .. nfull-1 are full, block nfull is the short tail
+    const int nblk = (B + 15) >> 4;
+    // columns with a post-synaptic spike, and the union of their sample masks (uniform over the workgroup)
+    uint32_t cu[MWT] = {0}, cmr[8][MWT];                   // (scalar registers)
+    uint32_t postcols = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int w = 0; w < MWT; ++w) {
+            const bool on = c.nu1 != 0.f && q < CW && c0 + q < N && w < mw;
+            const uint32_t v = on ? (uint32_t)__builtin_amdgcn_readfirstlane(cm[q * mw + w]) : 0u;
+            cmr[q][w] = v; cu[w] |= v; o |= v;
+        }
+        if (o) postcols |= 1u << q;
+    }
+    const float nu1c = 1.0f * c.nu1;
+    for (int i = tid; i < Nin; i += NT) {
+        const bool active = (ab[i >> 5] >> (i & 31)) & 1u;
+        if (!full && !active && !postcols) continue;
+        float w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = q < CW ? wt[i * CW + q] : 0.f;
+        if (c.nu0 != 0.f) {                                // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+            float a1[8], tl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a1[q] = tl[q] = 0.f;
+            if (active) {
+                const uint32_t *m = am + (int)ridx[i] * mw;   // samples in which row i spiked
+                for (int blk = 0; blk < nblk; ++blk) {
+                    uint32_t mm = (m[blk >> 1] >> ((blk & 1) * 16)) & 0xFFFFu;
+                    if (!mm) continue;
+                    float a0[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a0[q] = 0.f;
+                    while (mm) {
+                        const int b = blk * 16 + __ffs(mm) - 1; mm &= mm - 1;
+                        const float4 lo = *(const float4 *)(xnu0 + b * 8), hi = *(const float4 *)(xnu0 + b * 8 + 4);
+                        const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a0[q] += 1.0f * xv[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { if (blk < nfull) a1[q] = a1[q] + a0[q]; else tl[q] = a0[q]; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q >= CW) break;
+                float uu = ((tl[q] + a1[q]) + 0.f) + 0.0f;
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] - uu;
+            }
+        }
+        if (c.nu1 != 0.f) {                                // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+            float a0[8], a1[8], tl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a0[q] = a1[q] = tl[q] = 0.f;
+            if (postcols) {
+                int wd = 0, cblk = -1;
+                uint32_t mm = cu[0];
+                // a chunk = up to 8 samples of ONE mask word (scalar bookkeeping: the masks are the same for every thread)
+                auto load_chunk = [&](int (&bs)[8], float (&x)[8], int &cwd) {
+                    while (!mm && wd + 1 < mw) {
+                        ++wd; mm = cu[0];
+#pragma unroll
+                        for (int w = 1; w < MWT; ++w) mm = wd == w ? cu[w] : mm;
+                    }
+                    cwd = wd;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (mm) { bs[k] = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; x[k] = xs[bs[k] * Nin + i]; }
+                        else { bs[k] = -1; x[k] = 0.f; }
+                    }
+                };
+                auto close = [&](int blk) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (blk < nfull) a1[q] = a1[q] + a0[q]; else tl[q] = a0[q];
+                        a0[q] = 0.f;
+                    }
+                };
+                auto accumulate = [&](const int (&bs)[8], const float (&x)[8], int cwd) {
+                    uint32_t cw[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        cw[q] = cmr[q][0];
+#pragma unroll
+                        for (int w = 1; w < MWT; ++w) cw[q] = cwd == w ? cmr[q][w] : cw[q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int b = bs[k];
+                        if (b < 0) break;
+                        if ((b >> 4) != cblk) { if (cblk >= 0) close(cblk); cblk = b >> 4; }
+                        const float term = x[k] * nu1c;
+                        const int bb = b & 31;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if ((cw[q] >> bb) & 1u) a0[q] += term;
+                    }
+                };
+                int bsA[8], bsB[8], wA, wB;
+                float xA[8], xB[8];
+                load_chunk(bsA, xA, wA);
+                while (bsA[0] >= 0) {                      // the next chunk's loads are in flight while this one is added up
+                    load_chunk(bsB, xB, wB);
+                    accumulate(bsA, xA, wA);
+                    if (bsB[0] < 0) break;
+                    load_chunk(bsA, xA, wA);
+                    accumulate(bsB, xB, wB);
+                }
+                if (cblk >= 0) close(cblk);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q >= CW) break;
+                float uu = ((postcols >> q) & 1u) ? ((tl[q] + a1[q]) + 0.f) + 0.0f : 0.f;
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] + uu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q >= CW) break;
+            float v = w[q] * c.wdecay;
+            if (c.has_min && v < c.wmin) v = c.wmin;
+            if (c.has_max && v > c.wmax) v = c.wmax;
+            if (c0 + q < N && (active || full || ((postcols >> q) & 1u))) wt[i * CW + q] = v;
+        }
+    }
+}
+
 // MSTDP update of one step on the LDS weight tile (learning.py:1504-1574 with the eligibility factored as in
 // snn_mstdp_step): w += nu0 * sum_b reward[b] * (p_plus[b,i] * s_tgt[b,j] + s_src[b,i] * p_minus[b,j]), decay, clamp,
 // all four factors being those of the PREVIOUS step.  Samples in which neither side spiked contribute +0.0 and are
@@ -418,6 +567,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     uint32_t *am = (uint32_t *)(smem + off); off += (size_t)Nin * mw * 4;                 // [active rows][MW] sample masks
     uint16_t *ar = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;
     uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
+    uint16_t *ridx = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;       // source row -> index in ar / am
     float *xnu0 = (float *)(smem + off); off += (size_t)BC * 8 * 4;                       // [B][CW] x_tgt * nu0
     uint32_t *colmask = (uint32_t *)(smem + off); off += (size_t)2 * CMS * 4;             // [2][8][MW]: samples whose neuron (column q) spiked
     float *rvl = (float *)(smem + off); off += (size_t)BC * 4;                            // MSTDP: reward per sample
@@ -497,7 +647,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 if (k < META) meta[k] = (int)r_dg[u];
                 else if ((k -= META) < n1) ((uint32_t *)ent)[k] = r_dg[u];
                 else if ((k -= n1) < n2) am[k] = r_dg[u];
-                else if ((k -= n2) < n3) ((uint32_t *)ar)[k] = r_dg[u];
+                else if ((k -= n2) < n3) {
+                    ((uint32_t *)ar)[k] = r_dg[u];
+                    ridx[r_dg[u] & 0xFFFFu] = (uint16_t)(2 * k);               // (two u16 rows per word; a stale second half
+                    if (2 * k + 1 < nact) ridx[r_dg[u] >> 16] = (uint16_t)(2 * k + 1);   //  past nact is not an active row)
+                }
                 else if ((k -= n3) < n4) ab[k] = r_dg[u];
             }
             // traces prefetched at the end of the previous iteration, and the spike masks this iteration will fill
@@ -526,7 +680,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             const bool full = (t == 1) || c.wdecay != 1.0f;   // first update of a run (or a real decay) touches every element
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
             if (Etot != Emain) two_stdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
-            else two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            else if (sbytes || c.rowmajor == 0) two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            else two_stdp_rowmajor<MWT>(c, wt, am, ab, ridx, xnu0, cm, xs, full, c0, tid);
         }
         TMARK(3);
         lds_barrier();
@@ -717,7 +872,7 @@ size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
            (size_t)c.Nin * (c.MW - 1) * 4 +
-           al((size_t)c.NinW * 4) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
+           al((size_t)c.NinW * 4) + al((size_t)c.Nin * 2) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
            (size_t)(c.T + 2) * 8 +
            (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
@@ -755,8 +910,9 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (c.T + 1 > 4096) return false;
     c.prodw = 0;
     if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) { c.prodw = 4096; if (run_lds(c) > 140 * 1024) c.prodw = 0; }
+    c.rowmajor = !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     c.use_xsl = 0;
-    if (Nin <= NT && c.rule == SNN_RULE_POSTPRE) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
+    if (Nin <= NT && c.rule == SNN_RULE_POSTPRE && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
     if (META + c.LCAP / 2 + Nin * c.MW + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
     return true;

@@ -92,7 +92,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     for make in (cfg1, cfg3_shard, cfg3_b32, cfg3, cfg4, cfg5):
-        if a.only and make.__name__ != a.only:
+        if a.only and make.__name__ not in a.only.split(','):
             continue
         name, net, inputs, T, kw = make()
         r = timed(net, inputs, T, a.runs, **kw)
