@@ -65,6 +65,7 @@ struct TwoCtx {
     long long *dbg;                                      // developer aid (SNN_TWO_TIMING=1): phase timestamps of workgroup 0
 };
 
+#define WMARK() do { if (c.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) c.dbg[(size_t)8 * 4096 + (size_t)t * 16 + (threadIdx.x >> 6)] = (long long)wall_clock64(); } while (0)
 #define TMARK(slot) do { if (c.dbg && blockIdx.x == 0 && threadIdx.x == 0) c.dbg[(size_t)t * 8 + (slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ uint32_t nz4(uint32_t w) {
@@ -356,143 +357,179 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
 //
 // Batch sums here have B <= 128 terms, for which ATen's cascade (snn_order.hpp CascadeFlat) is: one partial per block of
 // 16 samples, the partials of the full blocks added up in ascending order, and the partial of the trailing short block
-// (B % 16 samples) added in front: ((tail + sum_blocks) + 0) + 0.  Samples that contribute nothing add +0.0, which never
-// changes a partial (partials start at +0.0 and so are never -0.0); the loops below skip them.
+// (B % 16 samples) added to that: ((tail + sum_blocks) + 0) + 0.  Samples that contribute nothing add +0.0, which never
+// changes a partial (partials start at +0.0 and so are never -0.0); the loops below skip them.  With a0 = the running
+// partial of the current block and a1 = the sum of the closed ones, the result is ((a0 + a1) + 0) + 0 whether the last
+// block is the tail (tail + a1) or a full one (0 + (a1 + a0)).
+//
+// Where a term applies to some columns only, it is multiplied by a 0/1 factor inside an fma: the product is exact
+// (x*1, x*0), so the fma rounds once -- to the same value as the plain add (or no add) it stands for.
 template <int MWT>
 __device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, const uint32_t *am, const uint32_t *ab,
-                                                  const uint16_t *ridx, const float *xnu0, const uint32_t *cm,
-                                                  const float *__restrict__ xs, bool full, int c0, int tid) {
+                                                  const uint16_t *ridx, const float *xnu0, const uint32_t *ul,
+                                                  const float4 *fac, const float *__restrict__ xs, bool full, int c0, int tid) {
     const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;
-    const int nfull = B >> 4;                              // blocks 0 .. nfull-1 are full, block nfull is the short tail
-    const int nblk = (B + 15) >> 4;
-    // columns with a post-synaptic spike, and the union of their sample masks (uniform over the workgroup)
-    uint32_t cu[MWT] = {0}, cmr[8][MWT];                   // (scalar registers)
-    uint32_t postcols = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int w = 0; w < MWT; ++w) {
-            const bool on = c.nu1 != 0.f && q < CW && c0 + q < N && w < mw;
-            const uint32_t v = on ? (uint32_t)__builtin_amdgcn_readfirstlane(cm[q * mw + w]) : 0u;
-            cmr[q][w] = v; cu[w] |= v; o |= v;
-        }
-        if (o) postcols |= 1u << q;
-    }
+    // the samples with a post-synaptic spike in this tile, ascending (bytes of ul[0..8 mw)), their number, the columns that
+    // spiked at all, and per listed sample one 0/1 factor per column (fac): built by two_union_list
+    const int nun = c.nu1 != 0.f ? __builtin_amdgcn_readfirstlane(ul[8 * mw]) : 0;
+    const uint32_t postcols = c.nu1 != 0.f ? (uint32_t)__builtin_amdgcn_readfirstlane(ul[8 * mw + 1]) : 0u;
     const float nu1c = 1.0f * c.nu1;
+    // x_src[b, i] = one buffer load: descriptor of the slab (scalar), row offset b*Nin*4 (scalar), lane offset i*4
+    const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void *)xs, 0, B * Nin * 4, 0x00020000);
     for (int i = tid; i < Nin; i += NT) {
         const bool active = (ab[i >> 5] >> (i & 31)) & 1u;
         if (!full && !active && !postcols) continue;
         float w[8];
+        if (CW == 8) {
+            const float4 lo = *(const float4 *)(wt + i * 8), hi = *(const float4 *)(wt + i * 8 + 4);
+            w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = q < CW ? wt[i * CW + q] : 0.f;
+            for (int q = 0; q < 8; ++q) w[q] = q < CW ? wt[i * CW + q] : 0.f;
+        }
+        // eight samples per chunk; list entries past nun are stale but valid sample numbers: loaded, never added
+        auto load_chunk = [&](int k0, uint32_t (&id)[2], float (&x)[8]) {
+            id[0] = __builtin_amdgcn_readfirstlane(ul[k0 >> 2]);
+            id[1] = __builtin_amdgcn_readfirstlane(ul[(k0 >> 2) + 1]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t b = (id[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slab, i * 4, (int)(b * (uint32_t)Nin * 4u), 0));
+            }
+        };
+        uint32_t idA[2], idB[2];
+        float xA[8], xB[8];
+        if (nun > 0) load_chunk(0, idA, xA);               // in flight behind the pre-synaptic part
+        float a0[8], a1[8];
         if (c.nu0 != 0.f) {                                // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
-            float a1[8], tl[8];
+            // per lane: walk the row's samples in ascending order
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a1[q] = tl[q] = 0.f;
+            for (int q = 0; q < 8; ++q) a0[q] = a1[q] = 0.f;
             if (active) {
-                const uint32_t *m = am + (int)ridx[i] * mw;   // samples in which row i spiked
-                for (int blk = 0; blk < nblk; ++blk) {
-                    uint32_t mm = (m[blk >> 1] >> ((blk & 1) * 16)) & 0xFFFFu;
-                    if (!mm) continue;
-                    float a0[8];
+                uint32_t m[MWT];
+                const uint32_t *mp = am + (int)ridx[i] * mw;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a0[q] = 0.f;
+                for (int wd = 0; wd < MWT; ++wd) m[wd] = wd < mw ? mp[wd] : 0u;
+                int cblk = 0;
+#pragma unroll
+                for (int wd = 0; wd < MWT; ++wd) {
+                    uint32_t mm = m[wd];
                     while (mm) {
-                        const int b = blk * 16 + __ffs(mm) - 1; mm &= mm - 1;
+                        const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1;
                         const float4 lo = *(const float4 *)(xnu0 + b * 8), hi = *(const float4 *)(xnu0 + b * 8 + 4);
                         const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        // a block change closes the running partial: a1 += a0, a0 = 0 (closing an empty block adds +0.0)
+                        const float same = (b >> 4) == cblk ? 1.f : 0.f, diff = 1.f - same;
+                        cblk = b >> 4;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) a0[q] += 1.0f * xv[q];
+                        for (int q = 0; q < 8; ++q) {
+                            a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+                            a0[q] = __builtin_fmaf(a0[q], same, 1.0f * xv[q]);
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { if (blk < nfull) a1[q] = a1[q] + a0[q]; else tl[q] = a0[q]; }
                 }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (q >= CW) break;
-                float uu = ((tl[q] + a1[q]) + 0.f) + 0.0f;
+                float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
                 if (c.use_dt) uu = uu * c.dt;
                 w[q] = w[q] - uu;
             }
         }
         if (c.nu1 != 0.f) {                                // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
-            float a0[8], a1[8], tl[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a0[q] = a1[q] = tl[q] = 0.f;
-            if (postcols) {
-                int wd = 0, cblk = -1;
-                uint32_t mm = cu[0];
-                // a chunk = up to 8 samples of ONE mask word (scalar bookkeeping: the masks are the same for every thread)
-                auto load_chunk = [&](int (&bs)[8], float (&x)[8], int &cwd) {
-                    while (!mm && wd + 1 < mw) {
-                        ++wd; mm = cu[0];
+            for (int q = 0; q < 8; ++q) a0[q] = a1[q] = 0.f;
+            int cblk = 0;
+            auto accumulate = [&](int k0, const uint32_t (&id)[2], const float (&x)[8]) {
 #pragma unroll
-                        for (int w = 1; w < MWT; ++w) mm = wd == w ? cu[w] : mm;
+                for (int k = 0; k < 8; ++k) {
+                    if (k0 + k >= nun) break;
+                    const int b = (int)((id[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    const float4 f0 = fac[2 * (k0 + k)], f1 = fac[2 * (k0 + k) + 1];   // (same address in every lane)
+                    const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                    if ((b >> 4) != cblk) {
+                        cblk = b >> 4;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { a1[q] = a1[q] + a0[q]; a0[q] = 0.f; }
                     }
-                    cwd = wd;
+                    const float term = x[k] * nu1c;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (mm) { bs[k] = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; x[k] = xs[bs[k] * Nin + i]; }
-                        else { bs[k] = -1; x[k] = 0.f; }
-                    }
-                };
-                auto close = [&](int blk) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (blk < nfull) a1[q] = a1[q] + a0[q]; else tl[q] = a0[q];
-                        a0[q] = 0.f;
-                    }
-                };
-                auto accumulate = [&](const int (&bs)[8], const float (&x)[8], int cwd) {
-                    uint32_t cw[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        cw[q] = cmr[q][0];
-#pragma unroll
-                        for (int w = 1; w < MWT; ++w) cw[q] = cwd == w ? cmr[q][w] : cw[q];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int b = bs[k];
-                        if (b < 0) break;
-                        if ((b >> 4) != cblk) { if (cblk >= 0) close(cblk); cblk = b >> 4; }
-                        const float term = x[k] * nu1c;
-                        const int bb = b & 31;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) if ((cw[q] >> bb) & 1u) a0[q] += term;
-                    }
-                };
-                int bsA[8], bsB[8], wA, wB;
-                float xA[8], xB[8];
-                load_chunk(bsA, xA, wA);
-                while (bsA[0] >= 0) {                      // the next chunk's loads are in flight while this one is added up
-                    load_chunk(bsB, xB, wB);
-                    accumulate(bsA, xA, wA);
-                    if (bsB[0] < 0) break;
-                    load_chunk(bsA, xA, wA);
-                    accumulate(bsB, xB, wB);
+                    for (int q = 0; q < 8; ++q) a0[q] = __builtin_fmaf(term, f[q], a0[q]);
                 }
-                if (cblk >= 0) close(cblk);
+            };
+            for (int k0 = 0; k0 < nun; k0 += 16) {         // the next chunk's loads are in flight while this one is added up
+                if (k0 + 8 < nun) load_chunk(k0 + 8, idB, xB);
+                accumulate(k0, idA, xA);
+                if (k0 + 8 >= nun) break;
+                if (k0 + 16 < nun) load_chunk(k0 + 16, idA, xA);
+                accumulate(k0 + 8, idB, xB);
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (q >= CW) break;
-                float uu = ((postcols >> q) & 1u) ? ((tl[q] + a1[q]) + 0.f) + 0.0f : 0.f;
+                float uu = ((postcols >> q) & 1u) ? ((a0[q] + a1[q]) + 0.f) + 0.0f : 0.f;
                 if (c.use_dt) uu = uu * c.dt;
                 w[q] = w[q] + uu;
             }
         }
+        const bool whole = CW == 8 && c0 + 8 <= N && (active || full || postcols == 0xFFu);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q >= CW) break;
             float v = w[q] * c.wdecay;
             if (c.has_min && v < c.wmin) v = c.wmin;
             if (c.has_max && v > c.wmax) v = c.wmax;
-            if (c0 + q < N && (active || full || ((postcols >> q) & 1u))) wt[i * CW + q] = v;
+            w[q] = v;
+            if (!whole && c0 + q < N && (active || full || ((postcols >> q) & 1u))) wt[i * CW + q] = v;
+        }
+        if (whole) {
+            *(float4 *)(wt + i * 8) = make_float4(w[0], w[1], w[2], w[3]);
+            *(float4 *)(wt + i * 8 + 4) = make_float4(w[4], w[5], w[6], w[7]);
         }
     }
+}
+
+// The row-major PostPre's view of one step's post-synaptic spikes, built by the first B threads once the step's spike
+// masks are final: bytes of ul[0..8 mw) = the samples in which any column of the tile spiked (ascending), fac[2k], fac[2k+1]
+// = 1.0 / 0.0 per column for the k-th of them, ul[8 mw] = how many, ul[8 mw + 1] = the columns that spiked at all.
+template <int MWT>
+__device__ __forceinline__ void two_union_list(const TwoCtx &c, const uint32_t *cmn, uint32_t *ul, float4 *fac, int mw, int c0, int tid) {
+    if (tid >= c.B) return;
+    const int w = tid >> 5, bit = tid & 31;
+    uint32_t cmv[8][MWT];                                  // all loads first (independent), then the arithmetic
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool on = q < c.CW && c0 + q < c.N;
+#pragma unroll
+        for (int w2 = 0; w2 < MWT; ++w2) cmv[q][w2] = (on && w2 < mw) ? cmn[q * mw + w2] : 0u;
+    }
+    uint32_t colbits = 0, any = 0;
+    int rank = 0, total = 0;
+    bool in = false;
+#pragma unroll
+    for (int w2 = 0; w2 < MWT; ++w2) {
+        uint32_t un = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t v = cmv[q][w2];
+            un |= v;
+            if (v) any |= 1u << q;
+            if (w2 == w && ((v >> bit) & 1u)) colbits |= 1u << q;
+        }
+        total += __popc(un);
+        if (w2 < w) rank += __popc(un);
+        else if (w2 == w) { rank += __popc(un & ((1u << bit) - 1u)); in = (un >> bit) & 1u; }
+    }
+    if (in) {
+        ((uint8_t *)ul)[rank] = (uint8_t)tid;
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = ((colbits >> q) & 1u) ? 1.f : 0.f;
+        fac[2 * rank] = make_float4(f[0], f[1], f[2], f[3]);
+        fac[2 * rank + 1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (tid == 0) { ul[8 * mw] = (uint32_t)total; ul[8 * mw + 1] = any; }
 }
 
 // MSTDP update of one step on the LDS weight tile (learning.py:1504-1574 with the eligibility factored as in
@@ -572,6 +609,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     uint32_t *colmask = (uint32_t *)(smem + off); off += (size_t)2 * CMS * 4;             // [2][8][MW]: samples whose neuron (column q) spiked
     float *rvl = (float *)(smem + off); off += (size_t)BC * 4;                            // MSTDP: reward per sample
     float *zl = (float *)(smem + off); off += (size_t)BC * 8 * 4;                         // MSTDP: reward * p_minus per (sample, column)
+    uint32_t *ul = (uint32_t *)rvl; float4 *fac = (float4 *)zl;                           // PostPre, row-major form: see two_union_list (the MSTDP arrays are free)
     float *prod = (float *)(smem + off); off += c.prodw ? (size_t)c.prodw * 4 : 0;        // dense dot: staged products
     int *szt = (int *)(smem + off); off += (size_t)(c.T + 2) * 8;                         // (events, active rows) of every digest entry
     float *xsl = (float *)(smem + off); off += c.use_xsl ? (size_t)Nin * CW * 4 : 0;      // source trace of the first spiking sample of each column
@@ -598,6 +636,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (do_mstdp) pm = c.p_minus[kst];
     }
     if (tid < 2 * CMS) colmask[tid] = 0;
+    if (tid < 8 * mw + 2) ul[tid] = 0;
     if (tid < BC) rvl[tid] = (do_mstdp && tid < B) ? (c.reward_vec ? c.reward_vec[tid] : c.reward) : 0.f;
     if (do_mstdp) {      // the target spikes the rule remembers from its last update: "previous step" of iteration 0
         __syncthreads();
@@ -681,8 +720,9 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
             if (Etot != Emain) two_stdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
             else if (sbytes || c.rowmajor == 0) two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
-            else two_stdp_rowmajor<MWT>(c, wt, am, ab, ridx, xnu0, cm, xs, full, c0, tid);
+            else two_stdp_rowmajor<MWT>(c, wt, am, ab, ridx, xnu0, ul, fac, xs, full, c0, tid);
         }
+        WMARK();
         TMARK(3);
         lds_barrier();
         TMARK(4);
@@ -770,6 +810,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
         }
         lds_barrier();                                   // this step's spike masks are final
+        if (RULE == SNN_RULE_POSTPRE && do_stdp && c.rowmajor) two_union_list<MWT>(c, cmn, ul, fac, mw, c0, tid);   // (read after the next barrier)
         if (c.use_xsl && do_stdp && tid < Nin) {         // source traces the next PostPre needs: in flight across the loop edge
             const float *xs = c.xall + (size_t)t * B * Nin;
 #pragma unroll
@@ -986,7 +1027,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     hipLaunchKernelGGL(k_two_prep, dim3(mstdp ? c.T + 2 : c.T + 1), dim3(NT), prep_lds, st, c);
     static long long *dbg = nullptr;
     if (getenv("SNN_TWO_TIMING")) {
-        if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 8 * 4096);
+        if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 24 * 4096);
         if (c.T + 1 <= 4096) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * (c.T + 1), st); c.dbg = dbg; }
     }
     {
@@ -1018,6 +1059,15 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         }
         fprintf(stderr, "[twolayer timing, us/step %.2f] commit %.2f | issue %.2f | stdp %.2f | barrier %.2f | currents+lif %.2f | publish %.2f\n",
                 a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n);
+        std::vector<long long> hw((size_t)16 * (c.T + 1));
+        (void)hipMemcpy(hw.data(), dbg + (size_t)8 * 4096, hw.size() * 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[twolayer timing] learning phase per wave, us:");
+        for (int w = 0; w < 16; ++w) {
+            double sum = 0;
+            for (int t = 2; t < c.T; ++t) sum += (double)(hw[(size_t)t * 16 + w] - h[(size_t)t * 8 + 2]) / 100.0;
+            fprintf(stderr, " %.2f", sum / n);
+        }
+        fprintf(stderr, "\n");
     }
     if (c.has_norm) *normalized |= 1u;                    // connection 0 was normalised in the kernel's epilogue
     snn_set_plan_name("twolayer-fused");
