@@ -276,7 +276,7 @@ def main():
                                    "network.run(), PostPre STDP on, 3 spike monitors (X, Ae, Ai), reset_state_variables() per input",
                        "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
-                       "plan": net.last_plan, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+                       "plan": net.last_plan, "plan_retries(lean,resident)": [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)], "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": par,

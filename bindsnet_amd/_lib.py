@@ -13,6 +13,40 @@ SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
 ABI_VERSION = 2
 
 
+# ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
+# connection, feature, learning rule, monitor, the network itself) and every Module._apply (.to(), .cuda(), .float())
+# advances this counter; Network.run() re-uses the descriptor arrays of its previous call only while it stands still.
+_EPOCH = [0]
+
+
+def epoch() -> int:
+    return _EPOCH[0]
+
+
+def touch() -> None:
+    _EPOCH[0] += 1
+
+
+class Touching:
+    """Mixin: assignments to attributes of the object invalidate cached run descriptors."""
+
+    def __setattr__(self, key, value):
+        _EPOCH[0] += 1
+        super().__setattr__(key, value)
+
+    def __delattr__(self, key):
+        _EPOCH[0] += 1
+        super().__delattr__(key)
+
+
+class TouchingModule(Touching):
+    """Touching for torch.nn.Module subclasses: moving / casting the module replaces its tensors without __setattr__."""
+
+    def _apply(self, fn, *args, **kwargs):
+        _EPOCH[0] += 1
+        return super()._apply(fn, *args, **kwargs)
+
+
 class SnnError(RuntimeError):
     pass
 

@@ -497,12 +497,22 @@ template <int MWT>
 __device__ __forceinline__ void two_union_list(const TwoCtx &c, const uint32_t *cmn, uint32_t *ul, float4 *fac, int mw, int c0, int tid) {
     if (tid >= c.B) return;
     const int w = tid >> 5, bit = tid & 31;
-    uint32_t cmv[8][MWT];                                  // all loads first (independent), then the arithmetic
+    uint32_t cmv[8][MWT];                                  // (the words of columns outside the tile / the layer are zero)
+    if (MWT == 1) {
+        const uint4 lo = ((const uint4 *)cmn)[0], hi = ((const uint4 *)cmn)[1];
+        cmv[0][0] = lo.x; cmv[1][0] = lo.y; cmv[2][0] = lo.z; cmv[3][0] = lo.w;
+        cmv[4][0] = hi.x; cmv[5][0] = hi.y; cmv[6][0] = hi.z; cmv[7][0] = hi.w;
+    } else if (mw == MWT) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const bool on = q < c.CW && c0 + q < c.N;
+        for (int q = 0; q < 8; ++q) {
+            const uint4 v = ((const uint4 *)cmn)[q];
+            cmv[q][0] = v.x; cmv[q][1 % MWT] = v.y; cmv[q][2 % MWT] = v.z; cmv[q][3 % MWT] = v.w;
+        }
+    } else {
 #pragma unroll
-        for (int w2 = 0; w2 < MWT; ++w2) cmv[q][w2] = (on && w2 < mw) ? cmn[q * mw + w2] : 0u;
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int w2 = 0; w2 < MWT; ++w2) cmv[q][w2] = w2 < mw ? cmn[q * mw + w2] : 0u;
     }
     uint32_t colbits = 0, any = 0;
     int rank = 0, total = 0;

@@ -6,8 +6,10 @@ from typing import Optional, Sequence, Union
 
 import torch
 
+from .. import _lib
 
-class MCC_LearningRule:
+
+class MCC_LearningRule(_lib.Touching):
     """Reference: MCC_learning.py:16-118 (nu parsing, reduction default, decay, clamp range)."""
 
     def __init__(self, connection, feature_value, range: Optional[Union[list, tuple]] = None,

@@ -7,8 +7,10 @@ from typing import Optional, Sequence, Union
 import numpy as np
 import torch
 
+from .. import _lib
 
-class LearningRule:
+
+class LearningRule(_lib.Touching):
     """Reference: learning.py:25-104."""
 
     def __init__(self, connection, nu: Optional[Union[float, Sequence[float], Sequence[torch.Tensor]]] = None,

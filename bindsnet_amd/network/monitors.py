@@ -14,8 +14,10 @@ from typing import Iterable, Optional
 
 import torch
 
+from .. import _lib
 
-class AbstractMonitor:
+
+class AbstractMonitor(_lib.Touching):
     pass
 
 

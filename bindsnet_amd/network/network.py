@@ -7,6 +7,7 @@ device (bindsnet/network/network.py:380-465 restated in bindsnet_amd/csrc/snn_ru
 Anything the kernels do not implement raises NotImplementedError -- there is no fallback.
 """
 import ctypes as C
+import os
 import tempfile
 from typing import Dict, Optional, Type
 
@@ -27,11 +28,14 @@ def load(file_name: str, map_location: str = "cpu", learning: bool = None) -> "N
     return network
 
 
+_DESC_CACHE = os.environ.get("SNN_DESC_CACHE", "1") != "0"      # developer switch: rebuild the descriptors on every call
+
+
 def _dptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-class Network(torch.nn.Module):
+class Network(_lib.TouchingModule, torch.nn.Module):
     def __init__(self, dt: float = 1.0, batch_size: int = 1, learning: bool = True,
                  reward_fn: Optional[Type] = None) -> None:
         super().__init__()
@@ -69,7 +73,8 @@ class Network(torch.nn.Module):
         f.seek(0)
         return torch.load(f, weights_only=False)
 
-    _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown")
+    _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown",
+                  "_run_cache", "_reset_cache")
 
     def __getstate__(self):
         """save() / clone() pickle the whole object like the reference (network.py:163-209); device scratch, the
@@ -86,31 +91,62 @@ class Network(torch.nn.Module):
     def reset_state_variables(self) -> None:
         """Reference: network.py:467-481.  The state tensors of the stock layer classes (s, x, refrac_count <- 0,
         v <- rest; theta is NOT reset, nodes.py:1113-1120) are filled by ONE launch (snn_fill_segments) instead of
-        four small fills per layer."""
+        four small fills per layer.  The segment table is kept while nothing has been assigned to a network object
+        (_lib.epoch()); only Input.s, which aliases the last input slice of the previous run, is looked up again."""
         import struct
-        segs = []
-        for l in self.layers.values():
-            if type(l) in (Input, LIFNodes, DiehlAndCookNodes) and l.s.is_cuda and l.s.is_contiguous():
-                segs.append((l.s, 0))
-                if l.traces:
-                    segs.append((l.x, 0))
-                if type(l) is not Input:
-                    segs += [(l.refrac_count, 0), (l.v, struct.unpack("<I", struct.pack("<f", _f(l.rest)))[0])]
-            else:
-                l.reset_state_variables()
-        if segs and all(t.is_contiguous() for t, _ in segs) and len(segs) <= _lib.MAX_FILL_SEGMENTS:
-            arr = (_lib.FillSegment * len(segs))()
-            for k, (t, pat) in enumerate(segs):
-                arr[k].ptr, arr[k].bytes, arr[k].pattern = t.data_ptr(), t.numel() * t.element_size(), pat
-            _lib.check(_lib.lib().snn_fill_segments(arr, len(segs), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                       "snn_fill_segments")
+        plan = self.__dict__.get("_reset_cache")
+        if plan is None or plan["epoch"] != _lib.epoch() or not _DESC_CACHE:
+            segs, others, rebind = [], [], []
+            for l in self.layers.values():
+                if type(l) in (Input, LIFNodes, DiehlAndCookNodes) and l.s.is_cuda and l.s.is_contiguous():
+                    if type(l) is Input:
+                        rebind.append((len(segs), l))
+                    segs.append((l.s, 0))
+                    if l.traces:
+                        segs.append((l.x, 0))
+                    if type(l) is not Input:
+                        segs += [(l.refrac_count, 0), (l.v, struct.unpack("<I", struct.pack("<f", _f(l.rest)))[0])]
+                else:
+                    others.append(l)
+            arr = None
+            if segs and all(t.is_contiguous() for t, _ in segs) and len(segs) <= _lib.MAX_FILL_SEGMENTS:
+                arr = (_lib.FillSegment * len(segs))()
+                for k, (t, pat) in enumerate(segs):
+                    arr[k].ptr, arr[k].bytes, arr[k].pattern = t.data_ptr(), t.numel() * t.element_size(), pat
+            plan = {"epoch": _lib.epoch(), "segs": segs, "arr": arr, "others": others, "rebind": rebind,
+                    "rests": [(l.rest, l.rest._version) for l in self.layers.values()
+                              if type(l) is not Input and isinstance(getattr(l, "rest", None), torch.Tensor)]}
+            self.__dict__["_reset_cache"] = plan if all(t._version == v for t, v in plan["rests"]) else None
+        elif any(t._version != v for t, v in plan["rests"]):     # layer.rest changed in place: rebuild next time, and now
+            self.__dict__["_reset_cache"] = None
+            return self.reset_state_variables()
         else:
-            for t, pat in segs:
+            for k, l in plan["rebind"]:
+                s = l.s
+                if not (s.is_cuda and s.is_contiguous()):
+                    self.__dict__["_reset_cache"] = None
+                    return self.reset_state_variables()
+                plan["segs"][k] = (s, 0)
+                if plan["arr"] is not None:
+                    plan["arr"][k].ptr, plan["arr"][k].bytes = s.data_ptr(), s.numel() * s.element_size()
+        for l in plan["others"]:
+            l.reset_state_variables()
+        if plan["arr"] is not None:
+            _lib.check(_lib.lib().snn_fill_segments(plan["arr"], len(plan["segs"]),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "snn_fill_segments")
+        else:
+            for t, pat in plan["segs"]:
                 t.zero_() if pat == 0 else t.view(torch.int32).fill_(pat - (1 << 32) if pat >> 31 else pat)
         for c in self.connections.values():
             c.reset_state_variables()
+        before = _lib.epoch()
         for m in self.monitors.values():
             m.reset_state_variables()
+        # a monitor emptying its recording is an assignment, but not one the descriptors depend on
+        for key in ("_run_cache", "_reset_cache"):
+            kept = self.__dict__.get(key)
+            if kept is not None and kept["epoch"] == before:
+                kept["epoch"] = _lib.epoch()
 
     def train(self, mode: bool = True) -> "torch.nn.Module":
         self.learning = mode
@@ -149,98 +185,163 @@ class Network(torch.nn.Module):
         if dev.type != "cuda":
             raise _lib.SnnError("bindsnet_amd executes on an MI355X only: move the network with network.to('cuda') "
                                 "(there is no CPU fallback)")
+        # The descriptor arrays are kept from one call to the next: while nothing has been assigned to any object of the
+        # network since they were built (_lib.epoch(), plus the in-place versions of the scalar parameter tensors they
+        # were filled from) only the per-call pointers are rebound -- inputs, Input.s, monitor buffers.  Calls with
+        # keyword arguments (clamp, masks, reward, ...) or one_step always build afresh.
+        plain = not kwargs and not one_step and self.reward_fn is None and _DESC_CACHE
+        built = self.__dict__.get("_run_cache") if plain else None
+        if built is not None and not self._cache_valid(built, T, B, dev):
+            built = None
+        if built is None:
+            built = self._build_descriptors(T, B, dev, one_step, kwargs, clamps, unclamps, injects_v, masks)
+            self.__dict__["_run_cache"] = built if plain else None
+        L, Cn, R, names = built["L"], built["Cn"], built["R"], built["names"]
+        rasters, keep = self._bind_call(built, inputs, T, B, dev)
+        gen_bufs, max_draws = built["gen_bufs"], built["max_draws"]
+        lib = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # plan request of this run: automatic, unless the lean kernel form gave up on one of the last inputs (it is then
+        # left alone for a while: an input it cannot finish costs a whole second run)
+        cool = self.__dict__.get("_lean_cooldown", 0)
+        R.plan = 3 if cool > 0 else 0
+        if cool > 0:
+            self.__dict__["_lean_cooldown"] = cool - 1
+        for attempt in (0, 1, 2):
+            with DeviceGenerator(dev, max_draws, gen_bufs) as ns:  # host generator <-> device, exact (rng.py)
+                R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
+                R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
+                _lib.check(lib.snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R), stream), "snn_net_run")
+                self.__dict__["last_plan"] = lib.snn_plan_name().decode()
+                # plans that hand spikes between workgroups report a failed hand-off (or a step the lean form does not
+                # handle) through the status word: it is read back after EVERY such run, with or without one_spike
+                ns.always_read = self.last_plan.startswith("dc2015-resident")
+                status = ns.finish(check_status=attempt == 2)
+            if status == 0:
+                break
+            # The kernel returned without touching any state tensor or the generator, so the same input is simply run
+            # again: SNN_ERR_RETRY (lean form, unsupported step) -> the general resident kernel; SNN_ERR_TIMEOUT (the GPU
+            # was shared and the grid was not co-resident in time) -> the one-launch-per-timestep plan, which cannot wait
+            # on another workgroup.
+            if status == _lib.SNN_ERR_RETRY:
+                self.__dict__["lean_retries"] = self.__dict__.get("lean_retries", 0) + 1
+                self.__dict__["_lean_cooldown"] = 16
+                R.plan = 3
+            else:
+                self.__dict__["resident_retries"] = self.__dict__.get("resident_retries", 0) + 1
+                R.plan = 2
+        # Input.s aliases the last input slice, as in the reference (nodes.py:219)
+        before = _lib.epoch()
+        for i, name, layer, _ in built["inputs"]:
+            layer.s = inputs[name][T - 1]
+        for mon, key, buf in rasters:
+            if isinstance(key, tuple):
+                mon._append(key[0], key[1], buf)       # NetworkMonitor: (layer name, variable)
+            else:
+                mon._append(key, buf)
+        self.__dict__["_keep"] = keep
+        for kept in (built, self.__dict__.get("_reset_cache")):    # the assignments just made are this call's own
+            if kept is not None and kept["epoch"] == before:
+                kept["epoch"] = _lib.epoch()
+
+    # ------------------------------------------------------------------ descriptors
+    def _cache_valid(self, built, T, B, dev) -> bool:
+        if built["epoch"] != _lib.epoch() or built["T"] != T or built["B"] != B or built["dev"] != dev:
+            return False
+        if built["n_objects"] != (len(self.layers), len(self.connections), len(self.monitors)):
+            return False
+        for t, ver in built["scalars"]:               # parameter tensors changed in place (layer.thresh.fill_(...))
+            if t._version != ver:
+                return False
+        for seq, vals in built["lists"]:              # list-valued parameters changed element-wise (rule.nu[0] = ...)
+            if (seq._version if isinstance(seq, torch.Tensor) else tuple(seq)) != vals:
+                return False
+        return True
+
+    def _build_descriptors(self, T, B, dev, one_step, kwargs, clamps, unclamps, injects_v, masks):
+        """Everything of the snn_net_run arguments that does not change from call to call."""
+        from . import nodes as _nodes
+        epoch0 = _lib.epoch()
         keep = []                                 # tensors that must outlive the asynchronous launch
         names = list(self.layers)
         index = {n: i for i, n in enumerate(names)}
         L = (_lib.LayerDesc * len(names))()
-        rasters = []                              # (monitor, var, tensor)
+        dyn_inputs, dyn_layers = [], []
         max_draws = 0
-        for i, name in enumerate(names):
-            layer, d = self.layers[name], L[i]
-            d.n = layer.n
-            if isinstance(layer, Input):
-                if name not in inputs:
-                    raise NotImplementedError(f"bindsnet_amd: Input layer '{name}' needs an entry in `inputs`")
-                x = inputs[name]
-                if x.shape[0] < T:
-                    raise ValueError(f"inputs['{name}'] has {x.shape[0]} timesteps, run() needs {T}")
-                if x.dtype not in (torch.uint8, torch.bool):
-                    raise NotImplementedError("bindsnet_amd: input spike trains must be uint8 or bool "
-                                              f"(got {x.dtype}); encoders produce uint8")
-                x = x.to(dev).contiguous()
-                if x.numel() != x.shape[0] * B * layer.n:
-                    raise ValueError(f"inputs['{name}'] has shape {tuple(x.shape)}, expected [T, {B}, {layer.n}]")
-                entry = layer.s
-                if entry.dtype not in (torch.uint8, torch.bool) or entry.numel() != B * layer.n or entry.device != dev:
-                    entry = torch.zeros(B, layer.n, dtype=torch.uint8, device=dev)
-                entry = entry.contiguous()
-                keep += [x, entry]
-                d.kind, d.ext_spikes, d.s = _lib.LAYER_INPUT, _dptr(x), _dptr(entry)
-                layer._trace_fields(d.p.lif)
+        scalars = _nodes._SCALARS = []
+        try:
+            for i, name in enumerate(names):
+                layer, d = self.layers[name], L[i]
+                d.n = layer.n
+                if isinstance(layer, Input):
+                    d.kind = _lib.LAYER_INPUT
+                    layer._trace_fields(d.p.lif)
+                    d.x = _dptr(layer.x) if layer.traces else None
+                    wanted = []                        # (monitor, key) pairs recording this layer's spikes
+                    for m in self.monitors.values():
+                        if isinstance(m, Monitor) and m.obj is layer:
+                            if list(m.state_vars) != ["s"]:
+                                raise NotImplementedError("bindsnet_amd: Input layers can only be monitored for 's'")
+                            wanted.append((m, "s"))
+                        elif isinstance(m, NetworkMonitor) and (name, "s") in m._wanted():
+                            wanted.append((m, (name, "s")))
+                    dyn_inputs.append((i, name, layer, wanted))
+                    continue
+                self._check_state(layer, B, dev)
+                requests = self._monitor_requests(layer, name)
+                cur = self._scratch("cur_" + name, (B, layer.n), torch.float32, dev)
+                d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
                 d.x = _dptr(layer.x) if layer.traces else None
-                xcopy = None
-                for m in self.monitors.values():   # the raster of an input layer is a COPY of its input, like
-                    if isinstance(m, Monitor) and m.obj is layer:      # Monitor.record's clone (monitors.py:94-111):
-                        if list(m.state_vars) != ["s"]:                # the caller may refill its buffer in place
-                            raise NotImplementedError("bindsnet_amd: Input layers can only be monitored for 's'")
-                        if xcopy is None:
-                            xcopy = x[:T].clone().view(T, B, *layer.shape)
-                        rasters.append((m, "s", xcopy))
-                    elif isinstance(m, NetworkMonitor) and (name, "s") in m._wanted():
-                        if xcopy is None:
-                            xcopy = x[:T].clone().view(T, B, *layer.shape)
-                        rasters.append((m, (name, "s"), xcopy))
-                inputs[name] = x
-                continue
-            if name in inputs:
-                raise NotImplementedError("bindsnet_amd: external input currents into non-Input layers are "
-                                          "outside the accelerated path")
-            self._check_state(layer, B, dev)
-            mon_s, mon_v = self._monitor_buffers(layer, name, T, B, dev, rasters)
-            cur = self._scratch("cur_" + name, (B, layer.n), torch.float32, dev)
-            d.v, d.refrac, d.s, d.current = _dptr(layer.v), _dptr(layer.refrac_count), _dptr(layer.s), _dptr(cur)
-            d.x = _dptr(layer.x) if layer.traces else None
-            d.raster_s, d.raster_v = _dptr(mon_s), _dptr(mon_v)
-            # clamp / unclamp / injects_v (network.py:395-429): [n] masks or values, or one slice per timestep
-            for key, table in (("clamp", clamps), ("unclamp", unclamps)):
-                m = table.get(name)
-                if m is not None:
-                    m = torch.as_tensor(m).to(dev)
-                    per_step = m.dim() >= 2
-                    if m.numel() != (T if per_step else 1) * layer.n and not (per_step and m.shape[0] >= T and m[0].numel() == layer.n):
-                        raise ValueError(f"{key}['{name}'] must have {layer.n} entries (optionally one row per timestep)")
-                    m = (m[:T] if per_step else m).ne(0).to(torch.uint8).contiguous()
-                    keep.append(m)
-                    setattr(d, key, _dptr(m))
-                    setattr(d, key + "_per_step", int(per_step))
-            inj = injects_v.get(name)
-            if inj is not None:
-                inj = torch.as_tensor(inj).to(dev, torch.float32)
-                per_step = inj.dim() >= 2
-                one = inj[0] if per_step else inj
-                if one.numel() not in (layer.n, B * layer.n) or (per_step and inj.shape[0] < T):
-                    raise ValueError(f"injects_v['{name}'] must have {layer.n} (or batch x {layer.n}) entries, optionally per timestep")
-                inj = (inj[:T] if per_step else inj).contiguous()
-                keep.append(inj)
-                d.inject_v, d.inject_per_step, d.inject_len = _dptr(inj), int(per_step), one.numel()
-            if isinstance(layer, DiehlAndCookNodes):
-                d.kind, d.p, d.theta = _lib.LAYER_DC, layer._dc_params(), _dptr(layer.theta)
-                if layer.one_spike:
-                    max_draws = max(max_draws, B * layer.n)
-            elif isinstance(layer, LIFNodes):
-                d.kind = _lib.LAYER_LIF
-                d.p.lif = layer._lif_params()
-            else:
-                raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
-                                          "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
+                dyn_layers.append((i, layer, requests))
+                # clamp / unclamp / injects_v (network.py:395-429): [n] masks or values, or one slice per timestep
+                for key, table in (("clamp", clamps), ("unclamp", unclamps)):
+                    m = table.get(name)
+                    if m is not None:
+                        m = torch.as_tensor(m).to(dev)
+                        per_step = m.dim() >= 2
+                        if m.numel() != (T if per_step else 1) * layer.n and not (per_step and m.shape[0] >= T and m[0].numel() == layer.n):
+                            raise ValueError(f"{key}['{name}'] must have {layer.n} entries (optionally one row per timestep)")
+                        m = (m[:T] if per_step else m).ne(0).to(torch.uint8).contiguous()
+                        keep.append(m)
+                        setattr(d, key, _dptr(m))
+                        setattr(d, key + "_per_step", int(per_step))
+                inj = injects_v.get(name)
+                if inj is not None:
+                    inj = torch.as_tensor(inj).to(dev, torch.float32)
+                    per_step = inj.dim() >= 2
+                    one = inj[0] if per_step else inj
+                    if one.numel() not in (layer.n, B * layer.n) or (per_step and inj.shape[0] < T):
+                        raise ValueError(f"injects_v['{name}'] must have {layer.n} (or batch x {layer.n}) entries, optionally per timestep")
+                    inj = (inj[:T] if per_step else inj).contiguous()
+                    keep.append(inj)
+                    d.inject_v, d.inject_per_step, d.inject_len = _dptr(inj), int(per_step), one.numel()
+                if isinstance(layer, DiehlAndCookNodes):
+                    d.kind, d.p, d.theta = _lib.LAYER_DC, layer._dc_params(), _dptr(layer.theta)
+                    if layer.one_spike:
+                        max_draws = max(max_draws, B * layer.n)
+                elif isinstance(layer, LIFNodes):
+                    d.kind = _lib.LAYER_LIF
+                    d.p.lif = layer._lif_params()
+                else:
+                    raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
+                                              "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
+        finally:
+            _nodes._SCALARS = None
 
         for table, what in ((clamps, "clamp"), (unclamps, "unclamp"), (injects_v, "injects_v")):
             for lname in table:
                 if lname not in self.layers or isinstance(self.layers[lname], Input):
                     raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
         Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
+        lists = []
         for k, ((src, dst), conn) in enumerate(self.connections.items()):
             self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+            rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else getattr(conn, "update_rule", None)
+            nu = getattr(rule, "nu", None)
+            if isinstance(nu, torch.Tensor):
+                lists.append((nu, nu._version))
+            elif isinstance(nu, (list, tuple)):
+                lists.append((nu, tuple(nu)))
             mask = masks.get((src, dst))
             if mask is None:
                 mask = getattr(conn, "mask", None)         # LocalConnection's structural mask (topology.py:1468-1470)
@@ -258,56 +359,68 @@ class Network(torch.nn.Module):
         R.one_step = int(bool(one_step))                  # network.py:388-393 (generic plan)
         need = int(_lib.lib().snn_net_workspace_bytes(L, len(names), Cn, len(self.connections), C.byref(R)))
         if need:
-            ws = getattr(self, "_workspace", None)
+            ws = self.__dict__.get("_workspace")
             if ws is None or ws.numel() < need or ws.device != dev:
-                ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                ws = self.__dict__["_workspace"] = torch.empty(need, dtype=torch.uint8, device=dev)
             R.workspace, R.workspace_bytes = _dptr(ws), need
         pool = self.__dict__.setdefault("_scratch_pool", {})
         if "rng_host" not in pool:
             pool["rng_host"] = torch.zeros(640, dtype=torch.int32).pin_memory()
         gen_bufs = (self._scratch("rng_block", (640,), torch.int32, dev),
                     self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev), pool["rng_host"])
-        lib = _lib.lib()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        # plan request of this run: automatic, unless the lean kernel form gave up on one of the last inputs (it is then
-        # left alone for a while: an input it cannot finish costs a whole second run)
-        cool = self.__dict__.get("_lean_cooldown", 0)
-        R.plan = 3 if cool > 0 else 0
-        if cool > 0:
-            self._lean_cooldown = cool - 1
-        for attempt in (0, 1, 2):
-            with DeviceGenerator(dev, max_draws, gen_bufs) as ns:  # host generator <-> device, exact (rng.py)
-                R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
-                R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
-                _lib.check(lib.snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R), stream), "snn_net_run")
-                self.last_plan = lib.snn_plan_name().decode()
-                # plans that hand spikes between workgroups report a failed hand-off (or a step the lean form does not
-                # handle) through the status word: it is read back after EVERY such run, with or without one_spike
-                ns.always_read = self.last_plan.startswith("dc2015-resident")
-                status = ns.finish(check_status=attempt == 2)
-            if status == 0:
-                break
-            # The kernel returned without touching any state tensor or the generator, so the same input is simply run
-            # again: SNN_ERR_RETRY (lean form, unsupported step) -> the general resident kernel; SNN_ERR_TIMEOUT (the GPU
-            # was shared and the grid was not co-resident in time) -> the one-launch-per-timestep plan, which cannot wait
-            # on another workgroup.
-            if status == _lib.SNN_ERR_RETRY:
-                self.lean_retries = getattr(self, "lean_retries", 0) + 1
-                self._lean_cooldown = 16
-                R.plan = 3
-            else:
-                self.resident_retries = getattr(self, "resident_retries", 0) + 1
-                R.plan = 2
-        # Input.s aliases the last input slice, as in the reference (nodes.py:219)
-        for name in names:
-            if isinstance(self.layers[name], Input):
-                self.layers[name].s = inputs[name][T - 1]
-        for mon, key, buf in rasters:
-            if isinstance(key, tuple):
-                mon._append(key[0], key[1], buf)       # NetworkMonitor: (layer name, variable)
-            else:
-                mon._append(key, buf)
-        self._keep = keep
+        # (assignments made while building -- a state tensor re-created by _check_state, a rule's lazily allocated
+        #  memory -- belong to this build: the descriptors already point at the new objects)
+        return {"L": L, "Cn": Cn, "R": R, "names": names, "keep": keep, "inputs": dyn_inputs, "layers": dyn_layers,
+                "max_draws": max_draws, "gen_bufs": gen_bufs, "T": T, "B": B, "dev": dev, "scalars": scalars,
+                "lists": lists, "epoch": _lib.epoch(), "n_objects": (len(self.layers), len(self.connections), len(self.monitors)),
+                "epoch0": epoch0}
+
+    def _bind_call(self, built, inputs, T, B, dev):
+        """The per-call part of the descriptors: input spike trains, Input.s (it aliases the previous call's last
+        slice), freshly allocated monitor buffers."""
+        L = built["L"]
+        keep = list(built["keep"])
+        rasters = []                              # (monitor, key, tensor)
+        for i, name, layer, wanted in built["inputs"]:
+            if name not in inputs:
+                raise NotImplementedError(f"bindsnet_amd: Input layer '{name}' needs an entry in `inputs`")
+            x = inputs[name]
+            if x.shape[0] < T:
+                raise ValueError(f"inputs['{name}'] has {x.shape[0]} timesteps, run() needs {T}")
+            if x.dtype not in (torch.uint8, torch.bool):
+                raise NotImplementedError("bindsnet_amd: input spike trains must be uint8 or bool "
+                                          f"(got {x.dtype}); encoders produce uint8")
+            x = x.to(dev).contiguous()
+            if x.numel() != x.shape[0] * B * layer.n:
+                raise ValueError(f"inputs['{name}'] has shape {tuple(x.shape)}, expected [T, {B}, {layer.n}]")
+            entry = layer.s
+            if entry.dtype not in (torch.uint8, torch.bool) or entry.numel() != B * layer.n or entry.device != dev:
+                entry = torch.zeros(B, layer.n, dtype=torch.uint8, device=dev)
+            entry = entry.contiguous()
+            keep += [x, entry]
+            L[i].ext_spikes, L[i].s = _dptr(x), _dptr(entry)
+            if wanted:                             # the raster of an input layer is a COPY of its input, like Monitor.record's
+                xcopy = x[:T].clone().view(T, B, *layer.shape)   # clone (monitors.py:94-111): the caller may refill its buffer in place
+                rasters += [(m, key, xcopy) for m, key in wanted]
+            inputs[name] = x
+        for name in inputs:
+            if name in self.layers and not isinstance(self.layers[name], Input):
+                raise NotImplementedError("bindsnet_amd: external input currents into non-Input layers are "
+                                          "outside the accelerated path")
+        for i, layer, requests in built["layers"]:
+            mon_s = mon_v = None
+            for m, key, var in requests:
+                if var == "s":
+                    if mon_s is None:              # bool like layer.s; the node kernels store a 0/1 byte for EVERY
+                        # (step, sample, neuron), so the buffer needs no initialisation
+                        mon_s = torch.empty(T, B, *layer.shape, dtype=torch.bool, device=dev)
+                    rasters.append((m, key, mon_s))
+                else:
+                    if mon_v is None:
+                        mon_v = torch.empty(T, B, *layer.shape, device=dev)
+                    rasters.append((m, key, mon_v))
+            L[i].raster_s, L[i].raster_v = _dptr(mon_s), _dptr(mon_v)
+        return rasters, keep
 
     # ------------------------------------------------------------------ helpers
     def _scratch(self, key, shape, dtype, dev):
@@ -341,9 +454,9 @@ class Network(torch.nn.Module):
                 or not layer.s.is_contiguous():
             layer.s = torch.zeros(B, *layer.shape, dtype=torch.bool, device=dev)
 
-    def _monitor_buffers(self, layer, name, T, B, dev, rasters):
-        mon_s = mon_v = None
-        requests = []                                  # (monitor, key handed back to its _append, variable)
+    def _monitor_requests(self, layer, name):
+        """(monitor, key handed back to its _append, variable) for every monitor recording this layer."""
+        requests = []
         for m in self.monitors.values():
             if isinstance(m, NetworkMonitor):
                 requests += [(m, (l, v), v) for l, v in m._wanted() if l == name]
@@ -353,19 +466,10 @@ class Network(torch.nn.Module):
                 elif not isinstance(m.obj, Nodes):
                     raise NotImplementedError("bindsnet_amd: monitors on connections/features are not supported")
         for m, key, var in requests:
-            if var == "s":
-                if mon_s is None:              # bool like layer.s; the node kernels store a 0/1 byte for EVERY
-                    # (step, sample, neuron), so the buffer needs no initialisation
-                    mon_s = torch.empty(T, B, *layer.shape, dtype=torch.bool, device=dev)
-                rasters.append((m, key, mon_s))
-            elif var == "v" and hasattr(layer, "v"):
-                if mon_v is None:
-                    mon_v = torch.empty(T, B, *layer.shape, device=dev)
-                rasters.append((m, key, mon_v))
-            else:
+            if var != "s" and not (var == "v" and hasattr(layer, "v")):
                 raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "
                                           "outside the accelerated path (supported: 's', 'v')")
-        return mon_s, mon_v
+        return requests
 
     @staticmethod
     def _fill_mstdp(d, rule, kwargs, dev, keep):

@@ -14,6 +14,7 @@ import torch
 from .. import _lib, ops
 
 Scalar = Union[float, torch.Tensor]
+_SCALARS = None          # collector of the parameter tensors read while run descriptors are being built
 
 
 def _f(t) -> float:
@@ -22,6 +23,8 @@ def _f(t) -> float:
     if isinstance(t, torch.Tensor):
         # .item() on a device tensor is a blocking copy (~15 us each, ~20 per run()): remember the value on the
         # tensor object itself, keyed by its in-place version counter
+        if _SCALARS is not None:
+            _SCALARS.append((t, t._version))       # (Network._build_descriptors: what the descriptors were filled from)
         hit = getattr(t, "_snn_scalar", None)
         if hit is not None and hit[0] == t._version:
             return hit[1]
@@ -36,7 +39,7 @@ def _f(t) -> float:
     return float(t)
 
 
-class Nodes(torch.nn.Module):
+class Nodes(_lib.TouchingModule, torch.nn.Module):
     """Base class (reference: nodes.py:9-162): spikes `s`, optional trace `x`."""
 
     def __init__(self, n: Optional[int] = None, shape: Optional[Iterable[int]] = None, traces: bool = False,

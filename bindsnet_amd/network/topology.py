@@ -10,11 +10,11 @@ import torch
 from torch.nn import Module, Parameter
 from torch.nn.modules.utils import _pair
 
-from .. import ops
+from .. import _lib, ops
 from .nodes import Nodes
 
 
-class AbstractConnection(Module):
+class AbstractConnection(_lib.TouchingModule, Module):
     """Reference: topology.py:17-156 (wmin/wmax/norm/update_rule plumbing)."""
 
     def __init__(self, source: Nodes, target: Nodes, nu=None, reduction: Optional[callable] = None,
@@ -211,7 +211,7 @@ class Conv2dConnection(AbstractConnection):
             raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not on the accelerated path")
 
 
-class AbstractMulticompartmentConnection(Module):
+class AbstractMulticompartmentConnection(_lib.TouchingModule, Module):
     """Reference: topology.py:159-262 (feature pipeline bookkeeping)."""
 
     def __init__(self, source: Nodes, target: Nodes, device, pipeline: list = None, **kwargs) -> None:

@@ -7,8 +7,10 @@ from typing import Optional, Sequence, Union
 import torch
 from torch.nn import Parameter
 
+from .. import _lib
 
-class AbstractFeature:
+
+class AbstractFeature(_lib.Touching):
     """Reference: topology_features.py:15-362 (constructor contract, priming, normalisation)."""
 
     def __init__(self, name: str, value=None, value_dtype: torch.dtype = torch.float32, range=None,
