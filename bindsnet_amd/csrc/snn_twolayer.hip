@@ -614,7 +614,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     uint32_t *am = (uint32_t *)(smem + off); off += (size_t)Nin * mw * 4;                 // [active rows][MW] sample masks
     uint16_t *ar = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;
     uint32_t *ab = (uint32_t *)(smem + off); off += ((size_t)NinW * 4 + 15) & ~(size_t)15;
-    uint16_t *ridx = (uint16_t *)(smem + off); off += ((size_t)Nin * 2 + 15) & ~(size_t)15;       // source row -> index in ar / am
+    uint16_t *ridx = (uint16_t *)(smem + off); off += c.rowmajor ? (((size_t)Nin * 2 + 15) & ~(size_t)15) : 0;   // source row -> index in ar / am (row-major PostPre)
     float *xnu0 = (float *)(smem + off); off += (size_t)BC * 8 * 4;                       // [B][CW] x_tgt * nu0
     uint32_t *colmask = (uint32_t *)(smem + off); off += (size_t)2 * CMS * 4;             // [2][8][MW]: samples whose neuron (column q) spiked
     float *rvl = (float *)(smem + off); off += (size_t)BC * 4;                            // MSTDP: reward per sample
@@ -698,8 +698,10 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 else if ((k -= n1) < n2) am[k] = r_dg[u];
                 else if ((k -= n2) < n3) {
                     ((uint32_t *)ar)[k] = r_dg[u];
-                    ridx[r_dg[u] & 0xFFFFu] = (uint16_t)(2 * k);               // (two u16 rows per word; a stale second half
-                    if (2 * k + 1 < nact) ridx[r_dg[u] >> 16] = (uint16_t)(2 * k + 1);   //  past nact is not an active row)
+                    if (c.rowmajor) {
+                        ridx[r_dg[u] & 0xFFFFu] = (uint16_t)(2 * k);           // (two u16 rows per word; a stale second half
+                        if (2 * k + 1 < nact) ridx[r_dg[u] >> 16] = (uint16_t)(2 * k + 1);   //  past nact is not an active row)
+                    }
                 }
                 else if ((k -= n3) < n4) ab[k] = r_dg[u];
             }
@@ -923,7 +925,7 @@ size_t run_lds(const TwoCtx &c) {
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     return (size_t)c.Nin * c.CW * 4 + META * 4 + al((size_t)c.LCAP * 2) + (size_t)c.Nin * 4 + al((size_t)c.Nin * 2) +
            (size_t)c.Nin * (c.MW - 1) * 4 +
-           al((size_t)c.NinW * 4) + al((size_t)c.Nin * 2) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
+           al((size_t)c.NinW * 4) + (c.rowmajor ? al((size_t)c.Nin * 2) : 0) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
            (size_t)(c.T + 2) * 8 +
            (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
 }
@@ -946,6 +948,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.MW = (B + 31) / 32; c.BC = 32 * c.MW;
     c.dt = R->dt; c.learning = R->learning;
     c.rule = C[0].rule;
+    c.rowmajor = c.rule == SNN_RULE_POSTPRE && c.learning && !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
     // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
@@ -961,7 +964,6 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (c.T + 1 > 4096) return false;
     c.prodw = 0;
     if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) { c.prodw = 4096; if (run_lds(c) > 140 * 1024) c.prodw = 0; }
-    c.rowmajor = !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     c.use_xsl = 0;
     if (Nin <= NT && c.rule == SNN_RULE_POSTPRE && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
