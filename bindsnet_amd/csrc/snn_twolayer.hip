@@ -55,6 +55,7 @@ struct TwoCtx {
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
     float inv_hwps;
     int prodw;                                           // floats of LDS for the staged products of the dense dot (0: off)
+    int mstdp_rows;                                      // MSTDP in its row-per-thread forms (developer switch SNN_TWO_MSTDP_ROWS=0: off)
     int rowmajor;                                        // PostPre in its row-major form (developer switch SNN_TWO_ROWMAJOR=0: off)
     int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= NT)
     // MSTDP (learning.py:1504-1574), factored eligibility: p_plus / p_minus traces, previous-step spike factors
@@ -600,6 +601,159 @@ __device__ __forceinline__ void two_mstdp(const TwoCtx &c, float *wt, const uint
     }
 }
 
+// MSTDP update of a step in which no column of the tile had a target spike (the usual case: learning.py:1504-1574 then
+// reduces to w[i,j] += nu0 * sum_b s_src[b,i] * reward[b] * p_minus[b,j], terms staged in zl): one thread per ACTIVE
+// source row, all columns of the tile in registers, the row's samples walked in ascending order with the block partial
+// sums of two_stdp_rowmajor.  Rows without a source spike are not touched (the caller sends steps that must touch
+// every element -- first step of a run, weight decay -- through two_mstdp).
+template <int MWT>
+__device__ __forceinline__ void two_mstdp_rows(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
+                                               const float *zl, int nact, int c0, int tid) {
+    const int N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;
+    for (int kq = tid; kq < nact; kq += NT) {
+        const int i = (int)ar[kq];
+        float a0[8], a1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a0[q] = a1[q] = 0.f;
+        uint32_t m[MWT];
+#pragma unroll
+        for (int wd = 0; wd < MWT; ++wd) m[wd] = wd < mw ? am[kq * mw + wd] : 0u;
+        int cblk = 0;
+#pragma unroll
+        for (int wd = 0; wd < MWT; ++wd) {
+            uint32_t mm = m[wd];
+            while (mm) {
+                const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1;
+                const float4 lo = *(const float4 *)(zl + b * 8), hi = *(const float4 *)(zl + b * 8 + 4);
+                const float zv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const float same = (b >> 4) == cblk ? 1.f : 0.f, diff = 1.f - same;   // (0/1 factors: exact products, see two_stdp_rowmajor)
+                cblk = b >> 4;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+                    a0[q] = __builtin_fmaf(a0[q], same, zv[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q >= CW || c0 + q >= N) break;
+            const float u = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+            float w = wt[i * CW + q];
+            w = w + c.nu0 * u;                                // learning.py:1561
+            w = w * c.wdecay;
+            if (c.has_min && w < c.wmin) w = c.wmin;
+            if (c.has_max && w > c.wmax) w = c.wmax;
+            wt[i * CW + q] = w;
+        }
+    }
+}
+
+// MSTDP update of a step in which columns of the tile DID spike (bursts: then every row of those columns changes, and
+// each element sums up to B terms).  One thread per source row, the tile's columns in registers, the samples walked in
+// ascending order by the whole workgroup together: p_plus[b, :] is loaded once per sample (coalesced, eight samples in
+// flight) and serves all columns.  A sample that contributes nothing to an element adds reward * (+0 + -+0) = -+0 to its
+// partial sum, which (partials start at +0.0) leaves it unchanged: the reference's dense batch sum adds those zeros too.
+//   term(b) = reward[b] * (p_plus[b,i] * s_tgt[b,j] + s_src[b,i] * p_minus[b,j]);  the 0/1 spike factors enter through
+//   exact products (fma(x, 1 or 0, y) rounds once, like the sum it stands for).
+// Rows with a source spike come from the digest's list (pass A), the others from the row bitmap (pass B, no p_minus part).
+template <int MWT, int CWT>
+__device__ __forceinline__ void two_mstdp_burst(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
+                                                const uint32_t *ab, const float *pml, const uint32_t *cm, const float *rvl,
+                                                const float *__restrict__ pp, int nact, int c0, int tid) {
+    const int B = c.B, Nin = c.Nin, N = c.N, mw = MWT == 1 ? 1 : c.MW;      // (CWT = c.CW, known at compile time here)
+    uint32_t cu[MWT] = {0}, cmr[CWT][MWT];                 // column spike masks and their union (scalar registers)
+    uint32_t postcols = 0;
+#pragma unroll
+    for (int q = 0; q < CWT; ++q) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int w = 0; w < MWT; ++w) {
+            const bool on = c0 + q < N && w < mw;
+            const uint32_t v = on ? (uint32_t)__builtin_amdgcn_readfirstlane(cm[q * mw + w]) : 0u;
+            cmr[q][w] = v; cu[w] |= v; o |= v;
+        }
+        if (o) postcols |= 1u << q;
+    }
+    const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void *)pp, 0, B * Nin * 4, 0x00020000);
+    auto word = [&](const uint32_t (&a)[MWT], int wd) -> uint32_t {   // a[wd] without indexing registers dynamically
+        uint32_t v = a[0];
+#pragma unroll
+        for (int w = 1; w < MWT; ++w) v = wd == w ? a[w] : v;
+        return v;
+    };
+    // The rows of this thread, one after the other: first its share of the digest's list of rows with a source spike,
+    // then its share of all rows (those with the bitmap bit clear).  Every thread makes the same number of turns.
+    const int SA = (nact + NT - 1) / NT, S = SA + (Nin + NT - 1) / NT, NU = (B + 15) >> 4;
+    auto rowinfo = [&](int s_, int &i, int &kq, bool &live, bool &hasrow) {
+        if (s_ < SA) { kq = tid + s_ * NT; live = kq < nact; i = live ? (int)ar[kq] : 0; hasrow = true; }
+        else { kq = 0; i = tid + (s_ - SA) * NT; live = i < Nin && !((ab[i >> 5] >> (i & 31)) & 1u); hasrow = false; if (!live) i = 0; }
+    };
+    // p_plus[b0 + k, i].  Loaded unconditionally (a value that is not needed meets a zero factor below; rows past the
+    // batch repeat the last one): a load under a branch makes the compiler wait for ALL loads in flight at the join.
+    auto issue = [&](int i, int b0, int k) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(slab, i * 4, min(b0 + k, B - 1) * Nin * 4, 0));
+    };
+    int i, kq; bool live, hasrow;
+    rowinfo(0, i, kq, live, hasrow);
+    float x[16];                                           // one unit = 16 samples = one block of the batch sum; a slot is refilled
+#pragma unroll                                             // for the NEXT unit (of this row, or the first of the next row) once used
+    for (int k = 0; k < 16; ++k) x[k] = issue(i, 0, k);
+    for (int s_ = 0; s_ < S; ++s_) {
+        int i2 = 0, kq2 = 0; bool live2 = false, hasrow2 = false;
+        if (s_ + 1 < S) rowinfo(s_ + 1, i2, kq2, live2, hasrow2);
+        uint32_t m[MWT];
+#pragma unroll
+        for (int wd = 0; wd < MWT; ++wd) m[wd] = (hasrow && live && wd < mw) ? am[kq * mw + wd] : 0u;
+        float w[CWT], a0[CWT], a1[CWT];
+#pragma unroll
+        for (int q = 0; q < CWT; ++q) { w[q] = live ? wt[i * CWT + q] : 0.f; a0[q] = a1[q] = 0.f; }
+        for (int u = 0; u < NU; ++u) {
+            const int b0 = u * 16, wd = b0 >> 5, sh = b0 & 31;
+            const bool lastu = u + 1 == NU;
+            const int nb0 = lastu ? 0 : b0 + 16, ni = lastu ? i2 : i;
+            const uint32_t cbits = (word(cu, wd) >> sh) & 0xFFFFu;
+            const uint32_t rbits = (word(m, wd) >> sh) & 0xFFFFu;                      // (per lane)
+            uint32_t cw[CWT];
+#pragma unroll
+            for (int q = 0; q < CWT; ++q) cw[q] = (word(cmr[q], wd) >> sh) & 0xFFFFu;
+#pragma unroll
+            for (int q = 0; q < CWT; ++q) { a1[q] = a1[q] + a0[q]; a0[q] = 0.f; }      // the previous block is complete (+0.0 at u == 0)
+            const bool anyrow = __ballot(rbits != 0) != 0;                             // (uniform)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float xk = x[k];
+                x[k] = issue(ni, nb0, k);
+                const bool cb = (cbits >> k) & 1u;
+                if (!cb && !anyrow) continue;                                          // nobody's sample (uniform)
+                const int b = min(b0 + k, B - 1);                                      // (samples past the batch: all factors are zero)
+                const float rowf = ((rbits >> k) & 1u) ? 1.0f : 0.0f;
+                const float rv = rvl[b];
+#pragma unroll
+                for (int q = 0; q < CWT; ++q) {
+                    const float fq = ((cw[q] >> k) & 1u) ? 1.0f : 0.0f;
+                    const float e = __builtin_fmaf(xk, fq, rowf * pml[b * 8 + q]);     // p_plus (x) s_tgt + s_src (x) p_minus
+                    a0[q] = a0[q] + rv * e;
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < CWT; ++q) {
+                if (c0 + q >= N) break;
+                if (!hasrow && !((postcols >> q) & 1u)) continue;     // (row silent, column silent: the element is not touched)
+                const float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+                float v = w[q] + c.nu0 * uu;                          // learning.py:1561
+                v = v * c.wdecay;
+                if (c.has_min && v < c.wmin) v = c.wmin;
+                if (c.has_max && v > c.wmax) v = c.wmax;
+                wt[i * CWT + q] = v;
+            }
+        }
+        i = i2; kq = kq2; live = live2; hasrow = hasrow2;
+    }
+}
+
 // CASC: MulticompartmentConnection (ATen cascade order) vs dense Connection (ascending sequential order);
 // RULE: the connection's learning rule.  Compile-time so that each variant carries only its own code (and registers).
 // MWT: 1 = batch <= 32 (one sample-mask word, compiled without the word loops), 4 = up to 128 samples.
@@ -760,8 +914,11 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             for (int b = 0; b < B; ++b) maxn = max(maxn, meta[5 + b] - meta[4 + b]);
             for (int e0 = 0; e0 < maxn; e0 += CH) {
                 const int lim = min(CH, (maxn - e0 + 3) & ~3);
+                const float inv_lim = 1.0f / (float)lim;
                 for (int it = tid; it < npairs * lim; it += NT) {
-                    const int p = it / lim, e = it - p * lim;
+                    int p = (int)((float)it * inv_lim);          // it / lim without the integer division (it < 2^24: one step of correction)
+                    if (p * lim > it) --p; else if ((p + 1) * lim <= it) ++p;
+                    const int e = it - p * lim;
                     const int pb = p >> cwl, pq = p & (CW - 1);
                     const int k = meta[4 + pb] + e0 + e;
                     float term = 0.f;
@@ -771,7 +928,16 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 lds_barrier();
                 if (tid < npairs) {
                     const float4 *row = (const float4 *)(prod + tid * ST);
-                    for (int e = 0; e < lim; e += 4) { const float4 x = row[e >> 2]; r_dot += x.x; r_dot += x.y; r_dot += x.z; r_dot += x.w; }
+                    for (int e = 0; e < lim; e += 16) {      // four LDS reads in flight per 16 dependent adds (lim is a multiple of 4)
+                        float4 x[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[k] = e + 4 * k < lim ? row[(e >> 2) + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (e + 4 * k >= lim) break;
+                            r_dot += x[k].x; r_dot += x[k].y; r_dot += x[k].z; r_dot += x[k].w;
+                        }
+                    }
                 }
                 if (e0 + CH < maxn) lds_barrier();
             }
@@ -849,7 +1015,18 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 sb = (D[2] & 1u) ? c.s_src_prev : nullptr;
                 __syncthreads();
             }
+            TMARK(7);
             const bool full = (t == 0) || c.wdecay != 1.0f;
+            uint32_t anycol = 0;                             // did any column of the tile spike in the step this update pairs with?
+            for (int k = 0; k < CMS; ++k) anycol |= cm[k];
+            if (c.dbg && blockIdx.x == 0 && tid == 0 && anycol) c.dbg[(size_t)8 * 4096 + (size_t)16 * 4096 - 1 - t] = 1;
+            if (Etot == Emain && !full && !sb && c.mstdp_rows && !__builtin_amdgcn_readfirstlane(anycol)) two_mstdp_rows<MWT>(c, wt, ar, am, zl, na, c0, tid);
+            else if (Etot == Emain && !full && !sb && c.mstdp_rows && CW >= 2) {
+                if (CW == 8) two_mstdp_burst<MWT, 8>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, na, c0, tid);
+                else if (CW == 4) two_mstdp_burst<MWT, 4>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, na, c0, tid);
+                else two_mstdp_burst<MWT, 2>(c, wt, ar, am, ab, xnu0, cm, rvl, pp, na, c0, tid);
+            }
+            else
             if (Etot != Emain) two_mstdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
             else two_mstdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, zl, cm, rvl, pp, sb, na, full, c0, tid, cwl, Emain);
             lds_barrier();                               // tile and row tables are free for the next iteration
@@ -949,6 +1126,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.dt = R->dt; c.learning = R->learning;
     c.rule = C[0].rule;
     c.rowmajor = c.rule == SNN_RULE_POSTPRE && c.learning && !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
+    c.mstdp_rows = !(getenv("SNN_TWO_MSTDP_ROWS") && atoi(getenv("SNN_TWO_MSTDP_ROWS")) == 0);
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
     // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
@@ -1040,7 +1218,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     static long long *dbg = nullptr;
     if (getenv("SNN_TWO_TIMING")) {
         if (!dbg) (void)hipMalloc(&dbg, sizeof(long long) * 24 * 4096);
-        if (c.T + 1 <= 4096) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * (c.T + 1), st); c.dbg = dbg; }
+        if (c.T + 1 <= 4096) { (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 24 * 4096, st); c.dbg = dbg; }
     }
     {
         const dim3 grid(c.G), blk(NT);
@@ -1073,6 +1251,18 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
                 a[0] / n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n);
         std::vector<long long> hw((size_t)16 * (c.T + 1));
         (void)hipMemcpy(hw.data(), dbg + (size_t)8 * 4096, hw.size() * 8, hipMemcpyDeviceToHost);
+        if (mstdp) {
+            double pub = 0, upd = 0, upd_slow = 0; int slow = 0;
+            std::vector<long long> fl((size_t)c.T + 1);
+            (void)hipMemcpy(fl.data(), dbg + (size_t)8 * 4096 + (size_t)16 * 4096 - 1 - c.T, fl.size() * 8, hipMemcpyDeviceToHost);
+            for (int t = 2; t < c.T; ++t) {
+                const long long *r = &h[(size_t)t * 8];
+                pub += (double)(r[7] - r[5]) / 100.0; upd += (double)(r[6] - r[7]) / 100.0;
+                if (fl[(size_t)c.T - t] != 0) { ++slow; upd_slow += (double)(r[6] - r[7]) / 100.0; }
+            }
+            fprintf(stderr, "[twolayer timing] publish = spikes/state %.2f + MSTDP update %.2f (%d steps with a target spike in workgroup 0: %.2f each, the other %d: %.2f)\n",
+                    pub / n, upd / n, slow, slow ? upd_slow / slow : 0.0, n - slow, n - slow ? (upd - upd_slow) / (n - slow) : 0.0);
+        }
         fprintf(stderr, "[twolayer timing] learning phase per wave, us:");
         for (int w = 0; w < 16; ++w) {
             double sum = 0;
