@@ -804,6 +804,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         c.exs = (unsigned long long *)(p + al2((size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8));
         c.xtr = (float *)((unsigned char *)c.exs + al2(resident_summary_bytes(N)));
         c.status = R->status;
+        c.rows4 = !(getenv("SNN_DC_ROWS4") && atoi(getenv("SNN_DC_ROWS4")) == 0);
         c.stall_wg = getenv("SNN_DC_TEST_STALL") ? atoi(getenv("SNN_DC_TEST_STALL")) : -1;
         c.zone_shift = 19;
         if (getenv("SNN_DC_TEST_ZONE")) { const int z = atoi(getenv("SNN_DC_TEST_ZONE")); if (z >= 0 && z <= 19) c.zone_shift = z; }

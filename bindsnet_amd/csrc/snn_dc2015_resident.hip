@@ -91,6 +91,78 @@ __device__ __forceinline__ void stdp_rows_lds(const DcCtx &c, int nact, const ui
     }
 }
 
+// The same update for 4-column tiles without `row_sum` tail elements and 0/1 spikes (the lean form), one thread per
+// listed ROW: the row's four weights in registers (one 16-byte LDS access each way), x_tgt*nu0 of a sample read as one
+// float4 for all columns.  The batch sum of a column (<= 32 terms) in ATen's order = one partial per block of 16 samples,
+// the closed partials added in order, ((open + closed) + 0) + 0 at the end; a block change is applied through 0/1
+// factors inside fmas whose products are exact (x*1, x*0), i.e. the same single rounding as the plain adds.  Columns
+// with a post-synaptic spike (rare with one_spike) take the plain cascade.
+template <int NTL>
+__device__ __forceinline__ void stdp_rows4(const DcCtx &c, int nact, const uint16_t *arows, const uint32_t *rowmask,
+                                           const uint32_t *colmask, const float *xnu0, const float *__restrict__ xsrc,
+                                           float *wtile, int c0, int tid) {
+    const int B = c.B, Nin = c.Nin, N = c.N;
+    uint32_t cm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cm[q] = (c.nu1 != 0.f && c0 + q < N) ? (uint32_t)__builtin_amdgcn_readfirstlane(colmask[q]) : 0u;
+    const bool whole = c0 + 4 <= N;
+    for (int k = tid; k < nact; k += NTL) {
+        const int i = (int)arows[k];
+        uint32_t m = rowmask[i];
+        const float4 w4 = *(const float4 *)(wtile + i * 4);
+        float w[4] = {w4.x, w4.y, w4.z, w4.w};
+        if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            int cblk = 0;
+            while (m) {
+                const int b = __ffs(m) - 1; m &= m - 1;
+                const float4 xn = *(const float4 *)(xnu0 + b * 4);
+                const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+                const float same = (b >> 4) == cblk ? 1.f : 0.f, diff = 1.f - same;
+                cblk = b >> 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+                    a0[q] = __builtin_fmaf(a0[q], same, 1.0f * xv[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] - uu;
+            }
+        }
+        if (c.nu1 != 0.f) {                                      // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float uu = 0.f;
+                if (cm[q]) {
+                    CascadeT acc; acc.init(false);
+                    uint32_t mm = cm[q];
+                    while (mm) {
+                        const int b = __ffs(mm) - 1; mm &= mm - 1;
+                        acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+                    }
+                    uu = acc.finish(B);
+                }
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] + uu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c.has_min && w[q] < c.wmin) w[q] = c.wmin;
+            if (c.has_max && w[q] > c.wmax) w[q] = c.wmax;
+        }
+        if (whole) *(float4 *)(wtile + i * 4) = make_float4(w[0], w[1], w[2], w[3]);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c0 + q < N) wtile[i * 4 + q] = w[q];
+        }
+    }
+}
+
 // Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike, on the LDS-resident slice.
 template <class SUM, int CWL, int NTL>
 __device__ __forceinline__ void stdp_cols_lds(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
@@ -229,6 +301,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                      O_LSTIB = O_MISC + 32, O_CNTIB = O_LSTIB + MAXB * LR * 2,
                      O_CURB = O_CNTIB + MAXB * 4, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
     static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
+    static_assert(O_XNU0 % 16 == 0, "x_tgt*nu0 is read as float4");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);            // [B][NW] Ae crossings of step t-1 (B * NW <= NT)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);          // ... final Ae spikes
     uint32_t *spI2 = (uint32_t *)(smem + O_SPI);           // ... Ai spikes, two buffers by step parity (the raster rows of
@@ -647,6 +720,10 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                         stdp_rows_lds<OuterSum, false, CW, NT>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
                         stdp_cols_lds<OuterSum, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     } else {
+                        if constexpr (LEAN && CW == 4) {
+                            if (c.rows4) stdp_rows4<NT>(c, nact, arows, rowmask, colmask, xnu0, xsrc, wtile, c0, tid);
+                            else stdp_rows_lds<CascadeT, false, CW, NT>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
+                        } else
                         stdp_rows_lds<CascadeT, false, CW, NT>(c, nact, arows, rowmask, colmask, sbytes, xnu0, xsrc, wtile, c0, tid, Emain);
                         stdp_cols_lds<CascadeT, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
                     }
