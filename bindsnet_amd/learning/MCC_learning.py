@@ -1,6 +1,6 @@
 """Learning rules for MulticompartmentConnection features: API mirror of
-bindsnet/learning/MCC_learning.py for `MCC_LearningRule`, `NoOp`, `PostPre`, `MSTDP`.
-The updates themselves are snn_stdp_postpre (use_dt = 1) / snn_mstdp_step."""
+bindsnet/learning/MCC_learning.py for `MCC_LearningRule`, `NoOp`, `PostPre`, `MSTDP`, `MSTDPET`.
+The updates themselves are snn_stdp_postpre (use_dt = 1) / snn_mstdp_step / snn_mstdpet_step."""
 import warnings
 from typing import Optional, Sequence, Union
 
@@ -159,5 +159,61 @@ class MSTDP(MCC_LearningRule):
 
 
 class MSTDPET(MCC_LearningRule):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("bindsnet_amd: MCC MSTDPET is outside the accelerated path")
+    """Reward-modulated STDP with an eligibility trace on a MulticompartmentConnection's Weight (reference:
+    MCC_learning.py:554-733).  Same arithmetic as the dense rule (learning.py:2187-2248, snn_mstdpet_step) and, like it,
+    defined for batch size 1 (the spikes are flattened, :665-666).  `eligibility_trace` is the rule's dense [Nin, N]
+    state on the device; the point eligibility is kept as its two factors."""
+
+    def __init__(self, connection, feature_value, range=None, nu=None, reduction=None, decay: float = 0.0,
+                 enforce_polarity: bool = False, **kwargs) -> None:
+        super().__init__(connection=connection, feature_value=feature_value,
+                         range=[-1, +1] if range is None else range, nu=nu, reduction=reduction, decay=decay,
+                         enforce_polarity=enforce_polarity, **kwargs)
+        from ..network.topology import MulticompartmentConnection
+        if not isinstance(connection, MulticompartmentConnection):
+            raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        if kwargs.get("average_update", 0):
+            raise NotImplementedError("bindsnet_amd: average_update buffers are outside the accelerated path")
+        self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
+        self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
+        self.tc_e_trace = torch.tensor(kwargs.get("tc_e_trace", 25.0))
+
+    def _ensure_state(self):
+        dev = self.feature_value.device
+        if not hasattr(self, "p_plus") or self.p_plus.device != dev:
+            self.p_plus = torch.zeros(self.source.n, device=dev)
+            self.p_minus = torch.zeros(self.target.n, device=dev)
+            self.eligibility_trace = torch.zeros(*self.feature_value.shape, device=dev)
+            self._s_src_prev = torch.zeros(self.source.n, dtype=torch.uint8, device=dev)
+            self._s_tgt_prev = torch.zeros(self.target.n, dtype=torch.uint8, device=dev)
+
+    def _decays(self):
+        dt = torch.as_tensor(self.connection.dt, dtype=torch.float32)
+        return (float(torch.exp(-dt / self.tc_plus)), float(torch.exp(-dt / self.tc_minus)),       # MCC_learning.py:711,713
+                float(torch.exp(-dt / self.tc_e_trace)))                                           # :684-686
+
+    @property
+    def eligibility(self) -> torch.Tensor:
+        """Dense view of the point eligibility (MCC_learning.py:724-726), for inspection only."""
+        self._ensure_state()
+        return torch.outer(self.p_plus, self._s_tgt_prev.float()) + torch.outer(self._s_src_prev.float(), self.p_minus)
+
+    def update(self, **kwargs) -> None:
+        from .. import ops
+        if self.source.batch_size != 1:
+            raise NotImplementedError("MCC MSTDPET is defined for batch size 1 (MCC_learning.py:665-666)")
+        self._ensure_state()
+        dp, dm, de = self._decays()
+        lo, hi = self._bounds()
+        ops.mstdpet_step(self.feature_value.data, self.eligibility_trace, self.p_plus, self.p_minus, self._s_src_prev,
+                         self._s_tgt_prev, self.source.s.reshape(-1).contiguous(), self.target.s.reshape(-1), float(kwargs["reward"]),
+                         float(self.nu[0]), float(self.connection.dt), float(kwargs.get("a_plus", 1.0)),
+                         float(kwargs.get("a_minus", -1.0)), dp, dm, de, float(self.tc_e_trace),
+                         wdecay=float(self.decay), wmin=lo, wmax=hi)
+
+    def reset_state_variables(self) -> None:
+        """MCC_learning.py:731-734: the point eligibility and its trace are cleared, P+ / P- are kept."""
+        if hasattr(self, "p_plus"):
+            self.eligibility_trace.zero_()
+            self._s_src_prev.zero_()
+            self._s_tgt_prev.zero_()

@@ -74,7 +74,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return torch.load(f, weights_only=False)
 
     _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown",
-                  "_run_cache", "_reset_cache")
+                  "_run_cache", "_reset_cache", "_shard_state", "_defer_norm")
 
     def __getstate__(self):
         """save() / clone() pickle the whole object like the reference (network.py:163-209); device scratch, the
@@ -250,6 +250,8 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             return False
         if built["n_objects"] != (len(self.layers), len(self.connections), len(self.monitors)):
             return False
+        if built["defer_norm"] != bool(self.__dict__.get("_defer_norm", False)):
+            return False
         for t, ver in built["scalars"]:               # parameter tensors changed in place (layer.thresh.fill_(...))
             if t._version != ver:
                 return False
@@ -336,6 +338,8 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         lists = []
         for k, ((src, dst), conn) in enumerate(self.connections.items()):
             self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+            if self.__dict__.get("_defer_norm", False):    # parallel.sharded_run normalises the MERGED weights itself
+                Cn[k].has_norm = 0
             rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else getattr(conn, "update_rule", None)
             nu = getattr(rule, "nu", None)
             if isinstance(nu, torch.Tensor):
@@ -373,7 +377,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return {"L": L, "Cn": Cn, "R": R, "names": names, "keep": keep, "inputs": dyn_inputs, "layers": dyn_layers,
                 "max_draws": max_draws, "gen_bufs": gen_bufs, "T": T, "B": B, "dev": dev, "scalars": scalars,
                 "lists": lists, "epoch": _lib.epoch(), "n_objects": (len(self.layers), len(self.connections), len(self.monitors)),
-                "epoch0": epoch0}
+                "epoch0": epoch0, "defer_norm": bool(self.__dict__.get("_defer_norm", False))}
 
     def _bind_call(self, built, inputs, T, B, dev):
         """The per-call part of the descriptors: input spike trains, Input.s (it aliases the previous call's last
@@ -488,6 +492,21 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         d.p_plus, d.p_minus = _dptr(rule.p_plus), _dptr(rule.p_minus)
         d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
 
+    @staticmethod
+    def _fill_mstdpet(d, rule, wdecay, kwargs):
+        """MSTDPET's keyword arguments and device state (learning.py:2187-2248, MCC_learning.py:652-729)."""
+        lo, hi = rule._bounds()
+        d.wdecay = wdecay
+        d.has_min, d.wmin = int(lo is not None), lo or 0.0
+        d.has_max, d.wmax = int(hi is not None), hi or 0.0
+        d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
+        dp, dm, de = rule._decays()
+        d.rule, d.reward = _lib.RULE_MSTDPET, float(kwargs["reward"])
+        d.a_plus, d.a_minus = float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0))
+        d.decay_plus, d.decay_minus, d.decay_e, d.tc_e = dp, dm, de, float(rule.tc_e_trace)
+        d.p_plus, d.p_minus, d.e_trace = _dptr(rule.p_plus), _dptr(rule.p_minus), _dptr(rule.eligibility_trace)
+        d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
+
     def _fill_conn(self, d, conn, src, dst, B, dev, keep, kwargs):
         from ..learning import learning as dense_rules
         from ..learning import MCC_learning as mcc_rules
@@ -523,6 +542,13 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 d.has_max, d.wmax = int(hi is not None), hi or 0.0
                 d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
                 self._fill_mstdp(d, rule, kwargs, dev, keep)
+            elif isinstance(rule, mcc_rules.MSTDPET) and not conn.manual_update:
+                if B != 1:
+                    raise NotImplementedError("MCC MSTDPET is defined for batch size 1 (MCC_learning.py:665-666)")
+                if "reward" not in kwargs:
+                    raise KeyError("reward")
+                rule._ensure_state()
+                self._fill_mstdpet(d, rule, float(rule.decay), kwargs)
             elif not isinstance(rule, mcc_rules.NoOp):
                 raise NotImplementedError(f"bindsnet_amd: MCC rule {type(rule).__name__} is not supported")
             if feat.norm is not None:
@@ -578,17 +604,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             if "reward" not in kwargs:
                 raise KeyError("reward")
             rule._ensure_state()
-            lo, hi = rule._bounds()
-            d.wdecay = float(rule.weight_decay)
-            d.has_min, d.wmin = int(lo is not None), lo or 0.0
-            d.has_max, d.wmax = int(hi is not None), hi or 0.0
-            d.nu0, d.nu1 = float(rule.nu[0]), float(rule.nu[1])
-            dp, dm, de = rule._decays()
-            d.rule, d.reward = _lib.RULE_MSTDPET, float(kwargs["reward"])
-            d.a_plus, d.a_minus = float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0))
-            d.decay_plus, d.decay_minus, d.decay_e, d.tc_e = dp, dm, de, float(rule.tc_e_trace)
-            d.p_plus, d.p_minus, d.e_trace = _dptr(rule.p_plus), _dptr(rule.p_minus), _dptr(rule.eligibility_trace)
-            d.s_src_prev, d.s_tgt_prev = _dptr(rule._s_src_prev), _dptr(rule._s_tgt_prev)
+            self._fill_mstdpet(d, rule, float(rule.weight_decay), kwargs)
         elif not isinstance(rule, dense_rules.NoOp):
             raise NotImplementedError(f"bindsnet_amd: rule {type(rule).__name__} is not supported")
         elif rule.weight_decay != 1.0 and self.learning:

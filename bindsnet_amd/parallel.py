@@ -48,20 +48,46 @@ def merge_deltas(tensors_before, tensors_after, group=None):
         off += n
 
 
+def _shard_buffers(network, tensors):
+    """Two flat f32 buffers (values before the run / deltas) with one view per merged tensor, kept on the network
+    between calls (not model state: dropped by Network.__getstate__)."""
+    key = tuple((t.data_ptr(), t.numel(), str(t.device)) for t in tensors)
+    st = network.__dict__.get("_shard_state")
+    if st is None or st["key"] != key:
+        total = sum(t.numel() for t in tensors)
+        dev = tensors[0].device if tensors else "cpu"
+        before, delta = torch.empty(total, device=dev), torch.empty(total, device=dev)
+        views, off = [], 0
+        for t in tensors:
+            n = t.numel()
+            views.append((before[off:off + n].view_as(t), delta[off:off + n].view_as(t)))
+            off += n
+        st = network.__dict__["_shard_state"] = {"key": key, "before": before, "delta": delta, "views": views}
+    return st
+
+
 def sharded_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, **kwargs) -> None:
-    """network.run on this rank's batch shard, then merge learning across ranks (see module doc)."""
+    """network.run on this rank's batch shard, then merge learning across ranks (see module doc): the weights and
+    thresholds become  before + sum_over_ranks(after - before), are clamped, and only then normalised.  The post-run
+    normalisation inside run() is switched off through the network's `_defer_norm` flag (part of the key of the kept
+    descriptor arrays, so consecutive sharded runs re-use them like plain runs do)."""
     learned = _learned(network)
     thetas = [l.theta for l in network.layers.values() if hasattr(l, "theta")] if network.learning else []
-    before = [t.clone() for t, _, _, _ in learned] + [t.clone() for t in thetas]
-    norms = [(h, h.norm) for _, _, _, h in learned]
-    for h, _ in norms:              # normalisation must see the MERGED weights: postpone it
-        h.norm = None
+    tensors = [t for t, _, _, _ in learned] + thetas
+    st = _shard_buffers(network, tensors)
+    for t, (b, _) in zip(tensors, st["views"]):
+        b.copy_(t)
+    network.__dict__["_defer_norm"] = True   # normalisation must see the MERGED weights: postponed
     try:
         network.run(inputs, time=time, **kwargs)
     finally:
-        for h, n in norms:
-            h.norm = n
-    merge_deltas(before, [t for t, _, _, _ in learned] + thetas, group)
+        network.__dict__["_defer_norm"] = False
+    for t, (b, d) in zip(tensors, st["views"]):
+        torch.sub(t, b, out=d)
+    if tensors and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(st["delta"], op=dist.ReduceOp.SUM, group=group)      # ONE flat collective per input
+    for t, (b, d) in zip(tensors, st["views"]):
+        torch.add(b, d, out=t)
     for t, lo, hi, _ in learned:
         if lo is not None or hi is not None:
             t.clamp_(min=lo, max=hi)

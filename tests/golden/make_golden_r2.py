@@ -6,6 +6,8 @@
   run_two_mcc_mstdp_*  Input -> MulticompartmentConnection[Weight, MCC_learning.MSTDP] -> LIFNodes, two consecutive runs
                        (reward +1, then a per-sample reward vector) -- everything on this path is ATen-ordered, so rasters,
                        weights and the rule's state are compared bit for bit.
+  run_two_mcc_mstdpet_b1  the same graph with MCC_learning.MSTDPET (:554-733; batch 1 like the dense rule), two runs with
+                       different rewards; the rule's dense eligibility trace is part of the fixture.
   net_monitor          NetworkMonitor / sparse Monitor recordings of a DiehlAndCook2015 run (monitors.py:30-329).
 """
 import os
@@ -21,6 +23,7 @@ import synth  # noqa: E402
 import make_golden as mg  # noqa: E402
 from make_golden import DiehlAndCook2015, Input, LIFNodes, Monitor, MulticompartmentConnection, Network, T_, Weight, save, sha  # noqa: E402
 from bindsnet.learning.MCC_learning import MSTDP as MCC_MSTDP  # noqa: E402
+from bindsnet.learning.MCC_learning import MSTDPET as MCC_MSTDPET  # noqa: E402
 from bindsnet.network.monitors import NetworkMonitor  # noqa: E402
 
 torch.set_num_threads(8)
@@ -58,6 +61,42 @@ def mcc_mstdp_case(name, Nin, N, B, T):
                decay_plus=torch.exp(-torch.tensor(1.0) / rule.tc_plus).numpy(),
                decay_minus=torch.exp(-torch.tensor(1.0) / rule.tc_minus).numpy())
     save(name, Nin=Nin, N=N, B=B, T=T, **out)
+
+
+def mcc_mstdpet_case(name, Nin, N, T):
+    """Input -> MulticompartmentConnection[Weight, MCC_learning.MSTDPET] -> LIFNodes at batch 1 (the rule flattens the
+    spikes, MCC_learning.py:665-666), two consecutive runs with different rewards, no reset of the rule's P+ / P- in
+    between (MSTDPET.reset_state_variables clears the eligibilities only, :731-734)."""
+    W0 = synth.weights_q12(11, Nin, N)
+    net = Network(dt=1.0)
+    X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    feat = Weight("weight", T_(W0).clone(), range=[0.0, 1.0], norm=0.1 * Nin, nu=(1e-1, 1e-1), learning_rule=MCC_MSTDPET)
+    conn = MulticompartmentConnection(X_, Y_, device="cpu", pipeline=[feat], tc_e_trace=25.0)
+    net.add_layer(X_, "X")
+    net.add_layer(Y_, "Y")
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    out = {}
+    rule = feat.learning_rule
+    for r in range(2):
+        spikes = synth.spike_train(30 + r, T, 1, Nin, active=0.3, max_rate=0.12)
+        net.run({"X": T_(spikes)}, time=T, reward=0.8 if r == 0 else -0.5, a_plus=1.0 if r == 0 else 0.75)
+        out[f"r{r}_sY"] = np.packbits(mon.get("s").numpy().astype(np.uint8))
+        out[f"r{r}_W"] = feat.value.detach().numpy().copy()
+        out[f"r{r}_vY"] = net.layers["Y"].v.numpy().copy()
+        out[f"r{r}_p_plus"] = rule.p_plus.numpy().copy()
+        out[f"r{r}_p_minus"] = rule.p_minus.numpy().copy()
+        out[f"r{r}_elig"] = rule.eligibility.numpy().copy()
+        out[f"r{r}_e_trace"] = rule.eligibility_trace.numpy().copy()
+        print(f"  {name} run {r}: Y spikes {int(mon.get('s').sum())}, |e_trace| max {float(rule.eligibility_trace.abs().max()):.4g}")
+        net.reset_state_variables()
+    Y, X = net.layers["Y"], net.layers["X"]
+    out.update(decay=Y.decay.numpy(), y_trace_decay=Y.trace_decay.numpy(), x_trace_decay=X.trace_decay.numpy(),
+               decay_plus=torch.exp(-torch.tensor(1.0) / rule.tc_plus).numpy(),
+               decay_minus=torch.exp(-torch.tensor(1.0) / rule.tc_minus).numpy(),
+               decay_e=torch.exp(-torch.tensor(1.0) / rule.tc_e_trace).numpy(), tc_e=rule.tc_e_trace.numpy())
+    save(name, Nin=Nin, N=N, B=1, T=T, **out)
 
 
 def net_monitor_case():
@@ -238,7 +277,9 @@ def one_step_case():
 
 
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "monitor", "rules", "extras", "one_step"]
+    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "monitor", "rules", "extras", "one_step"]
+    if "mstdpet" in jobs:
+        mcc_mstdpet_case("run_two_mcc_mstdpet_b1", 196, 48, 60)
     if "one_step" in jobs:
         one_step_case()
     if "extras" in jobs:

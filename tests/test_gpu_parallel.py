@@ -46,10 +46,14 @@ def test_sharded_run_single_rank_rccl():
         pytest.skip(f"RCCL process group could not be created: {e}")
     try:
         net = build()
+        kept = []
         for r in range(2):
             torch.manual_seed(3 + r)
             parallel.sharded_run(net, {"X": spikes[r]}, T)
             assert net.last_plan.startswith("dc2015-resident")
+            assert net.__dict__["_run_cache"]["defer_norm"] is True
+            kept.append(net.__dict__["_run_cache"]["L"])
+        assert kept[0] is kept[1], "consecutive sharded runs must re-use the kept descriptor arrays"
         dist.barrier()
         t = torch.ones(4, device=DEV)
         dist.all_reduce(t)

@@ -122,3 +122,54 @@ def test_network_run_with_the_rule_vs_oracle(rule):
     np.testing.assert_array_equal(bits(host(conn.w)), bits(st["W"]))
     if rule == "mstdpet":
         np.testing.assert_array_equal(bits(host(conn.update_rule.eligibility_trace)), bits(st["e_trace"]))
+
+
+def test_mcc_mstdpet_matches_reference():
+    """MulticompartmentConnection + Weight with MCC_learning.MSTDPET (MCC_learning.py:554-733, batch 1): two consecutive
+    Network.run() calls (different reward / a_plus, layers reset in between, the rule's state kept) bit for bit against
+    the reference fixture, plus single update() calls through the rule object afterwards against the oracle."""
+    from cases import unpack
+    from bindsnet_amd.learning.MCC_learning import MSTDPET
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    g = gold("run_two_mcc_mstdpet_b1")
+    Nin, N, T = int(g["Nin"]), int(g["N"]), int(g["T"])
+    net = Network(dt=1.0)
+    X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    feat = Weight("weight", torch.from_numpy(synth.weights_q12(11, Nin, N)), range=[0.0, 1.0], norm=0.1 * Nin, nu=(1e-1, 1e-1),
+                  learning_rule=MSTDPET)
+    conn = MulticompartmentConnection(X_, Y_, device="cpu", pipeline=[feat], tc_e_trace=25.0)
+    net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    net.to(DEV)
+    rule = feat.learning_rule
+    for r in range(2):
+        spikes = synth.spike_train(30 + r, T, 1, Nin, active=0.3, max_rate=0.12)
+        net.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T, reward=0.8 if r == 0 else -0.5, a_plus=1.0 if r == 0 else 0.75)
+        assert net.last_plan == "generic"
+        np.testing.assert_array_equal(host(mon.get("s")).reshape(T, 1, N).astype(u8), unpack(g[f"r{r}_sY"], (T, 1, N)))
+        for got, key in ((feat.value, "W"), (net.layers["Y"].v, "vY"), (rule.p_plus, "p_plus"), (rule.p_minus, "p_minus"),
+                         (rule.eligibility, "elig"), (rule.eligibility_trace, "e_trace")):
+            np.testing.assert_array_equal(bits(host(got).reshape(-1)), bits(g[f"r{r}_{key}"].reshape(-1)), err_msg=f"run {r} {key}")
+        net.reset_state_variables()
+    # the rule object driven by hand (connection.update -> feature.update -> rule.update) against the oracle
+    W = host(feat.value).copy(); et = host(rule.eligibility_trace).copy(); el = host(rule.eligibility).copy()
+    pp = host(rule.p_plus).copy(); pm = host(rule.p_minus).copy()
+    dp, dm, de = rule._decays()
+    for t in range(5):
+        s_src, s_tgt = synth.dense_spikes(960 + t, (1, Nin), 0.2), synth.dense_spikes(970 + t, (1, N), 0.2)
+        X_.s, Y_.s = dev(s_src), dev(s_tgt)
+        rule.update(reward=0.3, a_minus=-0.5)
+        oracle.mstdpet(W, el, et, pp, pm, s_src.reshape(-1), s_tgt.reshape(-1), reward=0.3, nu0=np.float32(1e-1), a_minus=-0.5,
+                       decay_plus=dp, decay_minus=dm, decay_e=de, tc_e=25.0, wmin=0.0, wmax=1.0)
+    for got, want, key in ((feat.value, W, "W"), (rule.eligibility_trace, et, "e_trace"), (rule.eligibility, el, "elig"),
+                           (rule.p_plus, pp, "p_plus"), (rule.p_minus, pm, "p_minus")):
+        np.testing.assert_array_equal(bits(host(got)), bits(want), err_msg=f"update() {key}")
+    with pytest.raises(NotImplementedError):
+        X_.batch_size = 2
+        rule.update(reward=0.3)

@@ -270,6 +270,29 @@ def test_mcc_mstdp_run_matches_reference(name):
     assert cases.sha(st["elig"]) == str(g["r0_elig_sha"])
 
 
+def test_mcc_mstdpet_run_matches_reference():
+    """Input -> MulticompartmentConnection[Weight, MCC MSTDPET] -> LIF at batch 1 (MCC_learning.py:554-733): two runs with
+    different rewards / a_plus; the layers are reset in between, the rule's state is not (Weight.reset_state_variables is
+    empty, topology_features.py:630-631).  Everything on this path is ATen-ordered: bit-exact."""
+    g = gold("run_two_mcc_mstdpet_b1")
+    P = mcc_mstdp_params(g)
+    P.rule, P.decay_e, P.tc_e = 5, float(g["decay_e"]), float(g["tc_e"])
+    st = two_state(P)
+    Nin, N = P.Nin, P.N
+    st.update(elig=np.zeros((Nin, N), f32), e_trace=np.zeros((Nin, N), f32), p_plus=np.zeros(Nin, f32), p_minus=np.zeros(N, f32))
+    for r in range(2):
+        spikes = synth.spike_train(30 + r, P.T, 1, Nin, active=0.3, max_rate=0.12)
+        P.reward, P.a_plus = (0.8, 1.0) if r == 0 else (-0.5, 0.75)
+        ras = oracle.run_two_layer(P, st, spikes)
+        assert ras.sum() > 20
+        np.testing.assert_array_equal(ras, unpack(g[f"r{r}_sY"], (P.T, 1, N)))
+        for key, name in (("W", "W"), ("vY", "vY"), ("p_plus", "p_plus"), ("p_minus", "p_minus"), ("elig", "elig"), ("e_trace", "e_trace")):
+            np.testing.assert_array_equal(bits(st[key].reshape(-1)), bits(g[f"r{r}_{name}"].reshape(-1)), err_msg=f"run {r} {key}")
+        fresh = two_state(P)                                    # network.reset_state_variables(): layer state only
+        for k in ("sX", "xX", "vY", "rY", "sY", "xY"):
+            st[k] = fresh[k]
+
+
 # --------------------------------------------------------------------------- Hebbian / WeightDependentPostPre / MSTDPET
 RULE_VARIANTS = {"hebb": (False, 1.0, 0.0, 1.0), "hebb_free": (False, 1.0, None, None), "wdpp": (True, 1.0, 0.0, 1.0),
                  "wdpp_decay": (True, 1.0 - 0.01, -0.5, 1.5)}      # tag -> (weight dependent, decay factor, wmin, wmax)
