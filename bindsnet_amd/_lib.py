@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -85,7 +85,7 @@ class ConnDesc(C.Structure):
                 ("decay_minus", C.c_float),
                 ("has_norm", C.c_int), ("norm", C.c_float), ("norm_abs", C.c_int), ("norm_ws", C.c_void_p),
                 ("e_trace", C.c_void_p), ("decay_e", C.c_float), ("tc_e", C.c_float), ("rule_ws", C.c_void_p),
-                ("mask", C.c_void_p)]
+                ("mask", C.c_void_p), ("raster_w", C.c_void_p)]
 
 
 class RunDesc(C.Structure):

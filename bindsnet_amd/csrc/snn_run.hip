@@ -225,6 +225,13 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
             if (C[c].mask && C[c].kind != SNN_CONN_CONV2D)
                 hipLaunchKernelGGL(k_mask_fill, dim3(grid_for((long)L[C[c].src].n * L[C[c].dst].n)), dim3(256), 0, st, C[c].w, C[c].mask,
                                    (long)L[C[c].src].n * L[C[c].dst].n);
+        for (int c = 0; c < nC; ++c)          // network.py:456-458: monitors record last, i.e. the weights this step leaves behind
+            if (C[c].raster_w) {
+                const size_t ne = C[c].kind == SNN_CONN_CONV2D ? (size_t)C[c].cout * C[c].cin * C[c].kh * C[c].kw
+                                                               : (size_t)L[C[c].src].n * L[C[c].dst].n;
+                if (hipMemcpyAsync(C[c].raster_w + (size_t)t * ne, C[c].w, ne * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    return SNN_ERR_LAUNCH;
+            }
         if (prof) snn_prof_end(st);
     }
     return snn_check_launch();
@@ -238,7 +245,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request
     for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v) mode = 1;   // only the generic plan implements these
-    for (int c = 0; c < nC; ++c) if (C[c].mask || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
+    for (int c = 0; c < nC; ++c) if (C[c].mask || C[c].raster_w || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
     if (R->one_step) mode = 1;
     if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));

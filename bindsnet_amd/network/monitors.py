@@ -4,8 +4,9 @@ The reference allocates and copies every monitored tensor once per timestep
 (monitors.py:94-111).  Here Network.run hands the node kernels a [T, B, *shape] buffer and they
 write the raster directly, so `get()` returns a tensor with the reference's shape and contents
 without any per-step host work.  Supported variables: `s` of any layer, `v` of LIF / D&C layers.  `Monitor(sparse=True)` hands the recording back as a
-sparse COO tensor like the reference; `NetworkMonitor` keeps float recordings of `s` / `v` of the chosen layers in a
-rolling window (per-step snapshots of connection weights are not kept by the resident kernels and are rejected).
+sparse COO tensor like the reference; `NetworkMonitor` keeps float recordings of `s` / `v` of the chosen layers -- and
+of `w` of the chosen connections -- in a rolling window.  A monitor on a connection's `w` makes the run take the generic
+plan (the fused plans keep the weights on chip for the whole run): the weights are copied out at the end of every step.
 """
 import os
 
@@ -69,7 +70,7 @@ class Monitor(AbstractMonitor):
 class NetworkMonitor(AbstractMonitor):
     """State variables of several layers at once (reference: monitors.py:127-329): `get()` returns
     {layer: {var: float tensor [time, batch, *shape]}}; with `time` set the recording is a rolling window that starts
-    out as zeros, without it the recording grows.  Supported: `s` and `v` of layers."""
+    out as zeros, without it the recording grows.  Supported: `s` and `v` of layers, `w` of connections."""
 
     def __init__(self, network, layers: Optional[Iterable[str]] = None, connections: Optional[Iterable] = None,
                  state_vars: Optional[Iterable[str]] = None, time: Optional[int] = None):
@@ -80,19 +81,25 @@ class NetworkMonitor(AbstractMonitor):
         self.time = time
         for c in self.connections:
             for v in self.state_vars:
-                if hasattr(network.connections[c], v):
-                    raise NotImplementedError(f"bindsnet_amd: NetworkMonitor cannot record '{v}' of connection {c} every "
-                                              "timestep (the resident kernels keep weights on chip for the whole run)")
+                if v != "w" and hasattr(network.connections[c], v):
+                    raise NotImplementedError(f"bindsnet_amd: NetworkMonitor records 'w' of connections; '{v}' of connection {c} "
+                                              "is outside the accelerated path")
         self.reset_state_variables()
 
     def _wanted(self):
         """(layer name, var) pairs this monitor records."""
         return [(l, v) for v in self.state_vars for l in self.layers if hasattr(self.network.layers[l], v)]
 
+    def _wanted_conns(self):
+        """(connection key, var) pairs this monitor records (monitors.py:176-178: whatever of `state_vars` the connection
+        has -- `w` of Connection / Conv2dConnection / LocalConnection; a MulticompartmentConnection has none)."""
+        return [(c, v) for v in self.state_vars for c in self.connections if hasattr(self.network.connections[c], v)]
+
     def get(self):
         return self.recording
 
-    def _append(self, layer: str, var: str, chunk: torch.Tensor) -> None:
+    def _append(self, layer, var: str, chunk: torch.Tensor) -> None:
+        """`layer`: a layer name or a connection's (source, target) key."""
         data = chunk.float()
         old = self.recording[layer][var]
         if self.time is None:
@@ -105,6 +112,8 @@ class NetworkMonitor(AbstractMonitor):
         """Single-step recording for code that steps layers by hand (monitors.py:222-262)."""
         for l, v in self._wanted():
             self._append(l, v, getattr(self.network.layers[l], v).unsqueeze(0))
+        for c, v in self._wanted_conns():
+            self._append(c, v, getattr(self.network.connections[c], v).detach().unsqueeze(0).clone())
         if self.time is not None:
             self.i += 1
 
@@ -130,3 +139,6 @@ class NetworkMonitor(AbstractMonitor):
         for l, v in self._wanted():
             t = getattr(self.network.layers[l], v)
             self.recording[l][v] = torch.Tensor() if self.time is None else torch.zeros(self.time, *t.size(), device=t.device)
+        for c, v in self._wanted_conns():
+            t = getattr(self.network.connections[c], v)
+            self.recording[c][v] = torch.Tensor() if self.time is None else torch.zeros(self.time, *t.size(), device=t.device)

@@ -335,11 +335,14 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 if lname not in self.layers or isinstance(self.layers[lname], Input):
                     raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
         Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
-        lists = []
+        lists, dyn_conns = [], []
         for k, ((src, dst), conn) in enumerate(self.connections.items()):
             self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
             if self.__dict__.get("_defer_norm", False):    # parallel.sharded_run normalises the MERGED weights itself
                 Cn[k].has_norm = 0
+            wanted = self._conn_monitor_requests(conn, (src, dst))
+            if wanted:
+                dyn_conns.append((k, conn, wanted))
             rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else getattr(conn, "update_rule", None)
             nu = getattr(rule, "nu", None)
             if isinstance(nu, torch.Tensor):
@@ -374,7 +377,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                     self._scratch("rng_qbuf", (max(max_draws, 1),), torch.float32, dev), pool["rng_host"])
         # (assignments made while building -- a state tensor re-created by _check_state, a rule's lazily allocated
         #  memory -- belong to this build: the descriptors already point at the new objects)
-        return {"L": L, "Cn": Cn, "R": R, "names": names, "keep": keep, "inputs": dyn_inputs, "layers": dyn_layers,
+        return {"L": L, "Cn": Cn, "R": R, "names": names, "keep": keep, "inputs": dyn_inputs, "layers": dyn_layers, "conns": dyn_conns,
                 "max_draws": max_draws, "gen_bufs": gen_bufs, "T": T, "B": B, "dev": dev, "scalars": scalars,
                 "lists": lists, "epoch": _lib.epoch(), "n_objects": (len(self.layers), len(self.connections), len(self.monitors)),
                 "epoch0": epoch0, "defer_norm": bool(self.__dict__.get("_defer_norm", False))}
@@ -424,6 +427,10 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                         mon_v = torch.empty(T, B, *layer.shape, device=dev)
                     rasters.append((m, key, mon_v))
             L[i].raster_s, L[i].raster_v = _dptr(mon_s), _dptr(mon_v)
+        for k, conn, wanted in built["conns"]:     # weights at the end of every timestep (monitors.py:94-111, 222-262)
+            mon_w = torch.empty(T, *conn.w.shape, device=dev)
+            built["Cn"][k].raster_w = _dptr(mon_w)
+            rasters += [(m, key, mon_w) for m, key in wanted]
         return rasters, keep
 
     # ------------------------------------------------------------------ helpers
@@ -467,12 +474,28 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             elif isinstance(m, Monitor):
                 if m.obj is layer:
                     requests += [(m, v, v) for v in m.state_vars]
-                elif not isinstance(m.obj, Nodes):
-                    raise NotImplementedError("bindsnet_amd: monitors on connections/features are not supported")
+                elif not isinstance(m.obj, Nodes) and not any(m.obj is c for c in self.connections.values()):
+                    raise NotImplementedError("bindsnet_amd: monitors on objects other than the network's layers and "
+                                              "connections (features, ...) are not supported")
         for m, key, var in requests:
             if var != "s" and not (var == "v" and hasattr(layer, "v")):
                 raise NotImplementedError(f"bindsnet_amd: monitoring '{var}' of {type(layer).__name__} is "
                                           "outside the accelerated path (supported: 's', 'v')")
+        return requests
+
+    def _conn_monitor_requests(self, conn, cname):
+        """(monitor, key handed back to its _append) for every monitor recording this connection's weights."""
+        requests = []
+        for m in self.monitors.values():
+            if isinstance(m, NetworkMonitor):
+                requests += [(m, (c, v)) for c, v in m._wanted_conns() if c == cname]
+            elif isinstance(m, Monitor) and m.obj is conn:
+                if list(m.state_vars) != ["w"] or not hasattr(conn, "w"):
+                    raise NotImplementedError(f"bindsnet_amd: monitoring {list(m.state_vars)} of {type(conn).__name__} is outside "
+                                              "the accelerated path (supported on connections: 'w')")
+                requests.append((m, "w"))
+        if requests and (conn.w.dtype != torch.float32 or not conn.w.is_contiguous()):
+            raise NotImplementedError("bindsnet_amd: monitored connection weights must be contiguous float32")
         return requests
 
     @staticmethod

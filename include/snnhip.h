@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 2
+#define SNN_ABI_VERSION 3
 
 typedef void *snn_stream_t;
 
@@ -283,6 +283,9 @@ typedef struct {
     float *rule_ws;             /* CONV2D + PostPre: scratch of 2 * B * Cout*Cin*KH*KW floats */
     const uint8_t *mask;        /* nullable [Nin,N] (same layout as w): weights forced to zero after every step's update --
                                    run(..., masks=) / LocalConnection.mask, topology.py:129-133 (generic plan) */
+    float *raster_w;            /* nullable [T, numel(w)] weight monitor (Monitor / NetworkMonitor on a connection's `w`,
+                                   monitors.py:94-111,222-262): w as it stands at the END of every timestep, i.e. after that
+                                   step's learning update and mask and before the post-run normalisation (generic plan) */
 } snn_conn_desc;
 
 typedef struct {

@@ -8,6 +8,7 @@
                        weights and the rule's state are compared bit for bit.
   run_two_mcc_mstdpet_b1  the same graph with MCC_learning.MSTDPET (:554-733; batch 1 like the dense rule), two runs with
                        different rewards; the rule's dense eligibility trace is part of the fixture.
+  conn_monitor         Monitor / NetworkMonitor on a Connection's `w` (one snapshot per timestep).
   net_monitor          NetworkMonitor / sparse Monitor recordings of a DiehlAndCook2015 run (monitors.py:30-329).
 """
 import os
@@ -97,6 +98,53 @@ def mcc_mstdpet_case(name, Nin, N, T):
                decay_minus=torch.exp(-torch.tensor(1.0) / rule.tc_minus).numpy(),
                decay_e=torch.exp(-torch.tensor(1.0) / rule.tc_e_trace).numpy(), tc_e=rule.tc_e_trace.numpy())
     save(name, Nin=Nin, N=N, B=1, T=T, **out)
+
+
+def conn_monitor_case():
+    """Monitors on a connection's weights (monitors.py:94-111 Monitor.record, :222-262 NetworkMonitor.record, called at the
+    end of every timestep, network.py:456-458): Input -> Connection[PostPre] -> LIFNodes, batch 3, two consecutive runs;
+    a Monitor on `w` with a window of T steps and a NetworkMonitor with its default state_vars ("v", "s", "w") and no
+    window.  (`Connection.compute` is an MKL sgemm: rasters are compared exactly, weights within 1e-5 -- DESIGN.md 2.)"""
+    from make_golden import Connection, PostPre
+    Nin, N, B, T = 48, 16, 3, 24
+    net = Network(dt=1.0)
+    X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    conn = Connection(X_, Y_, w=T_(synth.weights_q12(12, Nin, N) * np.float32(2.0)).clone(), update_rule=PostPre, nu=(1e-2, 5e-2),
+                      reduction=torch.sum, wmin=0.0, wmax=2.0, norm=0.4 * Nin)
+    net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+    net.add_connection(conn, "X", "Y")
+    mw = Monitor(conn, ["w"], time=T)
+    nm = NetworkMonitor(net)
+    net.add_monitor(mw, "w"); net.add_monitor(nm, "all")
+    out = {}
+    for r in range(2):
+        spikes = synth.spike_train(40 + r, T, B, Nin, active=0.5, max_rate=0.3)
+        net.run({"X": T_(spikes)}, time=T)
+        out[f"r{r}_mon_w"] = mw.get("w").numpy().copy()
+        out[f"r{r}_final_w"] = conn.w.detach().numpy().copy()
+        net.reset_state_variables()          # (empties the Monitor; the NetworkMonitor is reset too, monitors.py:301-329)
+        print(f"  conn monitor run {r}: mon_w {out[f'r{r}_mon_w'].shape}")
+    # a NetworkMonitor that is NOT reset between two runs keeps growing
+    net2 = Network(dt=1.0)
+    X2, Y2 = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    conn2 = Connection(X2, Y2, w=T_(synth.weights_q12(12, Nin, N) * np.float32(2.0)).clone(), update_rule=PostPre, nu=(1e-2, 5e-2),
+                       reduction=torch.sum, wmin=0.0, wmax=2.0, norm=0.4 * Nin)
+    net2.add_layer(X2, "X"); net2.add_layer(Y2, "Y")
+    net2.add_connection(conn2, "X", "Y")
+    nm2 = NetworkMonitor(net2)
+    net2.add_monitor(nm2, "all")
+    for r in range(2):
+        net2.run({"X": T_(synth.spike_train(40 + r, T, B, Nin, active=0.5, max_rate=0.3))}, time=T)
+    rec = nm2.get()
+    out["nm_keys"] = np.array(sorted(f"{k}:{v}" for k in rec for v in rec[k]))
+    out["nm_w"] = rec[("X", "Y")]["w"].numpy().copy()
+    out["nm_Y_s"] = np.packbits(rec["Y"]["s"].numpy().astype(np.uint8))
+    out["nm_Y_s_shape"] = np.array(rec["Y"]["s"].shape)
+    out["nm_Y_v"] = rec["Y"]["v"].numpy().copy()
+    out["nm_X_s_shape"] = np.array(rec["X"]["s"].shape)
+    print("  NetworkMonitor keys:", list(out["nm_keys"]), "w", out["nm_w"].shape, "Y.s", rec["Y"]["s"].shape, "spikes", int(rec["Y"]["s"].sum()))
+    out.update(decay=Y_.decay.numpy(), y_trace_decay=Y_.trace_decay.numpy(), x_trace_decay=X_.trace_decay.numpy())
+    save("conn_monitor", Nin=Nin, N=N, B=B, T=T, **out)
 
 
 def net_monitor_case():
@@ -277,7 +325,9 @@ def one_step_case():
 
 
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "monitor", "rules", "extras", "one_step"]
+    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    if "conn_monitor" in jobs:
+        conn_monitor_case()
     if "mstdpet" in jobs:
         mcc_mstdpet_case("run_two_mcc_mstdpet_b1", 196, 48, 60)
     if "one_step" in jobs:

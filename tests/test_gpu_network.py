@@ -247,4 +247,75 @@ def test_sparse_monitor_and_network_monitor_match_reference():
     with pytest.raises(NotImplementedError):
         from bindsnet_amd.models import TwoLayerNetwork
         two = TwoLayerNetwork(n_inpt=16, n_neurons=4, reduction=torch.sum)
-        NetworkMonitor(two, state_vars=["w"])
+        NetworkMonitor(two, state_vars=["b"])              # (connections: 'w' only)
+
+
+def test_connection_weight_monitors_match_reference_and_oracle():
+    """Monitor(connection, ["w"]) and NetworkMonitor's default ("v", "s", "w") on Input -> Connection[PostPre] -> LIF
+    (monitors.py:94-111, 222-262; recorded at the end of every timestep): the per-step weights equal the oracle's, stepped,
+    bit for bit, and the reference fixture's within the dense family's MKL tolerance; rasters exactly."""
+    from test_oracle_golden import conn_monitor_params, oracle_weight_snapshots, two_state
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor, NetworkMonitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    g = gold("conn_monitor")
+    Nin, N, B, T = int(g["Nin"]), int(g["N"]), int(g["B"]), int(g["T"])
+
+    def build():
+        net = Network(dt=1.0)
+        X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+        conn = Connection(X_, Y_, w=torch.from_numpy(synth.weights_q12(12, Nin, N) * np.float32(2.0)), update_rule=PostPre,
+                          nu=(1e-2, 5e-2), reduction=torch.sum, wmin=0.0, wmax=2.0, norm=0.4 * Nin)
+        net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+        net.add_connection(conn, "X", "Y")
+        return net, conn
+
+    net, conn = build()
+    mw = Monitor(conn, ["w"], time=T)
+    net.add_monitor(mw, "w")
+    net.to(DEV)
+    P = conn_monitor_params(g)
+    st = two_state(P)
+    st["W"] = synth.weights_q12(12, Nin, N) * np.float32(2.0)
+    for r in range(2):
+        spikes = synth.spike_train(40 + r, T, B, Nin, active=0.5, max_rate=0.3)
+        net.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T)
+        assert net.last_plan == "generic"                  # (the fused plans keep the weights on chip for the whole run)
+        got = host(mw.get("w"))
+        assert got.shape == (T, Nin, N)
+        snaps, _ = oracle_weight_snapshots(P, st, spikes)
+        np.testing.assert_array_equal(bits(got), bits(snaps), err_msg=f"run {r}: per-step weights vs oracle")
+        np.testing.assert_array_equal(bits(host(conn.w)), bits(st["W"]), err_msg=f"run {r}: final weights vs oracle")
+        np.testing.assert_allclose(got, g[f"r{r}_mon_w"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(host(conn.w), g[f"r{r}_final_w"], rtol=0, atol=1e-5)
+        net.reset_state_variables()
+        fresh = two_state(P)
+        for k in ("sX", "xX", "vY", "rY", "sY", "xY"):
+            st[k] = fresh[k]
+    # NetworkMonitor with its default state_vars, no window, not reset between two runs: the recording grows
+    net2, conn2 = build()
+    nm = NetworkMonitor(net2)
+    net2.add_monitor(nm, "all")
+    net2.to(DEV)
+    for r in range(2):
+        net2.run({"X": torch.from_numpy(synth.spike_train(40 + r, T, B, Nin, active=0.5, max_rate=0.3)).to(DEV)}, time=T)
+        assert net2.last_plan == "generic"
+    rec = nm.get()
+    assert sorted(f"{k}:{v}" for k in rec for v in rec[k]) == [str(x) for x in g["nm_keys"]]
+    assert list(rec["Y"]["s"].shape) == list(g["nm_Y_s_shape"]) and list(rec["X"]["s"].shape) == list(g["nm_X_s_shape"])
+    np.testing.assert_array_equal(np.packbits(host(rec["Y"]["s"]).astype(u8)), g["nm_Y_s"])
+    np.testing.assert_allclose(host(rec[("X", "Y")]["w"]), g["nm_w"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(host(rec["Y"]["v"]), g["nm_Y_v"], rtol=0, atol=1e-4)
+    # a window shorter than the run keeps the tail
+    net3, conn3 = build()
+    short = Monitor(conn3, ["w"], time=5)
+    net3.add_monitor(short, "w")
+    net3.to(DEV)
+    spikes = synth.spike_train(40, T, B, Nin, active=0.5, max_rate=0.3)
+    net3.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T)
+    np.testing.assert_allclose(host(short.get("w")), g["r0_mon_w"][-5:], rtol=0, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        net3.add_monitor(Monitor(conn3, ["b"], time=5), "b")
+        net3.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T)

@@ -293,6 +293,55 @@ def test_mcc_mstdpet_run_matches_reference():
             st[k] = fresh[k]
 
 
+def conn_monitor_params(g):
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T = int(g["B"]), int(g["Nin"]), int(g["N"]), 1
+    P.rule, P.mcc, P.dt = 1, 0, 1.0
+    P.x_trace_decay = float(g["x_trace_decay"]); P.x_trace_scale = 1.0; P.x_traces = 1
+    P.decay = float(g["decay"]); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.y_traces = 1; P.y_trace_decay = float(g["y_trace_decay"]); P.y_trace_scale = 1.0
+    P.has_min = P.has_max = 1; P.wmin, P.wmax = 0.0, 2.0; P.has_norm = 0; P.norm = 0.4 * P.Nin
+    P.nu0, P.nu1 = 1e-2, 5e-2
+    P.learning = 1
+    return P
+
+
+def oracle_weight_snapshots(P, st, spikes):
+    """The oracle's run driver one timestep at a time: W at the end of every step (what a Monitor on `w` records), the
+    post-run normalisation applied at the end."""
+    T = spikes.shape[0]
+    snaps = np.zeros((T,) + st["W"].shape, f32)
+    ras = np.zeros((T, P.B, P.N), u8)
+    for t in range(T):
+        ras[t] = oracle.run_two_layer(P, st, np.ascontiguousarray(spikes[t:t + 1]))[0]
+        snaps[t] = st["W"]
+    oracle.normalize(st["W"], np.float32(P.norm), use_abs=True)
+    return snaps, ras
+
+
+def test_connection_weight_monitor_matches_reference():
+    """Monitor(connection, ["w"]) (monitors.py:94-111; recorded at the end of every timestep, network.py:456-458) of an
+    Input -> Connection[PostPre] -> LIF run: the oracle, stepped, reproduces the reference's per-step weights within the
+    MKL-sgemm tolerance of the dense family and its rasters exactly."""
+    g = gold("conn_monitor")
+    P = conn_monitor_params(g)
+    Nin, N, B, T = P.Nin, P.N, P.B, int(g["T"])
+    st = two_state(P)
+    st["W"] = synth.weights_q12(12, Nin, N) * np.float32(2.0)
+    ras_all = []
+    for r in range(2):
+        spikes = synth.spike_train(40 + r, T, B, Nin, active=0.5, max_rate=0.3)
+        snaps, ras = oracle_weight_snapshots(P, st, spikes)
+        np.testing.assert_allclose(snaps, g[f"r{r}_mon_w"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(st["W"], g[f"r{r}_final_w"], rtol=0, atol=1e-5)
+        assert np.abs(snaps[-1] - snaps[0]).max() > 1e-3          # (the weights do move)
+        ras_all.append(ras)
+        fresh = two_state(P)
+        for k in ("sX", "xX", "vY", "rY", "sY", "xY"):
+            st[k] = fresh[k]
+    assert ras_all[0].sum() + ras_all[1].sum() > 50
+
+
 # --------------------------------------------------------------------------- Hebbian / WeightDependentPostPre / MSTDPET
 RULE_VARIANTS = {"hebb": (False, 1.0, 0.0, 1.0), "hebb_free": (False, 1.0, None, None), "wdpp": (True, 1.0, 0.0, 1.0),
                  "wdpp_decay": (True, 1.0 - 0.01, -0.5, 1.5)}      # tag -> (weight dependent, decay factor, wmin, wmax)
