@@ -122,6 +122,7 @@ _SIGS = {
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
     "snn_conv2d_postpre": ([_vp] * 5 + [_i] * 9 + [_f, _f, _f, _i, _f, _i, _f, _vp, _vp], _i),
     "snn_stdp_hebbian": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _i, _f, _i, _f, _vp], _i),
+    "snn_conv2d_mstdp_step": ([_vp] * 6 + [_i] * 8 + [_f] * 7 + [_i, _f, _i, _f, _vp], _i),
     "snn_mstdpet_step": ([_vp] * 8 + [_i, _i] + [_f] * 10 + [_i, _f, _i, _f, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),

@@ -688,6 +688,77 @@ extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x
     return snn_check_launch();
 }
 
+// MSTDP on a Conv2dConnection (learning.py:1942-2015, batch 1).  State: E = eligibility [Cout, K], P = P^+ in input space
+// [Cin, H, W] (the reference's unfolded copy goes through the same elementwise operations), Q = P^- [Cout, L].
+// (1) w += nu0 * sum_over_output_channels(reward * E) -- the reference's torch.sum(update, dim=0) on a weight-shaped
+//     eligibility, broadcast back over the channels --, decay, clamp; one thread per kernel tap k, ATen order over co.
+__global__ __launch_bounds__(256) void k_conv_mstdp_apply(float *__restrict__ W, const float *__restrict__ E, int Cout, long K, float reward,
+                                                          float nu0, float wdecay, int has_min, float wmin, int has_max, float wmax) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    OuterSum acc; acc.init(k >= (K / 32) * 32);
+    for (int co = 0; co < Cout; ++co) acc.add(co, reward * E[(long)co * K + k], Cout);
+    const float S = acc.finish(Cout);
+    for (int co = 0; co < Cout; ++co) {
+        float w = W[(long)co * K + k] + nu0 * S;
+        w = w * wdecay;
+        if (has_min && w < wmin) w = wmin;
+        if (has_max && w > wmax) w = wmax;
+        W[(long)co * K + k] = w;
+    }
+}
+
+// (2) P = P * decay_plus + a_plus * s_src;  Q = Q * decay_minus + a_minus * s_tgt   (learning.py:1998-2001)
+__global__ __launch_bounds__(256) void k_conv_mstdp_traces(float *__restrict__ P, float *__restrict__ Q, const uint8_t *__restrict__ s_src,
+                                                           const uint8_t *__restrict__ s_tgt, long nP, long nQ, float a_plus,
+                                                           float a_minus, float decay_plus, float decay_minus) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nP) { const float p = P[i] * decay_plus; P[i] = p + a_plus * (float)s_src[i]; }
+    else if (i < nP + nQ) { const long q = i - nP; const float v = Q[q] * decay_minus; Q[q] = v + a_minus * (float)s_tgt[q]; }
+}
+
+// (3) E[co,k] = sum_l s_tgt[co,l] * unfold(P)[k,l] + sum_l Q[co,l] * unfold(s_src)[k,l], each sum ascending in l (the
+//     canonical order pinned for the reference's two torch.bmm calls, :2004-2007)
+__global__ __launch_bounds__(256) void k_conv_mstdp_elig(float *__restrict__ E, const float *__restrict__ P, const float *__restrict__ Q,
+                                                         const uint8_t *__restrict__ s_src, const uint8_t *__restrict__ s_tgt, int Cin,
+                                                         int H, int Wd, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+    const long K = (long)Cin * KH * KW;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)Cout * K) return;
+    const int co = (int)(e / K), k = (int)(e - (long)co * K);
+    const int ci = k / (KH * KW), ky = (k / KW) % KH, kx = k % KW;
+    const int L = OH * OW;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int oy = l / OW, ox = l - oy * OW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+        const size_t si = ((size_t)ci * H + (in ? iy : 0)) * Wd + (in ? ix : 0);
+        a += (float)s_tgt[(size_t)co * L + l] * (in ? P[si] : 0.0f);
+        b += Q[(size_t)co * L + l] * (in ? (float)s_src[si] : 0.0f);
+    }
+    E[e] = a + b;
+}
+
+extern "C" int snn_conv2d_mstdp_step(float *W, float *elig, float *p_plus, float *p_minus, const uint8_t *s_src, const uint8_t *s_tgt,
+                                     int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad, float reward, float nu0,
+                                     float a_plus, float a_minus, float decay_plus, float decay_minus, float wdecay, int has_min,
+                                     float wmin, int has_max, float wmax, snn_stream_t stream) {
+    if (!W || !elig || !p_plus || !p_minus || !s_src || !s_tgt || Cin <= 0 || H <= 0 || Wd <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 ||
+        stride <= 0 || pad < 0) return SNN_ERR_INVALID;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
+    const long K = (long)Cin * KH * KW, nP = (long)Cin * H * Wd, nQ = (long)Cout * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_conv_mstdp_apply, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, W, elig, Cout, K, reward, nu0, wdecay,
+                       has_min, wmin, has_max, wmax);
+    hipLaunchKernelGGL(k_conv_mstdp_traces, dim3((unsigned)((nP + nQ + 255) / 256)), dim3(256), 0, st, p_plus, p_minus, s_src, s_tgt, nP, nQ,
+                       a_plus, a_minus, decay_plus, decay_minus);
+    hipLaunchKernelGGL(k_conv_mstdp_elig, dim3((unsigned)((Cout * K + 255) / 256)), dim3(256), 0, st, elig, p_plus, p_minus, s_src, s_tgt,
+                       Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW);
+    return snn_check_launch();
+}
+
 extern "C" int snn_stdp_hebbian(float *W, const uint8_t *s_src, const float *x_src, const uint8_t *s_tgt, const float *x_tgt,
                                 int B, int Nin, int N, float nu0, float nu1, int weight_dependent, float decay, int has_min,
                                 float wmin, int has_max, float wmax, snn_stream_t stream) {

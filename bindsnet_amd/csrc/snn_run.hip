@@ -115,9 +115,12 @@ static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
         const snn_conn_desc &d = C[c];
         if (d.src < 0 || d.src >= nL || d.dst < 0 || d.dst >= nL || !d.w) return SNN_ERR_INVALID;
         if (L[d.dst].kind == SNN_LAYER_INPUT) return SNN_ERR_UNSUPPORTED;
-        if (d.kind == SNN_CONN_CONV2D && d.rule != SNN_RULE_NONE && (d.rule != SNN_RULE_POSTPRE || !d.rule_ws)) return SNN_ERR_UNSUPPORTED;
+        const bool conv_mstdp = d.kind == SNN_CONN_CONV2D && d.rule == SNN_RULE_MSTDP;      // learning.py:1942-2015, batch 1
+        if (d.kind == SNN_CONN_CONV2D && d.rule != SNN_RULE_NONE && !conv_mstdp && (d.rule != SNN_RULE_POSTPRE || !d.rule_ws)) return SNN_ERR_UNSUPPORTED;
+        if (conv_mstdp && (!d.p_plus || !d.p_minus || !d.e_trace || d.reward_vec)) return SNN_ERR_INVALID;
+        if (conv_mstdp && R->B != 1) return SNN_ERR_UNSUPPORTED;
         if (d.rule == SNN_RULE_POSTPRE && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
-        if ((d.rule == SNN_RULE_MSTDP || d.rule == SNN_RULE_MSTDPET) && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
+        if ((d.rule == SNN_RULE_MSTDP || d.rule == SNN_RULE_MSTDPET) && !conv_mstdp && (!d.p_plus || !d.p_minus || !d.s_src_prev || !d.s_tgt_prev)) return SNN_ERR_INVALID;
         if ((d.rule == SNN_RULE_HEBBIAN || d.rule == SNN_RULE_WDPOSTPRE) && (!L[d.src].x || !L[d.dst].x)) return SNN_ERR_INVALID;
         if (d.rule == SNN_RULE_MSTDPET && (!d.e_trace || R->B != 1)) return SNN_ERR_INVALID;
         if (d.rule < SNN_RULE_NONE || d.rule > SNN_RULE_MSTDPET) return SNN_ERR_INVALID;
@@ -203,7 +206,11 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 if (d.rule == SNN_RULE_NONE) continue;
                 const snn_layer_desc &S = L[d.src], &D = L[d.dst];
                 const uint8_t *ss = layer_spikes(S, B, t, true);
-                if (d.rule == SNN_RULE_POSTPRE && d.kind == SNN_CONN_CONV2D)
+                if (d.rule == SNN_RULE_MSTDP && d.kind == SNN_CONN_CONV2D)
+                    TRY(snn_conv2d_mstdp_step(d.w, d.e_trace, d.p_plus, d.p_minus, ss, D.s, d.cin, d.h, d.wd, d.cout, d.kh, d.kw, d.stride,
+                                              d.pad, d.reward, d.nu0, d.a_plus, d.a_minus, d.decay_plus, d.decay_minus, d.wdecay,
+                                              d.has_min, d.wmin, d.has_max, d.wmax, st));
+                else if (d.rule == SNN_RULE_POSTPRE && d.kind == SNN_CONN_CONV2D)
                     TRY(snn_conv2d_postpre(d.w, ss, S.x, D.s, D.x, B, d.cin, d.h, d.wd, d.cout, d.kh, d.kw, d.stride, d.pad, d.nu0, d.nu1,
                                            d.wdecay, d.has_min, d.wmin, d.has_max, d.wmax, d.rule_ws, st));
                 else if (d.rule == SNN_RULE_POSTPRE)

@@ -98,17 +98,30 @@ class PostPre(LearningRule):
 class MSTDP(LearningRule):
     """Reward-modulated STDP (reference: learning.py:1441-1574).  The dense eligibility tensor of the
     reference is kept factored on the device (see snn_mstdp_step); `p_plus`, `p_minus` keep their
-    reference meaning."""
+    reference meaning.
+
+    On a Conv2dConnection (learning.py:1942-2015; snn_conv2d_mstdp_step) the rule is defined at batch size 1, like the
+    reference's (its `eligibility.view(w.size())`, :2013, admits no other); `eligibility` is then the rule's dense
+    [Cout, Cin, KH, KW] state, `p_minus` is [Cout, OH*OW] and `p_plus` is kept in INPUT space [Cin, H, W] -- the
+    reference's attribute is its im2col (`bindsnet.utils.im2col_indices(rule.p_plus[None], ...)` gives that layout)."""
 
     def __init__(self, connection, nu=None, reduction=None, weight_decay: float = 0.0, **kwargs) -> None:
         super().__init__(connection=connection, nu=nu, reduction=reduction, weight_decay=weight_decay, **kwargs)
-        from ..network.topology import Connection, LocalConnection
-        if not isinstance(connection, (Connection, LocalConnection)):
+        from ..network.topology import Connection, Conv2dConnection, LocalConnection
+        if not isinstance(connection, (Connection, LocalConnection, Conv2dConnection)):
             raise NotImplementedError("This learning rule is not supported for this Connection type.")
+        self._conv = isinstance(connection, Conv2dConnection)
         self.tc_plus = torch.tensor(kwargs.get("tc_plus", 20.0))
         self.tc_minus = torch.tensor(kwargs.get("tc_minus", 20.0))
 
     def _ensure_state(self):
+        if self._conv:
+            w = self.connection.w
+            if not hasattr(self, "p_plus") or self.p_plus.device != w.device:
+                self.p_plus = torch.zeros(*self.source.shape, device=w.device)
+                self.p_minus = torch.zeros(w.shape[0], self.target.n // w.shape[0], device=w.device)
+                self._elig = torch.zeros_like(w.data)
+            return
         B, dev = self.source.batch_size, self.connection.w.device
         if not hasattr(self, "p_plus") or self.p_plus.shape[0] != B or self.p_plus.device != dev:
             self.p_plus = torch.zeros(B, self.source.n, device=dev)
@@ -120,8 +133,27 @@ class MSTDP(LearningRule):
         dt = torch.tensor(self.connection.dt)
         return float(torch.exp(-dt / self.tc_plus)), float(torch.exp(-dt / self.tc_minus))   # learning.py:1564,1566
 
+    def _conv_update(self, **kwargs) -> None:
+        from .. import ops
+        if self.source.batch_size != 1:
+            raise NotImplementedError("MSTDP on a Conv2dConnection is defined for batch size 1 (learning.py:2013)")
+        reward = kwargs["reward"]
+        if isinstance(reward, torch.Tensor):
+            if reward.numel() != 1:
+                raise NotImplementedError("bindsnet_amd: MSTDP on a Conv2dConnection takes a scalar reward")
+            reward = reward.item()
+        self._ensure_state()
+        dp, dm = self._decays()
+        lo, hi = self._bounds()
+        c = self.connection
+        ops.conv2d_mstdp_step(c.w.data, self._elig, self.p_plus, self.p_minus, self.source.s.contiguous(), self.target.s.contiguous(),
+                              float(reward), float(self.nu[0]), float(kwargs.get("a_plus", 1.0)), float(kwargs.get("a_minus", -1.0)),
+                              dp, dm, stride=c.stride[0], pad=c.padding[0], wdecay=float(self.weight_decay), wmin=lo, wmax=hi)
+
     def update(self, **kwargs) -> None:
         from .. import ops
+        if self._conv:
+            return self._conv_update(**kwargs)
         self._check_reduction()
         self._ensure_state()
         B = self.source.batch_size
@@ -138,8 +170,10 @@ class MSTDP(LearningRule):
 
     @property
     def eligibility(self) -> torch.Tensor:
-        """Dense view of the factored eligibility (for inspection only)."""
+        """Dense view of the factored eligibility (for inspection only); the rule's own state on a Conv2dConnection."""
         self._ensure_state()
+        if self._conv:
+            return self._elig
         return (self.p_plus.unsqueeze(2) * self._s_tgt_prev.float().unsqueeze(1)
                 + self._s_src_prev.float().unsqueeze(2) * self.p_minus.unsqueeze(1))
 

@@ -608,6 +608,23 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 if isinstance(conn, Conv2dConnection):       # learning.py:457-497: per-sample partial sums live in scratch
                     ws = self._scratch(f"convpp_{src}_{dst}", (2 * B * conn.w.numel(),), torch.float32, dev)
                     d.rule_ws = _dptr(ws)
+            elif isinstance(conn, Conv2dConnection):         # learning.py:1942-2015, batch 1
+                if B != 1:
+                    raise NotImplementedError("MSTDP on a Conv2dConnection is defined for batch size 1 (learning.py:2013)")
+                if "reward" not in kwargs:
+                    raise KeyError("reward")
+                reward = kwargs["reward"]
+                if isinstance(reward, torch.Tensor):
+                    if reward.numel() != 1:
+                        raise NotImplementedError("bindsnet_amd: MSTDP on a Conv2dConnection takes a scalar reward")
+                    reward = reward.item()
+                a_plus, a_minus = kwargs.get("a_plus", 1.0), kwargs.get("a_minus", -1.0)
+                if isinstance(a_plus, dict) or isinstance(a_minus, dict):
+                    raise NotImplementedError("bindsnet_amd: per-connection a_plus/a_minus dicts are not supported")
+                rule._ensure_state()
+                d.rule, d.reward, d.a_plus, d.a_minus = _lib.RULE_MSTDP, float(reward), float(a_plus), float(a_minus)
+                d.decay_plus, d.decay_minus = rule._decays()
+                d.p_plus, d.p_minus, d.e_trace = _dptr(rule.p_plus), _dptr(rule.p_minus), _dptr(rule._elig)
             else:
                 if "reward" not in kwargs:
                     raise KeyError("reward")

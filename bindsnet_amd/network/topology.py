@@ -161,7 +161,7 @@ class LocalConnection(AbstractConnection):
 
 
 class Conv2dConnection(AbstractConnection):
-    """2-D convolutional synapses (reference: topology.py:686-844); propagation only."""
+    """2-D convolutional synapses (reference: topology.py:686-844): propagation, PostPre, and MSTDP at batch 1."""
 
     def __init__(self, source: Nodes, target: Nodes, kernel_size: Union[int, Tuple[int, int]],
                  stride: Union[int, Tuple[int, int]] = 1, padding: Union[int, Tuple[int, int]] = 0,
@@ -173,8 +173,8 @@ class Conv2dConnection(AbstractConnection):
         if self.dilation != (1, 1) or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
             raise NotImplementedError("bindsnet_amd: conv2d supports dilation 1 and symmetric stride/padding only")
         rule = kwargs.get("update_rule", None)
-        if rule is not None and rule.__name__ not in ("PostPre", "NoOp"):
-            raise NotImplementedError(f"bindsnet_amd: {rule.__name__} on Conv2dConnection is not supported (PostPre is)")
+        if rule is not None and rule.__name__ not in ("PostPre", "MSTDP", "NoOp"):
+            raise NotImplementedError(f"bindsnet_amd: {rule.__name__} on Conv2dConnection is not supported (PostPre and MSTDP are)")
         self.in_channels, ih, iw = source.shape[0], source.shape[1], source.shape[2]
         if self.in_channels > 16:
             raise NotImplementedError("bindsnet_amd: Conv2dConnection with more than 16 input channels is not supported (the "

@@ -134,6 +134,18 @@ def conv2d_postpre(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, stride=1, pad=0, dec
                                    _ptr(ws, F32), _stream()), "conv2d_postpre")
 
 
+def conv2d_mstdp_step(W, elig, p_plus, p_minus, s_src, s_tgt, reward, nu0, a_plus, a_minus, decay_plus, decay_minus, stride=1, pad=0,
+                      wdecay=1.0, wmin=None, wmax=None):
+    """f4: MSTDP on Conv2dConnection weights [Cout,Cin,KH,KW] at batch 1; elig like W, p_plus [Cin,H,W], p_minus [Cout,OH*OW],
+    s_src [Cin,H,W], s_tgt [Cout,OH,OW] (a leading batch dimension of 1 is fine)."""
+    Cin, H, Wd = s_src.shape[-3:]
+    Cout, _, KH, KW = W.shape
+    check(lib().snn_conv2d_mstdp_step(_ptr(W, F32), _ptr(elig, F32), _ptr(p_plus, F32), _ptr(p_minus, F32), _ptr(s_src, "spike"),
+                                      _ptr(s_tgt, "spike"), Cin, H, Wd, Cout, KH, KW, stride, pad, reward, nu0, a_plus, a_minus,
+                                      decay_plus, decay_minus, wdecay, int(wmin is not None), 0.0 if wmin is None else wmin,
+                                      int(wmax is not None), 0.0 if wmax is None else wmax, _stream()), "conv2d_mstdp_step")
+
+
 def stdp_hebbian(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, weight_dependent=False, decay=1.0, wmin=None, wmax=None):
     """f3: Hebbian (weight_dependent=False) / WeightDependentPostPre (True) on a dense weight matrix."""
     B = s_src.shape[0]

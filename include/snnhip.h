@@ -193,6 +193,20 @@ int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x_src, const
                        int B, int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad, float nu0, float nu1,
                        float decay, int has_min, float wmin, int has_max, float wmax, float *ws, snn_stream_t stream);
 
+/* ---- f4: MSTDP on a Conv2dConnection (batch 1) -----------------------------------------------------------
+ * bindsnet/learning/learning.py:1942-2015 (+ :87-104), defined at batch size 1 only (the reference views its [B, Cout, K]
+ * eligibility as the weight's shape, :2013).  elig [Cout, K = Cin*KH*KW] is the rule's eligibility (in/out), p_plus the
+ * P^+ trace in input space [Cin, H, W] (the reference's unfolded copy carries the same values), p_minus P^- [Cout, OH*OW].
+ * Order:  W[co,k] += nu0 * sum_co' (reward * elig[co',k])  (the reference's torch.sum(update, dim=0) over a weight-shaped
+ * eligibility: summed over the OUTPUT CHANNELS in ATen's order and broadcast back, :1966-1967);  W *= wdecay; clamp;
+ * p_plus = p_plus * decay_plus + a_plus * s_src;  p_minus likewise with s_tgt;
+ * elig[co,k] = sum_l s_tgt[co,l] * unfold(p_plus)[k,l] + sum_l p_minus[co,l] * unfold(s_src)[k,l]  (each ascending in l; the
+ * reference's run inside torch.bmm: BLAS order, compared within tolerance).                                       */
+int snn_conv2d_mstdp_step(float *W, float *elig, float *p_plus, float *p_minus, const uint8_t *s_src, const uint8_t *s_tgt,
+                          int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad, float reward, float nu0,
+                          float a_plus, float a_minus, float decay_plus, float decay_minus, float wdecay, int has_min,
+                          float wmin, int has_max, float wmax, snn_stream_t stream);
+
 /* ---- f3: MSTDPET (dense Connection, batch 1) -----------------------------------------------------------
  * bindsnet/learning/learning.py:2187-2248.  e_trace [Nin,N] is the rule's dense eligibility trace (in/out); the point
  * eligibility is p_plus (x) s_tgt_prev + s_src_prev (x) p_minus of the previous call's factors, formed on the fly.
@@ -278,7 +292,8 @@ typedef struct {
     float reward; const float *reward_vec; float a_plus, a_minus, decay_plus, decay_minus;
     int has_norm; float norm; int norm_abs;   /* post-run normalisation (norm_abs: Connection) */
     float *norm_ws;             /* [N] scratch when has_norm */
-    float *e_trace;             /* MSTDPET: dense eligibility trace [Nin,N] */
+    float *e_trace;             /* MSTDPET: dense eligibility trace [Nin,N]; CONV2D + MSTDP: the eligibility [Cout,Cin*KH*KW]
+                                   (p_plus is then [Cin,H,W], p_minus [Cout,OH*OW]; batch 1, s_*_prev unused) */
     float decay_e, tc_e;        /* MSTDPET: exp(-dt / tc_e_trace), tc_e_trace */
     float *rule_ws;             /* CONV2D + PostPre: scratch of 2 * B * Cout*Cin*KH*KW floats */
     const uint8_t *mask;        /* nullable [Nin,N] (same layout as w): weights forced to zero after every step's update --

@@ -179,6 +179,17 @@ def conv2d_postpre(W, s_src, x_src, s_tgt, x_tgt, *, stride=1, pad=0, nu0, nu1, 
                              cf(wmin or 0.0), ci(wmax is not None), cf(wmax or 0.0))
 
 
+def conv2d_mstdp(W, E, P, Q, s_src, s_tgt, *, stride=1, pad=0, reward, nu0, a_plus=1.0, a_minus=-1.0, decay_plus, decay_minus,
+                 wdecay=1.0, wmin=None, wmax=None):
+    """W [Cout,Cin,KH,KW]; E like W; P [Cin,H,W]; Q [Cout,OH,OW]; s_src [Cin,H,W] u8; s_tgt [Cout,OH,OW] u8 (batch 1)."""
+    Cin, H, Wd = s_src.shape
+    Cout, _, KH, KW = W.shape
+    lib().orc_conv2d_mstdp(_p(W, f32), _p(E, f32), _p(P, f32), _p(Q, f32), _p(s_src, u8), _p(s_tgt, u8), ci(Cin), ci(H), ci(Wd),
+                           ci(Cout), ci(KH), ci(KW), ci(stride), ci(pad), cf(reward), cf(nu0), cf(a_plus), cf(a_minus),
+                           cf(decay_plus), cf(decay_minus), cf(wdecay), ci(wmin is not None), cf(wmin or 0.0),
+                           ci(wmax is not None), cf(wmax or 0.0))
+
+
 def normalize(W, norm, use_abs):
     Nin, N = W.shape
     lib().orc_normalize(_p(W, f32), ci(Nin), ci(N), cf(norm), ci(int(use_abs)))

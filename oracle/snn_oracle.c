@@ -389,6 +389,58 @@ ORC_API void orc_conv2d_postpre(float *W, const uint8_t *s_src, const float *x_s
     free(pre); free(post);
 }
 
+/* f4: MSTDP._conv2d_connection_update, learning.py:1942-2015 (+ LearningRule.update :87-104), batch size 1 -- the only
+ * batch size at which the reference's `eligibility.view(w.size())` (:2013) is defined.  State: E = eligibility
+ * [Cout, K] (K = Cin*KH*KW), P = P^+ and Q = P^-.  The reference keeps P^+ unfolded ([K, L], im2col of zeros at :1982-1988);
+ * every unfolded element goes through exactly the operations of the input pixel it copies (padding stays 0*d + a*0 = 0),
+ * so P is held in input space [Cin, H, W] and unfolded on the fly.  Order of one call:
+ *   w += nu0 * torch.sum(reward * E, dim=0)      -- :1966-1967.  After the first call E has the WEIGHT's shape, so this
+ *        sum runs over the OUTPUT CHANNELS and its [Cin, KH, KW] result is broadcast back over them (the reference's
+ *        behaviour, reproduced as is); during the first call E is zeros and the term vanishes either way;
+ *   P = P * decay_plus + a_plus * s_src;  Q = Q * decay_minus + a_minus * s_tgt                       -- :1998-2001
+ *   E[co,k] = sum_l s_tgt[co,l] * P_unf[k,l]  +  sum_l Q[co,l] * s_src_unf[k,l]                       -- :2004-2007
+ *        (two torch.bmm calls: BLAS order, not reproducible -- canonical order pinned here: ascending l, sequential f32)
+ *   w *= weight_decay; clamp                                                                          -- :87-104    */
+typedef struct { const float *E; long K, k; float reward; } cm_ctx;
+static float cm_term(const void *c, long co) { const cm_ctx *p = (const cm_ctx *)c; return p->reward * p->E[co * p->K + p->k]; }
+
+ORC_API void orc_conv2d_mstdp(float *W, float *E, float *P, float *Q, const uint8_t *s_src, const uint8_t *s_tgt,
+                              int Cin, int H, int Wd, int Cout, int KH, int KW, int stride, int pad,
+                              float reward, float nu0, float a_plus, float a_minus, float decay_plus, float decay_minus,
+                              float wdecay, int has_min, float wmin, int has_max, float wmax)
+{
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1, L = OH * OW;
+    const long K = (long)Cin * KH * KW;
+    for (long k = 0; k < K; ++k) {
+        cm_ctx c = { E, K, k, reward };
+        const float S = outer_sum(cm_term, &c, Cout, k, K);
+        for (int co = 0; co < Cout; ++co) {
+            float w = W[co * K + k] + nu0 * S;
+            w = w * wdecay;
+            if (has_min && w < wmin) w = wmin;
+            if (has_max && w > wmax) w = wmax;
+            W[co * K + k] = w;
+        }
+    }
+    for (long i = 0; i < (long)Cin * H * Wd; ++i) { float p = P[i] * decay_plus; P[i] = p + a_plus * (float)s_src[i]; }
+    for (long i = 0; i < (long)Cout * L; ++i) { float q = Q[i] * decay_minus; Q[i] = q + a_minus * (float)s_tgt[i]; }
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx) {
+                    float a = 0.f, b = 0.f;
+                    for (int l = 0; l < L; ++l) {
+                        const int oy = l / OW, ox = l - oy * OW;
+                        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+                        const int in = iy >= 0 && iy < H && ix >= 0 && ix < Wd;
+                        const long si = ((long)ci * H + (in ? iy : 0)) * Wd + (in ? ix : 0);
+                        a += (float)s_tgt[(long)co * L + l] * (in ? P[si] : 0.0f);
+                        b += Q[(long)co * L + l] * (in ? (float)s_src[si] : 0.0f);
+                    }
+                    E[(long)co * K + ((long)ci * KH + ky) * KW + kx] = a + b;
+                }
+}
+
 /* f3: MSTDPET._connection_update, learning.py:2187-2248 (batch size 1: the reference flattens the spikes).
  * elig / e_trace are the reference's dense [Nin,N] tensors.  Order: e_trace *= exp(-dt/tc_e); e_trace += elig / tc_e;
  * w += ((nu0 * dt) * reward) * e_trace; p_plus / p_minus; elig = p_plus (x) s_tgt + s_src (x) p_minus; decay; clamp. */

@@ -8,6 +8,7 @@
                        weights and the rule's state are compared bit for bit.
   run_two_mcc_mstdpet_b1  the same graph with MCC_learning.MSTDPET (:554-733; batch 1 like the dense rule), two runs with
                        different rewards; the rule's dense eligibility trace is part of the fixture.
+  op_conv_mstdp        MSTDP on a Conv2dConnection (learning.py:1942-2015; batch 1): update sequences + a run.
   conn_monitor         Monitor / NetworkMonitor on a Connection's `w` (one snapshot per timestep).
   net_monitor          NetworkMonitor / sparse Monitor recordings of a DiehlAndCook2015 run (monitors.py:30-329).
 """
@@ -145,6 +146,51 @@ def conn_monitor_case():
     print("  NetworkMonitor keys:", list(out["nm_keys"]), "w", out["nm_w"].shape, "Y.s", rec["Y"]["s"].shape, "spikes", int(rec["Y"]["s"].sum()))
     out.update(decay=Y_.decay.numpy(), y_trace_decay=Y_.trace_decay.numpy(), x_trace_decay=X_.trace_decay.numpy())
     save("conn_monitor", Nin=Nin, N=N, B=B, T=T, **out)
+
+
+CONV_MSTDP_CASES = [(1, 12, 12, 4, 5, 1, 0), (2, 9, 9, 3, 3, 2, 1), (3, 8, 8, 40, 3, 1, 1)]      # (Cin, H, W, Cout, K, stride, pad)
+
+
+def conv_mstdp_case():
+    """MSTDP on a Conv2dConnection (learning.py:1942-2015), batch 1 -- the only batch size at which the reference's
+    `eligibility.view(w.size())` works.  (a) sequences of update() calls on given spikes (three geometries; K = Cin*k*k is
+    25 / 18 / 27 columns with 4 / 3 / 40 output channels summed by :1967); (b) a Network.run()."""
+    from bindsnet.learning import MSTDP
+    from make_golden import Conv2dConnection, _set_layer
+    out = {"cases": np.array(CONV_MSTDP_CASES)}
+    for k, (Cin, H, Wd, Cout, K, stride, pad) in enumerate(CONV_MSTDP_CASES):
+        OH = (H + 2 * pad - K) // stride + 1
+        src, tgt = Input(shape=(Cin, H, Wd), traces=True), LIFNodes(shape=(Cout, OH, OH), traces=True)
+        c = Conv2dConnection(src, tgt, kernel_size=K, stride=stride, padding=pad, w=T_(synth.uniform_f32(2300 + k, (Cout, Cin, K, K), 0.0, 0.5)).clone(),
+                             update_rule=MSTDP, nu=(2e-2, 1e-2), wmin=0.0, wmax=0.6, weight_decay=0.0 if k != 1 else 1e-3)
+        c.dt = 1.0
+        for t in range(10):
+            _set_layer(src, 1, synth.dense_spikes(2310 + 20 * k + t, (1, Cin, H, Wd), 0.2), None)
+            _set_layer(tgt, 1, synth.dense_spikes(2700 + 20 * k + t, (1, Cout, OH, OH), 0.15).astype(bool), None)
+            c.update(learning=True, reward=0.7 if t % 3 else -0.4, a_plus=1.0, a_minus=-0.8)
+        ur = c.update_rule
+        out[f"w{k}"] = c.w.detach().numpy().copy()
+        out[f"elig{k}"] = ur.eligibility.numpy().copy()
+        out[f"p_plus{k}"] = ur.p_plus.numpy().copy()          # unfolded: [1, Cin*K*K, L]
+        out[f"p_minus{k}"] = ur.p_minus.numpy().copy()        # [1, Cout, L]
+    out.update(decay_plus=torch.exp(-torch.tensor(1.0) / ur.tc_plus).numpy(), decay_minus=torch.exp(-torch.tensor(1.0) / ur.tc_minus).numpy())
+    # (b) a run
+    T3 = 40
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(2290, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=MSTDP, nu=(2e-3, 1e-3), wmin=0.0, wmax=4.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T3)
+    net.add_monitor(mon, "s")
+    sp = synth.dense_spikes(2291, (T3, 1, 1, 12, 12), 0.2)
+    net.run({"X": T_(sp)}, time=T3, reward=0.6)
+    out.update(run_sY=np.packbits(mon.get("s").numpy().astype(np.uint8)), run_W=cc.w.detach().numpy().copy(),
+               run_elig=cc.update_rule.eligibility.numpy().copy(), run_Y_decay=net.layers["Y"].decay.numpy())
+    print("  conv MSTDP: run spikes", int(mon.get("s").sum()), "| max |w - w0| in the update sequences:",
+          [float(np.abs(out[f"w{k}"] - synth.uniform_f32(2300 + k, out[f"w{k}"].shape, 0.0, 0.5)).max()) for k in range(len(CONV_MSTDP_CASES))])
+    save("op_conv_mstdp", **out)
 
 
 def net_monitor_case():
@@ -325,7 +371,9 @@ def one_step_case():
 
 
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    if "conv_mstdp" in jobs:
+        conv_mstdp_case()
     if "conn_monitor" in jobs:
         conn_monitor_case()
     if "mstdpet" in jobs:

@@ -10,7 +10,7 @@ import torch
 
 import oracle
 import synth
-from cases import gold, u8, unpack
+from cases import f32, gold, u8, unpack
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -116,6 +116,74 @@ def test_conv2d_postpre_updates_and_run():
     assert net.last_plan == "generic"
     np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
     np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-4)
+
+
+def test_mstdp_on_conv2d_connection_matches_oracle_and_reference():
+    """MSTDP on a Conv2dConnection (learning.py:1942-2015; batch 1).  Update sequences through the rule object: bit-exact
+    against the oracle, within the BLAS tolerance against the reference (its eligibility comes out of two torch.bmm
+    calls).  A Network.run(): against a hand-stepped oracle (conv2d propagation, LIF step, rule) bit for bit, against
+    the reference fixture rasters exactly and weights / eligibility within tolerance."""
+    from test_oracle_golden import conv_mstdp_run_oracle, conv_mstdp_sequence, unfold_np
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    g = gold("op_conv_mstdp")
+    dp, dm = np.float32(g["decay_plus"]), np.float32(g["decay_minus"])
+    for k in range(len(g["cases"])):
+        Cin, H, Wd, Cout, K, stride, pad = (int(v) for v in g["cases"][k])
+        OH = (H + 2 * pad - K) // stride + 1
+        wdec = 1e-3 if k == 1 else 0.0
+        src, tgt = Input(shape=(Cin, H, Wd), traces=True), LIFNodes(shape=(Cout, OH, OH), traces=True)
+        c = Conv2dConnection(src, tgt, kernel_size=K, stride=stride, padding=pad, w=T_(synth.uniform_f32(2300 + k, (Cout, Cin, K, K), 0.0, 0.5)).clone(),
+                             update_rule=MSTDP, nu=(2e-2, 1e-2), wmin=0.0, wmax=0.6, weight_decay=wdec).to(DEV)
+        c.dt = 1.0
+        src.batch_size = tgt.batch_size = 1
+
+        def gpu_step(W, E, P, Q, s_src, s_tgt, reward):
+            src.s, tgt.s = T_(s_src[None]).to(DEV), T_(s_tgt[None]).to(DEV)
+            c.update(learning=True, reward=reward, a_plus=1.0, a_minus=-0.8)
+
+        def orc_step(W, E, P, Q, s_src, s_tgt, reward):
+            oracle.conv2d_mstdp(W, E, P, Q, s_src, s_tgt, stride=stride, pad=pad, reward=reward, nu0=np.float32(2e-2), a_plus=1.0,
+                                a_minus=-0.8, decay_plus=dp, decay_minus=dm, wdecay=np.float32(1.0 - wdec) if wdec else 1.0, wmin=0.0, wmax=0.6)
+
+        conv_mstdp_sequence(g, k, gpu_step)
+        W, E, P, Q, _ = conv_mstdp_sequence(g, k, orc_step)
+        ur = c.update_rule
+        for got, want, name in ((c.w, W, "w"), (ur.eligibility, E, "eligibility"), (ur.p_plus, P, "p_plus"), (ur.p_minus, Q.reshape(Cout, -1), "p_minus")):
+            np.testing.assert_array_equal(host(got).view(np.uint32), want.view(np.uint32), err_msg=f"case {k} {name} vs oracle")
+        np.testing.assert_allclose(host(c.w), g[f"w{k}"], rtol=0, atol=1e-5, err_msg=f"case {k} w vs reference")
+        np.testing.assert_allclose(host(ur.eligibility), g[f"elig{k}"], rtol=0, atol=1e-5, err_msg=f"case {k} eligibility vs reference")
+        np.testing.assert_array_equal(unfold_np(host(ur.p_plus), K, stride, pad).view(np.uint32), g[f"p_plus{k}"][0].view(np.uint32))
+        with pytest.raises(NotImplementedError):
+            src.batch_size = 2
+            c.update(learning=True, reward=0.5)
+    # ---- a run
+    T3 = 40
+    W0 = synth.uniform_f32(2290, (4, 1, 3, 3), 0.0, 3.0)
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(W0).clone(), update_rule=MSTDP, nu=(2e-3, 1e-3),
+                          wmin=0.0, wmax=4.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T3)
+    net.add_monitor(mon, "s")
+    net.to(DEV)
+    sp = synth.dense_spikes(2291, (T3, 1, 1, 12, 12), 0.2)
+    net.run({"X": T_(sp).to(DEV)}, time=T3, reward=0.6)
+    assert net.last_plan == "generic"
+    ras = host(mon.get("s")).reshape(T3, 400).astype(u8)
+    ras_o, W, E = conv_mstdp_run_oracle(g, T3)     # hand-stepped oracle (conv2d propagation, LIF step, rule), pinned on the CPU
+    np.testing.assert_array_equal(ras, ras_o)
+    np.testing.assert_array_equal(host(cc.w).view(np.uint32), W.view(np.uint32))
+    np.testing.assert_array_equal(host(cc.update_rule.eligibility).view(np.uint32), E.view(np.uint32))
+    np.testing.assert_array_equal(ras, unpack(g["run_sY"], (T3, 400)))
+    np.testing.assert_allclose(host(cc.w), g["run_W"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(host(cc.update_rule.eligibility), g["run_elig"], rtol=0, atol=1e-4)
+    assert ras.sum() > 500 and np.abs(host(cc.w) - W0).max() > 1e-2
 
 
 def test_one_step_mode_matches_reference():

@@ -342,6 +342,84 @@ def test_connection_weight_monitor_matches_reference():
     assert ras_all[0].sum() + ras_all[1].sum() > 50
 
 
+# --------------------------------------------------------------------------- MSTDP on a Conv2dConnection
+def unfold_np(x, K, stride, pad):
+    """F.unfold of one [Cin, H, W] image -> [Cin*K*K, L] (what bindsnet.utils.im2col_indices returns per sample)."""
+    Cin, H, Wd = x.shape
+    OH, OW = (H + 2 * pad - K) // stride + 1, (Wd + 2 * pad - K) // stride + 1
+    xp = np.zeros((Cin, H + 2 * pad, Wd + 2 * pad), x.dtype)
+    xp[:, pad:pad + H, pad:pad + Wd] = x
+    out = np.zeros((Cin * K * K, OH * OW), x.dtype)
+    for ci in range(Cin):
+        for ky in range(K):
+            for kx in range(K):
+                out[(ci * K + ky) * K + kx] = xp[ci, ky:ky + stride * OH:stride, kx:kx + stride * OW:stride].reshape(-1)
+    return out
+
+
+def conv_mstdp_sequence(g, k, step):
+    """Drives `step(W, E, P, Q, s_src, s_tgt, reward)` through the fixture's 10-update sequence of geometry k."""
+    Cin, H, Wd, Cout, K, stride, pad = (int(v) for v in g["cases"][k])
+    OH = (H + 2 * pad - K) // stride + 1
+    W = synth.uniform_f32(2300 + k, (Cout, Cin, K, K), 0.0, 0.5)
+    E = np.zeros_like(W); P = np.zeros((Cin, H, Wd), f32); Q = np.zeros((Cout, OH, OH), f32)
+    for t in range(10):
+        s_src = synth.dense_spikes(2310 + 20 * k + t, (1, Cin, H, Wd), 0.2)[0]
+        s_tgt = synth.dense_spikes(2700 + 20 * k + t, (1, Cout, OH, OH), 0.15)[0]
+        step(W, E, P, Q, s_src, s_tgt, 0.7 if t % 3 else -0.4)
+    return W, E, P, Q, (K, stride, pad)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_conv2d_mstdp_sequence_matches_reference(k):
+    """learning.py:1942-2015 at batch 1.  P^+ / P^- are elementwise: bit-exact (P^+ compared through F.unfold's layout);
+    the eligibility and the weights go through two torch.bmm calls per step (BLAS order): within 1e-5."""
+    g = gold("op_conv_mstdp")
+    dp, dm = np.float32(g["decay_plus"]), np.float32(g["decay_minus"])
+
+    def step(W, E, P, Q, s_src, s_tgt, reward):
+        oracle.conv2d_mstdp(W, E, P, Q, s_src, s_tgt, stride=int(g["cases"][k][5]), pad=int(g["cases"][k][6]), reward=reward,
+                            nu0=np.float32(2e-2), a_plus=1.0, a_minus=-0.8, decay_plus=dp, decay_minus=dm,
+                            wdecay=np.float32(1.0 - 1e-3) if k == 1 else 1.0, wmin=0.0, wmax=0.6)
+
+    W, E, P, Q, (K, stride, pad) = conv_mstdp_sequence(g, k, step)
+    np.testing.assert_array_equal(bits(unfold_np(P, K, stride, pad)), bits(g[f"p_plus{k}"][0]))
+    np.testing.assert_array_equal(bits(Q.reshape(Q.shape[0], -1)), bits(g[f"p_minus{k}"][0]))
+    np.testing.assert_allclose(E, g[f"elig{k}"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(W, g[f"w{k}"], rtol=0, atol=1e-5)
+    assert np.abs(W - synth.uniform_f32(2300 + k, W.shape, 0.0, 0.5)).max() > 0.1
+
+
+def conv_mstdp_run_oracle(g, T3=40):
+    """network.py:380-458 for Input(1,12,12) -> Conv2dConnection 3x3x4 [MSTDP] -> LIFNodes(4,10,10) at batch 1, stepped by
+    hand through the oracle's operators: currents from the previous step's input spikes, LIF step, then the rule."""
+    dp, dm = np.float32(g["decay_plus"]), np.float32(g["decay_minus"])
+    W0 = synth.uniform_f32(2290, (4, 1, 3, 3), 0.0, 3.0)
+    sp = synth.dense_spikes(2291, (T3, 1, 1, 12, 12), 0.2)
+    W, E, P, Q = W0.copy(), np.zeros_like(W0), np.zeros((1, 12, 12), f32), np.zeros((4, 10, 10), f32)
+    v = np.full((1, 400), -65.0, f32); r = np.zeros((1, 400), f32); s = np.zeros((1, 400), u8); x = np.zeros((1, 400), f32)
+    s_prev = np.zeros((1, 1, 12, 12), u8)
+    ras = np.zeros((T3, 400), u8)
+    for t in range(T3):
+        I = oracle.prop_conv2d(W, s_prev).reshape(1, 400)
+        oracle.lif_step(v, r, s, x, I, decay=float(g["run_Y_decay"]), rest=-65.0, reset=-65.0, thresh=-52.0, refrac0=5.0,
+                        trace_decay=float(dp))                  # (LIFNodes' tc_trace = 20 = the rule's tc_plus)
+        s_prev = sp[t]
+        oracle.conv2d_mstdp(W, E, P, Q, sp[t, 0], s.reshape(4, 10, 10), reward=0.6, nu0=np.float32(2e-3), decay_plus=dp, decay_minus=dm,
+                            wmin=0.0, wmax=4.0)
+        ras[t] = s[0]
+    return ras, W, E
+
+
+def test_conv2d_mstdp_run_matches_reference():
+    g = gold("op_conv_mstdp")
+    ras, W, E = conv_mstdp_run_oracle(g)
+    np.testing.assert_array_equal(ras, unpack(g["run_sY"], (40, 400)))
+    np.testing.assert_allclose(W, g["run_W"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(E, g["run_elig"], rtol=0, atol=1e-4)
+    assert ras.sum() > 500
+
+
 # --------------------------------------------------------------------------- Hebbian / WeightDependentPostPre / MSTDPET
 RULE_VARIANTS = {"hebb": (False, 1.0, 0.0, 1.0), "hebb_free": (False, 1.0, None, None), "wdpp": (True, 1.0, 0.0, 1.0),
                  "wdpp_decay": (True, 1.0 - 0.01, -0.5, 1.5)}      # tag -> (weight dependent, decay factor, wmin, wmax)
