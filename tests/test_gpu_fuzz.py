@@ -103,3 +103,19 @@ def test_fuzz_convlif(seed):
     g, plan_g = conv.run(1, case)
     assert plan_g == "generic"
     _same(f, g, f"conv {case}")
+
+
+@pytest.mark.parametrize("N,B", [(30, 5), (98, 32), (402, 17), (6, 32)])
+def test_lean_resident_partial_last_tile(N, B):
+    """Column counts with N % 4 == 2 (and Nin * N % 32 == 0, so the lean form applies): the last workgroup's 4-column tile
+    is half empty -- the row-per-thread PostPre writes back single weights there, the exchange carries dead lanes."""
+    T = 24
+    spikes = [synth.dense_spikes(900 + r + N, (T, B, 784), 0.04) for r in range(2)]
+    res, plan = dc.run(0, N, B, T, spikes, w_scale=0.5)
+    assert plan.startswith("dc2015-resident")
+    gen, plan_g = dc.run(1, N, B, T, spikes, w_scale=0.5)
+    assert plan_g == "generic"
+    assert sum(int(r["sE"].sum()) for r in gen) > 0
+    _same(res, gen, f"resident (auto) N={N} B={B}")
+    gres, _ = dc.run(3, N, B, T, spikes, w_scale=0.5)
+    _same(gres, gen, f"resident (general) N={N} B={B}")
