@@ -673,7 +673,16 @@ __global__ __launch_bounds__(256) void k_dc2015_xtrace(const DcCtx c) {
     float x = c.xX[1][k];
     c.xtr[k] = x;
     int t = 0;
-    for (; t + 8 <= c.T; t += 8) {            // the spike loads do not depend on x: issue them together
+    // the spike loads do not depend on x: issue them together.  The kernel is a chain of load round trips (392 waves on
+    // 1024 SIMDs: nothing to switch to), so 32 loads per trip instead of 8 cut it from 23 to about a third at T = 250.
+    for (; t + 32 <= c.T; t += 32) {
+        uint8_t s[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
+    }
+    for (; t + 8 <= c.T; t += 8) {
         uint8_t s[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
