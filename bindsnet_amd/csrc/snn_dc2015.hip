@@ -666,32 +666,51 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
 
 
 // X trace after every step: entry 0 = trace at run entry, entry e = trace after step e-1 (nodes.py:96-103).
+// ADD: additive traces (x = x * decay + scale * s) / replacing ones (x = s ? scale : x * decay), branch-free either way.
+template <bool ADD>
+__device__ __forceinline__ float xtrace_next(float x, uint8_t s, float decay, float scale) {
+    const float t = x * decay;
+    if (ADD) return t + scale * (float)s;
+    return s ? scale : t;
+}
+
+template <bool ADD>
+__device__ __forceinline__ void xtrace_body(const DcCtx &c, int n, int k) {
+    float x = c.xX[1][k];
+    c.xtr[k] = x;
+    int t = 0;
+    // The spike loads do not depend on x: 32 are issued together, and the NEXT 32 before the current 32 trace values are
+    // stored, so the loop body is "32 loads, 32 multiplies / selects / stores, one s_waitcnt vmcnt(32)".  (Measured: 20-21 us
+    // at cfg2 with 8 or 32 loads per batch, pipelined or not -- 25 MB written by 392 waves; not on the critical path's
+    // scale: the resident launch behind it takes 1.8 ms.)
+    if (c.T >= 32) {
+        uint8_t s[32], sn[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s[u] = c.in[(size_t)u * n + k];
+        for (; t + 32 <= c.T; t += 32) {
+            const bool more = t + 64 <= c.T;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) sn[u] = c.in[(size_t)(t + 32 + u) * n + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { x = xtrace_next<ADD>(x, s[u], c.x_decay, c.x_scale); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) s[u] = sn[u];
+            }
+        }
+    }
+    for (; t < c.T; ++t) { x = xtrace_next<ADD>(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale); c.xtr[(size_t)(t + 1) * n + k] = x; }
+    // (the caller's trace tensor is NOT touched here: the resident kernel copies entry T into it in its epilogue, once
+    //  the run is known to have succeeded -- a refused or timed-out run must leave every state tensor as it found it)
+}
+
 __global__ __launch_bounds__(256) void k_dc2015_xtrace(const DcCtx c) {
     const int n = c.B * c.Nin;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    float x = c.xX[1][k];
-    c.xtr[k] = x;
-    int t = 0;
-    // the spike loads do not depend on x: issue them together.  The kernel is a chain of load round trips (392 waves on
-    // 1024 SIMDs: nothing to switch to), so 32 loads per trip instead of 8 cut it from 23 to about a third at T = 250.
-    for (; t + 32 <= c.T; t += 32) {
-        uint8_t s[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
-    }
-    for (; t + 8 <= c.T; t += 8) {
-        uint8_t s[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] = c.in[(size_t)(t + u) * n + k];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { x = trace_next(x, s[u], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
-    }
-    for (; t < c.T; ++t) { x = trace_next(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale, c.x_additive); c.xtr[(size_t)(t + 1) * n + k] = x; }
-    // (the caller's trace tensor is NOT touched here: the resident kernel copies entry T into it in its epilogue, once
-    //  the run is known to have succeeded -- a refused or timed-out run must leave every state tensor as it found it)
+    if (c.x_additive) xtrace_body<true>(c, n, k); else xtrace_body<false>(c, n, k);
 }
 
 size_t lds_bytes(int B, int Nin, int N) {
