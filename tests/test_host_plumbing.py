@@ -133,3 +133,38 @@ def test_dataset_wrapper_and_plotting_with_the_torchvision_stand_in():
     plot_voltages(v, plot_type="color")
     import matplotlib.pyplot as plt
     plt.close("all")
+
+
+def test_monitors_record_by_hand_on_the_host():
+    """Monitor.record / NetworkMonitor.record (monitors.py:94-111, 222-262) for code that steps a network by hand: plain
+    tensor bookkeeping, no device involved -- layers' `s` / `v`, a connection's `w`, rolling windows."""
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor, NetworkMonitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    net = Network(dt=1.0)
+    X, Y = Input(n=6, traces=True), LIFNodes(n=4, traces=True)
+    conn = Connection(X, Y, w=torch.arange(24, dtype=torch.float32).view(6, 4) / 100)
+    net.add_layer(X, "X"); net.add_layer(Y, "Y"); net.add_connection(conn, "X", "Y")
+    mw, nm = Monitor(conn, ["w"], time=3), NetworkMonitor(net, time=3)
+    assert sorted(f"{k}:{v}" for k in nm.get() for v in nm.get()[k]) == ["('X', 'Y'):w", "X:s", "Y:s", "Y:v"]
+    assert nm.get()[("X", "Y")]["w"].shape == (3, 6, 4) and float(nm.get()[("X", "Y")]["w"].abs().sum()) == 0.0
+    snaps = []
+    for t in range(5):
+        conn.w.data += 1.0
+        Y.v = torch.full((1, 4), -60.0 - t)
+        snaps.append(conn.w.detach().clone())
+        mw.record(); nm.record()
+    got = mw.get("w")
+    assert got.shape == (3, 6, 4) and all(torch.equal(got[i], snaps[2 + i]) for i in range(3))      # the last `time` steps
+    rec = nm.get()
+    assert rec[("X", "Y")]["w"].shape == (3, 6, 4) and torch.equal(rec[("X", "Y")]["w"][-1], snaps[-1])
+    assert torch.equal(rec["Y"]["v"][:, 0, 0], torch.tensor([-62.0, -63.0, -64.0])) and nm.i == 5
+    nm.reset_state_variables()
+    assert float(nm.get()[("X", "Y")]["w"].abs().sum()) == 0.0 and nm.i == 0
+    grow = NetworkMonitor(net, connections=[("X", "Y")], layers=[], state_vars=["w"])              # no window: grows
+    for t in range(4):
+        grow.record()
+    assert grow.get()[("X", "Y")]["w"].shape == (4, 6, 4)
+    with pytest.raises(NotImplementedError):
+        NetworkMonitor(net, state_vars=["w", "b"])
