@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0):
+def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False):
     from bindsnet_amd import _lib
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
@@ -29,6 +29,11 @@ def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, 
         for l, m in mons.items():
             net.add_monitor(m, l)
         net.train(learning)
+        if additive:                                 # nodes.py:96-103: x = x * decay + trace_scale * s instead of x <- trace_scale on a spike
+            for l in net.layers.values():
+                l.traces_additive = True
+                if l.traces:                         # (the Ai layer of DiehlAndCook2015 records no trace)
+                    l.trace_scale.fill_(0.5)
         net.to(DEV)
         out = []
         for r in range(n_inputs):
@@ -111,3 +116,19 @@ def test_plan_refuses_unsupported_shapes_and_falls_back():
     spikes = [synth.dense_spikes(91, (5, 40, 784), 0.02)] * 2
     out, plan = run(0, 64, 40, 5, spikes)
     assert plan == "generic"
+
+
+@pytest.mark.parametrize("N,B", [(100, 8), (400, 32)])
+def test_additive_traces_every_plan_equals_generic(N, B):
+    """`traces_additive=True` on all three layers (nodes.py:96-103): the input-trace pre-pass, the Ae / Ai trace stages and
+    PostPre of every D&C plan against the generic per-operator plan, bit for bit."""
+    T = 25
+    spikes = [synth.dense_spikes(700 + r, (T, B, 784), 0.03) for r in range(2)]
+    gen, plan_g = run(1, N, B, T, spikes, w_scale=0.5, additive=True)
+    assert plan_g == "generic" and sum(int(r["sE"].sum()) for r in gen) > 0
+    plain, _ = run(1, N, B, T, spikes, w_scale=0.5)
+    assert not np.array_equal(gen[0]["xX"], plain[0]["xX"])               # (the switch does change the traces)
+    for mode, want in ((0, "dc2015-resident"), (3, "dc2015-resident"), (2, "dc2015-fused")):
+        res, plan = run(mode, N, B, T, spikes, w_scale=0.5, additive=True)
+        assert plan.startswith(want)
+        same(res, gen)

@@ -35,7 +35,7 @@ def build(kind, Nin, N, rule, bias):
     return net
 
 
-def run(generic, kind, Nin, N, B, T, rule=True, bias=False, n_inputs=2, dens=0.03, learning=True):
+def run(generic, kind, Nin, N, B, T, rule=True, bias=False, n_inputs=2, dens=0.03, learning=True, additive=False):
     from bindsnet_amd import _lib
     from bindsnet_amd.network.monitors import Monitor
     _lib.lib().snn_set_plan_mode(1 if generic else 0)
@@ -44,6 +44,10 @@ def run(generic, kind, Nin, N, B, T, rule=True, bias=False, n_inputs=2, dens=0.0
         ms, mv = Monitor(net.layers["Y"], ["s"], time=T), Monitor(net.layers["Y"], ["v"], time=T)
         net.add_monitor(ms, "s"); net.add_monitor(mv, "v")
         net.train(learning)
+        if additive:                                 # nodes.py:96-103: additive instead of replacing traces
+            for l in net.layers.values():
+                l.traces_additive = True
+                l.trace_scale.fill_(0.5)
         net.to(DEV)
         out = []
         for r in range(n_inputs):
@@ -233,3 +237,17 @@ def test_mcc_mstdp_matches_reference(name, generic):
             net.reset_state_variables()
     finally:
         _lib.lib().snn_set_plan_mode(0)
+
+
+@pytest.mark.parametrize("kind", ["dense", "mcc"])
+def test_additive_traces_fused_equals_generic(kind):
+    """`traces_additive=True` on both layers: the fused plan's input-trace pre-pass, target trace and PostPre against the
+    generic plan, bit for bit."""
+    f, plan = run(False, kind, 784, 96, 16, 30, additive=True)
+    g, plan_g = run(True, kind, 784, 96, 16, 30, additive=True)
+    assert plan_g == "generic" and plan == "twolayer-fused"
+    p, _ = run(True, kind, 784, 96, 16, 30)
+    assert not np.array_equal(g[0]["xX"], p[0]["xX"]) and g[0]["s"].sum() > 0
+    for a, b in zip(f, g):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=k)
