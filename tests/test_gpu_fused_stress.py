@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False):
+def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False, nu=(1e-4, 1e-2)):
     from bindsnet_amd import _lib
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
     _lib.lib().snn_set_plan_mode(int(mode))          # 0 auto (resident kernel), 1 generic, 2 one launch per timestep
     try:
         torch.manual_seed(0)
-        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape)
+        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape, nu=nu)
         W0 = synth.uniform_f32(3, (Nin, N), 0.0, w_scale)
         net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(W0, 1.0)))
         mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
@@ -130,5 +130,19 @@ def test_additive_traces_every_plan_equals_generic(N, B):
     assert not np.array_equal(gen[0]["xX"], plain[0]["xX"])               # (the switch does change the traces)
     for mode, want in ((0, "dc2015-resident"), (3, "dc2015-resident"), (2, "dc2015-fused")):
         res, plan = run(mode, N, B, T, spikes, w_scale=0.5, additive=True)
+        assert plan.startswith(want)
+        same(res, gen)
+
+
+@pytest.mark.parametrize("nu", [(0.0, 1e-2), (1e-3, 0.0)])
+def test_one_sided_learning_rates(nu):
+    """PostPre with only the post-synaptic (nu[0] = 0) or only the pre-synaptic term (MCC_learning.py:255, :279): the
+    row-per-thread and per-(row, column) forms of the resident plans skip the other term entirely."""
+    N, B, T = 100, 16, 25
+    spikes = [synth.dense_spikes(720 + r, (T, B, 784), 0.03) for r in range(2)]
+    gen, plan_g = run(1, N, B, T, spikes, w_scale=0.5, nu=nu)
+    assert plan_g == "generic" and sum(int(r["sE"].sum()) for r in gen) > 0
+    for mode, want in ((0, "dc2015-resident"), (3, "dc2015-resident"), (2, "dc2015-fused")):
+        res, plan = run(mode, N, B, T, spikes, w_scale=0.5, nu=nu)
         assert plan.startswith(want)
         same(res, gen)
