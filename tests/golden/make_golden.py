@@ -218,10 +218,11 @@ def gen_rng():
 
 
 # ----------------------------------------------------------------------------- full runs
-def dc_case(name, N, B, T, runs, full_w, inh=120.0, max_rate=0.0625):
+def dc_case(name, N, B, T, runs, full_w, inh=120.0, max_rate=0.0625, dt=1.0):
+    """T TIMESTEPS of length dt per run (network.py:376: timesteps = int(time / dt))."""
     Nin = 784
     torch.manual_seed(0)
-    net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05,
+    net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=dt, norm=78.4, theta_plus=0.05,
                            inpt_shape=(1, 28, 28))
     feat = net.connections[("X", "Ae")].pipeline[0]
     W0 = synth.weights_q12(10, Nin, N)
@@ -244,7 +245,7 @@ def dc_case(name, N, B, T, runs, full_w, inh=120.0, max_rate=0.0625):
         spikes = synth.spike_train(20 + r, T, B, Nin, max_rate=max_rate)
         torch.manual_seed(2 + r)
         counter["n"] = 0
-        net.run({"X": T_(spikes).view(T, B, 1, 28, 28)}, time=T)
+        net.run({"X": T_(spikes).view(T, B, 1, 28, 28)}, time=T * dt)
         out[f"r{r}_sE"] = np.packbits(mons["Ae"].get("s").numpy().astype(np.uint8))
         out[f"r{r}_sI"] = np.packbits(mons["Ai"].get("s").numpy().astype(np.uint8))
         out[f"r{r}_consumed"] = np.int64(counter["n"])
@@ -265,7 +266,8 @@ def dc_case(name, N, B, T, runs, full_w, inh=120.0, max_rate=0.0625):
     consts = dict(
         x_trace_decay=X.trace_decay.numpy(), e_decay=Ae.decay.numpy(), e_theta_decay=Ae.theta_decay.numpy(),
         e_trace_decay=Ae.trace_decay.numpy(), i_decay=Ai.decay.numpy())
-    save(name, N=N, B=B, T=T, runs=runs, inh=np.float32(inh), max_rate=np.float64(max_rate), **consts, **out)
+    extra = {} if dt == 1.0 else {"dt": np.float32(dt)}      # (the dt = 1 fixtures keep their original key set)
+    save(name, N=N, B=B, T=T, runs=runs, inh=np.float32(inh), max_rate=np.float64(max_rate), **extra, **consts, **out)
 
 
 def two_layer_case(name, rule, Nin, N, B, T):

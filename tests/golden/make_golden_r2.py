@@ -8,6 +8,7 @@
                        weights and the rule's state are compared bit for bit.
   run_two_mcc_mstdpet_b1  the same graph with MCC_learning.MSTDPET (:554-733; batch 1 like the dense rule), two runs with
                        different rewards; the rule's dense eligibility trace is part of the fixture.
+  run_dc_n100_b3_dt05  DiehlAndCook2015 at dt = 0.5 (the generator of make_golden.py with another timestep).
   op_conv_mstdp        MSTDP on a Conv2dConnection (learning.py:1942-2015; batch 1): update sequences + a run.
   conn_monitor         Monitor / NetworkMonitor on a Connection's `w` (one snapshot per timestep).
   net_monitor          NetworkMonitor / sparse Monitor recordings of a DiehlAndCook2015 run (monitors.py:30-329).
@@ -371,7 +372,9 @@ def one_step_case():
 
 
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "dc_dt", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    if "dc_dt" in jobs:      # a D&C run at dt = 0.5 ms: decays, refractory counters and MCC PostPre's `* dt` all depend on it
+        mg.dc_case("run_dc_n100_b3_dt05", 100, 3, 80, 2, False, max_rate=0.125, dt=0.5)
     if "conv_mstdp" in jobs:
         conv_mstdp_case()
     if "conn_monitor" in jobs:

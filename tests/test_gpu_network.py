@@ -24,11 +24,11 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def build_dc(N, B, inh):
+def build_dc(N, B, inh, dt=1.0):
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
     torch.manual_seed(0)
-    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05,
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=inh, dt=dt, norm=78.4, theta_plus=0.05,
                            inpt_shape=(1, 28, 28))
     net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(synth.weights_q12(10, 784, N)))
     return net
@@ -45,7 +45,8 @@ def test_dc2015_network_run_matches_reference(name, plan):
     from bindsnet_amd.network.monitors import Monitor
     g = gold(name)
     N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
-    net = build_dc(N, B, float(g["inh"]))
+    dt = float(g["dt"]) if "dt" in g.files else 1.0      # (run_dc_n100_b3_dt05: T timesteps of half a millisecond)
+    net = build_dc(N, B, float(g["inh"]), dt)
     mons = {}
     for l in ("X", "Ae", "Ai"):
         mons[l] = Monitor(net.layers[l], ["s"], time=T)
@@ -58,7 +59,7 @@ def test_dc2015_network_run_matches_reference(name, plan):
         for r in range(runs):
             spikes = synth.spike_train(20 + r, T, B, 784, max_rate=float(g["max_rate"]))
             torch.manual_seed(2 + r)
-            net.run({"X": torch.from_numpy(spikes).view(T, B, 1, 28, 28).to(DEV)}, time=T)
+            net.run({"X": torch.from_numpy(spikes).view(T, B, 1, 28, 28).to(DEV)}, time=T * dt)
             # host generator left exactly where the reference leaves it
             probe = torch.rand(4)
             torch.manual_seed(2 + r)

@@ -139,7 +139,7 @@ def test_mt19937_exponential_stream_matches_torch():
 def dc_params(g, learning=True):
     P = oracle.DcParams()
     P.B, P.Nin, P.N, P.T = int(g["B"]), 784, int(g["N"]), int(g["T"])
-    P.dt = 1.0
+    P.dt = float(g["dt"]) if "dt" in g.files else 1.0
     P.x_trace_decay = float(g["x_trace_decay"]); P.x_trace_scale = 1.0
     P.e_decay = float(g["e_decay"]); P.e_theta_decay = float(g["e_theta_decay"])
     P.e_trace_decay = float(g["e_trace_decay"]); P.e_trace_scale = 1.0; P.e_one_spike = 1
@@ -153,7 +153,7 @@ def dc_params(g, learning=True):
     return P
 
 
-DC_RUNS = ["run_dc_n100_b1", "run_dc_n100_b3", "run_dc_n100_b3_busy", "run_dc_n400_b4", "run_dc_n400_b32"]
+DC_RUNS = ["run_dc_n100_b1", "run_dc_n100_b3", "run_dc_n100_b3_busy", "run_dc_n400_b4", "run_dc_n400_b32", "run_dc_n100_b3_dt05"]
 
 
 @pytest.mark.parametrize("name", DC_RUNS)
