@@ -1,6 +1,6 @@
 """Live matplotlib views used by the examples: API mirror of bindsnet/analysis/plotting.py for the functions
 examples/mnist/eth_mnist.py calls (`plot_input`, `plot_spikes`, `plot_weights`, `plot_assignments`,
-`plot_performance`, `plot_voltages`) plus `plot_conv2d_weights`.  Same signatures and return values (the handles are
+`plot_performance`, `plot_voltages`) plus `plot_conv2d_weights` and `plot_locally_connected_weights`.  Same signatures and return values (the handles are
 passed back in to redraw instead of recreating figures).  Host-side only: tensors are copied to the CPU for drawing."""
 from typing import Dict, List, Optional, Sized, Tuple, Union
 
@@ -9,7 +9,7 @@ import numpy as np
 import torch
 from mpl_toolkits.axes_grid1 import make_axes_locatable
 
-from ..utils import reshape_conv2d_weights
+from ..utils import reshape_conv2d_weights, reshape_locally_connected_weights
 
 plt.ion()
 
@@ -109,6 +109,26 @@ def plot_conv2d_weights(weights: torch.Tensor, wmin: float = 0.0, wmax: float = 
                         figsize: Tuple[int, int] = (5, 5), cmap: str = "hot_r"):
     """Conv2dConnection kernels tiled into one image (plotting.py:264-319)."""
     return plot_weights(reshape_conv2d_weights(weights), wmin, wmax, im, figsize, cmap)
+
+
+def plot_locally_connected_weights(weights: torch.Tensor, n_filters: int, kernel_size, conv_size, locations: torch.Tensor, input_sqrt,
+                                   wmin: float = 0.0, wmax: float = 1.0, im=None, lines: bool = True,
+                                   figsize: Tuple[int, int] = (5, 5), cmap: str = "hot_r", title: Optional[str] = None):
+    """Receptive fields of a LocalConnection as one image, the blocks of neighbouring input regions separated by dashed
+    lines (plotting.py:322-401).  Returns the AxesImage."""
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    kernel_size, conv_size, input_sqrt = pair(kernel_size), pair(conv_size), pair(input_sqrt)
+    image = _np(reshape_locally_connected_weights(weights, n_filters, kernel_size, conv_size, locations, input_sqrt))
+    if im is not None:
+        im.set_data(image)
+        return im
+    im = _image_with_colorbar(image, figsize, cmap, wmin, wmax, None if title is None else title + " Weights")
+    if lines:
+        fs = int(np.ceil(np.sqrt(n_filters)))
+        for axis_line, k, c in ((im.axes.axhline, kernel_size[0], conv_size[0]), (im.axes.axvline, kernel_size[1], conv_size[1])):
+            for edge in range(fs * k, fs * c * k, fs * k):
+                axis_line(edge - 0.5, color="g", linestyle="--")
+    return im
 
 
 def plot_assignments(assignments: torch.Tensor, im=None, figsize: Tuple[int, int] = (5, 5),

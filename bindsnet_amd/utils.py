@@ -51,3 +51,24 @@ def reshape_conv2d_weights(weights: torch.Tensor) -> torch.Tensor:
             r0, c0 = (i + k * s1) * kh, (j + l * s1) * kw
             img[r0:r0 + kh, c0:c0 + kw] = weights[f, ci]
     return img
+
+
+def reshape_locally_connected_weights(w: Tensor, n_filters: int, kernel_size: Union[int, Tuple[int, int]],
+                                      conv_size: Union[int, Tuple[int, int]], locations: Tensor,
+                                      input_sqrt: Union[int, Tuple[int, int]]) -> Tensor:
+    """Weights [n_input, n_filters * c1 * c2] of a LocalConnection -> one image (utils.py:112-180): the k1 x k2 receptive
+    field of filter f at convolution position (n1, n2) -- rows `locations[:, n]`, column f * c1 * c2 + n of `w` -- lands in
+    block (n1 * fs + f // fs, n2 * fs + f % fs) of a grid with fs = ceil(sqrt(n_filters)).  With a single position
+    (c1 = c2 = 1, the kernel covers the whole input) the filters simply tile an fs x fs grid of input-sized images."""
+    (k1, k2), (c1, c2), (i1, i2) = _pair(kernel_size), _pair(conv_size), _pair(input_sqrt)
+    fs, C = int(math.ceil(math.sqrt(n_filters))), c1 * c2
+    cols = torch.arange(n_filters).view(-1, 1, 1) * C + torch.arange(C).view(1, -1, 1)          # [F, C, 1]
+    rows = locations.t().unsqueeze(0)                                                           # [1, C, k1*k2]
+    fields = w.detach().cpu()[rows, cols].view(n_filters, c1, c2, k1, k2).float()               # [F, n1, n2, k1, k2]
+    if c1 == 1 and c2 == 1:
+        grid = torch.zeros(fs * fs, i1, i2)
+        grid[:n_filters] = fields.view(n_filters, k1, k2)[:, :i1, :i2]
+        return grid.view(fs, fs, i1, i2).permute(0, 2, 1, 3).reshape(fs * i1, fs * i2)
+    grid = torch.zeros(c1, fs * fs, k1, c2, k2)
+    grid[:, :n_filters] = fields.permute(1, 0, 3, 2, 4)
+    return grid.view(c1, fs, fs, k1, c2, k2).permute(0, 1, 3, 4, 2, 5).reshape(c1 * fs * k1, c2 * fs * k2)

@@ -3,7 +3,7 @@
 the reference's encoders (spike trains AND the state they leave the global CPU generator in), its evaluation read-outs
 and its weight / assignment reshaping helpers, all on tests/synth.py inputs.
 
-    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz
+    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz
 """
 import os
 import sys
@@ -66,7 +66,35 @@ def gen_evaluation():
     save("op_evaluation", **out)
 
 
+def gen_reshape_local():
+    """bindsnet.utils.reshape_locally_connected_weights (utils.py:112-180) on the receptive fields of real LocalConnections:
+    3 x 3 positions of a 4 x 4 kernel with 5 filters, a non-square case, and the single-position case (kernel = input)."""
+    from bindsnet.network.nodes import Input, LIFNodes
+    from bindsnet.network.topology import LocalConnection
+    from bindsnet.utils import reshape_locally_connected_weights
+    out = {}
+    for k, (shape, ks, st, nf) in enumerate((((12, 12), 4, 4, 5), ((10, 10), (4, 2), (3, 2), 3), ((6, 6), 6, 1, 7))):
+        n_in = shape[0] * shape[1]
+        src = Input(n=n_in, shape=(1, *shape))
+        kp = (ks, ks) if np.isscalar(ks) else ks
+        sp = (st, st) if np.isscalar(st) else st
+        cs = (1, 1) if kp == shape else ((shape[0] - kp[0]) // sp[0] + 1, (shape[1] - kp[1]) // sp[1] + 1)
+        tgt = LIFNodes(n=nf * cs[0] * cs[1])
+        lc = LocalConnection(src, tgt, kernel_size=ks, stride=st, n_filters=nf, input_shape=shape)
+        w = synth.uniform_f32(880 + k, tuple(lc.w.shape), 0.0, 1.0)
+        out[f"loc{k}"] = lc.locations.numpy().copy()
+        out[f"img{k}"] = reshape_locally_connected_weights(T_(w), nf, lc.kernel_size, lc.conv_size, lc.locations, shape).numpy()
+        out[f"meta{k}"] = np.array([*shape, *lc.kernel_size, *lc.conv_size, nf, *w.shape])
+        print(f"  reshape_locally_connected_weights case {k}: w {w.shape} conv {tuple(lc.conv_size)} -> image {out[f'img{k}'].shape}")
+    save("op_reshape_local", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    gen_encoding()
-    gen_evaluation()
+    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local"]
+    if "encoding" in jobs:
+        gen_encoding()
+    if "evaluation" in jobs:
+        gen_evaluation()
+    if "reshape_local" in jobs:
+        gen_reshape_local()

@@ -131,6 +131,13 @@ def test_dataset_wrapper_and_plotting_with_the_torchvision_stand_in():
     ims, axes = plot_voltages(v, plot_type="line")
     plot_voltages(v, ims=ims, axes=axes, plot_type="line")
     plot_voltages(v, plot_type="color")
+    from bindsnet.analysis.plotting import plot_locally_connected_weights
+    from bindsnet.network.nodes import Input, LIFNodes
+    from bindsnet.network.topology import LocalConnection
+    lc = LocalConnection(Input(n=144, shape=(1, 12, 12)), LIFNodes(n=45), kernel_size=4, stride=4, n_filters=5, input_shape=(12, 12))
+    im = plot_locally_connected_weights(lc.w, 5, lc.kernel_size, lc.conv_size, lc.locations, 12, wmax=float(lc.wmax), title="X -> Y")
+    assert im.get_array().shape == (36, 36) and len(im.axes.lines) == 4        # 3 x 3 regions: two separators each way
+    plot_locally_connected_weights(lc.w * 0.5, 5, lc.kernel_size, lc.conv_size, lc.locations, 12, im=im)
     import matplotlib.pyplot as plt
     plt.close("all")
 
@@ -168,3 +175,22 @@ def test_monitors_record_by_hand_on_the_host():
     assert grow.get()[("X", "Y")]["w"].shape == (4, 6, 4)
     with pytest.raises(NotImplementedError):
         NetworkMonitor(net, state_vars=["w", "b"])
+
+
+def test_reshape_locally_connected_weights_matches_reference():
+    """utils.py:112-180 on the receptive fields of LocalConnections (3 x 3 positions, a non-square case, the
+    single-position case); the `locations` table of the mirror's LocalConnection equals the reference's."""
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import LocalConnection
+    from bindsnet_amd.utils import reshape_locally_connected_weights
+    g = gold("op_reshape_local")
+    for k, (shape, ks, st) in enumerate((((12, 12), 4, 4), ((10, 10), (4, 2), (3, 2)), ((6, 6), 6, 1))):
+        m = [int(v) for v in g[f"meta{k}"]]
+        kernel, conv, nf, wshape = tuple(m[2:4]), tuple(m[4:6]), m[6], tuple(m[7:9])
+        lc = LocalConnection(Input(n=shape[0] * shape[1], shape=(1, *shape)), LIFNodes(n=nf * conv[0] * conv[1]), kernel_size=ks,
+                             stride=st, n_filters=nf, input_shape=shape)
+        assert tuple(lc.kernel_size) == kernel and tuple(lc.conv_size) == conv and tuple(lc.w.shape) == wshape
+        np.testing.assert_array_equal(lc.locations.numpy(), g[f"loc{k}"])
+        w = T_(synth.uniform_f32(880 + k, wshape, 0.0, 1.0))
+        img = reshape_locally_connected_weights(w, nf, lc.kernel_size, lc.conv_size, lc.locations, shape)
+        np.testing.assert_array_equal(img.numpy(), g[f"img{k}"], err_msg=f"case {k}")
