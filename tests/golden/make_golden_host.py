@@ -3,7 +3,7 @@
 the reference's encoders (spike trains AND the state they leave the global CPU generator in), its evaluation read-outs
 and its weight / assignment reshaping helpers, all on tests/synth.py inputs.
 
-    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz
+    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz, op_reward.npz
 """
 import os
 import sys
@@ -89,9 +89,30 @@ def gen_reshape_local():
     save("op_reshape_local", **out)
 
 
+def reward_episodes():
+    rs = np.random.RandomState(3)
+    return [(float(rs.uniform(-3, 5)), int(rs.randint(5, 40)), [10.0, 4.0, 25.0][ep % 3]) for ep in range(12)]
+
+
+def gen_reward():
+    """bindsnet.learning.reward.MovingAvgRPE (reward.py:29-87) over 12 episodes: the prediction error handed to the rules
+    before every episode and both moving averages after it."""
+    from bindsnet.learning.reward import MovingAvgRPE
+    r = MovingAvgRPE()
+    rpe, per_step, per_episode = [], [], []
+    for acc, steps, win in reward_episodes():
+        rpe.append(r.compute(reward=torch.tensor(acc / steps)).numpy())
+        r.update(accumulated_reward=acc, steps=steps, ema_window=win)
+        per_step.append(r.reward_predict.numpy()); per_episode.append(r.reward_predict_episode.numpy())
+    save("op_reward", rpe=np.array(rpe), per_step=np.array(per_step), per_episode=np.array(per_episode),
+         history=np.array(r.rewards_predict_episode))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local"]
+    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local", "reward"]
+    if "reward" in jobs:
+        gen_reward()
     if "encoding" in jobs:
         gen_encoding()
     if "evaluation" in jobs:

@@ -194,3 +194,25 @@ def test_reshape_locally_connected_weights_matches_reference():
         w = T_(synth.uniform_f32(880 + k, wshape, 0.0, 1.0))
         img = reshape_locally_connected_weights(w, nf, lc.kernel_size, lc.conv_size, lc.locations, shape)
         np.testing.assert_array_equal(img.numpy(), g[f"img{k}"], err_msg=f"case {k}")
+
+
+def test_moving_average_reward_matches_reference():
+    """bindsnet.learning.reward.MovingAvgRPE (reward.py:29-87), reachable under both package names; as `reward_fn` of a
+    Network its compute() feeds the rules' `reward` keyword (network.py:318-320)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from bindsnet.learning.reward import AbstractReward, MovingAvgRPE
+    from bindsnet_amd.learning import reward as native
+    assert MovingAvgRPE is native.MovingAvgRPE and issubclass(MovingAvgRPE, AbstractReward)
+    g = gold("op_reward")
+    rs = np.random.RandomState(3)
+    episodes = [(float(rs.uniform(-3, 5)), int(rs.randint(5, 40)), [10.0, 4.0, 25.0][ep % 3]) for ep in range(12)]
+    r = MovingAvgRPE()
+    for k, (acc, steps, win) in enumerate(episodes):
+        np.testing.assert_array_equal(r.compute(reward=torch.tensor(acc / steps)).numpy(), g["rpe"][k])
+        r.update(accumulated_reward=acc, steps=steps, ema_window=win)
+        np.testing.assert_array_equal(r.reward_predict.numpy(), g["per_step"][k])
+        np.testing.assert_array_equal(r.reward_predict_episode.numpy(), g["per_episode"][k])
+    np.testing.assert_array_equal(np.array(r.rewards_predict_episode), g["history"])
+    from bindsnet_amd.network import Network
+    net = Network(dt=1.0, reward_fn=MovingAvgRPE)
+    assert isinstance(net.reward_fn, MovingAvgRPE)
