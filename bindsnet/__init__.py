@@ -15,6 +15,7 @@ import sys
 import bindsnet_amd as _impl
 
 __version__ = _impl.__version__
+ROOT_DIR = _impl.ROOT_DIR
 _PREFIX, _REAL = "bindsnet.", "bindsnet_amd."
 
 

@@ -3,7 +3,7 @@
 the reference's encoders (spike trains AND the state they leave the global CPU generator in), its evaluation read-outs
 and its weight / assignment reshaping helpers, all on tests/synth.py inputs.
 
-    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz, op_reward.npz
+    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz, op_reward.npz, op_collate.npz
 """
 import os
 import sys
@@ -22,7 +22,7 @@ from bindsnet.encoding import BernoulliEncoder, PoissonEncoder  # noqa: E402
 from bindsnet.evaluation import all_activity, assign_labels, ngram, proportion_weighting, update_ngram_scores  # noqa: E402
 from bindsnet.utils import get_square_assignments, get_square_weights, reshape_conv2d_weights  # noqa: E402
 
-from make_golden_host_cases import ENC_CASES, datum_for  # noqa: E402
+from make_golden_host_cases import ENC_CASES, collate_batch, datum_for, flatten_collated  # noqa: E402
 
 
 def gen_encoding():
@@ -89,6 +89,19 @@ def gen_reshape_local():
     save("op_reshape_local", **out)
 
 
+def gen_collate():
+    """bindsnet.datasets.collate.time_aware_collate (loaded from its file: importing bindsnet.datasets needs cv2)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_collate", "/root/reference/bindsnet/datasets/collate.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    flat = flatten_collated(ref.time_aware_collate(collate_batch()))
+    out = {"paths": np.array(sorted(flat))}
+    for i, k in enumerate(sorted(flat)):
+        out[f"t{i}"] = flat[k].numpy()
+    save("op_collate", **out)
+
+
 def reward_episodes():
     rs = np.random.RandomState(3)
     return [(float(rs.uniform(-3, 5)), int(rs.randint(5, 40)), [10.0, 4.0, 25.0][ep % 3]) for ep in range(12)]
@@ -110,7 +123,9 @@ def gen_reward():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local", "reward"]
+    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local", "reward", "collate"]
+    if "collate" in jobs:
+        gen_collate()
     if "reward" in jobs:
         gen_reward()
     if "encoding" in jobs:

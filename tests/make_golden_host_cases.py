@@ -1,5 +1,6 @@
 """Case table shared by tests/golden/make_golden_host.py (which needs the reference) and tests/test_host_plumbing.py."""
 import numpy as np
+import torch
 
 import synth
 
@@ -19,3 +20,30 @@ ENC_CASES = [  # (name, shape, scale, time, dt, kwargs)
 def datum_for(k, shape, scale):
     x = synth.uniform_f32(4000 + k, shape, 0.0, scale) * (synth.uniform_f32(4100 + k, shape, 0.0, 1.0) < 0.6)
     return x.astype(np.float32)
+
+
+def collate_batch():
+    """Four samples with every kind of field time_aware_collate distinguishes (collate.py:27-85)."""
+    import collections
+    P = collections.namedtuple("P", "a b")
+    rs = np.random.RandomState(1)
+
+    def sample(k):
+        return {"encoded_image": torch.from_numpy((rs.rand(20, 1, 6, 6) < 0.1).astype(np.uint8)), "image": torch.from_numpy(rs.rand(1, 6, 6).astype(np.float32)),
+                "label": torch.tensor(k), "encoded_label": k, "vec": torch.arange(5.0) + k, "np": rs.rand(3, 2).astype(np.float32),
+                "f": 0.5 * k, "npi": np.int64(k), "tup": P(torch.ones(2) * k, k), "lst": [k, torch.zeros(3)]}
+    return [sample(k) for k in range(4)]
+
+
+def flatten_collated(x, path="", out=None):
+    """{path: tensor} of a collated structure, the container types recorded in the path."""
+    out = {} if out is None else out
+    if isinstance(x, torch.Tensor):
+        out[path] = x
+    elif isinstance(x, dict):
+        for k in x:
+            flatten_collated(x[k], f"{path}/{k}", out)
+    else:
+        for i, v in enumerate(x):
+            flatten_collated(v, f"{path}<{type(x).__name__}>[{i}]", out)
+    return out

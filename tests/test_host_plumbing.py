@@ -216,3 +216,31 @@ def test_moving_average_reward_matches_reference():
     from bindsnet_amd.network import Network
     net = Network(dt=1.0, reward_fn=MovingAvgRPE)
     assert isinstance(net.reward_fn, MovingAvgRPE)
+
+
+def test_time_major_dataloader_matches_reference():
+    """bindsnet.datasets.DataLoader / time_aware_collate (datasets/dataloader.py, collate.py:27-85): every field kind
+    against the reference's collate, and a loader over the MNIST wrapper yielding [time, batch, 1, 28, 28] spike trains --
+    the layout examples/mnist/batch_eth_mnist.py hands to Network.run()."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import tv_shim
+    tv_shim.install()
+    from torchvision import transforms
+    import bindsnet
+    from bindsnet.datasets import MNIST, DataLoader, time_aware_collate
+    from bindsnet.encoding import PoissonEncoder
+    from make_golden_host_cases import collate_batch, flatten_collated
+    g = gold("op_collate")
+    flat = flatten_collated(time_aware_collate(collate_batch()))
+    assert sorted(flat) == [str(p) for p in g["paths"]]
+    for i, k in enumerate(sorted(flat)):
+        want = g[f"t{i}"]
+        assert flat[k].numpy().dtype == want.dtype and tuple(flat[k].shape) == want.shape, k
+        np.testing.assert_array_equal(flat[k].numpy(), want, err_msg=k)
+    ds = MNIST(PoissonEncoder(time=25, dt=1.0), None, root=os.path.join(bindsnet.ROOT_DIR, "data", "MNIST"), download=True, train=True,
+               transform=transforms.Compose([transforms.ToTensor(), transforms.Lambda(lambda x: x * 128)]))
+    torch.manual_seed(0)
+    batch = next(iter(DataLoader(ds, batch_size=4, shuffle=True)))
+    assert tuple(batch["encoded_image"].shape) == (25, 4, 1, 28, 28) and batch["encoded_image"].dtype == torch.uint8
+    assert tuple(batch["image"].shape) == (1, 4, 28, 28) and batch["label"].numel() == 4
+    assert os.path.isdir(os.path.join(bindsnet.ROOT_DIR, "bindsnet_amd"))
