@@ -1,3 +1,3 @@
-from .models import DiehlAndCook2015, TwoLayerNetwork
+from .models import DiehlAndCook2015, IncreasingInhibitionNetwork, TwoLayerNetwork
 
-__all__ = ["TwoLayerNetwork", "DiehlAndCook2015"]
+__all__ = ["TwoLayerNetwork", "DiehlAndCook2015", "IncreasingInhibitionNetwork"]

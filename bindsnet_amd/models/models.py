@@ -1,5 +1,5 @@
-"""Model constructors: API mirror of bindsnet/models/models.py for `TwoLayerNetwork` and
-`DiehlAndCook2015` (graph wiring only -- same layers, names, constants and the same draws from
+"""Model constructors: API mirror of bindsnet/models/models.py for `TwoLayerNetwork`, `DiehlAndCook2015` and
+`IncreasingInhibitionNetwork` (graph wiring only -- same layers, names, constants and the same draws from
 the global generator for the initial weights, so seed-for-seed construction matches)."""
 from typing import Iterable, Optional, Sequence, Union
 
@@ -67,3 +67,32 @@ class DiehlAndCook2015(Network):
         self.add_connection(x_e, source="X", target="Ae")
         self.add_connection(e_i, source="Ae", target="Ai")
         self.add_connection(i_e, source="Ai", target="Ae")
+
+
+class IncreasingInhibitionNetwork(Network):
+    """Hazan et al. (2018): Input -> dense Connection (PostPre) -> D&C nodes on a sqrt(n) x sqrt(n) grid with a recurrent
+    connection whose weights grow with the grid distance between two neurons.  Reference: models.py:349-454 (same
+    layers, names and constants, the same draw for the input weights; the recurrent weights are
+    start_inhib + max_inhib * sqrt(d_ij) / max sqrt(d), with start_inhib on the diagonal).  Runs on the generic plan."""
+
+    def __init__(self, n_input: int, n_neurons: int = 100, start_inhib: float = 1.0, max_inhib: float = 100.0, dt: float = 1.0,
+                 nu: Optional[Union[float, Sequence[float]]] = (1e-4, 1e-2), reduction: Optional[callable] = None,
+                 wmin: float = 0.0, wmax: float = 1.0, norm: float = 78.4, theta_plus: float = 0.05,
+                 tc_theta_decay: float = 1e7, inpt_shape: Optional[Iterable[int]] = None, exc_thresh: float = -52.0) -> None:
+        super().__init__(dt=dt)
+        self.n_input, self.n_neurons, self.n_sqrt = n_input, n_neurons, int(n_neurons ** 0.5)
+        self.start_inhib, self.max_inhib, self.dt, self.inpt_shape = start_inhib, max_inhib, dt, inpt_shape
+        self.add_layer(Input(n=n_input, shape=inpt_shape, traces=True, tc_trace=20.0), name="X")
+        self.add_layer(DiehlAndCookNodes(n=n_neurons, traces=True, rest=-65.0, reset=-60.0, thresh=exc_thresh, refrac=5,
+                                         tc_decay=100.0, tc_trace=20.0, theta_plus=theta_plus, tc_theta_decay=tc_theta_decay),
+                       name="Y")
+        w = 0.3 * torch.rand(n_input, n_neurons)                   # same generator draw as models.py:424
+        self.add_connection(Connection(source=self.layers["X"], target=self.layers["Y"], w=w, update_rule=PostPre, nu=nu,
+                                       reduction=reduction, wmin=wmin, wmax=wmax, norm=norm), source="X", target="Y")
+        # models.py:439-450: sqrt of the Euclidean distance between the grid positions (f64), stored as f32, scaled
+        idx = torch.arange(n_neurons)
+        gx, gy = (idx // self.n_sqrt).double(), (idx % self.n_sqrt).double()
+        dist = torch.sqrt((gx[:, None] - gx[None, :]) ** 2 + (gy[:, None] - gy[None, :]) ** 2)
+        w = torch.sqrt(dist).float()
+        w = (w / w.max()) * max_inhib + start_inhib
+        self.add_connection(Connection(source=self.layers["Y"], target=self.layers["Y"], w=w), source="Y", target="Y")

@@ -3,7 +3,7 @@
 the reference's encoders (spike trains AND the state they leave the global CPU generator in), its evaluation read-outs
 and its weight / assignment reshaping helpers, all on tests/synth.py inputs.
 
-    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz, op_reward.npz, op_collate.npz
+    python tests/golden/make_golden_host.py      -> tests/golden/op_encoding.npz, op_evaluation.npz, op_reshape_local.npz, op_reward.npz, op_collate.npz, op_models.npz
 """
 import os
 import sys
@@ -102,6 +102,27 @@ def gen_collate():
     save("op_collate", **out)
 
 
+IIN_CASES = [dict(n_input=64, n_neurons=25, inpt_shape=(1, 8, 8)),
+             dict(n_input=30, n_neurons=40, start_inhib=2.5, max_inhib=33.0, theta_plus=0.1, exc_thresh=-50.0)]
+
+
+def gen_models():
+    """bindsnet.models.IncreasingInhibitionNetwork (models.py:349-454): construction only -- the input weights' draw, the
+    distance-graded recurrent weights, and where the constructor leaves the global generator."""
+    from bindsnet.models import IncreasingInhibitionNetwork
+    out = {}
+    for k, kw in enumerate(IIN_CASES):
+        torch.manual_seed(4)
+        net = IncreasingInhibitionNetwork(**kw)
+        out[f"probe{k}"] = torch.rand(3).numpy()
+        out[f"w_xy{k}"] = net.connections[("X", "Y")].w.detach().numpy().copy()
+        out[f"w_yy{k}"] = net.connections[("Y", "Y")].w.detach().numpy().copy()
+        Y = net.layers["Y"]
+        out[f"consts{k}"] = np.array([float(Y.thresh), float(Y.rest), float(Y.reset), float(Y.refrac), float(Y.theta_plus),
+                                      float(net.connections[("X", "Y")].norm), net.n_sqrt], np.float64)
+    save("op_models", **out)
+
+
 def reward_episodes():
     rs = np.random.RandomState(3)
     return [(float(rs.uniform(-3, 5)), int(rs.randint(5, 40)), [10.0, 4.0, 25.0][ep % 3]) for ep in range(12)]
@@ -123,9 +144,11 @@ def gen_reward():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)
-    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local", "reward", "collate"]
+    jobs = sys.argv[1:] or ["encoding", "evaluation", "reshape_local", "reward", "collate", "models"]
     if "collate" in jobs:
         gen_collate()
+    if "models" in jobs:
+        gen_models()
     if "reward" in jobs:
         gen_reward()
     if "encoding" in jobs:

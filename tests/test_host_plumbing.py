@@ -244,3 +244,25 @@ def test_time_major_dataloader_matches_reference():
     assert tuple(batch["encoded_image"].shape) == (25, 4, 1, 28, 28) and batch["encoded_image"].dtype == torch.uint8
     assert tuple(batch["image"].shape) == (1, 4, 28, 28) and batch["label"].numel() == 4
     assert os.path.isdir(os.path.join(bindsnet.ROOT_DIR, "bindsnet_amd"))
+
+
+def test_increasing_inhibition_network_construction_matches_reference():
+    """bindsnet.models.IncreasingInhibitionNetwork (models.py:349-454): seed for seed the same input weights, the same
+    distance-graded recurrent weights (bit for bit) and the same generator position after construction."""
+    from bindsnet.models import IncreasingInhibitionNetwork
+    from bindsnet_amd.learning import PostPre
+    g = gold("op_models")
+    cases_ = [dict(n_input=64, n_neurons=25, inpt_shape=(1, 8, 8)),
+              dict(n_input=30, n_neurons=40, start_inhib=2.5, max_inhib=33.0, theta_plus=0.1, exc_thresh=-50.0)]
+    for k, kw in enumerate(cases_):
+        torch.manual_seed(4)
+        net = IncreasingInhibitionNetwork(**kw)
+        np.testing.assert_array_equal(torch.rand(3).numpy(), g[f"probe{k}"])
+        assert list(net.layers) == ["X", "Y"] and list(net.connections) == [("X", "Y"), ("Y", "Y")]
+        for key, conn in (("w_xy", ("X", "Y")), ("w_yy", ("Y", "Y"))):
+            np.testing.assert_array_equal(net.connections[conn].w.detach().numpy().view(np.uint32), g[f"{key}{k}"].view(np.uint32))
+        Y = net.layers["Y"]
+        got = [float(Y.thresh), float(Y.rest), float(Y.reset), float(Y.refrac), float(Y.theta_plus),
+               float(net.connections[("X", "Y")].norm), net.n_sqrt]
+        np.testing.assert_array_equal(np.array(got, np.float64), g[f"consts{k}"])
+        assert isinstance(net.connections[("X", "Y")].update_rule, PostPre) and Y.one_spike and Y.traces
