@@ -1,3 +1,4 @@
-from .models import DiehlAndCook2015, IncreasingInhibitionNetwork, TwoLayerNetwork
+from .models import (DiehlAndCook2015, DiehlAndCook2015v2, IncreasingInhibitionNetwork, LocallyConnectedNetwork,
+                     TwoLayerNetwork)
 
-__all__ = ["TwoLayerNetwork", "DiehlAndCook2015", "IncreasingInhibitionNetwork"]
+__all__ = ["TwoLayerNetwork", "DiehlAndCook2015", "DiehlAndCook2015v2", "IncreasingInhibitionNetwork", "LocallyConnectedNetwork"]

@@ -120,6 +120,16 @@ def gen_models():
         Y = net.layers["Y"]
         out[f"consts{k}"] = np.array([float(Y.thresh), float(Y.rest), float(Y.reset), float(Y.refrac), float(Y.theta_plus),
                                       float(net.connections[("X", "Y")].norm), net.n_sqrt], np.float64)
+    from bindsnet.models import DiehlAndCook2015v2, LocallyConnectedNetwork
+    from make_golden_host_cases import MODEL_CASES
+    for k, (name, kw) in enumerate(MODEL_CASES):
+        torch.manual_seed(4)
+        np.random.seed(7)                                   # (LocalConnection draws its weights from numpy, topology.py:1421)
+        net = {"DiehlAndCook2015v2": DiehlAndCook2015v2, "LocallyConnectedNetwork": LocallyConnectedNetwork}[name](**kw)
+        out[f"m{k}_probe"] = np.array([float(torch.rand(1)), np.random.rand()])
+        out[f"m{k}_w_xy"] = net.connections[("X", "Y")].w.detach().numpy().copy()
+        out[f"m{k}_w_yy"] = net.connections[("Y", "Y")].w.detach().numpy().copy()
+        out[f"m{k}_n"] = np.array([net.layers["X"].n, net.layers["Y"].n])
     save("op_models", **out)
 
 

@@ -47,3 +47,9 @@ def flatten_collated(x, path="", out=None):
         for i, v in enumerate(x):
             flatten_collated(v, f"{path}<{type(x).__name__}>[{i}]", out)
     return out
+
+
+MODEL_CASES = [("DiehlAndCook2015v2", dict(n_inpt=64, n_neurons=30, inh=20.0, inpt_shape=(1, 8, 8))),
+               ("LocallyConnectedNetwork", dict(n_inpt=144, input_shape=(12, 12), kernel_size=4, stride=4, n_filters=5)),
+               ("LocallyConnectedNetwork", dict(n_inpt=100, input_shape=(10, 10), kernel_size=(4, 2), stride=(3, 2), n_filters=3, inh=12.5, norm=0.4)),
+               ("LocallyConnectedNetwork", dict(n_inpt=36, input_shape=(6, 6), kernel_size=6, stride=1, n_filters=4))]

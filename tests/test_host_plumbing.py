@@ -266,3 +266,21 @@ def test_increasing_inhibition_network_construction_matches_reference():
                float(net.connections[("X", "Y")].norm), net.n_sqrt]
         np.testing.assert_array_equal(np.array(got, np.float64), g[f"consts{k}"])
         assert isinstance(net.connections[("X", "Y")].update_rule, PostPre) and Y.one_spike and Y.traces
+
+
+def test_v2_and_locally_connected_models_construction_matches_reference():
+    """bindsnet.models.DiehlAndCook2015v2 (models.py:247-346) and LocallyConnectedNetwork (:457-600): both weight matrices
+    bit for bit (incl. the sign of their zeros), layer sizes, and where the torch / numpy generators are left."""
+    import bindsnet.models as models
+    from make_golden_host_cases import MODEL_CASES
+    g = gold("op_models")
+    for k, (name, kw) in enumerate(MODEL_CASES):
+        torch.manual_seed(4)
+        np.random.seed(7)
+        net = getattr(models, name)(**kw)
+        np.testing.assert_array_equal(np.array([float(torch.rand(1)), np.random.rand()]), g[f"m{k}_probe"], err_msg=name)
+        for key, conn in (("w_xy", ("X", "Y")), ("w_yy", ("Y", "Y"))):
+            got = net.connections[conn].w.detach().numpy()
+            assert got.shape == g[f"m{k}_{key}"].shape
+            np.testing.assert_array_equal(got.view(np.uint32), g[f"m{k}_{key}"].view(np.uint32), err_msg=f"{name} {key}")
+        assert [net.layers["X"].n, net.layers["Y"].n] == list(g[f"m{k}_n"])
