@@ -8,6 +8,7 @@
                        weights and the rule's state are compared bit for bit.
   run_two_mcc_mstdpet_b1  the same graph with MCC_learning.MSTDPET (:554-733; batch 1 like the dense rule), two runs with
                        different rewards; the rule's dense eligibility trace is part of the fixture.
+  run_dc_v2_n64_b4     DiehlAndCook2015v2 (dense input connection, recurrent inhibition), two runs.
   run_dc_n100_b3_dt05  DiehlAndCook2015 at dt = 0.5 (the generator of make_golden.py with another timestep).
   op_conv_mstdp        MSTDP on a Conv2dConnection (learning.py:1942-2015; batch 1): update sequences + a run.
   conn_monitor         Monitor / NetworkMonitor on a Connection's `w` (one snapshot per timestep).
@@ -194,6 +195,46 @@ def conv_mstdp_case():
     save("op_conv_mstdp", **out)
 
 
+def dc_v2_case():
+    """DiehlAndCook2015v2 (models.py:247-346): Input -> Connection[PostPre] -> D&C nodes with a recurrent inhibitory
+    Connection -- dense propagation (MKL sgemm: rasters compared exactly, weights within 1e-5) into one_spike nodes that
+    consume the host generator; two runs with a reset in between."""
+    from bindsnet.models import DiehlAndCook2015v2
+    N, B, T = 64, 4, 80
+    torch.manual_seed(0)
+    net = DiehlAndCook2015v2(n_inpt=784, n_neurons=N, inh=60.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28), reduction=torch.sum)
+    conn = net.connections[("X", "Y")]
+    conn.w.data.copy_(T_(synth.weights_q12(10, 784, N)))
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    counter = {"n": 0}
+    orig = torch.multinomial
+
+    def counting(p, n, *a, **k):
+        counter["n"] += p.numel()
+        return orig(p, n, *a, **k)
+
+    torch.multinomial = counting
+    out = {}
+    Y, X = net.layers["Y"], net.layers["X"]
+    for r in range(2):
+        spikes = synth.spike_train(20 + r, T, B, 784, max_rate=0.25)
+        torch.manual_seed(2 + r)
+        counter["n"] = 0
+        net.run({"X": T_(spikes).view(T, B, 1, 28, 28)}, time=T)
+        out[f"r{r}_sY"] = np.packbits(mon.get("s").numpy().astype(np.uint8))
+        out[f"r{r}_consumed"] = np.int64(counter["n"])
+        out[f"r{r}_W_rows7"] = conn.w.detach().numpy()[::7].copy()          # every 7th source row (MKL propagation: compared within 1e-5)
+        out[f"r{r}_W_colsum"] = conn.w.detach().numpy().sum(0)
+        out[f"r{r}_theta"] = Y.theta.numpy().copy()
+        out[f"r{r}_vY"] = Y.v.numpy().copy()
+        print(f"  DiehlAndCook2015v2 run {r}: spikes {int(mon.get('s').sum())}, draws {counter['n']}")
+        net.reset_state_variables()
+    torch.multinomial = orig
+    out.update(x_trace_decay=X.trace_decay.numpy(), decay=Y.decay.numpy(), theta_decay=Y.theta_decay.numpy(), trace_decay=Y.trace_decay.numpy())
+    save("run_dc_v2_n64_b4", N=N, B=B, T=T, **out)
+
+
 def net_monitor_case():
     """NetworkMonitor over layers + connections, and sparse spike Monitors, on a small D&C run."""
     N, B, T = 100, 3, 30
@@ -372,7 +413,9 @@ def one_step_case():
 
 
 if __name__ == "__main__":
-    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "dc_dt", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    jobs = sys.argv[1:] or ["mstdp", "mstdpet", "dc_v2", "dc_dt", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
+    if "dc_v2" in jobs:
+        dc_v2_case()
     if "dc_dt" in jobs:      # a D&C run at dt = 0.5 ms: decays, refractory counters and MCC PostPre's `* dt` all depend on it
         mg.dc_case("run_dc_n100_b3_dt05", 100, 3, 80, 2, False, max_rate=0.125, dt=0.5)
     if "conv_mstdp" in jobs:

@@ -181,6 +181,47 @@ def test_dc2015_run_matches_reference(name):
         np.testing.assert_array_equal(bits(st["W_xe"]), bits(g["W_final"]))
 
 
+def dc_v2_run_oracle(g, r, st):
+    """network.py:380-465 for DiehlAndCook2015v2 (models.py:247-346), stepped by hand through the oracle's operators:
+    currents = zeros + X->Y (dense) + Y->Y (dense, previous spikes), Input step, D&C step with one_spike, dense PostPre on
+    X->Y; the column normalisation after the loop.  `st` carries W / theta across runs; the layers' state is fresh."""
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    spikes = synth.spike_train(20 + r, T, B, 784, max_rate=0.25)
+    Q = cases.exp_noise(2 + r, max(int(g[f"r{r}_consumed"]), 1) + B * N)
+    cur = np.zeros(1, np.int64)
+    sX = np.zeros((B, 784), u8); xX = np.zeros((B, 784), f32)
+    v = np.full((B, N), -65.0, f32); rc = np.zeros((B, N), f32); sY = np.zeros((B, N), u8); xY = np.zeros((B, N), f32)
+    ras = np.zeros((T, B, N), u8)
+    for t in range(T):
+        I = oracle.prop_dense(st["W"], sX)
+        oracle.prop_dense(st["W_yy"], sY, out=I, accumulate=True)
+        sX = np.ascontiguousarray(spikes[t])
+        oracle.input_step(sX, xX, float(g["x_trace_decay"]))
+        oracle.dc_step(v, rc, sY, xY, st["theta"], I, Q, cur, decay=float(g["decay"]), rest=-65.0, reset=-60.0, thresh=-52.0,
+                       refrac0=5.0, theta_decay=float(g["theta_decay"]), theta_plus=0.05, trace_decay=float(g["trace_decay"]))
+        oracle.postpre(st["W"], sX, xX, sY, xY, nu0=np.float32(1e-4), nu1=np.float32(1e-2), use_dt=False, wmin=0.0, wmax=1.0)
+        ras[t] = sY
+    oracle.normalize(st["W"], np.float32(78.4), use_abs=True)
+    return ras, v, int(cur[0])
+
+
+def test_dc2015_v2_run_matches_reference():
+    """DiehlAndCook2015v2: dense input connection (the reference's MKL sgemm: rasters exact, weights within 1e-5), recurrent
+    inhibition from the layer's own previous spikes, one_spike draws counted exactly."""
+    g = gold("run_dc_v2_n64_b4")
+    N = int(g["N"])
+    st = dict(W=synth.weights_q12(10, 784, N), W_yy=(-60.0 * (np.ones((N, N), f32) - np.eye(N, dtype=f32))).astype(f32),
+              theta=np.zeros(N, f32))
+    for r in range(2):
+        ras, v, consumed = dc_v2_run_oracle(g, r, st)
+        np.testing.assert_array_equal(ras, unpack(g[f"r{r}_sY"], ras.shape), err_msg=f"run {r} raster")
+        assert consumed == int(g[f"r{r}_consumed"]) and ras.sum(axis=2).max() <= 1 and ras.sum() > 20
+        np.testing.assert_allclose(st["W"][::7], g[f"r{r}_W_rows7"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(st["W"].sum(0), g[f"r{r}_W_colsum"], rtol=1e-5)
+        np.testing.assert_array_equal(bits(st["theta"]), bits(g[f"r{r}_theta"]))
+        np.testing.assert_allclose(v, g[f"r{r}_vY"], rtol=0, atol=1e-3)
+
+
 def two_params(g, rule):
     P = oracle.TwoParams()
     P.B, P.Nin, P.N, P.T = int(g["B"]), int(g["Nin"]), int(g["N"]), int(g["T"])
