@@ -320,3 +320,43 @@ def test_connection_weight_monitors_match_reference_and_oracle():
     with pytest.raises(NotImplementedError):
         net3.add_monitor(Monitor(conn3, ["b"], time=5), "b")
         net3.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T)
+
+
+def test_dc2015_v2_network_run_matches_oracle_and_reference():
+    """DiehlAndCook2015v2 (models.py:247-346) on the generic plan: dense input connection with PostPre, recurrent inhibitory
+    Connection fed by the layer's own previous spikes, one_spike arbitration on the device generator.  Bit for bit against
+    the hand-stepped oracle (itself pinned to the reference fixture on the CPU), rasters / draws exactly and weights within
+    the MKL tolerance against the reference."""
+    from test_oracle_golden import dc_v2_run_oracle
+    from bindsnet_amd.models import DiehlAndCook2015v2
+    from bindsnet_amd.network.monitors import Monitor
+    g = gold("run_dc_v2_n64_b4")
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    torch.manual_seed(0)
+    net = DiehlAndCook2015v2(n_inpt=784, n_neurons=N, inh=60.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28),
+                             reduction=torch.sum)
+    conn = net.connections[("X", "Y")]
+    conn.w.data.copy_(torch.from_numpy(synth.weights_q12(10, 784, N)))
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    net.to(DEV)
+    st = dict(W=synth.weights_q12(10, 784, N), W_yy=(-60.0 * (np.ones((N, N), f32) - np.eye(N, dtype=f32))).astype(f32),
+              theta=np.zeros(N, f32))
+    for r in range(2):
+        spikes = synth.spike_train(20 + r, T, B, 784, max_rate=0.25)
+        torch.manual_seed(2 + r)
+        net.run({"X": torch.from_numpy(spikes).view(T, B, 1, 28, 28).to(DEV)}, time=T)
+        assert net.last_plan == "generic"
+        probe = torch.rand(4)
+        torch.manual_seed(2 + r)
+        torch.empty(int(g[f"r{r}_consumed"])).exponential_(1)
+        assert torch.equal(probe, torch.rand(4)), "host RNG position after run"
+        ras_o, v_o, _ = dc_v2_run_oracle(g, r, st)
+        ras = host(mon.get("s")).reshape(T, B, N).astype(u8)
+        np.testing.assert_array_equal(ras, ras_o, err_msg=f"run {r} raster vs oracle")
+        np.testing.assert_array_equal(ras, unpack(g[f"r{r}_sY"], (T, B, N)), err_msg=f"run {r} raster vs reference")
+        np.testing.assert_array_equal(bits(host(conn.w)), bits(st["W"]), err_msg=f"run {r} weights vs oracle")
+        np.testing.assert_array_equal(bits(host(net.layers["Y"].theta)), bits(g[f"r{r}_theta"]))
+        np.testing.assert_array_equal(bits(host(net.layers["Y"].v)), bits(v_o))
+        np.testing.assert_allclose(host(conn.w)[::7], g[f"r{r}_W_rows7"], rtol=0, atol=1e-5)
+        net.reset_state_variables()
