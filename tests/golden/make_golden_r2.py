@@ -195,14 +195,19 @@ def conv_mstdp_case():
     save("op_conv_mstdp", **out)
 
 
-def dc_v2_case():
-    """DiehlAndCook2015v2 (models.py:247-346): Input -> Connection[PostPre] -> D&C nodes with a recurrent inhibitory
-    Connection -- dense propagation (MKL sgemm: rasters compared exactly, weights within 1e-5) into one_spike nodes that
-    consume the host generator; two runs with a reset in between."""
-    from bindsnet.models import DiehlAndCook2015v2
+def dc_v2_case(name="run_dc_v2_n64_b4", model="DiehlAndCook2015v2"):
+    """DiehlAndCook2015v2 (models.py:247-346) / IncreasingInhibitionNetwork (:349-454): Input -> Connection[PostPre] -> D&C
+    nodes with a recurrent Connection (uniform inhibition / distance-graded weights) -- dense propagation (MKL sgemm:
+    rasters compared exactly, weights within 1e-5) into one_spike nodes that consume the host generator; two runs with a
+    reset in between."""
+    from bindsnet.models import DiehlAndCook2015v2, IncreasingInhibitionNetwork
     N, B, T = 64, 4, 80
     torch.manual_seed(0)
-    net = DiehlAndCook2015v2(n_inpt=784, n_neurons=N, inh=60.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28), reduction=torch.sum)
+    if model == "DiehlAndCook2015v2":
+        net = DiehlAndCook2015v2(n_inpt=784, n_neurons=N, inh=60.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28), reduction=torch.sum)
+    else:       # start_inhib / max_inhib as examples/mnist/SOM_LM-SNNs.py:88-89 sets them
+        net = IncreasingInhibitionNetwork(n_input=784, n_neurons=N, start_inhib=10, max_inhib=-40.0, dt=1.0, norm=78.4, theta_plus=0.05,
+                                          inpt_shape=(1, 28, 28), reduction=torch.sum)
     conn = net.connections[("X", "Y")]
     conn.w.data.copy_(T_(synth.weights_q12(10, 784, N)))
     mon = Monitor(net.layers["Y"], ["s"], time=T)
@@ -228,11 +233,13 @@ def dc_v2_case():
         out[f"r{r}_W_colsum"] = conn.w.detach().numpy().sum(0)
         out[f"r{r}_theta"] = Y.theta.numpy().copy()
         out[f"r{r}_vY"] = Y.v.numpy().copy()
-        print(f"  DiehlAndCook2015v2 run {r}: spikes {int(mon.get('s').sum())}, draws {counter['n']}")
+        print(f"  {model} run {r}: spikes {int(mon.get('s').sum())}, draws {counter['n']}")
         net.reset_state_variables()
     torch.multinomial = orig
     out.update(x_trace_decay=X.trace_decay.numpy(), decay=Y.decay.numpy(), theta_decay=Y.theta_decay.numpy(), trace_decay=Y.trace_decay.numpy())
-    save("run_dc_v2_n64_b4", N=N, B=B, T=T, **out)
+    if model != "DiehlAndCook2015v2":
+        out["W_yy"] = net.connections[("Y", "Y")].w.detach().numpy().copy()
+    save(name, N=N, B=B, T=T, **out)
 
 
 def net_monitor_case():
@@ -416,6 +423,7 @@ if __name__ == "__main__":
     jobs = sys.argv[1:] or ["mstdp", "mstdpet", "dc_v2", "dc_dt", "conv_mstdp", "conn_monitor", "monitor", "rules", "extras", "one_step"]
     if "dc_v2" in jobs:
         dc_v2_case()
+        dc_v2_case("run_iin_n64_b4", "IncreasingInhibitionNetwork")
     if "dc_dt" in jobs:      # a D&C run at dt = 0.5 ms: decays, refractory counters and MCC PostPre's `* dt` all depend on it
         mg.dc_case("run_dc_n100_b3_dt05", 100, 3, 80, 2, False, max_rate=0.125, dt=0.5)
     if "conv_mstdp" in jobs:

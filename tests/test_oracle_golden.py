@@ -222,6 +222,24 @@ def test_dc2015_v2_run_matches_reference():
         np.testing.assert_allclose(v, g[f"r{r}_vY"], rtol=0, atol=1e-3)
 
 
+def test_increasing_inhibition_network_run_matches_reference():
+    """IncreasingInhibitionNetwork (models.py:349-454) with the SOM example's start_inhib = 10, max_inhib = -40: the same
+    hand-stepped operators as for DiehlAndCook2015v2, the recurrent weights now distance-graded (nearest neighbours excite,
+    distant ones inhibit) -- rasters and draws exact, weights within the MKL tolerance."""
+    from bindsnet_amd.models import IncreasingInhibitionNetwork
+    g = gold("run_iin_n64_b4")
+    N = int(g["N"])
+    torch_w = IncreasingInhibitionNetwork(n_input=784, n_neurons=N, start_inhib=10, max_inhib=-40.0).connections[("Y", "Y")].w.numpy()
+    np.testing.assert_array_equal(bits(torch_w), bits(g["W_yy"]))              # (the mirror's constructor, again)
+    st = dict(W=synth.weights_q12(10, 784, N), W_yy=np.ascontiguousarray(g["W_yy"]), theta=np.zeros(N, f32))
+    for r in range(2):
+        ras, v, consumed = dc_v2_run_oracle(g, r, st)
+        np.testing.assert_array_equal(ras, unpack(g[f"r{r}_sY"], ras.shape), err_msg=f"run {r} raster")
+        assert consumed == int(g[f"r{r}_consumed"]) and ras.sum(axis=2).max() <= 1 and ras.sum() > 50
+        np.testing.assert_allclose(st["W"][::7], g[f"r{r}_W_rows7"], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(bits(st["theta"]), bits(g[f"r{r}_theta"]))
+
+
 def two_params(g, rule):
     P = oracle.TwoParams()
     P.B, P.Nin, P.N, P.T = int(g["B"]), int(g["Nin"]), int(g["N"]), int(g["T"])
