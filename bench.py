@@ -17,11 +17,16 @@ each input the weight and threshold deltas are all-reduced over RCCL and re-norm
 `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); the JSON line reports the
 ranks RCCL actually formed (`rccl_ranks`) and the device every rank ran on.
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak),
-"cpu_baseline" (N = 1 only: oracle/torch_cpu_ref.py -- the reference's own ATen operator sequence on the
-host CPU -- at cpu_count()-1 threads [what eth_mnist.py:77 sets] and at 1 thread, plus the scalar C port)
-and "parity" (the first input re-run from a fresh network on the GPU and on the CPU restatement, same
-host, same run: rasters compared bit for bit, weights by max |dW|).
+Input: the generator BASELINE.md section 2 states for this config -- per sample a 28x28 image 128*U(0,1)*Bernoulli(0.19),
+Poisson-encoded (bindsnet.encoding.poisson, time=250, dt=1) from torch.manual_seed(1): ~1.17 % spike density; the first
+three batches are the trains tests/golden/full_cfg2_dc_n400_b32_poisson.npz holds from the REFERENCE encoder.
+
+Order of the legs (N = 1): CPU baseline first, then GPU warm-up + timed region, parity, roofline profile last.
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak), "cpu_baseline"
+(oracle/torch_cpu_ref.py -- the reference's own ATen operator sequence on the host CPU -- 8 threads = `value`,
+median of 3 whole inputs; 1 thread; cpu_count()-1 threads [eth_mnist.py:77]; the scalar C port) and "parity" (the
+same three inputs from a fresh network on the GPU vs that CPU run, same host, same process: rasters bit for bit,
+weights / theta after every input).
 """
 import argparse
 import json
@@ -34,7 +39,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 N_IN, N_EXC, BATCH, T = 784, 400, 32, 250
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -46,12 +50,12 @@ def algorithmic_bytes_per_timestep(Nin=N_IN, N=N_EXC, B=BATCH):
 
 
 def make_inputs(seed, n_batches, device):
-    import synth
-    out = []
-    for k in range(n_batches):
-        sp = synth.spike_train(seed + k, T, BATCH, N_IN)
-        out.append(torch.from_numpy(sp).view(T, BATCH, 1, 28, 28).to(device))
-    return out
+    """The input BASELINE.md section 2 states for cfg2: per sample img = 128*U(0,1)*Bernoulli(0.19), encoded by
+    bindsnet.encoding.poisson(img, time=250, dt=1.0) (this package's host-stream-exact mirror of
+    encodings.py:101-152) from torch's CPU generator seeded with `seed`.  Returns (device tensors, host arrays)."""
+    from bindsnet_amd import synth
+    host = synth.poisson_mnist_like(BATCH, T, n_batches, seed=seed)
+    return [torch.from_numpy(sp).view(T, BATCH, 1, 28, 28).to(device) for sp in host], host
 
 
 def build_network(device):
@@ -68,47 +72,46 @@ def build_network(device):
 
 def pmc_traffic(plan):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
-    name = {"dc2015-resident-lean": "r02_lean_pmc_hbm_traffic.json", "dc2015-resident": "r01_resident_pmc_hbm_traffic.json",
-            "dc2015-fused": "r01_pmc_hbm_traffic.json"}.get(plan)
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if not path or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")
+    command (profiles/*_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
+    names = {"dc2015-resident-lean": ["r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
+             "dc2015-resident": ["r01_resident_pmc_hbm_traffic.json"], "dc2015-fused": ["r01_pmc_hbm_traffic.json"]}.get(plan, [])
+    for name in names:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")
+    return None
 
 
-def c_port_baseline(steps=100):
+def c_port_baseline(spikes, steps=100):
     """Scalar C port of the reference algorithm (oracle/snn_oracle.c) on one host core."""
-    import cases
     import oracle
-    import synth
-    from test_oracle_golden import dc_params
-    g = cases.gold("run_dc_n400_b32")
-    P = dc_params(g)
-    P.T, P.B, P.N = steps, BATCH, N_EXC
-    st = cases.dc_state(N_EXC, BATCH)
-    sp = np.ascontiguousarray(synth.spike_train(20, T, BATCH, N_IN)[:steps])
-    Q = cases.exp_noise(2, 400_000)
+    P = oracle.eth_mnist_dc_params(N_EXC, BATCH, steps)
+    torch.manual_seed(0)
+    st = oracle.eth_mnist_dc_state(N_EXC, BATCH, (0.3 * torch.rand(N_IN, N_EXC)).numpy())
+    Q = oracle.exp_noise(2, 400_000)
     cur = np.zeros(1, np.int64)
     t0 = time.perf_counter()
     try:
-        oracle.run_dc2015(P, st, sp, Q, cur, rasters=False)
+        oracle.run_dc2015(P, st, np.ascontiguousarray(spikes[:steps].reshape(steps, BATCH, N_IN)), Q, cur, rasters=False)
     except RuntimeError:
         return None
     dt = time.perf_counter() - t0
     return {"value": round(steps / dt, 2), "unit": "timesteps/s", "cores": 1,
-            "sample": f"{steps} timesteps of one input, oracle/snn_oracle.c ({dt:.1f} s)"}
+            "sample": f"first {steps} timesteps of input 0, oracle/snn_oracle.c ({dt:.1f} s)"}
 
 
-def cpu_baseline_and_parity(dev, seed_inputs):
-    """The reference's CPU path restated operator for operator (oracle/torch_cpu_ref.py), on this host's
-    cores, in this run -- timed, and its outputs compared with a fresh GPU run of the same input."""
-    import synth
+def cpu_baseline(host_inputs):
+    """The reference's CPU path restated operator for operator (oracle/torch_cpu_ref.py) on this host's cores, BEFORE
+    the GPU leg.  Protocol (fixed, no best-of): 8 threads (SURVEY.md / BASELINE.md section 3's setting) = `value`,
+    median over 3 WHOLE consecutive inputs from the fixture's start state (weights and theta carry over, reset between:
+    the run tests/golden/full_cfg2_dc_n400_b32_poisson pins); 1 thread: median over the first 100 timesteps of the same
+    3 inputs; cpu_count()-1 threads (eth_mnist.py:77's setting): median over 3 samples of 3 timesteps (it runs at
+    < 1 timestep/s on a 256-thread host).  Returns (json object, records of the 8-thread run for the parity leg)."""
     from oracle.torch_cpu_ref import DcTorchRef
-    spikes = synth.spike_train(seed_inputs, T, BATCH, N_IN)
     ncpu = os.cpu_count() or 2
     threads0 = torch.get_num_threads()
+    spikes = [torch.from_numpy(h.reshape(T, BATCH, N_IN)) for h in host_inputs[:3]]
 
     def fresh():
         torch.manual_seed(0)
@@ -117,54 +120,61 @@ def cpu_baseline_and_parity(dev, seed_inputs):
         torch.manual_seed(2)
         return r
 
-    # --- thread-count probe on a bounded sample (6 timesteps after 1 untimed one, same start every time).  The
-    # reference's own setting is cpu_count()-1 (examples/mnist/eth_mnist.py:77); on a many-core host that
-    # oversubscribes these small operators badly, so the baseline VALUE is the best setting found, not that one.
-    probe = {}
-    for nt in sorted({1, 4, 8, 16, 32, max(1, ncpu - 1)}):
-        if nt > max(1, ncpu - 1):
-            continue
-        torch.set_num_threads(nt)
-        r = fresh()
-        r.run(torch.from_numpy(spikes[:1]))
-        t0 = time.perf_counter()
-        r.run(torch.from_numpy(spikes[1:7]))
-        probe[nt] = round(6 / (time.perf_counter() - t0), 2)
-    best = max(probe, key=probe.get)
-    # --- one whole input at the best thread count (also the parity witness)
-    torch.set_num_threads(best)
-    ref = fresh()
-    t0 = time.perf_counter()
-    rec = ref.run(torch.from_numpy(spikes))
-    dt_best = time.perf_counter() - t0
+    def leg(threads, n_steps, warm):
+        torch.set_num_threads(threads)
+        r, rates, recs = fresh(), [], []
+        for sp in spikes:
+            if warm:
+                r.run(sp[:warm])
+            t0 = time.perf_counter()
+            rec = r.run(sp[warm:warm + n_steps])
+            rates.append(n_steps / (time.perf_counter() - t0))
+            if n_steps == T:
+                recs.append({"Ae": rec["Ae"], "Ai": rec["Ai"], "W": r.W_xe.clone(), "theta": r.theta.clone()})
+            r.reset()
+        return sorted(rates)[1], [round(x, 2) for x in rates], recs
+
+    v8, all8, recs = leg(min(8, ncpu), T, 0)
+    v1, all1, _ = leg(1, 100, 0)
+    vd, alld, _ = leg(max(1, ncpu - 1), 3, 1)
     torch.set_num_threads(threads0)
-    cpu = {"value": round(T / dt_best, 2), "unit": "timesteps/s", "cores": best, "kind": "port",
-           "sample": f"1 input (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors) through oracle/torch_cpu_ref.py = the "
-                     f"reference's ATen operator sequence, {best} threads = the best of the probed settings ({dt_best:.1f} s); "
+    cpu = {"value": round(v8, 2), "unit": "timesteps/s", "cores": min(8, ncpu), "kind": "port",
+           "sample": f"median of 3 whole consecutive inputs (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors, reset between) "
+                     f"through oracle/torch_cpu_ref.py = the reference's ATen operator sequence, {min(8, ncpu)} threads; "
                      "/root/reference itself is absent on this box",
-           "threads_probe_timesteps_per_s": {str(k): v for k, v in probe.items()},
-           "reference_default_threads": {"threads": max(1, ncpu - 1), "value": probe[max(1, ncpu - 1)],
-                                         "note": "torch.set_num_threads(os.cpu_count() - 1), eth_mnist.py:77; 6-timestep sample"},
-           "one_thread": {"value": probe[1], "unit": "timesteps/s", "cores": 1, "sample": "6-timestep sample"},
-           "c_port": c_port_baseline(), "host_cpus": ncpu}
-    # --- parity: the same input from the same seeds on the GPU
-    torch.manual_seed(0)
+           "per_input_timesteps_per_s": all8,
+           "one_thread": {"value": round(v1, 2), "unit": "timesteps/s", "cores": 1, "per_sample": all1,
+                          "sample": "median over the first 100 timesteps of the same 3 inputs"},
+           "reference_default_threads": {"threads": max(1, ncpu - 1), "value": round(vd, 2), "per_sample": alld,
+                                         "note": "torch.set_num_threads(os.cpu_count() - 1), eth_mnist.py:77; median of 3 samples "
+                                                 "of 3 timesteps after 1 untimed one"},
+           "c_port": c_port_baseline(host_inputs[0]), "host_cpus": ncpu}
+    return cpu, recs
+
+
+def parity_leg(dev, pool, recs):
+    """The same 3 inputs from the same seeds on the GPU (fresh network), against the 8-thread CPU run of this process."""
     net = build_network(dev)
     torch.manual_seed(2)
-    net.run({"X": torch.from_numpy(spikes).view(T, BATCH, 1, 28, 28).to(dev)}, time=T)
-    torch.cuda.synchronize()
-    ok = {}
-    for l in ("Ae", "Ai"):
-        got = net.monitors[l + "_spikes"].get("s").reshape(T, BATCH, N_EXC).cpu()
-        ok[l] = bool(torch.equal(got.bool(), rec[l].bool()))
-    W = net.connections[("X", "Ae")].pipeline[0].value.detach().cpu()
-    theta = net.layers["Ae"].theta.cpu()
-    probe_gpu = torch.rand(4)                             # host generator position after the GPU run ...
-    par = {"rasters_bit_exact": all(ok.values()), "exc_spikes": int(rec["Ae"].sum()), "inh_spikes": int(rec["Ai"].sum()),
-           "max_abs_dW": float((W - ref.W_xe).abs().max()), "weights_bit_exact": bool(torch.equal(W, ref.W_xe)),
-           "max_abs_dtheta": float((theta - ref.theta).abs().max()),
-           "against": "oracle/torch_cpu_ref.py on this host in this run, one input from identical seeds"}
-    return cpu, par
+    ok, dW, dth, wexact = True, 0.0, 0.0, True
+    exc = inh = 0
+    for r, rec in enumerate(recs):
+        net.run({"X": pool[r]}, time=T)
+        torch.cuda.synchronize()
+        for l in ("Ae", "Ai"):
+            got = net.monitors[l + "_spikes"].get("s").reshape(T, BATCH, N_EXC).cpu()
+            ok = ok and bool(torch.equal(got.bool(), rec[l].bool()))
+        W = net.connections[("X", "Ae")].pipeline[0].value.detach().cpu()
+        dW = max(dW, float((W - rec["W"]).abs().max()))
+        wexact = wexact and bool(torch.equal(W, rec["W"]))
+        dth = max(dth, float((net.layers["Ae"].theta.cpu() - rec["theta"]).abs().max()))
+        exc, inh = exc + int(rec["Ae"].sum()), inh + int(rec["Ai"].sum())
+        net.reset_state_variables()
+    return {"rasters_bit_exact": ok, "inputs": len(recs), "exc_spikes": exc, "inh_spikes": inh, "max_abs_dW": dW,
+            "weights_bit_exact": wexact, "max_abs_dtheta": dth, "plan": net.last_plan,
+            "plan_retries(lean,resident)": [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)],
+            "against": "oracle/torch_cpu_ref.py on this host in this run, 3 consecutive inputs from identical seeds "
+                       "(weights, theta compared after each)"}
 
 
 def respawn_under_launcher(args):
@@ -214,7 +224,18 @@ def main():
     from bindsnet_amd import _lib, parallel
     _lib.lib().snn_set_plan_mode({"auto": 0, "generic": 1, "per-step": 2}[args.plan])
     net = build_network(dev)
-    pool = make_inputs(1000 + 17 * rank, 4, dev)           # resident in HBM before the timed region
+    pool, host_pool = make_inputs(1 + 17 * rank, 4, dev)   # resident in HBM before the timed region
+    from bindsnet_amd import synth
+    per = np.stack([h.reshape(T, BATCH, N_IN).sum(2) for h in host_pool])
+    input_stats = {"generator": "torch.manual_seed(1 + 17*rank); per sample img = 128*U(0,1)*Bernoulli(0.19); "
+                                "bindsnet.encoding.poisson(img, time=250, dt=1.0) (BASELINE.md section 2)",
+                   "density": round(float(np.mean([h.mean() for h in host_pool])), 5),
+                   "events_per_sample_timestep": {"mean": round(float(per.mean()), 2), "max": int(per.max())},
+                   "matches_reference_encoded_fixture": (
+                       [synth.sha(h.reshape(T, BATCH, N_IN)) for h in host_pool[:3]] == synth.POISSON_CFG2_SHA) if rank == 0 else None}
+    cpu = recs = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs BEFORE the GPU leg (N = 1 only)
+        cpu, recs = cpu_baseline(host_pool)
 
     def one(k):
         x = {"X": pool[k % len(pool)]}
@@ -249,22 +270,21 @@ def main():
         dist.all_gather_object(ids, f"rank{rank}=cuda:{dev.index}")
         devices = ids
 
-    # ---- roofline of the dominant kernel: HIP events around single launches, after the timed region
-    roof = None
     if rank == 0:
-        prof = _lib.profile_run(net, {"X": pool[0]}, T)
+        plan_timed = net.last_plan
+        retries = [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)]
+        par = parity_leg(dev, pool, recs) if recs else None
+        # ---- roofline of the dominant kernel: HIP events (on the launch stream) around single launches of further
+        # runs of the same input pool, LAST, so the device is busy until the process prints its line
+        roof = None
+        prof = _lib.profile_run(net, {"X": pool[0]}, T, repeats=25)
         if prof is not None:
             ab = algorithmic_bytes_per_timestep() * prof["timesteps_per_launch"]
             ach = ab / (prof["avg_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": prof["kernel"], "avg_launch_us": round(prof["avg_ms"] * 1e3, 3),
                     "launches_timed": prof["n"], "algorithmic_bytes_per_launch": ab, "achieved": round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic(net.last_plan)}
-
-    if rank == 0:
-        cpu = par = None
-        if not (args.no_cpu_baseline or world > 1):        # N = 1 only
-            cpu, par = cpu_baseline_and_parity(dev, 1000)
+                    "traffic": pmc_traffic(plan_timed)}
         steps_total = world * args.steps * T
         line = {
             "metric": "simulated timesteps/sec (whole node), DiehlAndCook2015 784->400 batch32",
@@ -273,10 +293,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": ranks_seen, "devices": devices,
             "config": {"workload": "configs[1]: DiehlAndCook2015 784->400 exc, batch 32/GPU, 250 timesteps per "
-                                   "network.run(), PostPre STDP on, 3 spike monitors (X, Ae, Ai), reset_state_variables() per input",
+                                   "network.run(), PostPre STDP on, 3 spike monitors (X, Ae, Ai), reset_state_variables() per input; "
+                                   "input = BASELINE.md's stated generator (Poisson-encoded 128*U*Bernoulli(0.19) images), "
+                                   "4 resident batches cycled",
+                       "input": input_stats,
                        "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
-                       "plan": net.last_plan, "plan_retries(lean,resident)": [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)], "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+                       "plan": plan_timed, "plan_retries(lean,resident)": retries, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": par,

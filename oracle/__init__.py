@@ -230,3 +230,41 @@ def mt_exponential(mt_state: np.ndarray, pos: int, n: int):
     p = C.c_int(pos)
     lib().orc_mt_exponential(_p(mt_state, np.uint32), C.byref(p), _p(out, f32), cl(n))
     return out, p.value
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The eth_mnist.py D&C case (examples/mnist/eth_mnist.py:91-100 -> bindsnet/models/models.py:156-236) as oracle
+# arguments; bench.py's cpu_baseline leg and the tests build the checker's inputs through these.
+def eth_mnist_dc_params(N, B, T, Nin=784, learning=True) -> DcParams:
+    """Decay constants as the reference computes them: torch.exp(-dt / tc) in f32 (nodes.py:122-131,540-548,1122-1133)."""
+    import torch
+
+    def dec(tc):
+        return float(torch.exp(-torch.tensor(1.0) / torch.tensor(float(tc))))
+    P = DcParams()
+    P.B, P.Nin, P.N, P.T, P.dt = B, Nin, N, T, 1.0
+    P.x_trace_decay, P.x_trace_scale = dec(20.0), 1.0
+    P.e_decay, P.e_theta_decay, P.e_trace_decay, P.e_trace_scale, P.e_one_spike = dec(100.0), dec(1e7), dec(20.0), 1.0, 1
+    P.i_decay = dec(10.0)
+    P.e_rest, P.e_reset, P.e_thresh, P.e_refrac, P.e_theta_plus = -65.0, -60.0, -52.0, 5.0, 0.05
+    P.i_rest, P.i_reset, P.i_thresh, P.i_refrac = -60.0, -45.0, -40.0, 2.0
+    P.nu0, P.nu1, P.wmin, P.wmax, P.norm = 1e-4, 1e-2, 0.0, 1.0, 78.4
+    P.learning = int(learning)
+    return P
+
+
+def eth_mnist_dc_state(N, B, W_xe, Nin=784, exc=22.5, inh=120.0) -> dict:
+    return dict(
+        W_xe=np.ascontiguousarray(W_xe, f32), W_ei=(exc * np.eye(N)).astype(f32),
+        W_ie=(-inh * (np.ones((N, N)) - np.eye(N))).astype(f32),
+        sX=np.zeros((B, Nin), u8), xX=np.zeros((B, Nin), f32),
+        vE=np.full((B, N), -65.0, f32), rE=np.zeros((B, N), f32), sE=np.zeros((B, N), u8),
+        xE=np.zeros((B, N), f32), theta=np.zeros(N, f32),
+        vI=np.full((B, N), -60.0, f32), rI=np.zeros((B, N), f32), sI=np.zeros((B, N), u8))
+
+
+def exp_noise(seed, n):
+    """The Exp(1) stream torch.multinomial consumes after torch.manual_seed(seed)."""
+    import torch
+    torch.manual_seed(int(seed))
+    return torch.empty(int(n)).exponential_(1).numpy()

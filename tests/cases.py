@@ -39,6 +39,20 @@ def unpack(bits, shape):
     return np.unpackbits(bits)[:n].reshape(shape).astype(u8)
 
 
+def fixture_input(g, r, T, B, n=784):
+    """Input `r` of a D&C full-size fixture: the stored reference-encoded Poisson train (bit-packed,
+    sha-checked) when the fixture has one, else round 1/2's synth.spike_train(1000 + r)."""
+    if f"r{r}_in" in g.files:
+        sp = unpack(g[f"r{r}_in"], (T, B, n))
+        assert sha(sp) == str(g[f"r{r}_in_sha"])
+        return sp
+    return synth.spike_train(1000 + r, T, B, n)
+
+
+DC_FULL = ["full_cfg1_dc_n100_b1", "full_cfg2_dc_n400_b32", "full_cfg1_dc_n100_b1_poisson", "full_cfg2_dc_n400_b32_poisson",
+           "full_cfg2_dc_n400_b32_bold"]
+
+
 def exp_noise(seed, n):
     """The Exp(1) stream torch.multinomial consumes after torch.manual_seed(seed)."""
     import torch

@@ -31,7 +31,26 @@ def ref_init_weights(n_in, n, scale=0.3):
 
 
 # --------------------------------------------------------------------------------------------- cfg1 / cfg2
-@pytest.mark.parametrize("name", ["full_cfg1_dc_n100_b1", "full_cfg2_dc_n400_b32"])
+@pytest.mark.parametrize("name,bold", [("full_cfg1_dc_n100_b1_poisson", ()), ("full_cfg2_dc_n400_b32_poisson", ()),
+                                       ("full_cfg2_dc_n400_b32_bold", (1,))])
+def test_stated_poisson_input_regenerates_through_the_package_encoder(name, bold):
+    """BASELINE.md section 2's cfg1/cfg2 input (seed 1, 128*U*Bernoulli(0.19), bindsnet.encoding.poisson): the
+    fixture holds the REFERENCE encoder's trains; this package's host encoder (same torch draws in the same order)
+    must reproduce them bit for bit -- bench.py builds its input pool this way."""
+    g = gold(name)
+    B, T, runs = int(g["B"]), int(g["T"]), int(g["runs"])
+    trains = synth.poisson_mnist_like(B, T, runs, seed=1, bold=bold)
+    for r in range(runs):
+        assert cases.sha(trains[r].reshape(T, B, 784)) == str(g[f"r{r}_in_sha"]), f"input {r}"
+        np.testing.assert_array_equal(trains[r].reshape(T, B, 784), cases.fixture_input(g, r, T, B))
+    d = np.mean([t.mean() for t in trains])
+    if name == "full_cfg2_dc_n400_b32_poisson":
+        assert [str(g[f"r{r}_in_sha"]) for r in range(3)] == synth.POISSON_CFG2_SHA
+    if not bold:
+        assert 0.010 < d < 0.0135            # the stated generator's density (~1.17 %), not round 2's 0.62 %
+
+
+@pytest.mark.parametrize("name", cases.DC_FULL)
 def test_oracle_dc2015_full_size(name):
     g = gold(name)
     N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
@@ -43,7 +62,7 @@ def test_oracle_dc2015_full_size(name):
     Q = cases.exp_noise(2, total + B * N)
     cur = np.zeros(1, np.int64)
     for r in range(runs):
-        spikes = synth.spike_train(1000 + r, T, B, 784)
+        spikes = cases.fixture_input(g, r, T, B)
         before = int(cur[0])
         rasE, rasI = oracle.run_dc2015(P, st, spikes, Q, cur)
         np.testing.assert_array_equal(rasE, unpack(g[f"r{r}_sE"], (T, B, N)), err_msg=f"run {r} Ae raster")
@@ -57,7 +76,8 @@ def test_oracle_dc2015_full_size(name):
         cases.dc_reset(st)
 
 
-@pytest.mark.parametrize("name,runs", [("full_cfg1_dc_n100_b1", 3), ("full_cfg2_dc_n400_b32", 1)])
+@pytest.mark.parametrize("name,runs", [("full_cfg1_dc_n100_b1", 3), ("full_cfg2_dc_n400_b32", 1),
+                                       ("full_cfg1_dc_n100_b1_poisson", 3), ("full_cfg2_dc_n400_b32_poisson", 1)])
 def test_torch_cpu_restatement_full_size(name, runs):
     from oracle.torch_cpu_ref import DcTorchRef
     g = gold(name)
@@ -68,7 +88,7 @@ def test_torch_cpu_restatement_full_size(name, runs):
     ref.set_batch(B)
     torch.manual_seed(2)
     for r in range(runs):
-        spikes = synth.spike_train(1000 + r, T, B, 784)
+        spikes = cases.fixture_input(g, r, T, B)
         rec = ref.run(torch.from_numpy(spikes))
         np.testing.assert_array_equal(rec["Ae"].numpy().astype(u8), unpack(g[f"r{r}_sE"], (T, B, N)))
         np.testing.assert_array_equal(rec["Ai"].numpy().astype(u8), unpack(g[f"r{r}_sI"], (T, B, N)))

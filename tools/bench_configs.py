@@ -14,8 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import synth  # noqa: E402
+from bindsnet_amd import synth  # noqa: E402
 
 DEV = "cuda"
 
@@ -36,7 +35,7 @@ def cfg1():
     from bindsnet_amd.models import DiehlAndCook2015
     torch.manual_seed(0)
     net = DiehlAndCook2015(n_inpt=784, n_neurons=100, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28)).to(DEV)
-    x = torch.from_numpy(synth.spike_train(1, 250, 1, 784)).view(250, 1, 1, 28, 28).to(DEV)
+    x = torch.from_numpy(synth.poisson_mnist_like(1, 250, 1, seed=1)[0]).view(250, 1, 1, 28, 28).to(DEV)   # BASELINE.md cfg1 input
     return "cfg1 D&C 784->100 B=1 T=250 PostPre", net, {"X": x}, 250, {}
 
 

@@ -15,8 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import synth  # noqa: E402
+from bindsnet_amd import synth  # noqa: E402
 from bindsnet_amd import ops  # noqa: E402
 
 DEV = "cuda"
