@@ -175,25 +175,25 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
     }
     __syncthreads();
     uint16_t *D_l2 = D_rp + 2 * ((Nin + 1) / 2);                     // [B][LX] events grouped by row_sum lane
-    uint32_t *D_gc = (uint32_t *)(D_l2 + B * LX);                    // [B] five 5-bit group sizes
+    uint32_t *D_gc = (uint32_t *)(D_l2 + B * LX);                    // [B] five GCB-bit group sizes
     uint16_t *lscr = (uint16_t *)(misc + 4) + wave * LX;             // this wave's scratch list
     for (int b = wave; b < B; b += NT / 64) {
         const int nx = build_list(sXw + b * NinW, NinW, lane, lscr, LX);
-        if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > 16) atomicOr((unsigned int *)&misc[1], 2u); }
+        if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > LXF) atomicOr((unsigned int *)&misc[1], 2u); if (nx > LX - 1) atomicOr((unsigned int *)&misc[1], 4u); }
         // (LDS operations of one wave execute in program order: the list is readable right away)
         const bool have = lane < LX && lane < nx;
         const int i = have ? (int)lscr[lane] : 0;
         if (lane < LX) ((uint16_t *)D_xl)[b * LX + lane] = (uint16_t)i;
         // the same events grouped by ATen row_sum lane (index mod 4; group 4 = the n % 4 leftover sources), ascending
         // inside a group: what a quad of threads walks for a column >= 32*floor(N/32)
-        const bool in16 = have && lane < 16;
+        const bool in16 = have;                     // (every listed event: the consumers walk group sizes, not 16 slots)
         const int grp = (i >= ((Nin >> 2) << 2)) ? 4 : (i & 3);
         int start = 0, my = 0; uint32_t gc = 0;
         for (int k = 0; k < 5; ++k) {
             const uint64_t mk = __ballot(in16 && grp == k);
             const int ck = __popcll(mk);
             if (grp == k) my = start + __popcll(mk & ((1ull << lane) - 1ull));
-            start += ck; gc |= (uint32_t)ck << (5 * k);
+            start += ck; gc |= (uint32_t)min(ck, (1 << GCB) - 1) << (GCB * k);
         }
         uint16_t *perm = lscr + (NT / 64) * LX;        // second per-wave scratch: permute in LDS, store each slot once
         if (lane < LX) perm[lane] = 0;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
             uint32_t gq = 0;
             for (int k = 0; k < 4; ++k) {
                 const uint64_t mk = __ballot(in16 && min(i >> 8, 3) == k);
-                gq |= (uint32_t)__popcll(mk) << (5 * k);
+                gq |= (uint32_t)min((int)__popcll(mk), (1 << GCB) - 1) << (GCB * k);
             }
             if (lane == 0) D_gc[B + b] = gq;
         }
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     const int stepoff = t * B * Nin;                                   // < 2^31 (host check)
     const uint8_t *sprev_g = (t == 0) ? c.sX0 : c.in + (stepoff - B * Nin);
     const uint32_t *Dg = c.dig + (size_t)t * c.DW;                   // digest of step t-1 (entry t): the part staged in LDS comes first
-    uint32_t r_dg[3];                                                  // DGW <= 3 * NT (host check)
+    uint32_t r_dg[4];                                                  // DGW <= 4 * NT (host check)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int k = tid + u * NT; r_dg[u] = k < c.DGW ? Dg[k] : 0u; }
+    for (int u = 0; u < 4; ++u) { const int k = tid + u * NT; r_dg[u] = k < c.DGW ? Dg[k] : 0u; }
     // exchange word owned by this thread: (sample wb, word wj)
     const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;
     uint32_t r_crs = 0, r_spi = 0, r_mt = 0;                           // B*NW <= NT and 624 <= NT
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
     DBG_MARK(11);
     // ---- into LDS: the digest verbatim, the exchanged bit words, the generator block
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int k = tid + u * NT; if (k < c.DGW) dg[k] = r_dg[u]; }
+    for (int u = 0; u < 4; ++u) { const int k = tid + u * NT; if (k < c.DGW) dg[k] = r_dg[u]; }
     if (tid < BW) { (phaseA ? crs : finE)[tid] = r_crs; spI[tid] = r_spi; }
     if (use_rng && tid < 624) mt[tid] = r_mt;
     lds_barrier();
@@ -768,7 +768,7 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
     if (R->T < 1) return false;
     if (lds_bytes(R->B, L[0].n, L[1].n) > 150 * 1024) return false;
     if (!R->workspace || R->workspace_bytes < fused_workspace_total(R->B, L[0].n, L[1].n, R->T)) return false;
-    if (digest_lds_words(R->B, L[0].n) > 3 * NT) return false;
+    if (digest_lds_words(R->B, L[0].n) > 4 * NT) return false;
     return true;
 }
 

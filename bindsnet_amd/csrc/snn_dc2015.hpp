@@ -36,7 +36,9 @@ struct DcCtx {
     // per-step digest of the X spikes, produced once per run by k_dc2015_prep (entry e <-> spikes of step e-1):
     // [B*NinW] bit words | [B*LX/2] u16 event lists | [40] meta (counts, n active rows, flags) | [Nin] row masks |
     // [Nin/2] u16 active rows | [Nin/2] u16 row -> compact index | [B*LX/2] u16 event lists grouped by row_sum lane |
-    // [B] group sizes (5 bits each: lanes 0..3, leftover sources) | [B] events per 256-position group (5 bits each)
+    // [B] group sizes (GCB = 6 bits each: lanes 0..3, leftover sources) | [B] events per 256-position group (6 bits each)
+    // meta[33] flags: 1 = a spike byte other than 0/1, 2 = a sample with > LXF events (the 16-entry fast paths do not
+    // apply), 4 = a sample with > LX - 1 events (lists / packed group sizes overflow: the lean resident form gives up)
     uint32_t *dig; int DW, DGW, OXW;        // words per entry, words of its LDS part, offset of its bit words
     // resident plan (k_dc2015_run): 8-byte {epoch, bits} exchange granules [2][G][KB], the X trace after every
     // step [T+1][B][Nin] (entry 0 = trace at run entry), device status word
@@ -126,7 +128,9 @@ struct CascadeT {
     __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
 };
 
-constexpr int LX = 32, LR = 8;   // per-sample event-list capacities (X sources / recurrent sources)
+constexpr int LX = 64, LR = 8;   // per-sample event-list capacities (X sources / recurrent sources)
+constexpr int LXF = 16;          // ... of them the fixed-size fast paths of the per-step / general resident kernels unroll
+constexpr int GCB = 6;           // bits per group size in the digest's packed group counts (a group holds <= LX - 1 events)
 constexpr int NCAND = 2048;      // one_spike candidates evaluated one per thread (more: serial fallback)
 
 // One wave turns a row of spike bit words into the ascending list of set-bit indices (first `cap`

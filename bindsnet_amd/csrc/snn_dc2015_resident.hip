@@ -280,7 +280,7 @@ constexpr size_t resident_fixed_lds(int cw) {
 // wave (up to three {type, sample, column} events inline; more -> the full bit granules of the general form, read on
 // demand), and ONE wave receives, decodes AND scores the one_spike candidates while the others wait at the barrier, so
 // the separate list-building and scoring stages (and their barrier) disappear.  A step it does not handle (multi-valued
-// spike bytes, a sample with more than four inhibitory spikes, > 32 input events in a sample) is detected identically
+// spike bytes, a sample with more than four inhibitory spikes, > 63 input events in a sample) is detected identically
 // by every workgroup from the exchanged data: all of them leave the loop together with status SNN_ERR_RETRY, nothing
 // having been written back, and the host repeats the input on the general form.
 template <int CWR, int NTR, bool LEAN>
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
         DBG_MARK(16);
         const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
         const uint8_t *sbytes = LEAN ? nullptr : ((mflags & 1) ? sprev_g : nullptr);   // lean: such a step ends the launch (below)
-        if (tid == 0 && (mflags & 2)) atomicOr((unsigned int *)&misc[2], 2u);
+        if (tid == 0 && (mflags & (LEAN ? 4 : 2))) atomicOr((unsigned int *)&misc[2], 2u);   // lean: lists are walked by group size, any length up to LX - 1
         if (LEAN) {
             if (phaseA) { anym = (uint32_t)__builtin_amdgcn_readfirstlane(misc[3]); heavy = __builtin_amdgcn_readfirstlane(misc[6]) != 0; }
             else heavy = true;                                            // t == 0: lists from the layers' spike bytes
@@ -780,8 +780,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 {
                     (void)nX;
                     const uint32_t gc = gcnt[cb_];
-                    const int st = (cL > 0 ? (int)(gc & 31u) : 0) + (cL > 1 ? (int)((gc >> 5) & 31u) : 0) + (cL > 2 ? (int)((gc >> 10) & 31u) : 0);
-                    const int nL = (int)((gc >> (5 * cL)) & 31u);
+                    constexpr uint32_t GM = (1u << GCB) - 1u;
+                    const int st = (cL > 0 ? (int)(gc & GM) : 0) + (cL > 1 ? (int)((gc >> GCB) & GM) : 0) + (cL > 2 ? (int)((gc >> (2 * GCB)) & GM) : 0);
+                    const int nL = (int)((gc >> (GCB * cL)) & GM);
                     const uint16_t *l2 = lst2 + cb_ * LX;
                     const int n4 = Nin >> 2;
                     int ix[8]; float wx[8];
@@ -798,8 +799,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                     }
                     float v = a.finish(n4);
                     if (cL == 0) {
-                        const int s4 = (int)(gc & 31u) + (int)((gc >> 5) & 31u) + (int)((gc >> 10) & 31u) + (int)((gc >> 15) & 31u);
-                        const int n5 = (int)((gc >> 20) & 31u);
+                        const int s4 = (int)(gc & GM) + (int)((gc >> GCB) & GM) + (int)((gc >> (2 * GCB)) & GM) + (int)((gc >> (3 * GCB)) & GM);
+                        const int n5 = (int)((gc >> (4 * GCB)) & GM);
                         for (int u = 0; u < n5; ++u) {
                             const int i = (int)l2[s4 + u];
                             v += wtile[i * CW + cj_] * (xb ? (float)xb[i] : 1.0f);
@@ -828,8 +829,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
                 const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
                 const bool pv = c0 + pq < N;
                 const uint32_t gq = gqn[pb];
-                const int st = (pL > 0 ? (int)(gq & 31u) : 0) + (pL > 1 ? (int)((gq >> 5) & 31u) : 0) + (pL > 2 ? (int)((gq >> 10) & 31u) : 0);
-                const int nL = (int)((gq >> (5 * pL)) & 31u);
+                constexpr uint32_t GM = (1u << GCB) - 1u;
+                const int st = (pL > 0 ? (int)(gq & GM) : 0) + (pL > 1 ? (int)((gq >> GCB) & GM) : 0) + (pL > 2 ? (int)((gq >> (2 * GCB)) & GM) : 0);
+                const int nL = (int)((gq >> (GCB * pL)) & GM);
                 const uint16_t *lx = lstX + pb * LX;
                 const uint8_t *xb = sbytes ? sbytes + pb * Nin : nullptr;
                 int ix[8]; float wx[8];
