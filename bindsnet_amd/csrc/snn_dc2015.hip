@@ -861,8 +861,12 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     // lean form of the resident kernel (snn_dc2015_resident.hip): the common case compiled on its own.  Its receive stage
     // relies on the barrier that closes the currents stage (row_sum workgroups, or X currents on the spare threads).
     static const bool lean_on = !(getenv("SNN_DC_LEAN") && atoi(getenv("SNN_DC_LEAN")) == 0);
-    const bool lean = resident && allow_lean && lean_on && rcw == 4 && rnt == 1024 && L[1].p.one_spike &&
-                      ((size_t)Nin * N) % 32 == 0 && Nin <= 1024 && 1024 - MAXB * 4 >= B * 4 * 4;
+    const bool lean1 = resident && allow_lean && lean_on && rcw == 4 && rnt == 1024 && L[1].p.one_spike &&
+                       ((size_t)Nin * N) % 32 == 0 && Nin <= 1024 && 1024 - MAXB * 4 >= B * 4 * 4;
+    // ... and its second generation (k_dc2015_spec, "speculate, then repair"): the default wherever the lean form applies
+    // and the extra weight copy fits (developer switch SNN_DC_SPEC=0: first generation)
+    static const bool spec_on = !(getenv("SNN_DC_SPEC") && atoi(getenv("SNN_DC_SPEC")) == 0);
+    const int lean = !lean1 ? 0 : (spec_on && snn_dc2015_spec_lds(B, Nin, N) <= 150 * 1024 ? 2 : 1);
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
     static int dbg_T = 0;
@@ -889,7 +893,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
-            const int rcl = snn_dc2015_resident_launch(c, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
+            const int rcl = snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
             if (prof) snn_prof_end(qs);
             return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
@@ -972,6 +976,22 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         }
     }
     if (rc) return rc;
+    if (c.dbg && resident && lean == 2) {   // developer aid, second-generation lean kernel: its own marks (us since the iteration's start)
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h((size_t)24 * (R->T + 1));
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double a[8] = {0}, step = 0; int n = 0, nwin = 0; double awin = 0;
+        for (int t = 2; t < R->T; ++t, ++n) {
+            const long long *r = &h[(size_t)t * 24];
+            for (int k = 1; k < 8; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
+            step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
+            if (r[6] - r[5] > 30) { awin += (double)(r[6] - r[5]) / 100.0; ++nwin; }
+        }
+        fprintf(stderr, "[dc2015 spec, us from iteration start, workgroup %d] spec PostPre+X currents done %.2f | poll+decode done %.2f | rng run-ahead done %.2f | "
+                        "behind barrier R %.2f | arbitration + finals %.2f | own-winner repair %.2f | membrane + publish %.2f || iteration %.2f us; "
+                        "%d of %d iterations with a repair (avg %.2f us)\n", c.dbg_wg, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, step / n, nwin, n,
+                nwin ? awin / nwin : 0.0);
+    } else
     if (c.dbg) {   // developer aid: average phase durations (100 MHz wall clock ticks -> us)
         (void)hipStreamSynchronize(st);
         std::vector<long long> h((size_t)24 * (R->T + 1));

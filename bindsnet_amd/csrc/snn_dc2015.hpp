@@ -267,6 +267,7 @@ int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin 
 
 // resident form (snn_dc2015_resident.hip)
 size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw);
+size_t snn_dc2015_spec_lds(int B, int Nin, int N);
 int snn_dc2015_resident_cw(int N);
 int snn_dc2015_resident_nt();
 int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, int lean, hipStream_t st);

@@ -163,6 +163,63 @@ __device__ __forceinline__ void stdp_rows4(const DcCtx &c, int nact, const uint1
     }
 }
 
+// Speculative PostPre of the second-generation lean kernel (k_dc2015_spec): stdp_rows4 under the assumption that no own
+// column has a post-synaptic spike, by the `nthreads` threads qt = 0.., and with the OLD weights of every touched row
+// saved to `wold` (the repair of a winning column restarts from them).  full: every row (the first update of a run
+// clamps every element).
+__device__ __forceinline__ void spec_rows4(const DcCtx &c, bool full, int nact, const uint16_t *arows, const uint32_t *rowmask,
+                                           const float *xnu0, float *wtile, float *wold, int c0, int qt, int nthreads) {
+    const int N = c.N;
+    const bool whole = c0 + 4 <= N;
+    for (int k = qt; k < nact; k += nthreads) {
+        const int i = full ? k : (int)arows[k];
+        uint32_t m = rowmask[i];
+        const float4 w4 = *(const float4 *)(wtile + i * 4);
+        *(float4 *)(wold + i * 4) = w4;
+        float w[4] = {w4.x, w4.y, w4.z, w4.w};
+        if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            int cblk = 0;
+            while (m) {
+                const int b = __ffs(m) - 1; m &= m - 1;
+                const float4 xn = *(const float4 *)(xnu0 + b * 4);
+                const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+                const float same = (b >> 4) == cblk ? 1.f : 0.f, diff = 1.f - same;
+                cblk = b >> 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+                    a0[q] = __builtin_fmaf(a0[q], same, 1.0f * xv[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] - uu;
+            }
+        }
+        if (c.nu1 != 0.f) {                                      // + dt * (empty sum): what the update adds without a post-synaptic spike
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float uu = 0.f;
+                if (c.use_dt) uu = uu * c.dt;
+                w[q] = w[q] + uu;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c.has_min && w[q] < c.wmin) w[q] = c.wmin;
+            if (c.has_max && w[q] > c.wmax) w[q] = c.wmax;
+        }
+        if (whole) *(float4 *)(wtile + i * 4) = make_float4(w[0], w[1], w[2], w[3]);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c0 + q < N) wtile[i * 4 + q] = w[q];
+        }
+    }
+}
+
 // Columns with a post-synaptic spike x rows WITHOUT a pre-synaptic spike, on the LDS-resident slice.
 template <class SUM, int CWL, int NTL>
 __device__ __forceinline__ void stdp_cols_lds(const DcCtx &c, uint32_t active_cols, const uint32_t *rowmask,
@@ -1045,6 +1102,668 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     }
 }
 
+// =====================================================================================================================
+// Lean form, second generation ("speculate, then repair"): the same arithmetic and the same compact exchange as
+// k_dc2015_run<4, 1024, true>, re-ordered so that everything of a timestep that does NOT depend on the spike exchange
+// runs while the exchange is in flight.
+//
+// What of "finish step t-1, start step t" depends on the other workgroups' spikes of step t-1?  Only (1) which of the own
+// crossings WON the one_spike arbitration (-> Ae trace, PostPre post-synaptic term of that column, the Ae -> Ai current)
+// and (2) the inhibitory currents.  A (sample, column) pair without a winner -- all but ~3 of the 12 800 pairs of a step
+// at cfg2 -- has a trace that just decays, a PostPre that is its pre-synaptic term, and X -> Ae currents that follow from
+// those.  So, per iteration t:
+//
+//   speculative window (no workgroup barrier; the exchange of epoch t is in flight):
+//     waves 2..9    PostPre of step t-1 for every active row under the assumption "no own winner" (old weights of the
+//                   touched rows kept in `wold`), LDS-counter barrier among these 8 waves, X -> Ae currents of step t
+//     waves 10..13  poll + decode the summary granules of epoch t (crossings / Ai spikes of step t-1)
+//     wave 14       spike-raster rows of step t-2, digest of step t+1 -> LDS
+//     wave 15       generator run-ahead
+//   barrier R
+//   arbitration (as before), barrier when a sample crossed
+//   every wave derives from the winners whether an OWN column won (no barrier needed for that).  Only then (uniform):
+//     trace / x_tgt*nu0 of the winners, barrier, PostPre of the winning column(s) redone for all rows from `wold`
+//     (pre-synaptic term with the new trace + post-synaptic term), barrier, their X -> Ae currents redone, barrier
+//   tile threads: recurrent currents (at most one Ai spike and one final Ae spike per sample, else the launch gives
+//   up with SNN_ERR_RETRY like for any other step the lean form does not take), membrane update, publish epoch t+1,
+//   speculative trace of step t (x_tgt*nu0 for the next window)
+//   barrier E
+// Bit-exactness: every value is produced by the same operations in the same order as in the first-generation kernel;
+// a repaired element is recomputed from its OLD weight by the (row, column) form of the update (stdp_rows_lds).
+template <int NTR>
+__global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
+    constexpr int CW = 4, TT = MAXB * CW, NT = NTR;
+    constexpr int NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW;
+    constexpr int NWV = NT / 64;
+    constexpr int W_Q0 = 2, W_QN = 8;                     // waves doing the speculative PostPre + X currents (QT threads)
+    constexpr int QT = W_QN * 64;
+    constexpr int W_P0 = 10, W_PN = 4;                    // polling / decoding waves
+    constexpr int W_AUX = 14, W_RNG = 15;
+    static_assert(NT == 1024 && QT >= MAXB * CW * 4, "wave roles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
+    (void)NinW;
+    constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + 2 * kBitWords * 4,
+                     O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + 8 * 624 * 4,
+                     O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
+                     O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
+                     O_LSTIB = O_MISC + 32, O_CNTIB = O_LSTIB + MAXB * LR * 2,
+                     O_CURB = O_CNTIB + MAXB * 4, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
+    static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
+    uint32_t *crs = (uint32_t *)(smem + O_CRS);
+    uint32_t *finE = (uint32_t *)(smem + O_FINE);
+    uint32_t *spI2 = (uint32_t *)(smem + O_SPI);
+    float *xnu0 = (float *)(smem + O_XNU0);
+    uint32_t *mt = (uint32_t *)(smem + O_MT);
+    unsigned long long *keys = (unsigned long long *)(smem + O_KEYS);
+    uint16_t *lstI0 = (uint16_t *)(smem + O_LSTI), *lstI1 = (uint16_t *)(smem + O_LSTIB);
+    uint16_t *lstE = (uint16_t *)(smem + O_LSTE);
+    int *cntI0 = (int *)(smem + O_CNTI), *cntI1 = (int *)(smem + O_CNTIB);
+    int *cnt = (int *)(smem + O_CNT);
+    uint32_t *colmask = (uint32_t *)(smem + O_COLM);
+    int *misc = (int *)(smem + O_MISC);                    // [2] give-up flag (monotonic: once set the launch ends)
+    // cnt[0..7]: crossing counts of the own columns by step parity; [16 + p]: samples with a crossing, [18 + p]: overflow
+    // mark (p = iteration parity: the decode of iteration t fills what iteration t-1's aux wave cleared); [20]: counter of
+    // the barrier among the speculative waves
+    float *curX = (float *)(smem + O_CURB);                // [B][CW] X -> Ae part of the Ae current of step t
+    float *stl = (float *)(smem + O_ST);
+    float *wtile = (float *)(smem + O_WT);
+    float *wieT = wtile + (size_t)Nin * CW;
+    float *weiT = wieT + (size_t)N * CW;
+    const int DGS = (c.DGW + 63) & ~63;
+    uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
+    float *wold = (float *)(dgbuf + 2 * DGS);              // [Nin][CW] weights as they were before this step's speculative PostPre
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, c0 = g * CW;
+    if (g == c.stall_wg) return;
+    const int jj = tid % CW, bl = tid / CW;
+    const int j = c0 + jj;
+    const bool colv = j < N;
+    const bool tailcol = c0 >= (N / 32) * 32;
+    const int BW = B * NW;
+    const bool mine = tid < TT && bl < B && colv;
+    const unsigned kst = (unsigned)(bl * N + j);
+    const int wb = (int)(((float)tid + 0.5f) * c.inv_NW), wj = tid - wb * NW;
+    const int KB = c.KB, NG = c.G * KB;
+    const int NGS = c.G * NTW;
+
+    for (int k = tid; k < Nin * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wtile[k] = (c0 + q < N) ? c.Wxe[i * N + c0 + q] : 0.f;
+    }
+    for (int k = tid; k < N * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wieT[k] = (c0 + q < N) ? c.Wie[i * N + c0 + q] : 0.f;
+        weiT[k] = (c0 + q < N) ? c.Wei[i * N + c0 + q] : 0.f;
+    }
+    auto fetch_digest = [&](int e, int first_wave, int nwaves) {        // by `nwaves` whole waves starting at `first_wave`
+        const uint32_t *Dg = c.dig + (size_t)e * c.DW;
+        uint32_t *dst = dgbuf + (e & 1) * DGS;
+        for (int base = (wave - first_wave) * 256; base < c.DGW; base += nwaves * 256) {
+            const int ub = __builtin_amdgcn_readfirstlane(base);
+            if (ub + lane * 4 < c.DGW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(dst + ub), 16, 0, 0);
+        }
+    };
+    fetch_digest(0, 0, NWV);
+    bool last_sE = false, last_sI = false;
+    if (mine) {
+        stl[0 * TT + tid] = c.vE[kst]; stl[1 * TT + tid] = c.rE[kst]; stl[2 * TT + tid] = c.vI[kst]; stl[3 * TT + tid] = c.rI[kst];
+        stl[4 * TT + tid] = c.pE.lif.traces ? c.xE[kst] : 0.f;
+        stl[5 * TT + tid] = c.pI.traces ? c.xI[kst] : 0.f;
+        stl[6 * TT + tid] = c.theta[j];
+        last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
+    }
+    int rng_pos = 0, mb = 0, ahead = 0; long long rng_consumed = 0;
+    {
+        for (int k = tid; k < 624; k += NT) mt[k] = c.rng[0]->mt[k];
+        rng_pos = __builtin_amdgcn_readfirstlane(c.rng[0]->pos);
+        const long long cons0 = c.rng[0]->consumed;
+        rng_consumed = ((long long)__builtin_amdgcn_readfirstlane((int)(cons0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cons0);
+    }
+    if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
+    if (tid < 8) misc[tid] = 0;
+    if (tid < MAXB) { keys[tid] = 0ull; cntI0[tid] = 0; cntI1[tid] = 0; }
+    if (tid < TT) { xnu0[tid] = 0.f; curX[tid] = 0.f; }
+    if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
+    bool failed = false;
+    int sub_target = 0;                                     // LDS-counter barrier among the W_QN speculative waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto win_of = [&](int b) -> int { return (int)(0xFFFFFFFFu - (uint32_t)(keys[b] & 0xFFFFFFFFull)); };
+    // raster rows (final Ae spikes / Ai spikes) of one step, whole [N]-byte rows, row r of the 2*B rows by workgroup r mod G
+    auto raster_rows = [&](int step, const uint32_t *spi_bits, int first_thread, int nthreads) {
+        for (int r = g; r < 2 * B; r += c.G) {
+            const int b = r < B ? r : r - B;
+            uint8_t *ras = r < B ? c.rasE : c.rasI;
+            const uint32_t *bitsrc = (r < B ? finE : spi_bits) + b * NW;
+            if (ras) { uint8_t *row = ras + ((size_t)step * B + b) * N; for (int jx = tid - first_thread; jx < N; jx += nthreads) row[jx] = (uint8_t)bit_of(bitsrc, jx); }
+        }
+    };
+
+    for (int t = 0; t <= T; ++t) {
+        const bool phaseA = t >= 1, phaseB = t < T;
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 0] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 8] = (long long)clock64(); }
+        if (c.dbg && threadIdx.x == 0) atomicMin((unsigned long long *)&c.dbg[(size_t)t * 24 + 20], (unsigned long long)wall_clock64());
+        uint32_t *spI = spI2 + (t & 1) * kBitWords;
+        const uint32_t *dg = dgbuf + (t & 1) * DGS;                       // digest of the X spikes of step t-1
+        const uint16_t *lstX = (const uint16_t *)dg;
+        const int *meta = (const int *)(dg + B * (LX / 2));
+        const uint32_t *rowmask = dg + B * (LX / 2) + 40;
+        const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
+        const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);
+        const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
+        const uint32_t *gqn = gcnt + B;
+        uint16_t *lstI = (t & 1) ? lstI1 : lstI0;
+        int *cntI = (t & 1) ? cntI1 : cntI0;
+        const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
+        const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
+        const bool stdp_full = t == 1;
+        const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
+        const float *xsrc = c.xtr + (size_t)t * B * Nin;                  // X trace after step t-1
+        const bool use_rng = phaseA;
+
+        // X -> Ae part of the Ae currents of step t (from the X spikes of step t-1 and the CURRENT weight slice) for the
+        // columns in `cols`, four threads per (sample, column) pair: qt <-> (sample qt / 16, column (qt / 4) % 4, lane qt % 4)
+        auto x_currents = [&](int qt, uint32_t cols) {
+            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+            if (pb >= B || !((cols >> pq) & 1u)) return;
+            const bool pv = c0 + pq < N;
+            constexpr uint32_t GM = (1u << GCB) - 1u;
+            if (tailcol) {
+                // row_sum columns: lane pL walks ITS sub-list of the sample's events (grouped by source index mod 4), lane 0
+                // then adds the n % 4 leftover sources in order
+                const uint32_t gc = gcnt[pb];
+                const int st = (pL > 0 ? (int)(gc & GM) : 0) + (pL > 1 ? (int)((gc >> GCB) & GM) : 0) + (pL > 2 ? (int)((gc >> (2 * GCB)) & GM) : 0);
+                const int nL = (int)((gc >> (GCB * pL)) & GM);
+                const uint16_t *l2 = lst2 + pb * LX;
+                const int n4 = Nin >> 2;
+                int ix[8]; float wx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + pq];
+                CascadeFlat a; a.init();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u] >> 2, wx[u] * 1.0f, n4);
+                for (int u = 8; u < nL; ++u) {
+                    const int i = (int)l2[st + u];
+                    a.add(i >> 2, wtile[i * CW + pq] * 1.0f, n4);
+                }
+                float v = a.finish(n4);
+                if (pL == 0) {
+                    const int s4 = (int)(gc & GM) + (int)((gc >> GCB) & GM) + (int)((gc >> (2 * GCB)) & GM) + (int)((gc >> (3 * GCB)) & GM);
+                    const int n5 = (int)((gc >> (4 * GCB)) & GM);
+                    for (int u = 0; u < n5; ++u) {
+                        const int i = (int)l2[s4 + u];
+                        v += wtile[i * CW + pq] * 1.0f;
+                    }
+                }
+                const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
+                const float e1 = ((v + v1) + v2) + v3;
+                if (pL == 0 && pv) curX[pb * CW + pq] = 0.0f + e1;
+            } else {
+                // multi_row_sum columns: the cascade's 256-position groups are independent partial sums
+                const uint32_t gq = gqn[pb];
+                const int st = (pL > 0 ? (int)(gq & GM) : 0) + (pL > 1 ? (int)((gq >> GCB) & GM) : 0) + (pL > 2 ? (int)((gq >> (2 * GCB)) & GM) : 0);
+                const int nL = (int)((gq >> (GCB * pL)) & GM);
+                const uint16_t *lx = lstX + pb * LX;
+                int ix[8]; float wx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ix[u] = min((int)lx[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + pq];
+                CascadeFlat a; a.init();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u], wx[u] * 1.0f, Nin);
+                for (int u = 8; u < nL; ++u) {
+                    const int ii2 = (int)lx[st + u];
+                    a.add(ii2, wtile[ii2 * CW + pq] * 1.0f, Nin);
+                }
+                const float G = a.a1 + a.a0;
+                const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
+                if (pL == 0 && pv) {
+                    const int GL = (Nin >> 4) >> 4;
+                    const float Gs[4] = {G, G1, G2, G3};
+                    float A2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
+                    float Gl = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
+                    const float res = ((0.0f + Gl) + A2) + 0.0f;
+                    curX[pb * CW + pq] = 0.0f + res;
+                }
+            }
+        };
+
+        // ------------------------------------------------------------------ t == 0: spikes of the step before the run
+        if (!phaseA) {
+            if (tid < BW) {
+                uint32_t me = 0, mi = 0;
+                for (int qq = 0; qq < 32; ++qq) {
+                    const int jx = wj * 32 + qq;
+                    if (jx < N) { me |= (uint32_t)(c.sE[wb * N + jx] != 0) << qq; mi |= (uint32_t)(c.sI[wb * N + jx] != 0) << qq; }
+                }
+                finE[tid] = me; spI[tid] = mi;
+            }
+            lds_barrier();
+        }
+        // ================================================================== speculative window
+        if (wave >= W_Q0 && wave < W_Q0 + W_QN) {
+            const int qt = tid - W_Q0 * 64;
+            if (do_stdp) {
+                spec_rows4(c, stdp_full, nact, arows, rowmask, xnu0, wtile, wold, c0, qt, QT);
+                // barrier among these waves only: the pollers must not be held up, and they cannot join a workgroup barrier
+                sub_target += W_QN;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&cnt[20], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(&cnt[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sub_target) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            }
+            if (phaseB) x_currents(qt, 0xFu);
+            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_Q0 * 64) c.dbg[(size_t)t * 24 + 1] = (long long)wall_clock64();
+        } else if (wave >= W_P0 && wave < W_P0 + W_PN) {
+            if (phaseA) {
+                // ---- one thread per summary granule: poll it, decode its events into the bit words / Ai event lists /
+                //      crossing-sample mask
+                const unsigned long long *sums = c.exs + (size_t)(t & 1) * NGS;
+                const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
+                for (int gi = tid - W_P0 * 64; gi < NGS; gi += W_PN * 64) {
+                    unsigned long long x;
+                    for (unsigned spins = 0;; ++spins) {
+                        x = granule_load(sums + gi);
+                        if ((uint32_t)(x >> 32) == (uint32_t)t || failed) break;
+                        if (spins > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    const uint32_t pay = (uint32_t)x;
+                    if (!pay) continue;
+                    uint32_t my_any = 0;
+                    auto event = [&](int bsm, int jx, bool inh) {       // one crossing / inhibitory spike of step t-1
+                        if (bsm >= B || jx >= N) return;
+                        if (!inh) { atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31)); my_any |= 1u << bsm; }
+                        else {
+                            atomicOr((unsigned int *)&spI[bsm * NW + (jx >> 5)], 1u << (jx & 31));
+                            const int slot = atomicAdd(&cntI[bsm], 1);
+                            if (slot < LR) lstI[bsm * LR + slot] = (uint16_t)jx;
+                            if (slot >= 1) atomicOr((unsigned int *)&misc[2], 2u);   // more than the one-entry fast path takes
+                        }
+                    };
+                    const int gsrc = gi / NTW, w = gi - gsrc * NTW;
+                    if ((pay & 0xFFu) == 0xFFu) {                        // overflow: that wave's full bit granules
+                        cnt[18 + (t & 1)] = 1;
+                        for (int q = 0; q < SPW / SPG; ++q) {
+                            const int k = w * (SPW / SPG) + q;
+                            if (k >= KB) break;
+                            unsigned long long d;
+                            for (unsigned sp2 = 0;; ++sp2) {
+                                d = granule_load(exr + gsrc * KB + k);
+                                if ((uint32_t)(d >> 32) == (uint32_t)t || failed) break;
+                                if (sp2 > kPollLimit) { failed = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            uint32_t be = (uint32_t)d & 0xFFFFu, bi = ((uint32_t)d >> 16) & 0xFFFFu;
+                            while (be) { const int p_ = __ffs(be) - 1; be &= be - 1; event(k * SPG + p_ / CW, gsrc * CW + p_ % CW, false); }
+                            while (bi) { const int p_ = __ffs(bi) - 1; bi &= bi - 1; event(k * SPG + p_ / CW, gsrc * CW + p_ % CW, true); }
+                        }
+                    } else {
+                        const int ne = (int)(pay >> 30);
+                        for (int e = 0; e < ne; ++e) {
+                            const uint32_t ev = (pay >> (8 * e)) & 0xFFu;
+                            const int p_ = (int)(ev & 0x3Fu);
+                            event(w * SPW + p_ / CW, gsrc * CW + p_ % CW, (ev & 0x40u) != 0);
+                        }
+                    }
+                    if (my_any) atomicOr((unsigned int *)&cnt[16 + (t & 1)], my_any);
+                }
+            } else {
+                // t == 0: lists / "winners" straight from the layers' spike bits (more than one spike per sample: give up)
+                for (int b = wave - W_P0; b < B; b += W_PN) {
+                    const int ni = build_list(spI + b * NW, NW, lane, lstI + b * LR, LR);
+                    const int ne = build_list(finE + b * NW, NW, lane, lstE + b * LR, LR);
+                    if (lane == 0) {
+                        cntI[b] = ni;
+                        if (ni > 1 || ne > 1) atomicOr((unsigned int *)&misc[2], 2u);
+                        if (ne) { keys[b] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)lstE[b * LR]); atomicOr((unsigned int *)&cnt[16], 1u << b); }
+                    }
+                }
+            }
+            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_P0 * 64) c.dbg[(size_t)t * 24 + 2] = (long long)wall_clock64();
+        } else if (wave == W_AUX) {
+            // scratch of the iterations to come: their last readers ended before barrier E, their writers start behind R
+            if (lane < CW) cnt[(t & 1) * CW + lane] = 0;                     // this step's crossing counts
+            if (lane == 8) { cnt[16 + ((t + 1) & 1)] = 0; cnt[18 + ((t + 1) & 1)] = 0; }   // what the NEXT decode accumulates into
+            if (t >= 1 && lane < MAXB) keys[lane] = 0ull;                   // (t == 0: the list pass above writes them)
+            if (t >= 2) raster_rows(t - 2, spI2 + ((t - 1) & 1) * kBitWords, W_AUX * 64, 64);
+            if (t < T) { fetch_digest(t + 1, W_AUX, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        } else if (wave == W_RNG) {
+            if (use_rng)
+                for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
+            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_RNG * 64) c.dbg[(size_t)t * 24 + 3] = (long long)wall_clock64();
+        }
+        if (use_rng) ahead = 7;
+        lds_barrier();                                                    // ---- R: exchange decoded, speculative results in place
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 4] = (long long)wall_clock64();
+        // ---- a step the lean form does not handle: every workgroup derives this from the same exchanged data / input
+        //      digest, so all of them leave here in the same iteration and nobody is left waiting for a granule
+        if ((__builtin_amdgcn_readfirstlane(misc[2]) & 2) || (mflags & 5)) {
+            if (tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            failed = true;
+            break;
+        }
+        const uint32_t anym = (uint32_t)__builtin_amdgcn_readfirstlane(cnt[16 + (t & 1)]);   // samples with an Ae crossing (t == 0: with an Ae spike)
+        bool heavy = phaseA && __builtin_amdgcn_readfirstlane(cnt[18 + (t & 1)]) != 0;
+        if (phaseB) {   // what the NEXT decode accumulates into: its previous readers ended before barrier R
+            for (int k = tid; k < BW; k += NT) spI2[((t + 1) & 1) * kBitWords + k] = 0;
+            if (tid < MAXB) ((t & 1) ? cntI0 : cntI1)[tid] = 0;
+        }
+        // ---- one_spike arbitration, identical in every workgroup (see k_dc2015_run for the reasoning)
+        int arb_rows = 0, arb_E = 0, arb_ntw = 0;
+        if (use_rng) {
+            arb_rows = __popc(anym);
+            arb_E = rng_pos + 2 * arb_rows * N;
+            arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
+            if (arb_ntw > 7) heavy = true;
+            if (!heavy && arb_rows) {
+                int r = 0;
+                for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
+                    if ((r % NWV) != wave) continue;
+                    const int bsm = __ffs(rem) - 1;
+                    const uint32_t bits = lane < NW ? crs[bsm * NW + lane] : 0u;
+                    unsigned long long k1 = ~0ull, k2 = ~0ull;
+                    for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                        const int jx = lane * 32 + __ffs(bb) - 1;
+                        const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
+                        const int m0 = w0 / 624, m1 = w1 / 624;
+                        const uint32_t hi = mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]);
+                        const uint32_t lo = mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]);
+                        const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
+                        const unsigned long long key = (m << 10) | (unsigned long long)jx;
+                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                    }
+                    if (lane == 0) keys[bsm] = ~0ull;
+                    if (bits) atomicMin(&keys[bsm], k1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long kmin = *(volatile unsigned long long *)&keys[bsm];
+                    const unsigned long long mmin = kmin >> 10, zone = mmin + (mmin >> c.zone_shift) + 1ull;
+                    const bool close = (k1 != ~0ull && k1 != kmin && (k1 >> 10) <= zone) || (k2 != ~0ull && (k2 >> 10) <= zone);
+                    int win = (int)(kmin & 1023ull);
+                    if (__any(close)) {
+                        if (lane == 0) keys[bsm] = 0ull;
+                        for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                            const int jx = lane * 32 + __ffs(bb) - 1;
+                            const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
+                            const int m0 = w0 / 624, m1 = w1 / 624;
+                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                            mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                            const float val = 1.0f / q;
+                            atomicMax(&keys[bsm], ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        win = (int)(0xFFFFFFFFu - (uint32_t)(*(volatile unsigned long long *)&keys[bsm] & 0xFFFFFFFFull));
+                    }
+                    if (lane == 0) keys[bsm] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)win);
+                }
+            }
+            if (heavy && arb_ntw <= 7 && tid < BW) {
+                uint32_t bits = crs[tid];
+                const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
+                while (bits) {
+                    const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                    const int d = myrank * N + jx;
+                    const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
+                    const int m0 = w0 / 624, m1 = w1 / 624;
+                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
+                                                    mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                    const float val = 1.0f / q;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                    atomicMax(&keys[wb], key);
+                }
+            }
+        }
+        if (heavy || arb_rows > 0) lds_barrier();
+        if (use_rng) {
+            const int rows = arb_rows, pos = rng_pos, E = arb_E, ntw = arb_ntw;
+            if (ntw > 7) {
+                const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
+                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT);
+                ahead = ntw;
+                lds_barrier();
+            }
+            for (int k = tid; k < BW; k += NT) crs[k] = 0;   // (every reader of this step's crossings is done)
+            if (tid < BW) {        // final spikes (for the raster rows): the winner's bit, or nothing
+                uint32_t wbits = 0;
+                if ((anym >> wb) & 1u) {
+                    const int win = win_of(wb);
+                    if ((win >> 5) == wj) wbits = 1u << (win & 31);
+                }
+                finE[tid] = wbits;
+            }
+            mb = (mb + ntw) & 7; ahead -= ntw;
+            rng_pos = E - 624 * ntw;
+            rng_consumed += (long long)rows * N;
+        }
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 5] = (long long)wall_clock64();
+        // ---- did an OWN column win?  Every wave reads the winners itself (uniform result, no barrier)
+        uint32_t ownwin = 0;
+        if (phaseA && anym) {
+            const int bsm = lane & 31;
+            int q = -1;
+            if (lane < 32 && bsm < B && ((anym >> bsm) & 1u)) { const int win = win_of(bsm); if (win >= c0 && win < c0 + CW) q = win - c0; }
+#pragma unroll
+            for (int qq = 0; qq < CW; ++qq) if (__ballot(q == qq)) ownwin |= 1u << qq;
+        }
+        // ---- Ae trace of step t-1 with the final spikes (nodes.py:96-103); winners also refresh x_tgt*nu0
+        if (phaseA && tid < TT && bl < B && colv) {
+            const bool sp = ((anym >> bl) & 1u) && win_of(bl) == j;
+            if (c.pE.lif.traces) {
+                const float xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                stl[4 * TT + tid] = xn;
+                if (sp) xnu0[bl * CW + jj] = xn * c.nu0;
+            }
+            if (sp && do_stdp) atomicOr(&colmask[jj], 1u << bl);
+            last_sE = sp;
+        }
+        if (ownwin && do_stdp) {
+            // ---- repair: the winning column(s) only.  Every row of such a column gets the post-synaptic term; rows with a
+            //      pre-synaptic spike restart from their old weight with the winner's new trace in the pre-synaptic term.
+            lds_barrier();
+            const int Emain = Nin * N;                                   // (lean form: Nin*N % 32 == 0, no tail elements)
+            for (uint32_t cols = ownwin; cols; cols &= cols - 1) {
+                const int q = __ffs(cols) - 1, jq = c0 + q;
+                if (jq >= N) continue;
+                const uint32_t cm = (c.nu1 != 0.f) ? colmask[q] : 0u;
+                for (int i = tid; i < Nin; i += NT) {
+                    uint32_t m = rowmask[i];
+                    const bool touched = stdp_full || m != 0;
+                    float w = touched ? wold[i * CW + q] : wtile[i * CW + q];
+                    const int e = i * N + jq;
+                    if (c.nu0 != 0.f) {
+                        float uu = 0.f;
+                        if (m) {
+                            CascadeT acc; acc.init(e >= Emain);
+                            while (m) {
+                                const int b = __ffs(m) - 1; m &= m - 1;
+                                acc.add(b, 1.0f * xnu0[b * CW + q], B);
+                            }
+                            uu = acc.finish(B);
+                        }
+                        if (c.use_dt) uu = uu * c.dt;
+                        w = w - uu;
+                    }
+                    if (c.nu1 != 0.f) {
+                        uint32_t mm = cm;
+                        float uu = 0.f;
+                        if (mm) {
+                            CascadeT acc; acc.init(e >= Emain);
+                            while (mm) {
+                                const int b = __ffs(mm) - 1; mm &= mm - 1;
+                                acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
+                            }
+                            uu = acc.finish(B);
+                        }
+                        if (c.use_dt) uu = uu * c.dt;
+                        w = w + uu;
+                    }
+                    if (c.has_min && w < c.wmin) w = c.wmin;
+                    if (c.has_max && w > c.wmax) w = c.wmax;
+                    wtile[i * CW + q] = w;
+                }
+            }
+            lds_barrier();
+            if (phaseB && wave >= W_Q0 && wave < W_Q0 + W_QN) x_currents(tid - W_Q0 * 64, ownwin);
+            if (tid < CW) colmask[tid] = 0;
+            lds_barrier();
+        }
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 6] = (long long)wall_clock64();
+        if (!phaseB) break;
+
+        // ================================================================== start step t (tile threads)
+        float curE = 0.f, curI = 0.f;
+        if (mine) {
+            const int nI = cntI[bl];                                       // Ai spikes of step t-1 in this sample: 0 or 1
+            const int iI = min((int)lstI[bl * LR], N - 1);
+            const float e2 = nI ? wieT[iI * CW + jj] * 1.0f + 0.0f : 0.0f;
+            const bool hasE = (anym >> bl) & 1u;                           // final Ae spike of step t-1 in this sample: 0 or 1
+            const int iE = hasE ? min(win_of(bl), N - 1) : 0;
+            const float e3 = hasE ? weiT[iE * CW + jj] * 1.0f + 0.0f : 0.0f;
+            curE = curX[bl * CW + jj] + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
+            curI = 0.0f + e3;                                              // zeros + Ae->Ai
+        }
+        bool spE = false, spIn = false;
+        float r_vE = 0.f, r_vI = 0.f;
+        if (mine) {
+            float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
+            r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
+            if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)cnt[((t - 1) & 1) * CW + jj];
+            if (c.pE.learning) th = th * c.pE.theta_decay;
+            spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
+            if (spE) atomicAdd(&cnt[(t & 1) * CW + jj], 1);
+            float ci = curI;
+            if (r_rI > 0.f) ci = 0.f;
+            spIn = lif_update(r_vI, r_rI, ci, c.pI);
+            last_sI = spIn;
+            stl[0 * TT + tid] = r_vE; stl[1 * TT + tid] = r_rE; stl[2 * TT + tid] = r_vI; stl[3 * TT + tid] = r_rI; stl[6 * TT + tid] = th;
+            if (c.pI.traces) stl[5 * TT + tid] = trace_next(stl[5 * TT + tid], spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
+        }
+        if (wave < NTW) {
+            // publish step t as epoch t+1: ONE summary granule per tile wave (see k_dc2015_run)
+            const uint64_t mE = __ballot(spE), mI = __ballot(spIn);
+            const int nev = __popcll(mE) + __popcll(mI);
+            uint32_t pay;
+            if (nev <= 3) {
+                pay = (uint32_t)nev << 30;
+                int sh = 0;
+                for (uint64_t m = mE; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
+                for (uint64_t m = mI; m; m &= m - 1) { pay |= (uint32_t)(0x40 | (__ffsll((unsigned long long)m) - 1)) << sh; sh += 8; }
+            } else {
+                const int sidx = lane / CW, b = wave * SPW + sidx;
+                const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFFFull) << 16);
+                if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
+                    granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pay = 0xC0FFFFFFu;
+            }
+            if (lane == 0) granule_store(c.exs + (size_t)((t + 1) & 1) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+        }
+        if (tid < TT && bl < B) {
+            // speculative x_tgt*nu0 of step t for the next window: the trace as it is if this pair does not win
+            float xs = 0.f;
+            if (colv && c.pE.lif.traces) xs = trace_next(stl[4 * TT + tid], 0, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+            xnu0[bl * CW + jj] = xs * c.nu0;
+        }
+        if (mine) {
+            if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
+            if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
+        }
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 7] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 9] = (long long)clock64(); }
+        if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
+        lds_barrier();                                                    // ---- E
+    }
+
+    // ---- epilogue (as k_dc2015_run's): nothing the caller owns as STATE has been written so far
+    if (tid == 0) misc[4] = c.status ? __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (failed) misc[5] = 1;
+    __syncthreads();
+    if (misc[4] != 0 || misc[5] != 0) return;
+    raster_rows(T - 1, spI2 + (T & 1) * kBitWords, 0, NT);            // the last step's rows (the aux wave writes a step's rows two iterations later)
+    if (c.x_traces) {
+        const float *src = c.xtr + (size_t)T * B * Nin;
+        for (int k = g * NT + tid; k < B * Nin; k += c.G * NT) c.xX[1][k] = src[k];
+    }
+    if (mine) {
+        float th = stl[6 * TT + tid];
+        if (c.pE.learning) th = th + c.pE.theta_plus * (float)cnt[((T - 1) & 1) * CW + jj];
+        c.vE[kst] = stl[0 * TT + tid]; c.rE[kst] = stl[1 * TT + tid]; c.vI[kst] = stl[2 * TT + tid]; c.rI[kst] = stl[3 * TT + tid];
+        if (bl == 0) c.theta[j] = th;
+        if (c.pI.traces) c.xI[kst] = stl[5 * TT + tid];
+        if (c.pE.lif.traces) c.xE[kst] = stl[4 * TT + tid];
+        c.sE[kst] = last_sE; c.sI[kst] = last_sI;
+    }
+    if (c.has_norm) {
+        float *bsum = (float *)dgbuf;
+        float *sc = xnu0;
+        const int nfull = Nin >> 4;
+        __syncthreads();
+        if (!tailcol) {
+            for (int item = tid; item < nfull * CW; item += NT) {
+                const int blk = item / CW, q = item % CW;
+                float a0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const float w = wtile[(blk * 16 + k) * CW + q]; a0 += c.norm_abs ? fabsf(w) : w; }
+                bsum[item] = a0;
+            }
+            __syncthreads();
+            if (tid < CW) {
+                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int blk = 0; blk < nfull; ++blk) {
+                    a1 += bsum[blk * CW + tid];
+                    const int m = blk + 1;
+                    if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+                }
+                float a0 = 0.f;
+                for (int i = nfull * 16; i < Nin; ++i) { const float w = wtile[i * CW + tid]; a0 += c.norm_abs ? fabsf(w) : w; }
+                float cs = ((a0 + a1) + a2) + a3;
+                if (cs == 0.f) cs = 1.0f;
+                sc[tid] = (1.0f / cs) * c.norm;
+            }
+        } else {
+            __syncthreads();
+            if (tid < CW * 4) {
+                const int q = tid >> 2, s4 = tid & 3, n4 = Nin >> 2, nf4 = n4 >> 4;
+                Cascade cc; cc.init();
+                for (int p_ = 0; p_ < n4; ++p_) { const float w = wtile[(4 * p_ + s4) * CW + q]; cc.add(p_, c.norm_abs ? fabsf(w) : w, nf4); }
+                float lsum = cc.finish(nf4);
+                if (s4 == 0)
+                    for (int i = n4 * 4; i < Nin; ++i) { const float w = wtile[i * CW + q]; lsum += c.norm_abs ? fabsf(w) : w; }
+                const float l1 = __shfl_down(lsum, 1, 4), l2 = __shfl_down(lsum, 2, 4), l3 = __shfl_down(lsum, 3, 4);
+                float cs = ((lsum + l1) + l2) + l3;
+                if (cs == 0.f) cs = 1.0f;
+                if (s4 == 0) sc[q] = (1.0f / cs) * c.norm;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k] * sc[q];
+        }
+    } else if (c.learning && c.rule == SNN_RULE_POSTPRE) {
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k];
+        }
+    }
+    if (g == 0) {
+        snn_rng_state *wr = c.rng[0];
+        for (int k = tid; k < 624; k += NT) wr->mt[k] = mt[mb * 624 + k];
+        if (tid == 0) { wr->pos = rng_pos; wr->consumed = rng_consumed; }
+    }
+}
+
 // words of one digest entry / of its part that the step kernel copies into LDS
 size_t lds_bytes_resident(int B, int Nin, int N, int cw) {
     const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
@@ -1065,11 +1784,14 @@ int resident_cw(int N) {
 }  // namespace
 
 size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw) { return lds_bytes_resident(B, Nin, N, cw); }
+// second-generation lean form (k_dc2015_spec): + the [Nin][4] copy of the weights the speculative PostPre started from
+size_t snn_dc2015_spec_lds(int B, int Nin, int N) { return lds_bytes_resident(B, Nin, N, 4) + (size_t)Nin * 4 * 4; }
 int snn_dc2015_resident_cw(int N) { return resident_cw(N); }
 int snn_dc2015_resident_nt() { return resident_nt(); }
 
-static const void *resident_variant(int cw, int nt, bool lean = false) {
-    if (lean) return (const void *)k_dc2015_run<4, 1024, true>;         // the lean form exists for 4-column tiles only
+static const void *resident_variant(int cw, int nt, int lean = 0) {   // lean: 0 general form, 1 lean form, 2 its second generation
+    if (lean == 2) return (const void *)k_dc2015_spec<1024>;
+    if (lean) return (const void *)k_dc2015_run<4, 1024, true>;         // the lean forms exist for 4-column tiles only
     if (nt == 512 && cw == 4) return (const void *)k_dc2015_run<4, 512, false>;
     if (nt == 512) return (const void *)k_dc2015_run<2, 512, false>;
     if (cw == 8) return (const void *)k_dc2015_run<8, 1024, false>;
@@ -1081,9 +1803,9 @@ static bool resident_attr_once() {
     static int state = 0;          // 0 = not tried, 1 = ok, -1 = failed
     if (!state) {   // the kernel uses more than the default 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         state = 1;
-        const int cws[6] = {8, 4, 2, 4, 2, 4}, nts[6] = {1024, 1024, 1024, 512, 512, 1024};
-        for (int k = 0; k < 6; ++k)
-            if (snn_check(hipFuncSetAttribute(resident_variant(cws[k], nts[k], k == 5), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) state = -1;
+        const int cws[7] = {8, 4, 2, 4, 2, 4, 4}, nts[7] = {1024, 1024, 1024, 512, 512, 1024, 1024}, lns[7] = {0, 0, 0, 0, 0, 1, 2};
+        for (int k = 0; k < 7; ++k)
+            if (snn_check(hipFuncSetAttribute(resident_variant(cws[k], nts[k], lns[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) state = -1;
     }
     return state == 1;
 }
@@ -1109,7 +1831,7 @@ int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, int l
     static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
-    const void *fn = resident_variant(cw, nt, lean != 0);
+    const void *fn = resident_variant(cw, nt, lean);
     if (!coop)         // developer switch: ordinary launch (co-residency then rests on snn_dc2015_resident_capacity alone)
         return snn_check(hipLaunchKernel(fn, dim3(c.G), dim3(nt), args, lds, st));
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(c.G), dim3(nt), args, (unsigned)lds, st);
