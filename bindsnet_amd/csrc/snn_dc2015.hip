@@ -985,7 +985,17 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             const long long *r = &h[(size_t)t * 24];
             for (int k = 1; k < 8; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
-            if (r[6] - r[5] > 30) { awin += (double)(r[6] - r[5]) / 100.0; ++nwin; }
+            if (r[12]) { awin += (double)(r[6] - r[5]) / 100.0; ++nwin; }
+        }
+        {   // arbitration segment by kind of step: no crossing | ring-resident (fast) | overflow granules / more blocks than the ring
+            double s3[3] = {0, 0, 0}; int n3[3] = {0, 0, 0}; double rows = 0;
+            for (int t = 2; t < R->T; ++t) {
+                const long long *r = &h[(size_t)t * 24];
+                const int kind = r[10] == 0 ? 0 : (r[11] >= 100 ? 2 : 1);
+                s3[kind] += (double)(r[5] - r[4]) / 100.0; n3[kind]++; rows += (double)r[10];
+            }
+            fprintf(stderr, "[dc2015 spec arbitration] no crossing: %d steps %.2f us | ring-resident: %d steps %.2f us | heavy (overflow / > 7 blocks): %d steps %.2f us | crossing samples per step %.2f\n",
+                    n3[0], n3[0] ? s3[0] / n3[0] : 0.0, n3[1], n3[1] ? s3[1] / n3[1] : 0.0, n3[2], n3[2] ? s3[2] / n3[2] : 0.0, rows / n);
         }
         fprintf(stderr, "[dc2015 spec, us from iteration start, workgroup %d] spec PostPre+X currents done %.2f | poll+decode done %.2f | rng run-ahead done %.2f | "
                         "behind barrier R %.2f | arbitration + finals %.2f | own-winner repair %.2f | membrane + publish %.2f || iteration %.2f us; "

@@ -279,7 +279,7 @@ __device__ __attribute__((noinline)) Cur2 busy_currents(const float *wtile, cons
 // on entry; everything beyond is (re)computed on the way.  Every thread of the workgroup must call it.
 __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uint32_t *crs, unsigned long long *keys,
                                                          int mb, int pos, int N, int ntw, int rows, int myrank,
-                                                         int wb, int wj, int BW, int tid, int nthreads) {
+                                                         int wb, int wj, int BW, int tid, int nthreads, int RMK = 7) {
     const int lane = tid & 63, wave = tid >> 6;
     const int NWV = nthreads / 64;
     uint32_t parked = 0;
@@ -294,12 +294,12 @@ __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uin
                 const int m0 = w0 / 624, m1 = w1 / 624;
                 float q; bool have = false;
                 if (m0 >= lo && m1 <= hi) {
-                    q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
-                                        mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1])); have = true;
+                    q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
+                                        mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1])); have = true;
                 } else if (m0 >= lo && m0 <= hi) {             // pair straddles the resident range: park the high word
-                    parked = mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]);
+                    parked = mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]);
                 } else if (m1 >= lo && m1 <= hi) {
-                    q = exp1_from_words(parked, mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1])); have = true;
+                    q = exp1_from_words(parked, mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1])); have = true;
                 }
                 if (have) {
                     const float val = 1.0f / q;
@@ -312,8 +312,8 @@ __device__ __attribute__((noinline)) void arbitrate_slow(uint32_t *mt, const uin
         if (hi >= ntw) break;
         lds_barrier();
         if (wave == NWV - 1) {
-            mt_twist_block_wave(mt + ((mb + hi) & 7) * 624, mt + ((mb + hi + 1) & 7) * 624, lane);
-            if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((mb + hi + 1) & 7) * 624, mt + ((mb + hi + 2) & 7) * 624, lane);
+            mt_twist_block_wave(mt + ((mb + hi) & RMK) * 624, mt + ((mb + hi + 1) & RMK) * 624, lane);
+            if (hi + 2 <= ntw) mt_twist_block_wave(mt + ((mb + hi + 1) & RMK) * 624, mt + ((mb + hi + 2) & RMK) * 624, lane);
         }
         lo = hi + 1; hi = min(ntw, hi + 2);
         lds_barrier();
@@ -1130,6 +1130,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 //   barrier E
 // Bit-exactness: every value is produced by the same operations in the same order as in the first-generation kernel;
 // a repaired element is recomputed from its OLD weight by the (row, column) form of the update (stdp_rows_lds).
+constexpr int kSpecRing = 16;      // generator blocks resident in the second-generation lean kernel (a step with up to 11 crossing samples stays on the fast path)
+constexpr size_t spec_fixed_lds() { return resident_fixed_lds(4) + (size_t)(kSpecRing - 8) * 624 * 4; }
+
 template <int NTR>
 __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     constexpr int CW = 4, TT = MAXB * CW, NT = NTR;
@@ -1139,17 +1142,18 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     constexpr int QT = W_QN * 64;
     constexpr int W_P0 = 10, W_PN = 4;                    // polling / decoding waves
     constexpr int W_AUX = 14, W_RNG = 15;
+    constexpr int RB = kSpecRing, RMK = RB - 1;           // generator ring: RB blocks of 624 words
     static_assert(NT == 1024 && QT >= MAXB * CW * 4, "wave roles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     (void)NinW;
     constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + 2 * kBitWords * 4,
-                     O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + 8 * 624 * 4,
+                     O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + RB * 624 * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
                      O_CNTE = O_CNTI + MAXB * 4, O_CNT = O_CNTE + MAXB * 4, O_COLM = O_CNT + 32 * 4, O_MISC = O_COLM + 32 * 4,
                      O_LSTIB = O_MISC + 32, O_CNTIB = O_LSTIB + MAXB * LR * 2,
                      O_CURB = O_CNTIB + MAXB * 4, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
-    static_assert(O_WT == resident_fixed_lds(CW) && O_WT % 16 == 0, "fixed LDS part");
+    static_assert(O_WT == spec_fixed_lds() && O_WT % 16 == 0, "fixed LDS part");
     uint32_t *crs = (uint32_t *)(smem + O_CRS);
     uint32_t *finE = (uint32_t *)(smem + O_FINE);
     uint32_t *spI2 = (uint32_t *)(smem + O_SPI);
@@ -1442,10 +1446,10 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             if (t < T) { fetch_digest(t + 1, W_AUX, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         } else if (wave == W_RNG) {
             if (use_rng)
-                for (int m = ahead; m < 7; ++m) mt_twist_block_wave(mt + ((mb + m) & 7) * 624, mt + ((mb + m + 1) & 7) * 624, lane);
+                for (int m = ahead; m < RMK; ++m) mt_twist_block_wave(mt + ((mb + m) & RMK) * 624, mt + ((mb + m + 1) & RMK) * 624, lane);
             if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_RNG * 64) c.dbg[(size_t)t * 24 + 3] = (long long)wall_clock64();
         }
-        if (use_rng) ahead = 7;
+        if (use_rng) ahead = RMK;
         lds_barrier();                                                    // ---- R: exchange decoded, speculative results in place
         if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 4] = (long long)wall_clock64();
         // ---- a step the lean form does not handle: every workgroup derives this from the same exchanged data / input
@@ -1467,7 +1471,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             arb_rows = __popc(anym);
             arb_E = rng_pos + 2 * arb_rows * N;
             arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
-            if (arb_ntw > 7) heavy = true;
+            if (arb_ntw > RMK) heavy = true;
             if (!heavy && arb_rows) {
                 int r = 0;
                 for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
@@ -1479,8 +1483,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                         const int jx = lane * 32 + __ffs(bb) - 1;
                         const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
                         const int m0 = w0 / 624, m1 = w1 / 624;
-                        const uint32_t hi = mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]);
-                        const uint32_t lo = mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]);
+                        const uint32_t hi = mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]);
+                        const uint32_t lo = mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]);
                         const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
                         const unsigned long long key = (m << 10) | (unsigned long long)jx;
                         if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
@@ -1498,8 +1502,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                             const int jx = lane * 32 + __ffs(bb) - 1;
                             const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
                             const int m0 = w0 / 624, m1 = w1 / 624;
-                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
-                                                            mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
+                                                            mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]));
                             const float val = 1.0f / q;
                             atomicMax(&keys[bsm], ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
                         }
@@ -1509,7 +1513,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     if (lane == 0) keys[bsm] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)win);
                 }
             }
-            if (heavy && arb_ntw <= 7 && tid < BW) {
+            if (heavy && arb_ntw <= RMK && tid < BW) {
                 uint32_t bits = crs[tid];
                 const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
                 while (bits) {
@@ -1517,8 +1521,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     const int d = myrank * N + jx;
                     const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
                     const int m0 = w0 / 624, m1 = w1 / 624;
-                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & 7) * 624 + w0 - 624 * m0]),
-                                                    mt_temper(mt[((mb + m1) & 7) * 624 + w1 - 624 * m1]));
+                    const float q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
+                                                    mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]));
                     const float val = 1.0f / q;
                     const unsigned long long key = ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
                     atomicMax(&keys[wb], key);
@@ -1528,9 +1532,9 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
         if (heavy || arb_rows > 0) lds_barrier();
         if (use_rng) {
             const int rows = arb_rows, pos = rng_pos, E = arb_E, ntw = arb_ntw;
-            if (ntw > 7) {
+            if (ntw > RMK) {
                 const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
-                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT);
+                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT, RMK);
                 ahead = ntw;
                 lds_barrier();
             }
@@ -1543,11 +1547,11 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                 }
                 finE[tid] = wbits;
             }
-            mb = (mb + ntw) & 7; ahead -= ntw;
+            mb = (mb + ntw) & RMK; ahead -= ntw;
             rng_pos = E - 624 * ntw;
             rng_consumed += (long long)rows * N;
         }
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 5] = (long long)wall_clock64();
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 5] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 10] = arb_rows; c.dbg[(size_t)t * 24 + 11] = arb_ntw + (heavy ? 100 : 0); }
         // ---- did an OWN column win?  Every wave reads the winners itself (uniform result, no barrier)
         uint32_t ownwin = 0;
         if (phaseA && anym) {
@@ -1619,7 +1623,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             if (tid < CW) colmask[tid] = 0;
             lds_barrier();
         }
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 6] = (long long)wall_clock64();
+        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 6] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 12] = (ownwin && do_stdp) ? 1 : 0; }
         if (!phaseB) break;
 
         // ================================================================== start step t (tile threads)
@@ -1785,7 +1789,7 @@ int resident_cw(int N) {
 
 size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw) { return lds_bytes_resident(B, Nin, N, cw); }
 // second-generation lean form (k_dc2015_spec): + the [Nin][4] copy of the weights the speculative PostPre started from
-size_t snn_dc2015_spec_lds(int B, int Nin, int N) { return lds_bytes_resident(B, Nin, N, 4) + (size_t)Nin * 4 * 4; }
+size_t snn_dc2015_spec_lds(int B, int Nin, int N) { return lds_bytes_resident(B, Nin, N, 4) + (size_t)(kSpecRing - 8) * 624 * 4 + (size_t)Nin * 4 * 4; }
 int snn_dc2015_resident_cw(int N) { return resident_cw(N); }
 int snn_dc2015_resident_nt() { return resident_nt(); }
 

@@ -45,45 +45,31 @@ __device__ __forceinline__ void mt_twist_block(const uint32_t *src, uint32_t *ds
     __syncthreads();
 }
 
-// Same twist performed by ONE wave in lockstep, no workgroup barrier: lane l produces elements 4l..4l+3 of
-// each of the three dependent stripes.  LDS operations of a wave execute in program order, so a stripe's
-// reads see the previous stripe's writes.  All 64 lanes must call it.
+// Same twist performed by ONE wave in lockstep, no workgroup barrier: three dependent stripes, lane l producing the
+// elements base + l + 64 k of a stripe (consecutive lanes <-> consecutive words: every LDS access of the wave is
+// bank-conflict free; the former 4-elements-per-lane layout put lanes 16 apart on the same bank).  LDS operations of a
+// wave execute in program order, so a stripe's reads see the previous stripe's writes.  All 64 lanes must call it.
 __device__ __forceinline__ void mt_twist_block_wave(const uint32_t *src, uint32_t *dst, int lane) {
     {   // i in [0, 227): dst[i] = src[i+397] ^ mix(src[i], src[i+1])
-        const int i0 = lane * 4;
-        if (i0 < 227) {
-            uint32_t a[5], b[4];
+        uint32_t a[4], a1[4], b[4];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) a[k] = src[min(i0 + k, 623)];
+        for (int k = 0; k < 4; ++k) { const int i = min(lane + 64 * k, 226); a[k] = src[i]; a1[k] = src[i + 1]; b[k] = src[i + 397]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) b[k] = src[min(i0 + k + 397, 623)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k < 227) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
-        }
+        for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; if (i < 227) dst[i] = b[k] ^ mt_mix(a[k], a1[k]); }
     }
     {   // i in [227, 454): dst[i] = dst[i-227] ^ mix(src[i], src[i+1])
-        const int i0 = 227 + lane * 4;
-        if (i0 < 454) {
-            uint32_t a[5], b[4];
+        uint32_t a[4], a1[4], b[4];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) a[k] = src[min(i0 + k, 623)];
+        for (int k = 0; k < 4; ++k) { const int i = min(227 + lane + 64 * k, 453); a[k] = src[i]; a1[k] = src[i + 1]; b[k] = dst[i - 227]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) b[k] = dst[i0 + k - 227];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k < 454) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
-        }
+        for (int k = 0; k < 4; ++k) { const int i = 227 + lane + 64 * k; if (i < 454) dst[i] = b[k] ^ mt_mix(a[k], a1[k]); }
     }
-    {   // i in [454, 624): dst[i] = dst[i-227] ^ mix(src[i], i == 623 ? dst[0] : src[i+1])
-        const int i0 = 454 + lane * 4;
-        if (i0 < 624) {
-            uint32_t a[5], b[4];
+    {   // i in [454, 624): dst[i] = dst[i-227] ^ mix(src[i], i == 623 ? dst[0] : src[i+1])   (element 623 pairs with NEW dst[0])
+        uint32_t a[3], a1[3], b[3];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) a[k] = (i0 + k <= 623) ? src[i0 + k] : dst[0];   // element 623 pairs with NEW dst[0]
+        for (int k = 0; k < 3; ++k) { const int i = min(454 + lane + 64 * k, 623); a[k] = src[i]; a1[k] = (i == 623) ? dst[0] : src[i + 1]; b[k] = dst[i - 227]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) b[k] = dst[min(i0 + k, 623) - 227];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (i0 + k < 624) dst[i0 + k] = b[k] ^ mt_mix(a[k], a[k + 1]);
-        }
+        for (int k = 0; k < 3; ++k) { const int i = 454 + lane + 64 * k; if (i < 624) dst[i] = b[k] ^ mt_mix(a[k], a1[k]); }
     }
 }
 
