@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #include "snn_dc2015.hpp"
 
 unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
@@ -833,6 +834,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         c.xtr = (float *)((unsigned char *)c.exs + al2(resident_summary_bytes(N)));
         c.status = R->status;
         c.rows4 = !(getenv("SNN_DC_ROWS4") && atoi(getenv("SNN_DC_ROWS4")) == 0);
+        c.spec_flags = getenv("SNN_DC_SPECFLAGS") ? atoi(getenv("SNN_DC_SPECFLAGS")) : 0;
         c.stall_wg = getenv("SNN_DC_TEST_STALL") ? atoi(getenv("SNN_DC_TEST_STALL")) : -1;
         c.zone_shift = 19;
         if (getenv("SNN_DC_TEST_ZONE")) { const int z = atoi(getenv("SNN_DC_TEST_ZONE")); if (z >= 0 && z <= 19) c.zone_shift = z; }
@@ -871,8 +873,10 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     static long long *dbg = nullptr;
     static int dbg_T = 0;
     if (getenv("SNN_DC_TIMING")) {
-        if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * 24 * (R->T + 1)); dbg_T = R->T + 1; }
-        (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 24 * (R->T + 1), st);
+        // [T+1][24] marks of the chosen workgroup, then [T+1][256][4] per-workgroup marks (second-generation lean kernel)
+        const size_t dbg_words = (size_t)(24 + 256 * 4) * (R->T + 1);
+        if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * dbg_words); dbg_T = R->T + 1; }
+        (void)hipMemsetAsync(dbg, 0, sizeof(long long) * dbg_words, st);
         for (int t = 0; t <= R->T; ++t) (void)hipMemsetAsync(dbg + (size_t)t * 24 + 20, 0x7F, sizeof(long long), st);
         c.dbg = dbg; c.dbg_wg = atoi(getenv("SNN_DC_TIMING")); if (c.dbg_wg < 0 || c.dbg_wg >= c.G) c.dbg_wg = c.G - 1;
     }
@@ -986,6 +990,57 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             for (int k = 1; k < 8; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
             if (r[12]) { awin += (double)(r[6] - r[5]) / 100.0; ++nwin; }
+        }
+        {   // per workgroup: barrier R passed / published, relative to the earliest R of the iteration
+            const int G = c.G;
+            std::vector<long long> hw((size_t)(R->T + 1) * 256 * 4);
+            (void)hipMemcpy(hw.data(), dbg + (size_t)24 * (R->T + 1), hw.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<double> lagR(G, 0.0), chain(G, 0.0), lagP(G, 0.0); int nn = 0;
+            for (int t = 2; t + 1 < R->T; ++t, ++nn) {
+                long long r0 = hw[((size_t)t * 256) * 4], p0 = hw[((size_t)t * 256) * 4 + 1];
+                for (int gq = 1; gq < G; ++gq) { r0 = std::min(r0, hw[((size_t)t * 256 + gq) * 4]); p0 = std::min(p0, hw[((size_t)t * 256 + gq) * 4 + 1]); }
+                for (int gq = 0; gq < G; ++gq) {
+                    const long long *w = &hw[((size_t)t * 256 + gq) * 4];
+                    lagR[gq] += (double)(w[0] - r0) / 100.0; chain[gq] += (double)(w[1] - w[0]) / 100.0; lagP[gq] += (double)(w[1] - p0) / 100.0;
+                }
+            }
+            {   // arrival of each wave of the chosen workgroup at barrier R (us since its iteration start)
+                double aw[16] = {0};
+                for (int t = 2; t + 1 < R->T; ++t) for (int w = 0; w < 16; ++w) aw[w] += (double)(hw[((size_t)t * 256 + 200 + w) * 4 + 3] - h[(size_t)t * 24]) / 100.0;
+                fprintf(stderr, "[dc2015 spec wave arrival at R, workgroup %d, us]", c.dbg_wg);
+                for (int w = 0; w < 16; ++w) fprintf(stderr, " w%d %.2f", w, aw[w] / (R->T - 3));
+                fprintf(stderr, "\n");
+            }
+            {   // the workgroups that pass R latest on average, and where they run
+                std::vector<int> ord(G); for (int gq = 0; gq < G; ++gq) ord[gq] = gq;
+                std::sort(ord.begin(), ord.end(), [&](int x, int y) { return lagR[x] > lagR[y]; });
+                fprintf(stderr, "[dc2015 spec per workgroup] mean R lag, top 6:");
+                for (int k = 0; k < 6 && k < G; ++k) { const long long id = hw[((size_t)0 * 256 + ord[k]) * 4 + 3]; fprintf(stderr, " wg%d %.2f us (xcc %lld se %lld cu %lld)", ord[k], lagR[ord[k]] / nn, id >> 16, (id >> 13) & 7, (id >> 8) & 15); }
+                fprintf(stderr, " | median wg%d %.2f us\n", ord[G / 2], lagR[ord[G / 2]] / nn);
+            }
+            double mR = 0, mC = 0, mP = 0;
+            for (int gq = 0; gq < G; ++gq) { mR += lagR[gq] / nn / G; mC += chain[gq] / nn / G; mP += lagP[gq] / nn / G; }
+            fprintf(stderr, "[dc2015 spec per workgroup, us] mean over workgroups: R after the earliest R %.2f | R -> publish %.2f | publish after the earliest publish %.2f\n", mR, mC, mP);
+            // the steps' LAST publisher: who, and how late
+            std::vector<int> lastcnt(G, 0); double late = 0, lateR = 0, lateC = 0, medC = 0; int hist[8] = {0}; int kinds[3] = {0, 0, 0}, nprep = 0; double klate[3] = {0, 0, 0};
+            for (int t = 2; t + 1 < R->T; ++t) {
+                int arg = 0; long long pm = 0, p0 = hw[((size_t)t * 256) * 4 + 1], r0 = hw[((size_t)t * 256) * 4];
+                std::vector<double> ch(G);
+                for (int gq = 0; gq < G; ++gq) { const long long *w = &hw[((size_t)t * 256 + gq) * 4]; if (w[1] > pm) { pm = w[1]; arg = gq; } p0 = std::min(p0, w[1]); r0 = std::min(r0, w[0]); ch[gq] = (double)(w[1] - w[0]) / 100.0; }
+                lastcnt[arg]++; late += (double)(pm - p0) / 100.0;
+                { const long long kind = hw[((size_t)t * 256 + arg) * 4 + 2]; kinds[(kind & 1) ? 1 : ((kind & 2) ? 2 : 0)]++; klate[(kind & 1) ? 1 : ((kind & 2) ? 2 : 0)] += (double)(hw[((size_t)t * 256 + arg) * 4] - r0) / 100.0; }
+                for (int gq = 0; gq < G; ++gq) if (hw[((size_t)t * 256 + gq) * 4 + 2] & 1) nprep++;
+                lateR += (double)(hw[((size_t)t * 256 + arg) * 4] - r0) / 100.0; lateC += ch[arg];
+                std::nth_element(ch.begin(), ch.begin() + G / 2, ch.end()); medC += ch[G / 2];
+                hist[std::min(7, (int)((double)(pm - p0) / 100.0))]++;
+            }
+            fprintf(stderr, "[dc2015 spec per workgroup] the LAST publisher of a step: its R %.2f us after the earliest R, its R -> publish %.2f us (median workgroup %.2f); lateness histogram (us, 0..7+):", lateR / nn, lateC / nn, medC / nn);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hist[k]);
+            fprintf(stderr, "\n[dc2015 spec per workgroup] window of the last publisher: plain %d (R lag %.2f) | won branch prepared %d (R lag %.2f) | slow columns %d (R lag %.2f); workgroup-steps with a prepared branch per step %.2f",
+                    kinds[0], kinds[0] ? klate[0] / kinds[0] : 0.0, kinds[1], kinds[1] ? klate[1] / kinds[1] : 0.0, kinds[2], kinds[2] ? klate[2] / kinds[2] : 0.0, (double)nprep / nn);
+            fprintf(stderr, "\n[dc2015 spec per workgroup] last publisher is on average %.2f us behind the first; workgroups most often last:", late / nn);
+            for (int k = 0; k < 6; ++k) { int arg = 0; for (int gq = 0; gq < G; ++gq) if (lastcnt[gq] > lastcnt[arg]) arg = gq; fprintf(stderr, " wg%d x%d (chain %.2f)", arg, lastcnt[arg], chain[arg] / nn); lastcnt[arg] = -1; }
+            fprintf(stderr, "\n");
         }
         {   // arbitration segment by kind of step: no crossing | ring-resident (fast) | overflow granules / more blocks than the ring
             double s3[3] = {0, 0, 0}; int n3[3] = {0, 0, 0}; double rows = 0;

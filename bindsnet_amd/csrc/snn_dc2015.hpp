@@ -49,6 +49,7 @@ struct DcCtx {
     int has_norm; float norm; int norm_abs;   // post-run normalisation of Wxe, done in the resident kernel's epilogue
     int zone_shift;             // lean arbitration: draws within 2^-zone_shift (relative) of the smallest are evaluated exactly
                                 // (19; test hook SNN_DC_TEST_ZONE lowers it so that the exact branch runs all the time)
+    int spec_flags;             // second-generation lean form, developer switch SNN_DC_SPECFLAGS: 1 = no prepared won branch, 2 = every iteration on the slow order
     int rows4;                  // lean form: PostPre one thread per active row (developer switch SNN_DC_ROWS4=0: per (row, column))
     int stall_wg;               // test hook (SNN_DC_TEST_STALL=<workgroup>, -1 = none): that workgroup of the resident kernel
                                 // exits at once, as if it had never been scheduled -> every other one times out

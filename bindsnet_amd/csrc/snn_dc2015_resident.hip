@@ -164,18 +164,14 @@ __device__ __forceinline__ void stdp_rows4(const DcCtx &c, int nact, const uint1
 }
 
 // Speculative PostPre of the second-generation lean kernel (k_dc2015_spec): stdp_rows4 under the assumption that no own
-// column has a post-synaptic spike, by the `nthreads` threads qt = 0.., and with the OLD weights of every touched row
-// saved to `wold` (the repair of a winning column restarts from them).  full: every row (the first update of a run
-// clamps every element).
+// column has a post-synaptic spike, by the `nthreads` threads qt = 0.., from the committed weights `wsrc` (left as they
+// are) into `wdst`.  full: every row (the first update of a run clamps every element).
 __device__ __forceinline__ void spec_rows4(const DcCtx &c, bool full, int nact, const uint16_t *arows, const uint32_t *rowmask,
-                                           const float *xnu0, float *wtile, float *wold, int c0, int qt, int nthreads) {
-    const int N = c.N;
-    const bool whole = c0 + 4 <= N;
+                                           const float *xnu0, const float *wsrc, float *wdst, int c0, int qt, int nthreads) {
     for (int k = qt; k < nact; k += nthreads) {
         const int i = full ? k : (int)arows[k];
         uint32_t m = rowmask[i];
-        const float4 w4 = *(const float4 *)(wtile + i * 4);
-        *(float4 *)(wold + i * 4) = w4;
+        const float4 w4 = *(const float4 *)(wsrc + i * 4);
         float w[4] = {w4.x, w4.y, w4.z, w4.w};
         if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
             float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -212,11 +208,7 @@ __device__ __forceinline__ void spec_rows4(const DcCtx &c, bool full, int nact, 
             if (c.has_min && w[q] < c.wmin) w[q] = c.wmin;
             if (c.has_max && w[q] > c.wmax) w[q] = c.wmax;
         }
-        if (whole) *(float4 *)(wtile + i * 4) = make_float4(w[0], w[1], w[2], w[3]);
-        else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (c0 + q < N) wtile[i * 4 + q] = w[q];
-        }
+        *(float4 *)(wdst + i * 4) = make_float4(w[0], w[1], w[2], w[3]);   // (columns >= N of the last tile: unused values)
     }
 }
 
@@ -1103,36 +1095,46 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 }
 
 // =====================================================================================================================
-// Lean form, second generation ("speculate, then repair"): the same arithmetic and the same compact exchange as
-// k_dc2015_run<4, 1024, true>, re-ordered so that everything of a timestep that does NOT depend on the spike exchange
-// runs while the exchange is in flight.
+// Lean form, second generation ("speculate both ways"): the same arithmetic and the same compact exchange as
+// k_dc2015_run<4, 1024, true>, re-ordered so that nearly everything of a timestep runs while the spike exchange is in
+// flight, and what remains behind it is a lookup.
 //
 // What of "finish step t-1, start step t" depends on the other workgroups' spikes of step t-1?  Only (1) which of the own
-// crossings WON the one_spike arbitration (-> Ae trace, PostPre post-synaptic term of that column, the Ae -> Ai current)
+// crossings WON the one_spike arbitration (-> Ae trace, PostPre post-synaptic term of that column, its Ae -> Ai current)
 // and (2) the inhibitory currents.  A (sample, column) pair without a winner -- all but ~3 of the 12 800 pairs of a step
 // at cfg2 -- has a trace that just decays, a PostPre that is its pre-synaptic term, and X -> Ae currents that follow from
-// those.  So, per iteration t:
+// those; and a workgroup KNOWS which of its pairs crossed, so it can prepare the "it won" outcome of a crossing column
+// as well.  Weights are double-buffered for this: `wtile` holds the committed slice and is never written inside the
+// window, `wnew` the speculative new values of the rows PostPre touches, `wwin` the whole column(s) of the won branch.
+// Per iteration t:
 //
-//   speculative window (no workgroup barrier; the exchange of epoch t is in flight):
-//     waves 2..9    PostPre of step t-1 for every active row under the assumption "no own winner" (old weights of the
-//                   touched rows kept in `wold`), LDS-counter barrier among these 8 waves, X -> Ae currents of step t
+//   window (no workgroup barrier; the exchange of epoch t is in flight):
+//     waves 2..9    PostPre of step t-1 for every active row under the assumption "no own winner" (wtile -> wnew),
+//                   LDS-counter barrier among these 8 waves, X -> Ae currents of step t from wnew
+//     waves 0..1    for every own column with exactly ONE crossing sample: the column as it is if that pair wins
+//                   (new trace in the pre-synaptic term + post-synaptic term, all rows: wtile -> wwin), barrier among
+//                   the two, that column's X -> Ae currents from wwin
 //     waves 10..13  poll + decode the summary granules of epoch t (crossings / Ai spikes of step t-1)
-//     wave 14       spike-raster rows of step t-2, digest of step t+1 -> LDS
-//     wave 15       generator run-ahead
+//     wave 14       spike-raster rows of step t-2, digest of step t+1 -> LDS, scratch resets
+//     wave 15       generator run-ahead (16-block ring)
 //   barrier R
-//   arbitration (as before), barrier when a sample crossed
-//   every wave derives from the winners whether an OWN column won (no barrier needed for that).  Only then (uniform):
-//     trace / x_tgt*nu0 of the winners, barrier, PostPre of the winning column(s) redone for all rows from `wold`
-//     (pre-synaptic term with the new trace + post-synaptic term), barrier, their X -> Ae currents redone, barrier
-//   tile threads: recurrent currents (at most one Ai spike and one final Ae spike per sample, else the launch gives
-//   up with SNN_ERR_RETRY like for any other step the lean form does not take), membrane update, publish epoch t+1,
-//   speculative trace of step t (x_tgt*nu0 for the next window)
+//   fast iterations (no overflow granule, generator blocks resident, no own column with two crossing samples, Ae -> Ai
+//   weights diagonal in the own slice):
+//     waves 0..1    a crossing column won iff its sample has no other crossing (one candidate: no draw needed), else iff
+//                   the arbitration says so (they wait for that sample's result only); select the X currents of the
+//                   branch that happened, recurrent currents, membrane update, publish epoch t+1, the next window's
+//                   x_tgt*nu0 and crossing bookkeeping
+//     waves 2..15   arbitration (identical in every workgroup: generator position, rasters), LDS-counter barrier among
+//                   the 14, final spike words, commit wnew (and wwin of the winners) -> wtile
+//   slow iterations (anything else, and t = 0): first generation's order -- arbitration by everybody, barrier, winners'
+//     trace, PostPre of the winning column(s) redone for all rows, their X currents redone, then the tile threads.
 //   barrier E
-// Bit-exactness: every value is produced by the same operations in the same order as in the first-generation kernel;
-// a repaired element is recomputed from its OLD weight by the (row, column) form of the update (stdp_rows_lds).
-constexpr int kSpecRing = 16;      // generator blocks resident in the second-generation lean kernel (a step with up to 11 crossing samples stays on the fast path)
+// Bit-exactness: every value is produced by the same operations in the same order as in the first-generation kernel; a
+// column of the won branch is computed by the (row, column) form of the update (stdp_rows_lds) from the committed weights.
+constexpr int kSpecRing = 16;      // generator blocks resident (a step with up to 11 crossing samples stays on the fast path)
 constexpr size_t spec_fixed_lds() { return resident_fixed_lds(4) + (size_t)(kSpecRing - 8) * 624 * 4; }
-
+// behind the digests: wnew [Nin][4], wwin [Nin][4], second crossing-bit buffer, curXwin [32][4], xwin [2][4], arbdone [32]
+constexpr size_t spec_tail_lds(int Nin) { return (size_t)2 * Nin * 4 * 4 + kBitWords * 4 + MAXB * 4 * 4 + 8 * 4 + MAXB * 4; }
 template <int NTR>
 __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     constexpr int CW = 4, TT = MAXB * CW, NT = NTR;
@@ -1142,11 +1144,11 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     constexpr int QT = W_QN * 64;
     constexpr int W_P0 = 10, W_PN = 4;                    // polling / decoding waves
     constexpr int W_AUX = 14, W_RNG = 15;
+    constexpr int NOT = NT - TT, NOW_ = NWV - NTW;        // threads / waves that are not tile waves
     constexpr int RB = kSpecRing, RMK = RB - 1;           // generator ring: RB blocks of 624 words
-    static_assert(NT == 1024 && QT >= MAXB * CW * 4, "wave roles");
+    static_assert(NT == 1024 && QT >= MAXB * CW * 4 && NTW == 2, "wave roles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
-    (void)NinW;
+    const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, T = c.T;
     constexpr size_t O_CRS = 0, O_FINE = O_CRS + kBitWords * 4, O_SPI = O_FINE + kBitWords * 4, O_XNU0 = O_SPI + 2 * kBitWords * 4,
                      O_MT = O_XNU0 + MAXB * CW * 4, O_KEYS = O_MT + RB * 624 * 4,
                      O_LSTI = O_KEYS + MAXB * 8, O_LSTE = O_LSTI + MAXB * LR * 2, O_CNTI = O_LSTE + MAXB * LR * 2,
@@ -1154,7 +1156,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                      O_LSTIB = O_MISC + 32, O_CNTIB = O_LSTIB + MAXB * LR * 2,
                      O_CURB = O_CNTIB + MAXB * 4, O_ST = O_CURB + 2 * MAXB * CW * 4, O_WT = O_ST + 7 * MAXB * CW * 4;
     static_assert(O_WT == spec_fixed_lds() && O_WT % 16 == 0, "fixed LDS part");
-    uint32_t *crs = (uint32_t *)(smem + O_CRS);
+    uint32_t *crsA = (uint32_t *)(smem + O_CRS);           // Ae crossings of step t-1, two buffers by iteration parity (crsA: even)
     uint32_t *finE = (uint32_t *)(smem + O_FINE);
     uint32_t *spI2 = (uint32_t *)(smem + O_SPI);
     float *xnu0 = (float *)(smem + O_XNU0);
@@ -1163,23 +1165,38 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     uint16_t *lstI0 = (uint16_t *)(smem + O_LSTI), *lstI1 = (uint16_t *)(smem + O_LSTIB);
     uint16_t *lstE = (uint16_t *)(smem + O_LSTE);
     int *cntI0 = (int *)(smem + O_CNTI), *cntI1 = (int *)(smem + O_CNTIB);
+    // cnt[0..7]: crossing counts of the own columns by step parity; [16 + p]: samples with a crossing, [18 + p]: overflow mark
+    // (p = iteration parity: the decode of iteration t fills what iteration t-1's aux wave cleared); counters of the partial
+    // barriers: [20] the 8 speculative waves, [21] the 14 non-tile waves, [22] tile + speculative waves; [24 + p]: row chunks of the
+    // won branch handed out so far
     int *cnt = (int *)(smem + O_CNT);
+    // colmask[0..3]: samples with a final spike per own column (slow iterations); [8 + 4 p + q]: crossing samples of own
+    // column q at the step whose finish is iteration parity p; [16]: the own Ae -> Ai slice has an off-diagonal weight
     uint32_t *colmask = (uint32_t *)(smem + O_COLM);
     int *misc = (int *)(smem + O_MISC);                    // [2] give-up flag (monotonic: once set the launch ends)
-    // cnt[0..7]: crossing counts of the own columns by step parity; [16 + p]: samples with a crossing, [18 + p]: overflow
-    // mark (p = iteration parity: the decode of iteration t fills what iteration t-1's aux wave cleared); [20]: counter of
-    // the barrier among the speculative waves
-    float *curX = (float *)(smem + O_CURB);                // [B][CW] X -> Ae part of the Ae current of step t
+    float *curX = (float *)(smem + O_CURB);                // [B][CW] X -> Ae part of the Ae current of step t ("nobody won" branch)
     float *stl = (float *)(smem + O_ST);
-    float *wtile = (float *)(smem + O_WT);
+    float *wtile = (float *)(smem + O_WT);                 // [Nin][CW] committed weights: never written inside the window
     float *wieT = wtile + (size_t)Nin * CW;
     float *weiT = wieT + (size_t)N * CW;
     const int DGS = (c.DGW + 63) & ~63;
     uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
-    float *wold = (float *)(dgbuf + 2 * DGS);              // [Nin][CW] weights as they were before this step's speculative PostPre
+    float *wnew = (float *)(dgbuf + 2 * DGS);              // [Nin][CW] rows PostPre touches: their weights if no own pair wins
+    float *wwin = wnew + (size_t)Nin * CW;                 // [Nin][CW] column q: the whole column if its crossing pair wins
+    uint32_t *crsB = (uint32_t *)(wwin + (size_t)Nin * CW);
+    float *curXwin = (float *)(crsB + kBitWords);          // [B][CW] X -> Ae currents of column q in its won branch
+    float *xwinv = curXwin + MAXB * CW;                    // [2][CW] x_tgt*nu0 of the crossing pair of column q if it wins
+    int *arbdone = (int *)(xwinv + 8);                     // [B] iteration in which the sample's arbitration result was stored
+    // (buffers that are picked at run time are addressed as offsets from ONE base pointer each: a select between two
+    //  pointers makes the compiler lose the LDS address space and fall back to flat loads)
+    const int offN = (int)(wnew - wtile), offW = (int)(wwin - wtile), offCW = (int)(curXwin - curX), offCB = (int)(crsB - crsA);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, c0 = g * CW;
+    // (developer switch: the grid may be launched `mult` times too large, only every mult-th workgroup taking part -- spreads
+    //  the working workgroups over the compute units differently)
+    const int gmult = (c.spec_flags >> 8) > 1 ? (c.spec_flags >> 8) : 1;
+    if ((int)blockIdx.x % gmult != 0) return;
+    const int g = (int)blockIdx.x / gmult, c0 = g * CW;
     if (g == c.stall_wg) return;
     const int jj = tid % CW, bl = tid / CW;
     const int j = c0 + jj;
@@ -1192,16 +1209,25 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     const int KB = c.KB, NG = c.G * KB;
     const int NGS = c.G * NTW;
 
+    if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
+    if (tid < 8) misc[tid] = 0;
+    __syncthreads();
     for (int k = tid; k < Nin * CW; k += NT) {
         const int i = k / CW, q = k % CW;
         wtile[k] = (c0 + q < N) ? c.Wxe[i * N + c0 + q] : 0.f;
     }
-    for (int k = tid; k < N * CW; k += NT) {
-        const int i = k / CW, q = k % CW;
-        wieT[k] = (c0 + q < N) ? c.Wie[i * N + c0 + q] : 0.f;
-        weiT[k] = (c0 + q < N) ? c.Wei[i * N + c0 + q] : 0.f;
+    {
+        bool offdiag = false;
+        for (int k = tid; k < N * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            wieT[k] = (c0 + q < N) ? c.Wie[i * N + c0 + q] : 0.f;
+            const float we = (c0 + q < N) ? c.Wei[i * N + c0 + q] : 0.f;
+            weiT[k] = we;
+            offdiag = offdiag || (i != c0 + q && we != 0.f);
+        }
+        if (offdiag) colmask[16] = 1u;
     }
-    auto fetch_digest = [&](int e, int first_wave, int nwaves) {        // by `nwaves` whole waves starting at `first_wave`
+    auto fetch_digest = [&](int e, int first_wave, int nwaves) __attribute__((always_inline)) {        // by `nwaves` whole waves starting at `first_wave`
         const uint32_t *Dg = c.dig + (size_t)e * c.DW;
         uint32_t *dst = dgbuf + (e & 1) * DGS;
         for (int base = (wave - first_wave) * 256; base < c.DGW; base += nwaves * 256) {
@@ -1227,33 +1253,76 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
         const long long cons0 = c.rng[0]->consumed;
         rng_consumed = ((long long)__builtin_amdgcn_readfirstlane((int)(cons0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)cons0);
     }
-    if (tid < 32) { cnt[tid] = 0; colmask[tid] = 0; }
-    if (tid < 8) misc[tid] = 0;
-    if (tid < MAXB) { keys[tid] = 0ull; cntI0[tid] = 0; cntI1[tid] = 0; }
-    if (tid < TT) { xnu0[tid] = 0.f; curX[tid] = 0.f; }
-    if (tid < BW) { crs[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
+    if (tid < MAXB) { keys[tid] = 0ull; cntI0[tid] = 0; cntI1[tid] = 0; arbdone[tid] = -1; }
+    if (tid < TT) { xnu0[tid] = 0.f; curX[tid] = 0.f; curXwin[tid] = 0.f; }
+    if (tid < 8) xwinv[tid] = 0.f;
+    if (tid < BW) { crsA[tid] = 0; crsB[tid] = 0; finE[tid] = 0; spI2[tid] = 0; spI2[kBitWords + tid] = 0; }
     bool failed = false;
-    int sub_target = 0;                                     // LDS-counter barrier among the W_QN speculative waves
+    int sub_q = 0, sub_o = 0, sub_t = 0;                    // targets of the partial barriers (cnt[20], cnt[21], cnt[22])
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const bool diagE = colmask[16] == 0u;
 
-    auto win_of = [&](int b) -> int { return (int)(0xFFFFFFFFu - (uint32_t)(keys[b] & 0xFFFFFFFFull)); };
+    auto part_barrier = [&](int *ctr, int &target, int nwaves) __attribute__((always_inline)) {         // barrier among `nwaves` whole waves (LDS counter)
+        target += nwaves;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    auto win_of = [&](int b) __attribute__((always_inline)) -> int { return (int)(0xFFFFFFFFu - (uint32_t)(keys[b] & 0xFFFFFFFFull)); };
     // raster rows (final Ae spikes / Ai spikes) of one step, whole [N]-byte rows, row r of the 2*B rows by workgroup r mod G
-    auto raster_rows = [&](int step, const uint32_t *spi_bits, int first_thread, int nthreads) {
+    auto raster_rows = [&](int step, int spi_off, int first_thread, int nthreads) __attribute__((always_inline)) {   // spi_off: the Ai words, as an offset from finE
         for (int r = g; r < 2 * B; r += c.G) {
             const int b = r < B ? r : r - B;
             uint8_t *ras = r < B ? c.rasE : c.rasI;
-            const uint32_t *bitsrc = (r < B ? finE : spi_bits) + b * NW;
+            const uint32_t *bitsrc = finE + (r < B ? 0 : spi_off) + b * NW;
             if (ras) { uint8_t *row = ras + ((size_t)step * B + b) * N; for (int jx = tid - first_thread; jx < N; jx += nthreads) row[jx] = (uint8_t)bit_of(bitsrc, jx); }
         }
     };
+    // one element of PostPre in its (row, column) form (= stdp_rows_lds's update; lean form: no tail elements, 0/1 spikes):
+    // row i, column q, pre-synaptic samples m, post-synaptic samples cm; sample bst's x_tgt*nu0 replaced by xw when bst >= 0
+    auto postpre_elem = [&](float w, int i, int q, uint32_t m, uint32_t cm, int bst, float xw, const float *xs, bool have_x = false, float xval = 0.f) __attribute__((always_inline)) -> float {
+        if (c.nu0 != 0.f) {
+            float uu = 0.f;
+            if (m) {
+                CascadeT acc; acc.init(false);
+                while (m) {
+                    const int b = __ffs(m) - 1; m &= m - 1;
+                    acc.add(b, 1.0f * (b == bst ? xw : xnu0[b * CW + q]), B);
+                }
+                uu = acc.finish(B);
+            }
+            if (c.use_dt) uu = uu * c.dt;
+            w = w - uu;
+        }
+        if (c.nu1 != 0.f) {
+            float uu = 0.f;
+            if (cm) {
+                CascadeT acc; acc.init(false);
+                while (cm) {
+                    const int b = __ffs(cm) - 1; cm &= cm - 1;
+                    acc.add(b, (have_x ? xval : xs[b * Nin + i]) * (1.0f * c.nu1), B);   // (have_x: one post-synaptic sample, its X trace passed in)
+                }
+                uu = acc.finish(B);
+            }
+            if (c.use_dt) uu = uu * c.dt;
+            w = w + uu;
+        }
+        if (c.has_min && w < c.wmin) w = c.wmin;
+        if (c.has_max && w > c.wmax) w = c.wmax;
+        return w;
+    };
 
+    if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)0 * 256 + g) * 4 + 3] = (long long)((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 16) | (long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFF);   // XCC_ID, HW_ID
     for (int t = 0; t <= T; ++t) {
         const bool phaseA = t >= 1, phaseB = t < T;
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 0] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 8] = (long long)clock64(); }
+        const int par = t & 1;
+        if (c.dbg && g == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 0] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 8] = (long long)clock64(); }
         if (c.dbg && threadIdx.x == 0) atomicMin((unsigned long long *)&c.dbg[(size_t)t * 24 + 20], (unsigned long long)wall_clock64());
-        uint32_t *spI = spI2 + (t & 1) * kBitWords;
-        const uint32_t *dg = dgbuf + (t & 1) * DGS;                       // digest of the X spikes of step t-1
+        uint32_t *spI = spI2 + par * kBitWords;
+        uint32_t *crs = crsA + (par ? offCB : 0);
+        const uint32_t *dg = dgbuf + par * DGS;                           // digest of the X spikes of step t-1
         const uint16_t *lstX = (const uint16_t *)dg;
         const int *meta = (const int *)(dg + B * (LX / 2));
         const uint32_t *rowmask = dg + B * (LX / 2) + 40;
@@ -1261,20 +1330,26 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
         const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);
         const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
         const uint32_t *gqn = gcnt + B;
-        uint16_t *lstI = (t & 1) ? lstI1 : lstI0;
-        int *cntI = (t & 1) ? cntI1 : cntI0;
+        uint16_t *lstI = lstI0 + (par ? (int)(lstI1 - lstI0) : 0);
+        int *cntI = cntI0 + (par ? (int)(cntI1 - cntI0) : 0);
         const int mflags = __builtin_amdgcn_readfirstlane(meta[33]);
         const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
         const bool stdp_full = t == 1;
         const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
         const float *xsrc = c.xtr + (size_t)t * B * Nin;                  // X trace after step t-1
         const bool use_rng = phaseA;
+        // crossing samples of the own columns at step t-1 (set by the tile threads at the end of the previous iteration)
+        uint32_t xm[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) xm[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colmask[8 + 4 * par + q]);
+        const bool slowcols = __popc(xm[0]) > 1 || __popc(xm[1]) > 1 || __popc(xm[2]) > 1 || __popc(xm[3]) > 1 ||
+                              ((c.spec_flags & 1) && (xm[0] | xm[1] | xm[2] | xm[3]) != 0u) || (c.spec_flags & 2);
+        const bool prep = do_stdp && diagE && !slowcols && (xm[0] | xm[1] | xm[2] | xm[3]) != 0u;   // own columns with a prepared won branch
 
-        // X -> Ae part of the Ae currents of step t (from the X spikes of step t-1 and the CURRENT weight slice) for the
-        // columns in `cols`, four threads per (sample, column) pair: qt <-> (sample qt / 16, column (qt / 4) % 4, lane qt % 4)
-        auto x_currents = [&](int qt, uint32_t cols) {
-            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-            if (pb >= B || !((cols >> pq) & 1u)) return;
+        // X -> Ae part of the Ae current of step t of (sample pb, column pq), lane pL of its four threads (from the X spikes
+        // of step t-1 and the weights in `ws`): written by lane 0 to dst[pb][pq]
+        auto x_current = [&](int pb, int pq, int pL, int woff, int doff) __attribute__((always_inline)) {
+            const float *ws = wtile + woff; float *dst = curX + doff;
             const bool pv = c0 + pq < N;
             constexpr uint32_t GM = (1u << GCB) - 1u;
             if (tailcol) {
@@ -1289,13 +1364,13 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + pq];
+                for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
                 CascadeFlat a; a.init();
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u] >> 2, wx[u] * 1.0f, n4);
                 for (int u = 8; u < nL; ++u) {
                     const int i = (int)l2[st + u];
-                    a.add(i >> 2, wtile[i * CW + pq] * 1.0f, n4);
+                    a.add(i >> 2, ws[i * CW + pq] * 1.0f, n4);
                 }
                 float v = a.finish(n4);
                 if (pL == 0) {
@@ -1303,12 +1378,12 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     const int n5 = (int)((gc >> (4 * GCB)) & GM);
                     for (int u = 0; u < n5; ++u) {
                         const int i = (int)l2[s4 + u];
-                        v += wtile[i * CW + pq] * 1.0f;
+                        v += ws[i * CW + pq] * 1.0f;
                     }
                 }
                 const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
                 const float e1 = ((v + v1) + v2) + v3;
-                if (pL == 0 && pv) curX[pb * CW + pq] = 0.0f + e1;
+                if (pL == 0 && pv) dst[pb * CW + pq] = 0.0f + e1;
             } else {
                 // multi_row_sum columns: the cascade's 256-position groups are independent partial sums
                 const uint32_t gq = gqn[pb];
@@ -1319,13 +1394,13 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) ix[u] = min((int)lx[min(st + u, LX - 1)], Nin - 1);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wx[u] = wtile[ix[u] * CW + pq];
+                for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
                 CascadeFlat a; a.init();
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u], wx[u] * 1.0f, Nin);
                 for (int u = 8; u < nL; ++u) {
                     const int ii2 = (int)lx[st + u];
-                    a.add(ii2, wtile[ii2 * CW + pq] * 1.0f, Nin);
+                    a.add(ii2, ws[ii2 * CW + pq] * 1.0f, Nin);
                 }
                 const float G = a.a1 + a.a0;
                 const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
@@ -1339,9 +1414,15 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
                     const float res = ((0.0f + Gl) + A2) + 0.0f;
-                    curX[pb * CW + pq] = 0.0f + res;
+                    dst[pb * CW + pq] = 0.0f + res;
                 }
             }
+        };
+        // ... for the columns in `cols`, by the speculative waves: qt <-> (sample qt / 16, column (qt / 4) % 4, lane qt % 4)
+        auto x_currents = [&](int qt, uint32_t cols, int woff) __attribute__((always_inline)) {
+            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+            if (pb >= B || !((cols >> pq) & 1u)) return;
+            x_current(pb, pq, pL, woff, 0);
         };
 
         // ------------------------------------------------------------------ t == 0: spikes of the step before the run
@@ -1356,26 +1437,59 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             }
             lds_barrier();
         }
-        // ================================================================== speculative window
-        if (wave >= W_Q0 && wave < W_Q0 + W_QN) {
-            const int qt = tid - W_Q0 * 64;
-            if (do_stdp) {
-                spec_rows4(c, stdp_full, nact, arows, rowmask, xnu0, wtile, wold, c0, qt, QT);
-                // barrier among these waves only: the pollers must not be held up, and they cannot join a workgroup barrier
-                sub_target += W_QN;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(&cnt[20], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                while (__hip_atomic_load(&cnt[20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sub_target) __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");
+        // ================================================================== window
+        if (wave < NTW && t < T) fetch_digest(t + 1, 0, NTW);           // next iteration's digest, by the tile waves (waited for in front of barrier E)
+        if (wave < W_Q0 + W_QN) {
+            if (wave >= W_Q0) {
+                const int qt = tid - W_Q0 * 64;
+                if (do_stdp) {
+                    spec_rows4(c, stdp_full, nact, arows, rowmask, xnu0, wtile, wtile + offN, c0, qt, QT);
+                    part_barrier(&cnt[20], sub_q, W_QN);      // (the pollers must not be held up: no workgroup barrier here)
+                }
+                if (phaseB) x_currents(qt, 0xFu, do_stdp ? offN : 0);
+                if (c.dbg && g == c.dbg_wg && tid == W_Q0 * 64) c.dbg[(size_t)t * 24 + 1] = (long long)wall_clock64();
             }
-            if (phaseB) x_currents(qt, 0xFu);
-            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_Q0 * 64) c.dbg[(size_t)t * 24 + 1] = (long long)wall_clock64();
+            if (prep) {
+                // ---- the won branch of every own column with ONE crossing sample: the whole column from the committed weights
+                //      (wtile -> wwin), 64-row chunks handed out through an LDS counter: the tile waves start at once, the
+                //      speculative waves join when their own work is done.  Then that column's X currents (tile waves).
+                const int nch = (Nin + 63) >> 6;
+                uint32_t pcols = 0;
+#pragma unroll
+                for (int q = 0; q < CW; ++q) if (xm[q] && c0 + q < N) pcols |= 1u << q;
+                const int ntot = __popc(pcols) * nch;
+                for (;;) {
+                    int ch = 0;
+                    if (lane == 0) ch = atomicAdd(&cnt[24 + par], 1);
+                    ch = __builtin_amdgcn_readfirstlane(ch);
+                    if (ch >= ntot) break;
+                    const int ci = ch / nch, rc = ch - ci * nch;
+                    uint32_t pc = pcols;
+                    for (int u = 0; u < ci; ++u) pc &= pc - 1;
+                    const int q = __ffs(pc) - 1;
+                    const uint32_t xq = q == 0 ? xm[0] : (q == 1 ? xm[1] : (q == 2 ? xm[2] : xm[3]));
+                    const int bst = __ffs(xq) - 1;
+                    const int i = rc * 64 + lane;
+                    if (i < Nin) {
+                        const float xval = xsrc[bst * Nin + i];
+                        wtile[offW + i * CW + q] = postpre_elem(wtile[i * CW + q], i, q, rowmask[i], 1u << bst, bst, xwinv[4 * par + q], xsrc, true, xval);
+                    }
+                }
+                part_barrier(&cnt[22], sub_t, NTW + W_QN);
+                if (wave < NTW && phaseB) {
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        if (!((pcols >> q) & 1u)) continue;
+                        if ((tid >> 2) < B) x_current(tid >> 2, q, tid & 3, offW, offCW);
+                    }
+                }
+            }
         } else if (wave >= W_P0 && wave < W_P0 + W_PN) {
             if (phaseA) {
                 // ---- one thread per summary granule: poll it, decode its events into the bit words / Ai event lists /
                 //      crossing-sample mask
-                const unsigned long long *sums = c.exs + (size_t)(t & 1) * NGS;
-                const unsigned long long *exr = c.ex + (size_t)(t & 1) * NG;
+                const unsigned long long *sums = c.exs + (size_t)par * NGS;
+                const unsigned long long *exr = c.ex + (size_t)par * NG;
                 for (int gi = tid - W_P0 * 64; gi < NGS; gi += W_PN * 64) {
                     unsigned long long x;
                     for (unsigned spins = 0;; ++spins) {
@@ -1387,7 +1501,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     const uint32_t pay = (uint32_t)x;
                     if (!pay) continue;
                     uint32_t my_any = 0;
-                    auto event = [&](int bsm, int jx, bool inh) {       // one crossing / inhibitory spike of step t-1
+                    auto event = [&](int bsm, int jx, bool inh) __attribute__((always_inline)) {       // one crossing / inhibitory spike of step t-1
                         if (bsm >= B || jx >= N) return;
                         if (!inh) { atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31)); my_any |= 1u << bsm; }
                         else {
@@ -1399,7 +1513,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     };
                     const int gsrc = gi / NTW, w = gi - gsrc * NTW;
                     if ((pay & 0xFFu) == 0xFFu) {                        // overflow: that wave's full bit granules
-                        cnt[18 + (t & 1)] = 1;
+                        cnt[18 + par] = 1;
                         for (int q = 0; q < SPW / SPG; ++q) {
                             const int k = w * (SPW / SPG) + q;
                             if (k >= KB) break;
@@ -1422,7 +1536,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                             event(w * SPW + p_ / CW, gsrc * CW + p_ % CW, (ev & 0x40u) != 0);
                         }
                     }
-                    if (my_any) atomicOr((unsigned int *)&cnt[16 + (t & 1)], my_any);
+                    if (my_any) atomicOr((unsigned int *)&cnt[16 + par], my_any);
                 }
             } else {
                 // t == 0: lists / "winners" straight from the layers' spike bits (more than one spike per sample: give up)
@@ -1436,22 +1550,24 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     }
                 }
             }
-            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_P0 * 64) c.dbg[(size_t)t * 24 + 2] = (long long)wall_clock64();
+            if (c.dbg && g == c.dbg_wg && tid == W_P0 * 64) c.dbg[(size_t)t * 24 + 2] = (long long)wall_clock64();
         } else if (wave == W_AUX) {
             // scratch of the iterations to come: their last readers ended before barrier E, their writers start behind R
-            if (lane < CW) cnt[(t & 1) * CW + lane] = 0;                     // this step's crossing counts
-            if (lane == 8) { cnt[16 + ((t + 1) & 1)] = 0; cnt[18 + ((t + 1) & 1)] = 0; }   // what the NEXT decode accumulates into
+            if (lane < CW) { cnt[par * CW + lane] = 0; colmask[8 + 4 * (par ^ 1) + lane] = 0; }   // this step's crossing counts / crossing samples
+            if (lane == 8) { cnt[16 + (par ^ 1)] = 0; cnt[18 + (par ^ 1)] = 0; cnt[24 + (par ^ 1)] = 0; }   // what the NEXT decode accumulates into; the next won-branch chunk counter
+            for (int k = lane; k < BW; k += 64) crsA[(par ? 0 : offCB) + k] = 0;                      // ... its crossing words too
             if (t >= 1 && lane < MAXB) keys[lane] = 0ull;                   // (t == 0: the list pass above writes them)
-            if (t >= 2) raster_rows(t - 2, spI2 + ((t - 1) & 1) * kBitWords, W_AUX * 64, 64);
-            if (t < T) { fetch_digest(t + 1, W_AUX, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            if (t >= 2) raster_rows(t - 2, (int)(spI2 - finE) + (par ^ 1) * kBitWords, W_AUX * 64, 64);
         } else if (wave == W_RNG) {
             if (use_rng)
                 for (int m = ahead; m < RMK; ++m) mt_twist_block_wave(mt + ((mb + m) & RMK) * 624, mt + ((mb + m + 1) & RMK) * 624, lane);
-            if (c.dbg && blockIdx.x == c.dbg_wg && tid == W_RNG * 64) c.dbg[(size_t)t * 24 + 3] = (long long)wall_clock64();
+            if (c.dbg && g == c.dbg_wg && tid == W_RNG * 64) c.dbg[(size_t)t * 24 + 3] = (long long)wall_clock64();
         }
         if (use_rng) ahead = RMK;
+        if (c.dbg && g == c.dbg_wg && lane == 0) c.dbg[(size_t)t * 24 + 13] = c.dbg[(size_t)t * 24 + 13] | ((long long)1 << wave), c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + 200 + wave) * 4 + 3] = (long long)wall_clock64();   // arrival of every wave at R
         lds_barrier();                                                    // ---- R: exchange decoded, speculative results in place
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 4] = (long long)wall_clock64();
+        if (c.dbg && g == c.dbg_wg && threadIdx.x == 0) c.dbg[(size_t)t * 24 + 4] = (long long)wall_clock64();
+        if (c.dbg && threadIdx.x == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (prep ? 1 : 0) + (slowcols ? 2 : 0) + 4 * __popc(xm[0] | xm[1] | xm[2] | xm[3]); }   // per workgroup: behind R; kind of window
         // ---- a step the lean form does not handle: every workgroup derives this from the same exchanged data / input
         //      digest, so all of them leave here in the same iteration and nobody is left waiting for a granule
         if ((__builtin_amdgcn_readfirstlane(misc[2]) & 2) || (mflags & 5)) {
@@ -1459,194 +1575,244 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             failed = true;
             break;
         }
-        const uint32_t anym = (uint32_t)__builtin_amdgcn_readfirstlane(cnt[16 + (t & 1)]);   // samples with an Ae crossing (t == 0: with an Ae spike)
-        bool heavy = phaseA && __builtin_amdgcn_readfirstlane(cnt[18 + (t & 1)]) != 0;
-        if (phaseB) {   // what the NEXT decode accumulates into: its previous readers ended before barrier R
-            for (int k = tid; k < BW; k += NT) spI2[((t + 1) & 1) * kBitWords + k] = 0;
-            if (tid < MAXB) ((t & 1) ? cntI0 : cntI1)[tid] = 0;
-        }
-        // ---- one_spike arbitration, identical in every workgroup (see k_dc2015_run for the reasoning)
+        const uint32_t anym = (uint32_t)__builtin_amdgcn_readfirstlane(cnt[16 + par]);   // samples with an Ae crossing (t == 0: with an Ae spike)
+        bool heavy = phaseA && __builtin_amdgcn_readfirstlane(cnt[18 + par]) != 0;
         int arb_rows = 0, arb_E = 0, arb_ntw = 0;
         if (use_rng) {
             arb_rows = __popc(anym);
             arb_E = rng_pos + 2 * arb_rows * N;
             arb_ntw = arb_rows ? (arb_E - 1) / 624 : 0;
             if (arb_ntw > RMK) heavy = true;
-            if (!heavy && arb_rows) {
-                int r = 0;
-                for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
-                    if ((r % NWV) != wave) continue;
-                    const int bsm = __ffs(rem) - 1;
-                    const uint32_t bits = lane < NW ? crs[bsm * NW + lane] : 0u;
-                    unsigned long long k1 = ~0ull, k2 = ~0ull;
-                    for (uint32_t bb = bits; bb; bb &= bb - 1) {
-                        const int jx = lane * 32 + __ffs(bb) - 1;
-                        const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
-                        const int m0 = w0 / 624, m1 = w1 / 624;
-                        const uint32_t hi = mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]);
-                        const uint32_t lo = mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]);
-                        const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
-                        const unsigned long long key = (m << 10) | (unsigned long long)jx;
-                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-                    }
-                    if (lane == 0) keys[bsm] = ~0ull;
-                    if (bits) atomicMin(&keys[bsm], k1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const unsigned long long kmin = *(volatile unsigned long long *)&keys[bsm];
-                    const unsigned long long mmin = kmin >> 10, zone = mmin + (mmin >> c.zone_shift) + 1ull;
-                    const bool close = (k1 != ~0ull && k1 != kmin && (k1 >> 10) <= zone) || (k2 != ~0ull && (k2 >> 10) <= zone);
-                    int win = (int)(kmin & 1023ull);
-                    if (__any(close)) {
-                        if (lane == 0) keys[bsm] = 0ull;
-                        for (uint32_t bb = bits; bb; bb &= bb - 1) {
-                            const int jx = lane * 32 + __ffs(bb) - 1;
-                            const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
-                            const int m0 = w0 / 624, m1 = w1 / 624;
-                            const float q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
-                                                            mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]));
-                            const float val = 1.0f / q;
-                            atomicMax(&keys[bsm], ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        win = (int)(0xFFFFFFFFu - (uint32_t)(*(volatile unsigned long long *)&keys[bsm] & 0xFFFFFFFFull));
-                    }
-                    if (lane == 0) keys[bsm] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)win);
-                }
+        }
+        const bool fast = phaseA && !heavy && !slowcols && (diagE || !arb_rows);
+        // one sample's arbitration by one wave (see k_dc2015_run for the reasoning); r = the sample's rank among the crossing ones
+        auto arbitrate_sample = [&](int bsm, int r) __attribute__((always_inline)) {
+            const uint32_t bits = lane < NW ? crs[bsm * NW + lane] : 0u;
+            unsigned long long k1 = ~0ull, k2 = ~0ull;
+            for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                const int jx = lane * 32 + __ffs(bb) - 1;
+                const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
+                const int m0 = w0 / 624, m1 = w1 / 624;
+                const uint32_t hi = mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]);
+                const uint32_t lo = mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]);
+                const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
+                const unsigned long long key = (m << 10) | (unsigned long long)jx;
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
             }
-            if (heavy && arb_ntw <= RMK && tid < BW) {
-                uint32_t bits = crs[tid];
-                const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
-                while (bits) {
-                    const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
-                    const int d = myrank * N + jx;
-                    const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
+            if (lane == 0) keys[bsm] = ~0ull;
+            if (bits) atomicMin(&keys[bsm], k1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long kmin = *(volatile unsigned long long *)&keys[bsm];
+            const unsigned long long mmin = kmin >> 10, zone = mmin + (mmin >> c.zone_shift) + 1ull;
+            const bool close = (k1 != ~0ull && k1 != kmin && (k1 >> 10) <= zone) || (k2 != ~0ull && (k2 >> 10) <= zone);
+            int win = (int)(kmin & 1023ull);
+            if (__any(close)) {
+                if (lane == 0) keys[bsm] = 0ull;
+                for (uint32_t bb = bits; bb; bb &= bb - 1) {
+                    const int jx = lane * 32 + __ffs(bb) - 1;
+                    const int w0 = rng_pos + 2 * (r * N + jx), w1 = w0 + 1;
                     const int m0 = w0 / 624, m1 = w1 / 624;
                     const float q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
                                                     mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]));
                     const float val = 1.0f / q;
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
-                    atomicMax(&keys[wb], key);
+                    atomicMax(&keys[bsm], ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                win = (int)(0xFFFFFFFFu - (uint32_t)(*(volatile unsigned long long *)&keys[bsm] & 0xFFFFFFFFull));
+            }
+            if (lane == 0) { keys[bsm] = (unsigned long long)(0xFFFFFFFFu - (uint32_t)win); arbdone[bsm] = t; }
+        };
+        // final spike words of step t-1 (for the raster rows): the winner's bit, or nothing; word k <-> (sample k / NW, word k % NW)
+        auto final_words = [&](int first_thread, int nthreads) __attribute__((always_inline)) {
+            for (int k = tid - first_thread; k < BW; k += nthreads) {
+                const int b = k / NW, w = k - b * NW;
+                uint32_t wbits = 0;
+                if ((anym >> b) & 1u) { const int win = win_of(b); if ((win >> 5) == w) wbits = 1u << (win & 31); }
+                finE[k] = wbits;
+            }
+        };
+        // what the NEXT decode accumulates into (its previous readers ended before barrier R)
+        auto clear_next = [&](int first_thread, int nthreads) __attribute__((always_inline)) {
+            if (phaseB) {
+                for (int k = tid - first_thread; k < BW; k += nthreads) spI2[(par ^ 1) * kBitWords + k] = 0;
+                if (tid >= first_thread && tid < first_thread + MAXB) cntI0[(par ? 0 : (int)(cntI1 - cntI0)) + tid - first_thread] = 0;
+            }
+        };
+        // commit of step t-1's weights: wnew of the touched rows (and wwin of the columns in `wcols`) -> wtile
+        auto commit = [&](int first_thread, int nthreads, uint32_t wcols) __attribute__((always_inline)) {
+            if (!do_stdp) return;
+            if (!wcols) {
+                for (int k = tid - first_thread; k < nact; k += nthreads) {
+                    const int i = stdp_full ? k : (int)arows[k];
+                    *(float4 *)(wtile + i * 4) = *(const float4 *)(wtile + offN + i * 4);
+                }
+            } else {
+                for (int i = tid - first_thread; i < Nin; i += nthreads) {
+                    const bool touched = stdp_full || rowmask[i] != 0;
+                    float4 v = *(const float4 *)(wtile + (touched ? offN : 0) + i * 4);
+                    const float4 ww = *(const float4 *)(wtile + offW + i * 4);
+                    if (wcols & 1u) v.x = ww.x;
+                    if (wcols & 2u) v.y = ww.y;
+                    if (wcols & 4u) v.z = ww.z;
+                    if (wcols & 8u) v.w = ww.w;
+                    *(float4 *)(wtile + i * 4) = v;
                 }
             }
-        }
-        if (heavy || arb_rows > 0) lds_barrier();
-        if (use_rng) {
-            const int rows = arb_rows, pos = rng_pos, E = arb_E, ntw = arb_ntw;
-            if (ntw > RMK) {
+        };
+        // own columns with a winner, derived by every wave from the stored winners (uniform result)
+        auto own_winners = [&]() __attribute__((always_inline)) -> uint32_t {
+            uint32_t ow = 0;
+            if (phaseA && anym) {
+                const int bsm = lane & 31;
+                int q = -1;
+                if (lane < 32 && bsm < B && ((anym >> bsm) & 1u)) { const int win = win_of(bsm); if (win >= c0 && win < c0 + CW) q = win - c0; }
+#pragma unroll
+                for (int qq = 0; qq < CW; ++qq) if (__ballot(q == qq)) ow |= 1u << qq;
+            }
+            return ow;
+        };
+
+        float curE = 0.f, curI = 0.f;                                     // currents of step t of this tile thread's pair
+        if (fast) {
+            if (wave < NTW) {
+                // ---- tile waves: did the crossing pair of my column win?  One candidate in its sample: yes, no draw needed;
+                //      otherwise wait for that sample's arbitration (the other waves are at it)
+                bool colwon = false; int bst = -1;
+                const uint32_t xq = xm[0] * (jj == 0) + xm[1] * (jj == 1) + xm[2] * (jj == 2) + xm[3] * (jj == 3);
+                if (xq && colv) {
+                    bst = __ffs(xq) - 1;
+                    int n = 0;
+                    for (int w = 0; w < NW; ++w) n += __popc(crs[bst * NW + w]);
+                    if (n == 1) colwon = true;
+                    else {
+                        for (unsigned spins = 0; __hip_atomic_load(&arbdone[bst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t && spins < 100000000u; ++spins) __builtin_amdgcn_s_sleep(1);
+                        asm volatile("" ::: "memory");
+                        colwon = win_of(bst) == j;
+                    }
+                }
+                if (tid < TT && bl < B && colv) {
+                    const bool sp = colwon && bl == bst;
+                    if (c.pE.lif.traces) stl[4 * TT + tid] = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    last_sE = sp;
+                    if (phaseB) {
+                        const int nI = cntI[bl];                           // Ai spikes of step t-1 in this sample: 0 or 1
+                        const int iI = min((int)lstI[bl * LR], N - 1);
+                        const float e2 = nI ? wieT[iI * CW + jj] * 1.0f + 0.0f : 0.0f;
+                        const float e3 = sp ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;   // (own slice diagonal: only the own winner feeds Ai_j)
+                        curE = curX[((colwon && do_stdp) ? offCW : 0) + bl * CW + jj] + e2;
+                        curI = 0.0f + e3;
+                    }
+                }
+            } else {
+                // ---- the other 14 waves: arbitration of every crossing sample (generator position, rasters), commit
+                if (arb_rows) {
+                    int r = 0;
+                    for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
+                        if ((r % NOW_) + NTW != wave) continue;
+                        arbitrate_sample(__ffs(rem) - 1, r);
+                    }
+                    part_barrier(&cnt[21], sub_o, NOW_);
+                }
+                clear_next(TT, NOT);
+                final_words(TT, NOT);
+                commit(TT, NOT, own_winners());
+            }
+        } else {
+            // ---- slow iteration (and t == 0): the first generation's order
+            clear_next(0, NT);
+            if (use_rng) {
+                if (!heavy && arb_rows) {
+                    int r = 0;
+                    for (uint32_t rem = anym; rem; rem &= rem - 1, ++r) {
+                        if ((r % NWV) != wave) continue;
+                        arbitrate_sample(__ffs(rem) - 1, r);
+                    }
+                }
+                if (heavy && arb_ntw <= RMK && tid < BW) {
+                    uint32_t bits = crs[tid];
+                    const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
+                    while (bits) {
+                        const int jx = wj * 32 + __ffs(bits) - 1; bits &= bits - 1;
+                        const int d = myrank * N + jx;
+                        const int w0 = rng_pos + 2 * d, w1 = w0 + 1;
+                        const int m0 = w0 / 624, m1 = w1 / 624;
+                        const float q = exp1_from_words(mt_temper(mt[((mb + m0) & RMK) * 624 + w0 - 624 * m0]),
+                                                        mt_temper(mt[((mb + m1) & RMK) * 624 + w1 - 624 * m1]));
+                        const float val = 1.0f / q;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx);
+                        atomicMax(&keys[wb], key);
+                    }
+                }
+            }
+            if (heavy || arb_rows > 0) lds_barrier();
+            if (use_rng && arb_ntw > RMK) {
                 const int myrank = __popc(anym & ((1u << (wb & 31)) - 1u));
-                arbitrate_slow(mt, crs, keys, mb, pos, N, ntw, rows, myrank, wb, wj, BW, tid, NT, RMK);
-                ahead = ntw;
+                arbitrate_slow(mt, crs, keys, mb, rng_pos, N, arb_ntw, arb_rows, myrank, wb, wj, BW, tid, NT, RMK);
+                ahead = arb_ntw;
                 lds_barrier();
             }
-            for (int k = tid; k < BW; k += NT) crs[k] = 0;   // (every reader of this step's crossings is done)
-            if (tid < BW) {        // final spikes (for the raster rows): the winner's bit, or nothing
-                uint32_t wbits = 0;
-                if ((anym >> wb) & 1u) {
-                    const int win = win_of(wb);
-                    if ((win >> 5) == wj) wbits = 1u << (win & 31);
+            if (use_rng) final_words(0, NT);
+            const uint32_t ownwin = own_winners();
+            // Ae trace of step t-1 with the final spikes (nodes.py:96-103); winners also refresh x_tgt*nu0
+            if (phaseA && tid < TT && bl < B && colv) {
+                const bool sp = ((anym >> bl) & 1u) && win_of(bl) == j;
+                if (c.pE.lif.traces) {
+                    const float xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    stl[4 * TT + tid] = xn;
+                    if (sp) xnu0[bl * CW + jj] = xn * c.nu0;
                 }
-                finE[tid] = wbits;
+                if (sp && do_stdp) atomicOr(&colmask[jj], 1u << bl);
+                last_sE = sp;
             }
-            mb = (mb + ntw) & RMK; ahead -= ntw;
-            rng_pos = E - 624 * ntw;
-            rng_consumed += (long long)rows * N;
-        }
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 5] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 10] = arb_rows; c.dbg[(size_t)t * 24 + 11] = arb_ntw + (heavy ? 100 : 0); }
-        // ---- did an OWN column win?  Every wave reads the winners itself (uniform result, no barrier)
-        uint32_t ownwin = 0;
-        if (phaseA && anym) {
-            const int bsm = lane & 31;
-            int q = -1;
-            if (lane < 32 && bsm < B && ((anym >> bsm) & 1u)) { const int win = win_of(bsm); if (win >= c0 && win < c0 + CW) q = win - c0; }
-#pragma unroll
-            for (int qq = 0; qq < CW; ++qq) if (__ballot(q == qq)) ownwin |= 1u << qq;
-        }
-        // ---- Ae trace of step t-1 with the final spikes (nodes.py:96-103); winners also refresh x_tgt*nu0
-        if (phaseA && tid < TT && bl < B && colv) {
-            const bool sp = ((anym >> bl) & 1u) && win_of(bl) == j;
-            if (c.pE.lif.traces) {
-                const float xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
-                stl[4 * TT + tid] = xn;
-                if (sp) xnu0[bl * CW + jj] = xn * c.nu0;
-            }
-            if (sp && do_stdp) atomicOr(&colmask[jj], 1u << bl);
-            last_sE = sp;
-        }
-        if (ownwin && do_stdp) {
-            // ---- repair: the winning column(s) only.  Every row of such a column gets the post-synaptic term; rows with a
-            //      pre-synaptic spike restart from their old weight with the winner's new trace in the pre-synaptic term.
-            lds_barrier();
-            const int Emain = Nin * N;                                   // (lean form: Nin*N % 32 == 0, no tail elements)
-            for (uint32_t cols = ownwin; cols; cols &= cols - 1) {
-                const int q = __ffs(cols) - 1, jq = c0 + q;
-                if (jq >= N) continue;
-                const uint32_t cm = (c.nu1 != 0.f) ? colmask[q] : 0u;
-                for (int i = tid; i < Nin; i += NT) {
-                    uint32_t m = rowmask[i];
-                    const bool touched = stdp_full || m != 0;
-                    float w = touched ? wold[i * CW + q] : wtile[i * CW + q];
-                    const int e = i * N + jq;
-                    if (c.nu0 != 0.f) {
-                        float uu = 0.f;
-                        if (m) {
-                            CascadeT acc; acc.init(e >= Emain);
-                            while (m) {
-                                const int b = __ffs(m) - 1; m &= m - 1;
-                                acc.add(b, 1.0f * xnu0[b * CW + q], B);
-                            }
-                            uu = acc.finish(B);
-                        }
-                        if (c.use_dt) uu = uu * c.dt;
-                        w = w - uu;
+            if (ownwin && do_stdp) {
+                // ---- repair: the winning column(s) only, every row from its committed weight
+                lds_barrier();
+                for (uint32_t cols = ownwin; cols; cols &= cols - 1) {
+                    const int q = __ffs(cols) - 1;
+                    if (c0 + q >= N) continue;
+                    const uint32_t cm = colmask[q];
+                    for (int i = tid; i < Nin; i += NT) {
+                        const uint32_t m = rowmask[i];
+                        const float w = postpre_elem(wtile[i * CW + q], i, q, m, cm, -1, 0.f, xsrc);
+                        wtile[((stdp_full || m != 0) ? offN : 0) + i * CW + q] = w;
                     }
-                    if (c.nu1 != 0.f) {
-                        uint32_t mm = cm;
-                        float uu = 0.f;
-                        if (mm) {
-                            CascadeT acc; acc.init(e >= Emain);
-                            while (mm) {
-                                const int b = __ffs(mm) - 1; mm &= mm - 1;
-                                acc.add(b, xsrc[b * Nin + i] * (1.0f * c.nu1), B);
-                            }
-                            uu = acc.finish(B);
-                        }
-                        if (c.use_dt) uu = uu * c.dt;
-                        w = w + uu;
-                    }
-                    if (c.has_min && w < c.wmin) w = c.wmin;
-                    if (c.has_max && w > c.wmax) w = c.wmax;
-                    wtile[i * CW + q] = w;
                 }
+                lds_barrier();
+                if (phaseB && wave >= W_Q0 && wave < W_Q0 + W_QN) x_currents(tid - W_Q0 * 64, ownwin, offN);
+                if (tid < CW) colmask[tid] = 0;
+                lds_barrier();
             }
-            lds_barrier();
-            if (phaseB && wave >= W_Q0 && wave < W_Q0 + W_QN) x_currents(tid - W_Q0 * 64, ownwin);
-            if (tid < CW) colmask[tid] = 0;
-            lds_barrier();
+            if (wave >= NTW) commit(TT, NOT, 0u);
+            if (mine && phaseB) {
+                const int nI = cntI[bl];
+                const int iI = min((int)lstI[bl * LR], N - 1);
+                const float e2 = nI ? wieT[iI * CW + jj] * 1.0f + 0.0f : 0.0f;
+                const bool hasE = (anym >> bl) & 1u;                       // final Ae spike of step t-1 in this sample: 0 or 1
+                const int iE = hasE ? min(win_of(bl), N - 1) : 0;
+                const float e3 = hasE ? weiT[iE * CW + jj] * 1.0f + 0.0f : 0.0f;
+                curE = curX[bl * CW + jj] + e2;                            // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
+                curI = 0.0f + e3;                                          // zeros + Ae->Ai
+            }
         }
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 6] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 12] = (ownwin && do_stdp) ? 1 : 0; }
+        if (use_rng) {                                                    // generator bookkeeping (every thread, from the crossing mask alone)
+            if (fast || arb_ntw <= RMK) ahead -= arb_ntw; else ahead = 0;
+            mb = (mb + arb_ntw) & RMK;
+            rng_pos = arb_E - 624 * arb_ntw;
+            rng_consumed += (long long)arb_rows * N;
+        }
+        if (c.dbg && g == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 5] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 10] = arb_rows; c.dbg[(size_t)t * 24 + 11] = arb_ntw + (heavy ? 100 : 0); c.dbg[(size_t)t * 24 + 12] = fast ? 0 : 1; c.dbg[(size_t)t * 24 + 6] = c.dbg[(size_t)t * 24 + 5]; }
         if (!phaseB) break;
 
         // ================================================================== start step t (tile threads)
-        float curE = 0.f, curI = 0.f;
-        if (mine) {
-            const int nI = cntI[bl];                                       // Ai spikes of step t-1 in this sample: 0 or 1
-            const int iI = min((int)lstI[bl * LR], N - 1);
-            const float e2 = nI ? wieT[iI * CW + jj] * 1.0f + 0.0f : 0.0f;
-            const bool hasE = (anym >> bl) & 1u;                           // final Ae spike of step t-1 in this sample: 0 or 1
-            const int iE = hasE ? min(win_of(bl), N - 1) : 0;
-            const float e3 = hasE ? weiT[iE * CW + jj] * 1.0f + 0.0f : 0.0f;
-            curE = curX[bl * CW + jj] + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
-            curI = 0.0f + e3;                                              // zeros + Ae->Ai
-        }
         bool spE = false, spIn = false;
         float r_vE = 0.f, r_vI = 0.f;
         if (mine) {
             float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
             r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
-            if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)cnt[((t - 1) & 1) * CW + jj];
+            if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)cnt[(par ^ 1) * CW + jj];
             if (c.pE.learning) th = th * c.pE.theta_decay;
             spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
-            if (spE) atomicAdd(&cnt[(t & 1) * CW + jj], 1);
+            if (spE) atomicAdd(&cnt[par * CW + jj], 1);
             float ci = curI;
             if (r_rI > 0.f) ci = 0.f;
             spIn = lif_update(r_vI, r_rI, ci, c.pI);
@@ -1668,24 +1834,31 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                 const int sidx = lane / CW, b = wave * SPW + sidx;
                 const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull) | ((uint32_t)((mI >> (sidx * CW)) & 0xFFFFull) << 16);
                 if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
-                    granule_store(c.ex + (size_t)((t + 1) & 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                    granule_store(c.ex + (size_t)(par ^ 1) * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 pay = 0xC0FFFFFFu;
             }
-            if (lane == 0) granule_store(c.exs + (size_t)((t + 1) & 1) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            if (lane == 0) granule_store(c.exs + (size_t)(par ^ 1) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64();          // per workgroup: published
         }
         if (tid < TT && bl < B) {
-            // speculative x_tgt*nu0 of step t for the next window: the trace as it is if this pair does not win
+            // for the next window: x_tgt*nu0 of step t as it is if this pair does not win; a crossing pair also leaves its
+            // sample in the column's crossing mask and the value it has if it wins
             float xs = 0.f;
             if (colv && c.pE.lif.traces) xs = trace_next(stl[4 * TT + tid], 0, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
             xnu0[bl * CW + jj] = xs * c.nu0;
+            if (spE) {
+                atomicOr(&colmask[8 + 4 * (par ^ 1) + jj], 1u << bl);
+                if (c.pE.lif.traces) xwinv[4 * (par ^ 1) + jj] = trace_next(stl[4 * TT + tid], 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive) * c.nu0;
+            }
         }
         if (mine) {
             if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
             if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
         }
-        if (c.dbg && blockIdx.x == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 7] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 9] = (long long)clock64(); }
+        if (c.dbg && g == c.dbg_wg && threadIdx.x == 0) { c.dbg[(size_t)t * 24 + 7] = (long long)wall_clock64(); c.dbg[(size_t)t * 24 + 9] = (long long)clock64(); }
         if (c.dbg && threadIdx.x == 0) atomicMax((unsigned long long *)&c.dbg[(size_t)t * 24 + 21], (unsigned long long)wall_clock64());
+        if (wave < NTW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next iteration's digest has landed
         lds_barrier();                                                    // ---- E
     }
 
@@ -1694,7 +1867,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     if (failed) misc[5] = 1;
     __syncthreads();
     if (misc[4] != 0 || misc[5] != 0) return;
-    raster_rows(T - 1, spI2 + (T & 1) * kBitWords, 0, NT);            // the last step's rows (the aux wave writes a step's rows two iterations later)
+    raster_rows(T - 1, (int)(spI2 - finE) + (T & 1) * kBitWords, 0, NT);            // the last step's rows (the aux wave writes a step's rows two iterations later)
     if (c.x_traces) {
         const float *src = c.xtr + (size_t)T * B * Nin;
         for (int k = g * NT + tid; k < B * Nin; k += c.G * NT) c.xX[1][k] = src[k];
@@ -1788,8 +1961,8 @@ int resident_cw(int N) {
 }  // namespace
 
 size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw) { return lds_bytes_resident(B, Nin, N, cw); }
-// second-generation lean form (k_dc2015_spec): + the [Nin][4] copy of the weights the speculative PostPre started from
-size_t snn_dc2015_spec_lds(int B, int Nin, int N) { return lds_bytes_resident(B, Nin, N, 4) + (size_t)(kSpecRing - 8) * 624 * 4 + (size_t)Nin * 4 * 4; }
+// second-generation lean form (k_dc2015_spec): 16-block generator ring, speculative / won-branch weight buffers (spec_tail_lds)
+size_t snn_dc2015_spec_lds(int B, int Nin, int N) { return lds_bytes_resident(B, Nin, N, 4) + (size_t)(kSpecRing - 8) * 624 * 4 + spec_tail_lds(Nin); }
 int snn_dc2015_resident_cw(int N) { return resident_cw(N); }
 int snn_dc2015_resident_nt() { return resident_nt(); }
 
@@ -1838,7 +2011,8 @@ int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, int l
     const void *fn = resident_variant(cw, nt, lean);
     if (!coop)         // developer switch: ordinary launch (co-residency then rests on snn_dc2015_resident_capacity alone)
         return snn_check(hipLaunchKernel(fn, dim3(c.G), dim3(nt), args, lds, st));
-    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(c.G), dim3(nt), args, (unsigned)lds, st);
+    const int gmult = (lean == 2 && (c.spec_flags >> 8) > 1) ? (c.spec_flags >> 8) : 1;
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(c.G * gmult), dim3(nt), args, (unsigned)lds, st);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }
     return snn_check(e);
 }
