@@ -17,7 +17,7 @@ for path in glob.glob(out + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(path)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", ""))))
 ev.sort()
-runs = [i for i, e in enumerate(ev) if "k_dc2015_run" in e[2]]
+runs = [i for i, e in enumerate(ev) if "k_dc2015_spec" in e[2] or "k_dc2015_run" in e[2]]
 if len(runs) >= 4:
     a, b = runs[-3], runs[-2]
     t0 = ev[a][1]
