@@ -1863,6 +1863,8 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
     }
 
     // ---- epilogue (as k_dc2015_run's): nothing the caller owns as STATE has been written so far
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a digest fetch into LDS may still be in flight when the loop was left early:
+                                                         //  it must not land after this workgroup's LDS has been handed to another one)
     if (tid == 0) misc[4] = c.status ? __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     if (failed) misc[5] = 1;
     __syncthreads();
