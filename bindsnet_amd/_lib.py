@@ -199,7 +199,8 @@ def profile_run(net, inputs, time, stride=4, repeats=5):
         return None
     plan = net.last_plan
     if plan.startswith("dc2015-resident"):
-        return {"kernel": "k_dc2015_run%s (one launch per network.run())" % (" [lean form]" if plan.endswith("lean") else ""), "avg_ms": s.value / n.value, "n": n.value,
+        spec = plan.endswith("lean") and os.environ.get("SNN_DC_SPEC", "1") != "0"
+        return {"kernel": ("k_dc2015_spec [lean form, second generation]" if spec else "k_dc2015_run%s" % (" [lean form]" if plan.endswith("lean") else "")) + " (one launch per network.run())", "avg_ms": s.value / n.value, "n": n.value,
                 "timesteps_per_launch": int(round(time / net.dt))}
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}
