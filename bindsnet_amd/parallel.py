@@ -26,7 +26,7 @@ def _learned(network):
         if isinstance(conn, MulticompartmentConnection):
             feat = conn.pipeline[0]
             rule = feat.learning_rule
-            if type(rule).__name__ == "PostPre":
+            if type(rule).__name__ in ("PostPre", "MSTDP", "MSTDPET"):     # every MCC rule this package implements
                 lo, hi = rule._bounds()
                 out.append((feat.value.data, lo, hi, feat))
         elif type(conn.update_rule).__name__ in ("PostPre", "MSTDP", "Hebbian", "WeightDependentPostPre", "MSTDPET"):
@@ -91,8 +91,9 @@ def sharded_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None,
     for t, lo, hi, _ in learned:
         if lo is not None or hi is not None:
             t.clamp_(min=lo, max=hi)
-    for _, _, _, h in learned:
-        h.normalize()
+    # run() normalises EVERY connection after the loop (network.py:463-465), learning or not; with the in-run
+    # normalisation switched off that is done here, on the merged weights
+    network._normalize_all()
 
 
 # =====================================================================================================

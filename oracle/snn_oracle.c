@@ -604,7 +604,8 @@ ORC_API int orc_run_dc2015(const orc_dc_params *P,
     }
     if (rc == 0) {
         /* network.py:464-465: normalize every connection (only X->Ae has a norm) */
-        orc_normalize(W_xe, Nin, N, P->norm, 0);
+        if (P->norm > 0.0f) orc_normalize(W_xe, Nin, N, P->norm, 0);   /* norm <= 0: a run whose caller normalises later
+                                                                          (the batch-sharded schedule merges first) */
         if (P->T > 0) memcpy(sX_prev, inputs + (long)(P->T - 1) * B * Nin, (size_t)B * Nin);
     }
     free(IE); free(II);

@@ -142,3 +142,81 @@ def test_native_rccl_communicator_single_rank():
         assert torch.equal(g[0].cpu(), torch.arange(64, dtype=torch.uint8))
     finally:
         comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N = 2 for real: two processes, each with its own batch shard ON THE DEVICE, a torch.distributed group between them,
+# bindsnet_amd.parallel.sharded_run per input -- against the oracle run per shard + the merge in numpy.
+def _two_rank_run(backend, tmp_path):
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "parallel_worker.py"), "--rank", str(r), "--world", "2", "--port", str(port),
+                               "--backend", backend, "--out", outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=420)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append("timeout")
+    return [p.returncode for p in procs], logs, outs
+
+
+def _check_two_ranks(outs):
+    import cases
+    import oracle
+    name = "full_cfg2_dc_n400_b32_poisson"
+    g = cases.gold(name)
+    N, B, T = int(g["N"]), int(g["B"]), int(g["T"])
+    per = B // 2
+    res = [np.load(o) for o in outs]
+    torch.manual_seed(0)
+    W = (0.3 * torch.rand(784, N)).numpy()                        # the replicas' start (models.py:184 after manual_seed(0))
+    theta = np.zeros(N, np.float32)
+    P = oracle.eth_mnist_dc_params(N, per, T)
+    P.norm = 0.0                                                  # the shards do not normalise: the merged weights are (below)
+    Q = [oracle.exp_noise(2 + r, per * N * T * 2) for r in range(2)]
+    cur = [np.zeros(1, np.int64) for _ in range(2)]
+    for k in range(2):
+        Wg, thg = [], []
+        for r in range(2):
+            st = oracle.eth_mnist_dc_state(N, per, W.copy())
+            st["theta"][:] = theta
+            shard = np.ascontiguousarray(cases.fixture_input(g, k, T, B)[:, r * per:(r + 1) * per])
+            rasE, rasI = oracle.run_dc2015(P, st, shard, Q[r], cur[r])
+            np.testing.assert_array_equal(np.unpackbits(res[r][f"i{k}_sE"])[:T * per * N].reshape(T, per, N), rasE, err_msg=f"input {k} rank {r} Ae raster")
+            np.testing.assert_array_equal(np.unpackbits(res[r][f"i{k}_sI"])[:T * per * N].reshape(T, per, N), rasI, err_msg=f"input {k} rank {r} Ai raster")
+            Wg.append(st["W_xe"]); thg.append(st["theta"])
+            assert str(res[r][f"i{k}_plan"]).startswith("dc2015-resident")
+        # the merge of parallel.sharded_run in numpy f32: before + sum_over_ranks(after - before), clamp, normalise
+        W = (W + ((Wg[0] - W) + (Wg[1] - W))).astype(np.float32)
+        np.clip(W, 0.0, 1.0, out=W)
+        oracle.normalize(W, 78.4, False)
+        theta = (theta + ((thg[0] - theta) + (thg[1] - theta))).astype(np.float32)
+        for r in range(2):
+            np.testing.assert_array_equal(res[r][f"i{k}_W"].view(np.uint32), W.view(np.uint32), err_msg=f"input {k}: merged weights on rank {r}")
+            np.testing.assert_array_equal(res[r][f"i{k}_theta"].view(np.uint32), theta.view(np.uint32), err_msg=f"input {k}: merged theta on rank {r}")
+
+
+def test_two_ranks_on_one_gpu_gloo(tmp_path):
+    """World size 2 on the one GPU of the box (gloo between the processes, the shards and the merged tensors on the
+    device): B = 16 + 16 of the cfg2 Poisson fixture, two consecutive inputs.  Every rank's rasters = the oracle on its
+    shard from the merged weights / theta of the previous input, bit for bit; merged W and theta = the numpy merge."""
+    rcs, logs, outs = _two_rank_run("gloo", tmp_path)
+    assert rcs == [0, 0], "\n".join(logs)[-3000:]
+    _check_two_ranks(outs)
+
+
+def test_two_ranks_on_one_gpu_rccl(tmp_path):
+    """The same through RCCL (backend nccl) with both ranks on device 0 -- if RCCL accepts two ranks on one device;
+    where it refuses (duplicate GPU), that is reported as a skip with RCCL's own message."""
+    rcs, logs, outs = _two_rank_run("nccl", tmp_path)
+    if rcs != [0, 0]:
+        tail = "\n".join(logs)[-1500:]
+        pytest.skip("RCCL did not form a 2-rank group on one device: " + tail.replace("\n", " | ")[-600:])
+    _check_two_ranks(outs)
