@@ -7,6 +7,8 @@ from typing import Optional, Sequence, Union
 import numpy as np
 import torch
 
+from ..network.nodes import _f
+
 from .. import _lib
 
 
@@ -38,7 +40,7 @@ class LearningRule(_lib.Touching):
         c = self.connection
         if c.wmin.numel() != 1 or c.wmax.numel() != 1:
             raise NotImplementedError("bindsnet_amd: per-synapse wmin/wmax tensors are not supported")
-        lo, hi = float(c.wmin), float(c.wmax)
+        lo, hi = _f(c.wmin), _f(c.wmax)      # (through _f: an in-place edit of the bounds invalidates the kept run descriptors)
         clamp = (lo != -np.inf or hi != np.inf) and not isinstance(self, NoOp)   # learning.py:97-104
         if not clamp:
             return None, None

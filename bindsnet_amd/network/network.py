@@ -258,6 +258,10 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         for seq, vals in built["lists"]:              # list-valued parameters changed element-wise (rule.nu[0] = ...)
             if (seq._version if isinstance(seq, torch.Tensor) else tuple(seq)) != vals:
                 return False
+        for obj, attr, ptr in built["ptrs"]:          # tensors re-homed without an assignment (t.data = ..., set_(), resize_())
+            t = getattr(obj, attr, None)
+            if not isinstance(t, torch.Tensor) or t.data_ptr() != ptr:
+                return False
         return True
 
     def _build_descriptors(self, T, B, dev, one_step, kwargs, clamps, unclamps, injects_v, masks):
@@ -327,17 +331,23 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 else:
                     raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
                                               "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
-        finally:
+        except BaseException:
             _nodes._SCALARS = None
+            raise
 
         for table, what in ((clamps, "clamp"), (unclamps, "unclamp"), (injects_v, "injects_v")):
             for lname in table:
                 if lname not in self.layers or isinstance(self.layers[lname], Input):
+                    _nodes._SCALARS = None
                     raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
         Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
         lists, dyn_conns = [], []
         for k, ((src, dst), conn) in enumerate(self.connections.items()):
-            self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+            try:                                   # (the collector stays on: clamp bounds are read through _f() as well)
+                self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
+            except BaseException:
+                _nodes._SCALARS = None
+                raise
             if self.__dict__.get("_defer_norm", False):    # parallel.sharded_run normalises the MERGED weights itself
                 Cn[k].has_norm = 0
             wanted = self._conn_monitor_requests(conn, (src, dst))
@@ -361,6 +371,25 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 keep.append(m)
                 Cn[k].mask = _dptr(m)
 
+        _nodes._SCALARS = None
+        # every tensor whose ADDRESS went into the descriptors: `t.data = other`, set_() or resize_() re-home a tensor
+        # without any attribute assignment, so the kept arrays are only valid while these still are where they were
+        ptrs = []
+        for layer in self.layers.values():
+            for attr in ("v", "refrac_count", "x", "theta"):
+                t = getattr(layer, attr, None)
+                if isinstance(t, torch.Tensor):
+                    ptrs.append((layer, attr, t.data_ptr()))
+            if not isinstance(layer, Input) and isinstance(getattr(layer, "s", None), torch.Tensor):
+                ptrs.append((layer, "s", layer.s.data_ptr()))
+        for conn in self.connections.values():
+            if isinstance(conn, MulticompartmentConnection):
+                ptrs.append((conn._weight(), "value", conn._weight().value.data_ptr()))
+            else:
+                for attr in ("w", "b"):
+                    t = getattr(conn, attr, None)
+                    if isinstance(t, torch.Tensor):
+                        ptrs.append((conn, attr, t.data_ptr()))
         R = _lib.RunDesc()
         R.B, R.T, R.dt, R.learning = B, T, float(self.dt), int(self.learning)
         R.one_step = int(bool(one_step))                  # network.py:388-393 (generic plan)
@@ -380,7 +409,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return {"L": L, "Cn": Cn, "R": R, "names": names, "keep": keep, "inputs": dyn_inputs, "layers": dyn_layers, "conns": dyn_conns,
                 "max_draws": max_draws, "gen_bufs": gen_bufs, "T": T, "B": B, "dev": dev, "scalars": scalars,
                 "lists": lists, "epoch": _lib.epoch(), "n_objects": (len(self.layers), len(self.connections), len(self.monitors)),
-                "epoch0": epoch0, "defer_norm": bool(self.__dict__.get("_defer_norm", False))}
+                "epoch0": epoch0, "defer_norm": bool(self.__dict__.get("_defer_norm", False)), "ptrs": ptrs}
 
     def _bind_call(self, built, inputs, T, B, dev):
         """The per-call part of the descriptors: input spike trains, Input.s (it aliases the previous call's last

@@ -212,7 +212,7 @@ class DiehlAndCookNodes(Nodes):
         l.decay, l.rest, l.reset, l.thresh = _f(self.decay), _f(self.rest), _f(self.reset), _f(self.thresh)
         l.refrac, l.dt = _f(self.refrac), _f(self.dt)
         l.has_lbound = int(self.lbound is not None)
-        l.lbound = float(self.lbound) if self.lbound is not None else 0.0
+        l.lbound = (_f(self.lbound) if isinstance(self.lbound, torch.Tensor) else float(self.lbound)) if self.lbound is not None else 0.0
         self._trace_fields(l)
         p.theta_decay, p.theta_plus = _f(self.theta_decay), _f(self.theta_plus)
         p.learning, p.one_spike = int(self.learning), int(self.one_spike)

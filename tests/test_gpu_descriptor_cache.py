@@ -74,8 +74,31 @@ def other_batch(net):
     pass            # (the next input has another batch size: see `sequence`)
 
 
+def swap_weight_data(net):
+    """`.data = other` re-homes the tensor without any attribute assignment on a network object."""
+    feat = net.connections[("X", "Ae")].pipeline[0]
+    feat.value.data = 0.2 * torch.ones_like(feat.value)
+
+
+def swap_theta_data(net):
+    th = net.layers["Ae"].theta
+    th.data = torch.full_like(th, 0.3)
+
+
+def load_state(net):
+    """load_state_dict copies into the parameters / buffers IN PLACE."""
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    changed = 0
+    for k in sd:
+        if k.endswith("thresh"):
+            sd[k] = sd[k] - 2.0
+            changed += 1
+    assert changed
+    net.load_state_dict(sd)
+
+
 CHANGES = [change_thresh_in_place, change_nu_element, stop_learning, add_monitor, move_and_back, new_weights,
-           change_rest_in_place, other_batch]
+           change_rest_in_place, other_batch, swap_weight_data, swap_theta_data, load_state]
 
 
 def sequence(change, cached):
@@ -133,3 +156,42 @@ def test_kept_descriptors_are_used_and_dropped():
     e = _lib.epoch()
     net.layers["Ae"].v.add_(1.0)                # state tensors are addressed, not copied: in-place edits need no rebuild
     assert e == _lib.epoch()
+
+
+@pytest.mark.parametrize("edit", ["wmax_in_place", "w_data_swap"])
+def test_dense_connection_edits_between_calls_take_effect(edit):
+    """Dense Connection: its clamp bounds are Parameters (read into the descriptors as floats) and its weights can be
+    re-homed through `.data`; both must reach a run that would otherwise re-use the kept descriptors."""
+    from bindsnet_amd.models import TwoLayerNetwork
+    from bindsnet_amd.network import network as netmod
+
+    def seq(cached):
+        old = netmod._DESC_CACHE
+        netmod._DESC_CACHE = cached
+        try:
+            torch.manual_seed(0)
+            net = TwoLayerNetwork(n_inpt=784, n_neurons=64, reduction=torch.sum).to(DEV)
+            conn = net.connections[("X", "Y")]
+            xs = [torch.from_numpy(synth.dense_spikes(30 + k, (T, B, 784), 0.05)).to(DEV) for k in range(4)]
+            out = []
+            for k in range(2):
+                net.run({"X": xs[k]}, time=T)
+                net.reset_state_variables()
+            if edit == "wmax_in_place":
+                with torch.no_grad():
+                    conn.wmax.fill_(0.05)           # far below the learned weights: the clamp must bite in the next run
+            else:
+                conn.w.data = 0.1 * torch.ones_like(conn.w)
+            for k in range(2, 4):
+                net.run({"X": xs[k]}, time=T)
+                out.append(conn.w.detach().cpu().numpy().copy())
+                net.reset_state_variables()
+            return out
+        finally:
+            netmod._DESC_CACHE = old
+
+    a, b = seq(True), seq(False)
+    for wa, wb in zip(a, b):
+        np.testing.assert_array_equal(wa.view(np.uint32), wb.view(np.uint32))
+    if edit == "wmax_in_place":
+        assert float(a[0].max()) <= 0.05 * 78.4 / 1e-9      # (normalised afterwards; the point is cached == rebuilt)
