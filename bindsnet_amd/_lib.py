@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -69,7 +69,8 @@ class LayerDesc(C.Structure):
                 ("s", C.c_void_p), ("ext_spikes", C.c_void_p), ("raster_s", C.c_void_p),
                 ("raster_v", C.c_void_p), ("current", C.c_void_p),
                 ("clamp", C.c_void_p), ("unclamp", C.c_void_p), ("clamp_per_step", C.c_int), ("unclamp_per_step", C.c_int),
-                ("inject_v", C.c_void_p), ("inject_per_step", C.c_int), ("inject_len", C.c_int)]
+                ("inject_v", C.c_void_p), ("inject_per_step", C.c_int), ("inject_len", C.c_int),
+                ("ext_current", C.c_void_p)]
 
 
 class ConnDesc(C.Structure):

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256) void k_clamp(uint8_t *__restrict__ s, uint8_t 
 __global__ __launch_bounds__(256) void k_inject(float *__restrict__ v, const float *__restrict__ inj, long total, int len) {
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) v[k] = v[k] + inj[k % len];   // :399-404
 }
+__global__ __launch_bounds__(256) void k_add_current(float *__restrict__ cur, const float *__restrict__ ext, long total) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) cur[k] = cur[k] + ext[k];      // network.py:386-392
+}
 __global__ __launch_bounds__(256) void k_mask_fill(float *__restrict__ W, const uint8_t *__restrict__ mask, long total) {
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) if (mask[k]) W[k] = 0.f;     // topology.py:129-133
 }
@@ -177,6 +180,8 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 continue;
             }
             if (!fed[l]) TRY(snn_check(hipMemsetAsync(d.current, 0, sizeof(float) * (size_t)B * d.n, st)));  // :409-413
+            if (d.ext_current)                     // an external current for this layer: added behind the connections' sums (:386-392)
+                hipLaunchKernelGGL(k_add_current, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.current, d.ext_current + off, (long)B * d.n);
             if (d.inject_v) {
                 const int len = d.inject_len > 0 ? d.inject_len : d.n;
                 hipLaunchKernelGGL(k_inject, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.v,
@@ -190,14 +195,12 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                                             rs, st));
             } else TRY(snn_dc_step(d.v, d.refrac, d.s, d.x, d.theta, d.current, B, d.n, &d.p, R->noise_q, R->q_len,
                                    R->cursor, R->status, rs, rv, st));
-        }
-        for (int l = 0; l < nL; ++l) {        // clamps, after every layer has stepped (each layer's own `s` only: order-free)
-            const snn_layer_desc &d = L[l];
-            if (d.kind == SNN_LAYER_INPUT || (!d.clamp && !d.unclamp)) continue;
-            const size_t off = (size_t)t * B * d.n;
-            hipLaunchKernelGGL(k_clamp, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.s, d.raster_s ? d.raster_s + off : nullptr,
-                               d.clamp ? d.clamp + (d.clamp_per_step ? (size_t)t * d.n : 0) : nullptr,
-                               d.unclamp ? d.unclamp + (d.unclamp_per_step ? (size_t)t * d.n : 0) : nullptr, (long)B * d.n, d.n);
+            // clamp / unclamp right behind the layer's own step (network.py:394-429): with one_step a later layer's
+            // currents are taken from these spikes
+            if (d.clamp || d.unclamp)
+                hipLaunchKernelGGL(k_clamp, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.s, rs,
+                                   d.clamp ? d.clamp + (d.clamp_per_step ? (size_t)t * d.n : 0) : nullptr,
+                                   d.unclamp ? d.unclamp + (d.unclamp_per_step ? (size_t)t * d.n : 0) : nullptr, (long)B * d.n, d.n);
         }
         // (3) network.py:431-454 learning rules, connection order
         if (R->learning)
@@ -251,7 +254,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request
-    for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v) mode = 1;   // only the generic plan implements these
+    for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v || L[l].ext_current) mode = 1;   // only the generic plan implements these
     for (int c = 0; c < nC; ++c) if (C[c].mask || C[c].raster_w || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
     if (R->one_step) mode = 1;
     if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));

@@ -439,11 +439,18 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 xcopy = x[:T].clone().view(T, B, *layer.shape)   # clone (monitors.py:94-111): the caller may refill its buffer in place
                 rasters += [(m, key, xcopy) for m, key in wanted]
             inputs[name] = x
-        for name in inputs:
-            if name in self.layers and not isinstance(self.layers[name], Input):
-                raise NotImplementedError("bindsnet_amd: external input currents into non-Input layers are "
-                                          "outside the accelerated path")
         for i, layer, requests in built["layers"]:
+            # an entry of `inputs` for a non-Input layer is an external CURRENT (network.py:386-392): slice t is added to
+            # the layer's summed input behind the connections' contributions (generic plan)
+            ext = inputs.get(built["names"][i])
+            if ext is not None:
+                if ext.shape[0] < T or ext[0].numel() != B * layer.n:
+                    raise ValueError(f"inputs['{built['names'][i]}'] has shape {tuple(ext.shape)}, expected [T >= {T}, {B}, {layer.n}]")
+                ext = ext[:T].to(dev, torch.float32).contiguous()
+                keep.append(ext)
+                L[i].ext_current = _dptr(ext)
+            else:
+                L[i].ext_current = None
             mon_s = mon_v = None
             for m, key, var in requests:
                 if var == "s":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 3
+#define SNN_ABI_VERSION 4
 
 typedef void *snn_stream_t;
 
@@ -274,6 +274,9 @@ typedef struct {
      *                         slice [inject_len] with inject_len = n or B*n) */
     const uint8_t *clamp, *unclamp; int clamp_per_step, unclamp_per_step;
     const float *inject_v; int inject_per_step; int inject_len;
+    /* run(inputs={<non-Input layer>: current}), network.py:386-392 (nullable; generic plan): f32 [T,B,n], slice t is added
+     * to the layer's summed input current after the connections' contributions, before the layer steps */
+    const float *ext_current;
 } snn_layer_desc;
 
 typedef struct {

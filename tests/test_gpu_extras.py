@@ -212,3 +212,62 @@ def test_one_step_mode_matches_reference():
         for l, n in (("A", nA), ("B", nB)):
             np.testing.assert_array_equal(host(mons[l].get("s")).reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
     assert not np.array_equal(g["one_A"], g["sync_A"])
+
+
+def _r3_chain(T):
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    nX, nA, nB = 64, 40, 24
+    net = Network(dt=1.0, learning=False)
+    net.add_layer(Input(n=nX), "X"); net.add_layer(LIFNodes(n=nA, thresh=-60.0), "A"); net.add_layer(LIFNodes(n=nB, thresh=-61.0), "B")
+    for k, (src, dst, ns, nd, sc) in enumerate((("X", "A", nX, nA, 2.0), ("A", "B", nA, nB, 0.35), ("B", "A", nB, nA, -1.0))):
+        w = (synth.uniform_f32(3200 + k, (ns, nd), 0.0, abs(sc)) * np.sign(sc)).astype(np.float32)
+        net.add_connection(MulticompartmentConnection(net.layers[src], net.layers[dst], device="cpu", pipeline=[Weight("weight", T_(w).clone())]), src, dst)
+    mons = {l: Monitor(net.layers[l], ["s", "v"], time=T) for l in ("A", "B")}
+    for l, m in mons.items():
+        net.add_monitor(m, l)
+    return net.to(DEV), mons
+
+
+def test_external_currents_into_non_input_layers_match_reference():
+    """run(inputs={"X": spikes, "A": currents, "B": currents}): an entry for a non-Input layer is an external current,
+    added to that layer's summed input behind its connections' contributions (network.py:386-392).  Rasters and membrane
+    potentials of both layers, every timestep, bit for bit against the reference (tests/golden/make_golden_r3.py)."""
+    g = gold("run_ext_current")
+    nX, nA, nB, B, T = 64, 40, 24, 3, 30
+    net, mons = _r3_chain(T)
+    sp = synth.dense_spikes(3210, (T, B, nX), 0.10)
+    cA = synth.uniform_f32(3211, (T, B, nA), -1.0, 4.0)
+    cB = synth.uniform_f32(3212, (T, B, nB), 0.0, 2.5)
+    net.run({"X": T_(sp).to(DEV), "A": T_(cA).to(DEV), "B": T_(cB)}, time=T)      # (one of them left on the host: moved by run())
+    assert net.last_plan == "generic"
+    for l, n in (("A", nA), ("B", nB)):
+        np.testing.assert_array_equal(host(mons[l].get("s")).reshape(T, B, n).astype(u8), unpack(g[f"s_{l}"], (T, B, n)), err_msg=f"raster {l}")
+        np.testing.assert_array_equal(host(mons[l].get("v")).reshape(T, B, n).view(np.uint32), g[f"v_{l}"].reshape(T, B, n).view(np.uint32), err_msg=f"v {l}")
+    # ... and a later call WITHOUT the currents must not see the old ones (the kept descriptors are rebound per call)
+    net.reset_state_variables()
+    net.run({"X": T_(sp).to(DEV)}, time=T)
+    a = host(mons["A"].get("s")).copy()
+    net.reset_state_variables()
+    net.run({"X": T_(sp).to(DEV), "A": torch.zeros(T, B, nA), "B": torch.zeros(T, B, nB)}, time=T)
+    np.testing.assert_array_equal(a, host(mons["A"].get("s")))
+
+
+def test_one_step_with_clamp_matches_reference():
+    """one_step=True together with clamp / unclamp: the reference clamps a layer right behind its own step
+    (network.py:394-429), so the layers behind it take their currents from the CLAMPED spikes in the same timestep."""
+    g = gold("run_one_step_clamp")
+    nX, nA, nB, B, T = 64, 40, 24, 3, 30
+    net, mons = _r3_chain(T)
+    sp = synth.dense_spikes(3220, (T, B, nX), 0.15)
+    clampA = torch.zeros(nA, dtype=torch.bool); clampA[::7] = True
+    unclampA = torch.zeros(nA, dtype=torch.bool); unclampA[3::5] = True
+    for tag, flag in (("one", True), ("sync", False)):
+        net.reset_state_variables()
+        net.run({"X": T_(sp).to(DEV)}, time=T, one_step=flag, clamp={"A": clampA}, unclamp={"A": unclampA})
+        for l, n in (("A", nA), ("B", nB)):
+            np.testing.assert_array_equal(host(mons[l].get("s")).reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
+    assert not np.array_equal(g["one_B"], g["sync_B"])
