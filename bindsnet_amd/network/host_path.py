@@ -1,0 +1,220 @@
+"""Network.run() for networks that live on the HOST: a plain-PyTorch step loop with the reference's semantics.
+
+The product of this package is the MI355X path (csrc/*.hip behind the C ABI); this module exists so that the drop-in
+package still constructs and runs where there is no GPU (SURVEY.md 8(b) fallback rule) -- a laptop, a CI box -- and it is a
+second, independent statement of the same semantics: tests/test_host_path.py pins it to the reference-generated fixtures
+the GPU tests use.  It is selected by Network.run only when the network's tensors are CPU tensors; it never touches
+libsnnhip and has nothing to do with oracle/ (test infrastructure).  Supported on this path: Input / LIFNodes /
+DiehlAndCookNodes; MulticompartmentConnection + Weight (no rule / PostPre), Connection (no rule / PostPre / MSTDP),
+Conv2dConnection (no rule); clamp / unclamp / injects_v / masks / one_step / reward; Monitor / NetworkMonitor.
+
+What each function states (paths inside BindsNET): network.py:211-250,380-465 (loop, `zeros + c1 + c2` accumulation,
+normalise), nodes.py:96-107,211-221,500-529,1069-1111 (layers), topology.py:332-346,437-479,799-815 and
+topology_features.py:633-645 (propagation), MCC_learning.py:224-302,86-110 / learning.py:390-420,1504-1574,87-104 (rules).
+Per-step cost is the reference's (one ATen call per operation): this path is for function, not speed.
+"""
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def _trace(layer, s) -> None:
+    if not layer.traces:
+        return
+    layer.x *= layer.trace_decay
+    if layer.traces_additive:
+        layer.x += layer.trace_scale * s.float()
+    else:
+        layer.x.masked_fill_(s.bool(), float(layer.trace_scale))
+
+
+def _step_input(layer, x) -> None:
+    layer.s = x                                        # aliases the caller's tensor, like the reference
+    _trace(layer, x)
+
+
+def _step_lif(layer, x) -> None:
+    layer.v = layer.decay * (layer.v - layer.rest) + layer.rest
+    x.masked_fill_(layer.refrac_count > 0, 0.0)        # (in place on the summed input, as the reference does)
+    layer.refrac_count -= layer.dt
+    layer.v += x
+    layer.s = layer.v >= layer.thresh
+    layer.refrac_count.masked_fill_(layer.s, float(layer.refrac))
+    layer.v.masked_fill_(layer.s, float(layer.reset))
+    if layer.lbound is not None:
+        layer.v.masked_fill_(layer.v < layer.lbound, float(layer.lbound))
+    _trace(layer, layer.s)
+
+
+def _step_dc(layer, x) -> None:
+    B = x.shape[0]
+    layer.v = layer.decay * (layer.v - layer.rest) + layer.rest
+    if layer.learning:
+        layer.theta *= layer.theta_decay
+    layer.v += (layer.refrac_count <= 0).float() * x
+    layer.refrac_count -= layer.dt
+    layer.s = layer.v >= layer.thresh + layer.theta
+    layer.refrac_count.masked_fill_(layer.s, float(layer.refrac))
+    layer.v.masked_fill_(layer.s, float(layer.reset))
+    if layer.learning:
+        layer.theta += layer.theta_plus * layer.s.float().sum(0)
+    if layer.one_spike and layer.s.any():              # one winner per sample with a crossing, drawn from the global generator
+        rows = layer.s.view(B, -1).any(1)
+        ind = torch.multinomial(layer.s.float().view(B, -1)[rows], 1)
+        rows = rows.nonzero()
+        layer.s.zero_()
+        layer.s.view(B, -1)[rows, ind] = 1
+    if layer.lbound is not None:
+        layer.v.masked_fill_(layer.v < layer.lbound, layer.lbound)
+    _trace(layer, layer.s)
+
+
+def _propagate(conn, s):
+    from .topology import Connection, Conv2dConnection, LocalConnection, MulticompartmentConnection
+    B = s.shape[0]
+    if isinstance(conn, MulticompartmentConnection):
+        value = conn._weight().value
+        spikes = s.view(B, conn.source.n, 1).repeat(1, 1, conn.target.n)
+        return (value * spikes).sum(1).view(B, *conn.target.shape)
+    if isinstance(conn, Conv2dConnection):
+        return F.conv2d(s.float(), conn.w, conn.b, stride=conn.stride, padding=conn.padding, dilation=conn.dilation)
+    if isinstance(conn, (Connection, LocalConnection)):
+        post = s.view(B, -1).float() @ conn.w.view(conn.source.n, conn.target.n)
+        if getattr(conn, "b", None) is not None:
+            post = post + conn.b
+        return post.view(B, *conn.target.shape)
+    raise NotImplementedError(f"bindsnet_amd host path: connection type {type(conn).__name__}")
+
+
+def _reduce(rule, t):
+    return t.squeeze(0) if rule.reduction is torch.squeeze else rule.reduction(t, dim=0)
+
+
+def _update_mcc(conn, dt) -> None:
+    from ..learning import MCC_learning as rules
+    feat = conn._weight()
+    rule = feat.learning_rule
+    if isinstance(rule, rules.NoOp) or conn.manual_update:
+        return
+    if not isinstance(rule, rules.PostPre):
+        raise NotImplementedError(f"bindsnet_amd host path: MCC rule {type(rule).__name__} (supported: PostPre)")
+    B = conn.source.batch_size
+    W = feat.value.data
+    nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
+    if nu0:
+        pre = torch.bmm(conn.source.s.view(B, -1).unsqueeze(2).float(), conn.target.x.view(B, -1).unsqueeze(1) * nu0)
+        W -= _reduce(rule, pre) * dt
+    if nu1:
+        post = torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), conn.target.s.view(B, -1).unsqueeze(1).float() * nu1)
+        W += _reduce(rule, post) * dt
+    W *= float(rule.decay)
+    lo, hi = rule._bounds()
+    if lo is not None or hi is not None:
+        W.clamp_(lo, hi)
+
+
+def _update_dense(conn, kwargs, mask) -> None:
+    from ..learning import learning as rules
+    rule = conn.update_rule
+    if rule is None or isinstance(rule, rules.NoOp):
+        return
+    B = conn.source.batch_size
+    W = conn.w.data
+    if not isinstance(rule, rules.PostPre) or W.dim() != 2:
+        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on {type(conn).__name__} (supported: PostPre on Connection)")
+    rule._check_reduction()
+    nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
+    if nu0:
+        pre = torch.bmm(conn.source.s.view(B, -1).unsqueeze(2).float(), conn.target.x.view(B, -1).unsqueeze(1) * nu0)
+        W -= _reduce(rule, pre)
+    if nu1:
+        post = torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), conn.target.s.view(B, -1).unsqueeze(1).float() * nu1)
+        W += _reduce(rule, post)
+    W *= float(rule.weight_decay)
+    lo, hi = rule._bounds()
+    if lo is not None or hi is not None:
+        W.clamp_(lo, hi)
+    if mask is not None:
+        W.masked_fill_(mask.bool().view_as(W), 0.0)
+
+
+def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs) -> None:
+    from .nodes import DiehlAndCookNodes, Input, LIFNodes
+    from .topology import MulticompartmentConnection
+    clamps, unclamps = kwargs.get("clamp", {}) or {}, kwargs.get("unclamp", {}) or {}
+    injects_v, masks = kwargs.get("injects_v", {}) or {}, kwargs.get("masks", {}) or {}
+    dt = float(network.dt)
+    for name, layer in network.layers.items():
+        if not isinstance(layer, (Input, LIFNodes, DiehlAndCookNodes)):
+            raise NotImplementedError(f"bindsnet_amd host path: layer type {type(layer).__name__}")
+        if isinstance(layer, Input) and name not in inputs:
+            raise NotImplementedError(f"bindsnet_amd: Input layer '{name}' needs an entry in `inputs`")
+
+    def currents(only=None):
+        """Summed input per target layer from the sources' current `s` (network.py:211-250), connection order."""
+        cur = {}
+        for (src, dst), conn in network.connections.items():
+            if only is not None and dst != only:
+                continue
+            tgt = network.layers[dst]
+            if dst not in cur:
+                cur[dst] = torch.zeros(network.batch_size, *tgt.shape)
+            cur[dst] += _propagate(conn, network.layers[src].s)
+        return cur
+
+    for t in range(T):
+        cur = {} if one_step else currents()
+        for name, layer in network.layers.items():
+            if isinstance(layer, Input):
+                _step_input(layer, inputs[name][t])
+            else:
+                if one_step:
+                    cur.update(currents(name))
+                x = cur.get(name)
+                if name in inputs:                                     # an external current for a non-Input layer
+                    ext = inputs[name][t].float().view(network.batch_size, *layer.shape)
+                    x = ext.clone() if x is None else x + ext
+                if x is None:
+                    x = torch.zeros(network.batch_size, *layer.shape)
+                inj = injects_v.get(name)
+                if inj is not None:
+                    inj = torch.as_tensor(inj)
+                    layer.v += inj[t] if inj.dim() >= 2 else inj
+                (_step_dc if isinstance(layer, DiehlAndCookNodes) else _step_lif)(layer, x)
+                for table, value in ((clamps, 1), (unclamps, 0)):
+                    m = table.get(name)
+                    if m is not None:
+                        m = torch.as_tensor(m)
+                        m = (m[t] if m.dim() >= 2 else m).bool()
+                        layer.s[:, m.view(*layer.shape)] = bool(value)
+        if network.learning:
+            for key, conn in network.connections.items():
+                if isinstance(conn, MulticompartmentConnection):
+                    _update_mcc(conn, dt)
+                else:
+                    _update_dense(conn, kwargs, masks.get(key))
+        for key, mask in masks.items():                                # masks apply every step, learning or not
+            conn = network.connections[key]
+            if hasattr(conn, "w"):
+                conn.w.data.masked_fill_(torch.as_tensor(mask).bool().view_as(conn.w), 0.0)
+        for m in network.monitors.values():
+            m.record()
+    normalize(network)
+
+
+def normalize(network) -> None:
+    """network.py:463-465: every connection's normalisation -- Weight features by their SIGNED column sums
+    (topology_features.py:250-266), dense connections by the absolute ones (topology.py:383-392)."""
+    from .topology import MulticompartmentConnection
+    for conn in network.connections.values():
+        if isinstance(conn, MulticompartmentConnection):
+            feat = conn._weight()
+            if feat.norm is not None:
+                colsum = feat.value.data.sum(0).unsqueeze(0)
+                colsum[colsum == 0] = 1.0
+                feat.value.data *= feat.norm / colsum
+        elif getattr(conn, "norm", None) is not None and hasattr(conn, "w") and conn.w.dim() == 2:
+            colsum = conn.w.data.abs().sum(0).unsqueeze(0)
+            colsum[colsum == 0] = 1.0
+            conn.w.data *= conn.norm / colsum

@@ -178,13 +178,23 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             break
 
         T, B = int(time / self.dt), self.batch_size
+        dev = self._device()
+        if dev.type != "cuda":
+            # A network whose tensors live on the host: the plain-PyTorch step loop with the reference's semantics
+            # (network/host_path.py).  Function, not speed -- the product is the MI355X path below; nothing is ever
+            # silently moved between the two (a network on the GPU never falls back to this).
+            if any(v.is_cuda for v in inputs.values()):
+                raise _lib.SnnError("bindsnet_amd: the network is on the host but an input tensor is on the GPU: move the "
+                                    "network with network.to('cuda')")
+            from . import host_path
+            if T <= 0:
+                host_path.normalize(self)
+                return
+            host_path.run(self, inputs, T, one_step, kwargs)
+            return
         if T <= 0:
             self._normalize_all()
             return
-        dev = self._device()
-        if dev.type != "cuda":
-            raise _lib.SnnError("bindsnet_amd executes on an MI355X only: move the network with network.to('cuda') "
-                                "(there is no CPU fallback)")
         # The descriptor arrays are kept from one call to the next: while nothing has been assigned to any object of the
         # network since they were built (_lib.epoch(), plus the in-place versions of the scalar parameter tensors they
         # were filled from) only the per-call pointers are rebound -- inputs, Input.s, monitor buffers.  Calls with

@@ -1,0 +1,108 @@
+"""The package on a machine WITHOUT a GPU: Network.run() of a network whose tensors are CPU tensors takes the
+plain-PyTorch step loop (bindsnet_amd/network/host_path.py) -- pinned here against the same reference-generated
+fixtures the MI355X path is tested with (tests/golden/make_golden*.py), bit for bit: rasters, weights, theta, state,
+and the position of the host generator.  Also: the external-current and one_step + clamp fixtures of round 3."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from cases import gold, sha, unpack
+
+u8 = np.uint8
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("name", ["run_dc_n100_b1", "run_dc_n100_b3", "run_dc_n100_b3_busy", "run_dc_n400_b4"])
+def test_dc2015_on_the_host_matches_reference(name):
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    g = gold(name)
+    N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=float(g["inh"]), dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+    feat = net.connections[("X", "Ae")].pipeline[0]
+    feat.value.data.copy_(T_(synth.weights_q12(10, 784, N)))
+    mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
+    for l, m in mons.items():
+        net.add_monitor(m, l + "_s")
+    Ae, Ai, X = net.layers["Ae"], net.layers["Ai"], net.layers["X"]
+    for r in range(runs):
+        spikes = synth.spike_train(20 + r, T, B, 784, max_rate=float(g["max_rate"]))
+        torch.manual_seed(2 + r)
+        net.run({"X": T_(spikes).view(T, B, 1, 28, 28)}, time=T)
+        np.testing.assert_array_equal(mons["Ae"].get("s").numpy().reshape(T, B, N).astype(u8), unpack(g[f"r{r}_sE"], (T, B, N)), err_msg=f"run {r} Ae")
+        np.testing.assert_array_equal(mons["Ai"].get("s").numpy().reshape(T, B, N).astype(u8), unpack(g[f"r{r}_sI"], (T, B, N)), err_msg=f"run {r} Ai")
+        assert sha(feat.value.detach().numpy()) == str(g[f"r{r}_W_sha"]), f"run {r} weights"
+        for key, a in (("theta", Ae.theta), ("vE", Ae.v), ("rE", Ae.refrac_count), ("xE", Ae.x), ("xX", X.x.reshape(B, 784)), ("vI", Ai.v), ("rI", Ai.refrac_count)):
+            np.testing.assert_array_equal(bits(a.numpy()), bits(g[f"r{r}_{key}"]), err_msg=f"run {r} {key}")
+        if r % 2 == 0:
+            net.reset_state_variables()
+
+
+def test_two_layer_postpre_on_the_host_matches_reference():
+    """TwoLayerNetwork (dense Connection + PostPre): rasters identical to the reference; weights / state within the dense
+    family's tolerance (Connection.compute is an MKL sgemm whose summation order depends on the thread count of the
+    machine the fixture was made on -- SURVEY.md finding 5)."""
+    from bindsnet_amd.models import TwoLayerNetwork
+    from bindsnet_amd.network.monitors import Monitor
+    g = gold("run_two_postpre_b4")
+    Nin, N, B, T = int(g["Nin"]), int(g["N"]), int(g["B"]), int(g["T"])
+    torch.manual_seed(0)
+    net = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum, norm=78.4 * Nin / 784)
+    conn = net.connections[("X", "Y")]
+    conn.w.data.copy_(T_(synth.weights_q12(11, Nin, N)))
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    net.run({"X": T_(spikes)}, time=T)
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), unpack(g["sY"], (T, B, N)))
+    np.testing.assert_allclose(conn.w.detach().numpy(), g["W"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(net.layers["Y"].v.numpy(), g["vY"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(bits(net.layers["X"].x.numpy()), bits(g["xX"]))
+
+
+def test_external_currents_and_one_step_clamp_on_the_host():
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    nX, nA, nB, B, T = 64, 40, 24, 3, 30
+
+    def chain():
+        net = Network(dt=1.0, learning=False)
+        net.add_layer(Input(n=nX), "X"); net.add_layer(LIFNodes(n=nA, thresh=-60.0), "A"); net.add_layer(LIFNodes(n=nB, thresh=-61.0), "B")
+        for k, (src, dst, ns, nd, sc) in enumerate((("X", "A", nX, nA, 2.0), ("A", "B", nA, nB, 0.35), ("B", "A", nB, nA, -1.0))):
+            w = (synth.uniform_f32(3200 + k, (ns, nd), 0.0, abs(sc)) * np.sign(sc)).astype(np.float32)
+            net.add_connection(MulticompartmentConnection(net.layers[src], net.layers[dst], device="cpu", pipeline=[Weight("weight", T_(w).clone())]), src, dst)
+        mons = {l: Monitor(net.layers[l], ["s", "v"], time=T) for l in ("A", "B")}
+        for l, m in mons.items():
+            net.add_monitor(m, l)
+        return net, mons
+
+    g = gold("run_ext_current")
+    net, mons = chain()
+    sp = synth.dense_spikes(3210, (T, B, nX), 0.10)
+    net.run({"X": T_(sp), "A": T_(synth.uniform_f32(3211, (T, B, nA), -1.0, 4.0)), "B": T_(synth.uniform_f32(3212, (T, B, nB), 0.0, 2.5))}, time=T)
+    for l, n in (("A", nA), ("B", nB)):
+        np.testing.assert_array_equal(mons[l].get("s").numpy().reshape(T, B, n).astype(u8), unpack(g[f"s_{l}"], (T, B, n)), err_msg=f"raster {l}")
+        np.testing.assert_array_equal(bits(mons[l].get("v").numpy().reshape(T, B, n)), bits(g[f"v_{l}"].reshape(T, B, n)), err_msg=f"v {l}")
+
+    g = gold("run_one_step_clamp")
+    net, mons = chain()
+    sp = synth.dense_spikes(3220, (T, B, nX), 0.15)
+    clampA = torch.zeros(nA, dtype=torch.bool); clampA[::7] = True
+    unclampA = torch.zeros(nA, dtype=torch.bool); unclampA[3::5] = True
+    for tag, flag in (("one", True), ("sync", False)):
+        net.reset_state_variables()
+        net.run({"X": T_(sp)}, time=T, one_step=flag, clamp={"A": clampA}, unclamp={"A": unclampA})
+        for l, n in (("A", nA), ("B", nB)):
+            np.testing.assert_array_equal(mons[l].get("s").numpy().reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
