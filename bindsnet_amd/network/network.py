@@ -191,6 +191,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 host_path.normalize(self)
                 return
             host_path.run(self, inputs, T, one_step, kwargs)
+            self.__dict__["last_plan"] = "host-torch"
             return
         if T <= 0:
             self._normalize_all()

@@ -103,9 +103,14 @@ def test_api_surface_matches_reference_names():
         Connection(Input(n=4), LIFNodes(n=3), update_rule=PostPre, nu=1e-2)      # traces required
     with pytest.raises(AssertionError):
         net.run([1, 2], time=1)                                                   # inputs must be a dict
-    with pytest.raises(Exception) as e:
-        net.run({"X": torch.zeros(5, 1, 1, 28, 28, dtype=torch.uint8)}, time=5)   # CPU tensors: loud, no fallback
-    assert "MI355X" in str(e.value)
+    # a network on the host runs the plain-PyTorch step loop (network/host_path.py; tests/test_host_path.py pins it) ...
+    net.run({"X": torch.zeros(5, 1, 1, 28, 28, dtype=torch.uint8)}, time=5)
+    assert net.last_plan == "host-torch", "the host path is not a plan of libsnnhip"
+    # ... but nothing is moved between host and device behind the caller's back
+    if torch.cuda.is_available():
+        with pytest.raises(Exception) as e:
+            net.run({"X": torch.zeros(5, 1, 1, 28, 28, dtype=torch.uint8, device="cuda")}, time=5)
+        assert "network.to('cuda')" in str(e.value)
     with pytest.raises(NotImplementedError):
         Input(n=3, sum_input=True)
 
@@ -158,6 +163,5 @@ def test_scalar_parameter_cache_and_cpu_reset():
     assert not Ae.s.any() and not X.s.any() and float(Ae.x.abs().sum()) == 0.0 and float(X.x.abs().sum()) == 0.0
     assert float(Ae.refrac_count.abs().sum()) == 0.0 and float(Ai.refrac_count.abs().sum()) == 0.0
     assert torch.all(Ae.theta == 0.3)
-    from bindsnet_amd import _lib as lib_mod
-    with pytest.raises(lib_mod.SnnError):
-        net.run({"X": torch.zeros(5, 3, 1, 4, 4, dtype=torch.uint8)}, time=5)      # CPU tensors: no fallback
+    net.run({"X": torch.zeros(5, 3, 1, 4, 4, dtype=torch.uint8)}, time=5)          # CPU tensors: the host path (test_host_path.py)
+    assert net.last_plan == "host-torch"

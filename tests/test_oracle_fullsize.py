@@ -54,6 +54,9 @@ def test_stated_poisson_input_regenerates_through_the_package_encoder(name, bold
 def test_oracle_dc2015_full_size(name):
     g = gold(name)
     N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
+    if name == "full_cfg2_dc_n400_b32":
+        runs = 1          # round 1/2's sparser input: one run here (a minute per three for the scalar C port); the Poisson
+                          # fixtures below -- the input BASELINE.md states -- are checked over all three runs
     P = dc_params(g)
     st = cases.dc_state(N, B, inh=120.0)
     st["W_xe"] = ref_init_weights(784, N)
