@@ -258,7 +258,11 @@ struct CascT {             // batch sums have at most 32 terms: the branch-free 
     __device__ __forceinline__ float finish(int n) { return c.finish(n); }
 };
 
-template <class SUM, int MWT>
+// RL: PostPre, or the two rules with the same outer-product skeleton (generic plan: k_plasticity modes 2 / 3, same
+// arithmetic) -- Hebbian  w += nu0 * U1; w += nu1 * U2  (learning.py:1052-1135) and WeightDependentPostPre
+// w += 0 - (nu0 U1)(w - wmin) + (nu1 U2)(wmax - w)  (learning.py:562-653), U1 = sum_b s_src x_tgt, U2 = sum_b x_src s_tgt;
+// for these `xnu0` holds the plain target trace.
+template <class SUM, int MWT, int RL = SNN_RULE_POSTPRE>
 __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint16_t *ar, const uint32_t *am,
                                          const uint32_t *ab, const float *xnu0, const uint32_t *cm,
                                          const float *__restrict__ xs, const float *xsl, const uint8_t *__restrict__ sbytes,
@@ -281,6 +285,39 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
         if (c0 + q >= N) continue;
         const bool tl = i * N + c0 + q >= Emain;
         float w = wt[i * CW + q];
+        if constexpr (RL != SNN_RULE_POSTPRE) {
+            float u1, u2 = 0.f;
+            {
+                SUM acc; acc.init(tl);
+                for (int wd = 0; wd < mw; ++wd) {
+                    uint32_t mm = m[wd];
+                    while (mm) {
+                        const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1;
+                        const float sv = sbytes ? (float)sbytes[b * Nin + i] : 1.0f;
+                        acc.add(b, sv * xnu0[b * 8 + q], B);
+                    }
+                }
+                u1 = acc.finish(B);
+            }
+            if (any_of(cq)) {
+                SUM acc; acc.init(tl);
+                const int fb = first_of(cq);
+                for (int wd = 0; wd < mw; ++wd) {
+                    uint32_t mm = cq[wd];
+                    while (mm) { const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, fb) * 1.0f, B); }
+                }
+                u2 = acc.finish(B);
+            }
+            if constexpr (RL == SNN_RULE_HEBBIAN) {
+                w = w + c.nu0 * u1;
+                w = w + c.nu1 * u2;
+            } else {
+                float upd = 0.f; bool have = false;
+                if (c.nu0 != 0.f) { upd = 0.0f - (c.nu0 * u1) * (w - c.wmin); have = true; }
+                if (c.nu1 != 0.f) { const float y = (c.nu1 * u2) * (c.wmax - w); upd = have ? upd + y : y; have = true; }
+                if (have) w = w + upd;
+            }
+        } else {
         if (c.nu0 != 0.f) {                               // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
             SUM acc; acc.init(tl);
             for (int wd = 0; wd < mw; ++wd) {             // ascending sample index = the reference's batch-sum order
@@ -309,6 +346,7 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
             if (c.use_dt) uu = uu * c.dt;
             w = w + uu;
         }
+        }
         w = w * c.wdecay;
         if (c.has_min && w < c.wmin) w = c.wmin;
         if (c.has_max && w > c.wmax) w = c.wmax;
@@ -316,7 +354,7 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
     }
     // ---- pass 2: rows WITHOUT a pre-synaptic spike: the columns that spiked (every column when `full`)
     uint32_t todo = 0;                                    // columns to visit, as a bit mask
-    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || (c.nu1 != 0.f && any_of(cm + q * mw)))) todo |= 1u << q;
+    for (int q = 0; q < CW; ++q) if (c0 + q < N && (full || ((c.nu1 != 0.f || RL == SNN_RULE_HEBBIAN) && any_of(cm + q * mw)))) todo |= 1u << q;
     if (!todo) return;
     for (int i = tid; i < Nin; i += NT) {
         if ((ab[i >> 5] >> (i & 31)) & 1u) continue;
@@ -326,6 +364,27 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
             const uint32_t *cq = cm + q * mw;
             const bool cany = c.nu1 != 0.f && any_of(cq);
             float w = wt[i * CW + q];
+            if constexpr (RL != SNN_RULE_POSTPRE) {          // no pre-synaptic spike in this row: U1 is the empty sum
+                float u2 = 0.f;
+                if (any_of(cq)) {
+                    SUM acc; acc.init(i * N + c0 + q >= Emain);
+                    const int fb = first_of(cq);
+                    for (int wd = 0; wd < mw; ++wd) {
+                        uint32_t mm = cq[wd];
+                        while (mm) { const int b = wd * 32 + __ffs(mm) - 1; mm &= mm - 1; acc.add(b, xsrc(q, b, i, fb) * 1.0f, B); }
+                    }
+                    u2 = acc.finish(B);
+                }
+                if constexpr (RL == SNN_RULE_HEBBIAN) {
+                    w = w + c.nu0 * 0.0f;
+                    w = w + c.nu1 * u2;
+                } else {
+                    float upd = 0.f; bool have = false;
+                    if (c.nu0 != 0.f) { upd = 0.0f - (c.nu0 * 0.0f) * (w - c.wmin); have = true; }
+                    if (c.nu1 != 0.f) { const float y = (c.nu1 * u2) * (c.wmax - w); upd = have ? upd + y : y; have = true; }
+                    if (have) w = w + upd;
+                }
+            } else {
             if (c.nu0 != 0.f) w = w - (c.use_dt ? 0.0f * c.dt : 0.0f);
             if (c.nu1 != 0.f) {
                 float uu = 0.f;
@@ -340,6 +399,7 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
                 }
                 if (c.use_dt) uu = uu * c.dt;
                 w = w + uu;
+            }
             }
             w = w * c.wdecay;
             if (c.has_min && w < c.wmin) w = c.wmin;
@@ -786,7 +846,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
     const bool tailcol = CASC && j >= (N / 32) * 32;
     const int Etot = Nin * N, Emain = (Etot / 32) * 32;
     const int cwl = 31 - __clz(CW);                      // CW is a power of two
-    const bool do_stdp = RULE == SNN_RULE_POSTPRE && c.learning;
+    constexpr bool kOuter = RULE == SNN_RULE_POSTPRE || RULE == SNN_RULE_HEBBIAN || RULE == SNN_RULE_WDPOSTPRE;   // the rules of two_stdp
+    const bool do_stdp = kOuter && c.learning;
     const bool do_mstdp = RULE == SNN_RULE_MSTDP && c.learning;
 
     // ---- prologue: own weight slice and membrane state
@@ -884,9 +945,14 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
         if (t >= 1 && do_stdp) {
             const bool full = (t == 1) || c.wdecay != 1.0f;   // first update of a run (or a real decay) touches every element
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
+            if constexpr (RULE == SNN_RULE_HEBBIAN || RULE == SNN_RULE_WDPOSTPRE) {
+                if (Etot != Emain) two_stdp<OuterSum, MWT, RULE>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+                else two_stdp<CascT, MWT, RULE>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+            } else {
             if (Etot != Emain) two_stdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
             else if (sbytes || c.rowmajor == 0) two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
             else two_stdp_rowmajor<MWT>(c, wt, am, ab, ridx, xnu0, ul, fac, xs, full, c0, tid);
+            }
         }
         WMARK();
         TMARK(3);
@@ -982,7 +1048,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
                 const float p = pm * c.d_minus;           // learning.py:1566-1567
                 pm = p + c.a_minus * (float)sp;
             } else
-            xnu0[bl * 8 + jj] = xy * c.nu0;               // target_x * nu[0]
+            xnu0[bl * 8 + jj] = (RULE == SNN_RULE_POSTPRE) ? xy * c.nu0 : xy;   // target_x * nu[0] (Hebbian / WeightDependentPostPre: nu applied to the batch sum)
             if (sp) atomicOr(&cmn[jj * mw + (bl >> 5)], 1u << (bl & 31));
             if (c.rasY) c.rasY[(size_t)t * B * N + kst] = sp;
             if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
@@ -1112,10 +1178,12 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (L[0].kind != SNN_LAYER_INPUT || L[1].kind != SNN_LAYER_LIF) return false;
     if (C[0].src != 0 || C[0].dst != 1) return false;
     if (C[0].kind != SNN_CONN_MCC && C[0].kind != SNN_CONN_DENSE) return false;
-    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE && C[0].rule != SNN_RULE_MSTDP) return false;
+    const bool outer2 = C[0].rule == SNN_RULE_HEBBIAN || C[0].rule == SNN_RULE_WDPOSTPRE;     // dense Connection only
+    if (C[0].rule != SNN_RULE_NONE && C[0].rule != SNN_RULE_POSTPRE && C[0].rule != SNN_RULE_MSTDP && !(outer2 && C[0].kind == SNN_CONN_DENSE)) return false;
+    if (C[0].rule == SNN_RULE_WDPOSTPRE && !(C[0].has_min && C[0].has_max)) return false;
     if (C[0].rule == SNN_RULE_MSTDP && (!C[0].p_plus || !C[0].p_minus || !C[0].s_src_prev ||
                                         !C[0].s_tgt_prev || !(C[0].a_plus >= 0.f))) return false;
-    if (C[0].rule == SNN_RULE_POSTPRE && (!L[0].x || !L[1].x || !L[0].p.lif.traces || !L[1].p.lif.traces)) return false;
+    if ((C[0].rule == SNN_RULE_POSTPRE || outer2) && (!L[0].x || !L[1].x || !L[0].p.lif.traces || !L[1].p.lif.traces)) return false;
     if (C[0].kind == SNN_CONN_MCC && C[0].bias) return false;
     const int B = R->B, Nin = L[0].n, N = L[1].n;
     if (B > MAXB || R->T < 1 || Nin % 16 != 0 || Nin > 65535 || Nin > kMaxTerms) return false;
@@ -1143,7 +1211,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.prodw = 0;
     if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) { c.prodw = 4096; if (run_lds(c) > 140 * 1024) c.prodw = 0; }
     c.use_xsl = 0;
-    if (Nin <= NT && c.rule == SNN_RULE_POSTPRE && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
+    if (Nin <= NT && (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
     if (META + c.LCAP / 2 + Nin * c.MW + (Nin + 1) / 2 + c.NinW > PF * NT) return false;
     return true;
@@ -1180,7 +1248,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.dig = (uint32_t *)ws;
     float *big = (float *)(ws + al((size_t)(c.T + 2) * c.DW * 4));
     const bool mstdp = C[0].rule == SNN_RULE_MSTDP && R->learning;
-    c.xall = (C[0].rule == SNN_RULE_POSTPRE) ? big : nullptr;
+    c.xall = (C[0].rule == SNN_RULE_POSTPRE || C[0].rule == SNN_RULE_HEBBIAN || C[0].rule == SNN_RULE_WDPOSTPRE) ? big : nullptr;
     c.pall = mstdp ? big : nullptr;
     c.p_plus = C[0].p_plus; c.p_minus = C[0].p_minus; c.s_src_prev = C[0].s_src_prev; c.s_tgt_prev = C[0].s_tgt_prev;
     c.a_plus = C[0].a_plus; c.a_minus = C[0].a_minus; c.d_plus = C[0].decay_plus; c.d_minus = C[0].decay_minus;
@@ -1198,7 +1266,9 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
     c.has_min = C[0].has_min; c.wmin = C[0].wmin; c.has_max = C[0].has_max; c.wmax = C[0].wmax;
     static bool attr = false;
     if (!attr) {
-        const void *variants[12] = {
+        const void *variants[16] = {
+            (const void *)k_two_run<false, SNN_RULE_HEBBIAN, 1>, (const void *)k_two_run<false, SNN_RULE_WDPOSTPRE, 1>,
+            (const void *)k_two_run<false, SNN_RULE_HEBBIAN, 4>, (const void *)k_two_run<false, SNN_RULE_WDPOSTPRE, 4>,
             (const void *)k_two_run<true, SNN_RULE_NONE, 1>, (const void *)k_two_run<true, SNN_RULE_POSTPRE, 1>,
             (const void *)k_two_run<false, SNN_RULE_NONE, 1>, (const void *)k_two_run<false, SNN_RULE_POSTPRE, 1>,
             (const void *)k_two_run<false, SNN_RULE_MSTDP, 1>, (const void *)k_two_run<true, SNN_RULE_MSTDP, 1>,
@@ -1229,6 +1299,8 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         else if (c.cascade) hipLaunchKernelGGL((k_two_run<true, SNN_RULE_NONE, MWV>), grid, blk, lds, st, c); \
         else if (c.rule == SNN_RULE_POSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_POSTPRE, MWV>), grid, blk, lds, st, c); \
         else if (c.rule == SNN_RULE_MSTDP) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_MSTDP, MWV>), grid, blk, lds, st, c); \
+        else if (c.rule == SNN_RULE_HEBBIAN) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_HEBBIAN, MWV>), grid, blk, lds, st, c); \
+        else if (c.rule == SNN_RULE_WDPOSTPRE) hipLaunchKernelGGL((k_two_run<false, SNN_RULE_WDPOSTPRE, MWV>), grid, blk, lds, st, c); \
         else hipLaunchKernelGGL((k_two_run<false, SNN_RULE_NONE, MWV>), grid, blk, lds, st, c); } while (0)
         if (c.MW == 1) TWO_LAUNCH(1); else TWO_LAUNCH(4);
 #undef TWO_LAUNCH

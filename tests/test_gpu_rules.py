@@ -76,15 +76,18 @@ def test_mstdpet_update_sequence_vs_reference():
         np.testing.assert_array_equal(bits(host(got)), bits(g[key]), err_msg=key)
 
 
-@pytest.mark.parametrize("rule", ["hebbian", "wdpp", "mstdpet"])
-def test_network_run_with_the_rule_vs_oracle(rule):
+@pytest.mark.parametrize("rule,Nin,N,B,plan", [
+    ("hebbian", 196, 48, 6, "generic"), ("wdpp", 196, 48, 6, "generic"), ("mstdpet", 196, 48, 1, "generic"),
+    # Nin % 16 == 0: the one-launch plan (k_two_run<false, HEBBIAN / WDPOSTPRE, .>), one and two batch-mask words
+    ("hebbian", 208, 48, 6, "twolayer-fused"), ("wdpp", 208, 48, 6, "twolayer-fused"),
+    ("hebbian", 208, 40, 40, "twolayer-fused"), ("wdpp", 208, 40, 40, "twolayer-fused")])
+def test_network_run_with_the_rule_vs_oracle(rule, Nin, N, B, plan):
     from bindsnet_amd.learning import Hebbian, MSTDPET, WeightDependentPostPre
     from bindsnet_amd.network import Network
     from bindsnet_amd.network.monitors import Monitor
     from bindsnet_amd.network.nodes import Input, LIFNodes
     from bindsnet_amd.network.topology import Connection
-    Nin, N, T = 196, 48, 40
-    B = 1 if rule == "mstdpet" else 6
+    T = 40
     W0 = synth.weights_q12(11, Nin, N)
     net = Network(dt=1.0)
     net.add_layer(Input(n=Nin, traces=True), "X")
@@ -100,7 +103,7 @@ def test_network_run_with_the_rule_vs_oracle(rule):
     spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
     kw = {"reward": 0.8} if rule == "mstdpet" else {}
     net.run({"X": torch.from_numpy(spikes).to(DEV)}, time=T, **kw)
-    assert net.last_plan == "generic"
+    assert net.last_plan == plan
     P = oracle.TwoParams()
     P.B, P.Nin, P.N, P.T, P.dt = B, Nin, N, T, 1.0
     P.rule = {"hebbian": 3, "wdpp": 4, "mstdpet": 5}[rule]

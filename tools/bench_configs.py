@@ -85,12 +85,58 @@ def cfg5():
     return "cfg5 6400->500 LIF MSTDP B=16 T=100", net, {"X": x}, 100, {"reward": 1.0}
 
 
+def _rule_two_layer(rule_name, B=32, Nin=784, N=1600, T=100):
+    """Input -> Connection(rule) -> LIFNodes at cfg3's width (one GPU's share of the batch)."""
+    from bindsnet_amd import learning
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    torch.manual_seed(0)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True), "Y")
+    net.add_connection(Connection(net.layers["X"], net.layers["Y"], w=0.3 * torch.rand(Nin, N), wmin=0.0, wmax=1.0,
+                                  update_rule=getattr(learning, rule_name), nu=(1e-4, 1e-2), norm=78.4, reduction=torch.sum), "X", "Y")
+    net.to(DEV)
+    x = torch.from_numpy(synth.dense_spikes(2, (T, B, Nin), 0.012)).to(DEV)
+    return f"(f) {rule_name} 784->1600 B={B} T={T}", net, {"X": x}, T, {}
+
+
+def f_hebbian():
+    return _rule_two_layer("Hebbian")
+
+
+def f_wdpp():
+    return _rule_two_layer("WeightDependentPostPre")
+
+
+def f_postpre_ref():
+    return _rule_two_layer("PostPre")            # the same graph with PostPre, for comparison
+
+
+def f_conv_postpre():
+    """conv_mnist.py's training graph: Input -> Conv2dConnection(PostPre) -> LIFNodes (generic plan)."""
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    torch.manual_seed(0)
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 28, 28), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(32, 24, 24), traces=True), "Y")
+    net.add_connection(Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=5, stride=1, update_rule=PostPre, nu=(1e-4, 1e-2),
+                                        wmin=0.0, wmax=1.0, reduction=torch.sum, w=0.3 * torch.rand(32, 1, 5, 5)), "X", "Y")
+    net.to(DEV)
+    x = torch.from_numpy(synth.dense_spikes(3, (100, 16, 1, 28, 28), 0.05)).to(DEV)
+    return "(f) Conv2d 5x5x32 PostPre -> LIF B=16 T=100", net, {"X": x}, 100, {}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=5)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    for make in (cfg1, cfg3_shard, cfg3_b32, cfg3, cfg4, cfg5):
+    for make in (cfg1, cfg3_shard, cfg3_b32, cfg3, cfg4, cfg5, f_postpre_ref, f_hebbian, f_wdpp, f_conv_postpre):
         if a.only and make.__name__ not in a.only.split(','):
             continue
         name, net, inputs, T, kw = make()
