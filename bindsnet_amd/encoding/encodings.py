@@ -42,14 +42,15 @@ def bernoulli(datum: torch.Tensor, time: Optional[int] = None, dt: float = 1.0, 
     assert 0 <= max_prob <= 1, "Maximum firing probability must be in range [0, 1]"
     assert (datum >= 0).all(), "Inputs must be non-negative"
     shape = datum.shape
-    flat = datum.flatten()
+    # the reference normalises `datum.flatten().to(device)`: the caller's tensor is divided in place exactly when that
+    # expression is a view of it (contiguous datum already on `device`), a copy otherwise
+    flat = datum.flatten().to(device)
     steps = None if time is None else int(time / dt)
     if flat.max() > 1.0:
         flat /= flat.max()
     if torch.device(device).type == "cuda":
         from ..ops import encode_bernoulli
         return encode_bernoulli(flat, 1 if steps is None else steps, max_prob, device).view(*(() if steps is None else (steps,)), *shape)
-    flat = flat.to(device)
     if steps is None:
         return torch.bernoulli(max_prob * flat).view(*shape).byte()
     return torch.bernoulli(max_prob * flat.repeat([steps, 1])).view(steps, *shape).byte()

@@ -109,6 +109,12 @@ def sharded_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None,
 # This is the mode whose 2 / 4 / 8-GPU results meet the north star's parity bar; the batch-sharded `sharded_run` above
 # is the north star's RCCL schedule, which does not (SURVEY.md 8(e)).
 # =====================================================================================================
+def _scalar_bound(t) -> float:
+    if isinstance(t, torch.Tensor) and t.numel() != 1:
+        raise NotImplementedError("column sharding needs scalar wmin / wmax (per-synapse bounds are not supported)")
+    return float(t)
+
+
 def column_shard_bounds(n_columns: int, world: int, rank: int, align: int = 32):
     """[lo, hi) of rank's column slice: whole blocks of `align` columns dealt out as evenly as possible (the first
     ranks get the extra blocks); a trailing partial block belongs to the last non-empty slice."""
@@ -175,7 +181,7 @@ def column_shard(network, rank: int, world: int):
         if isinstance(rule, dense_rules.MSTDP):
             kw.update(tc_plus=float(rule.tc_plus), tc_minus=float(rule.tc_minus))
         c2 = Connection(X2, Y2, w=conn.w.data[:, lo:hi].clone().cpu(), b=None if conn.b is None else conn.b.data[lo:hi].clone().cpu(),
-                        wmin=float(conn.wmin), wmax=float(conn.wmax), norm=conn.norm, update_rule=rule_cls,
+                        wmin=_scalar_bound(conn.wmin), wmax=_scalar_bound(conn.wmax), norm=conn.norm, update_rule=rule_cls,
                         nu=None if rule_cls is None else (float(rule.nu[0]), float(rule.nu[1])), reduction=rule.reduction,
                         weight_decay=0.0 if rule.weight_decay == 1.0 else 1.0 - float(rule.weight_decay), **kw)
     else:
@@ -186,6 +192,18 @@ def column_shard(network, rank: int, world: int):
     dev = Y.v.device
     if dev.type != "cpu":
         shard.to(dev)
+    # an MSTDP rule keeps p_plus / p_minus / the previous spikes across run() and reset_state_variables() (learning.py:
+    # 1501-1574): a rule that has already run carries them into its shard -- p_plus and the source spikes whole, p_minus
+    # and the target spikes by column -- so that the exact mode stays exact for a network sharded in mid-training
+    old_rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else conn.update_rule
+    new_rule = c2._weight().learning_rule if isinstance(c2, MulticompartmentConnection) else c2.update_rule
+    if hasattr(old_rule, "p_plus") and hasattr(new_rule, "_ensure_state"):
+        if old_rule.p_plus.dim() != 2 or old_rule.p_minus.shape[-1] != N:
+            raise NotImplementedError("column sharding of a rule whose state is not [batch, n] (Conv2d MSTDP, MSTDPET) is not supported")
+        new_rule.p_plus = old_rule.p_plus.clone()
+        new_rule.p_minus = old_rule.p_minus[:, lo:hi].clone()
+        new_rule._s_src_prev = old_rule._s_src_prev.clone()
+        new_rule._s_tgt_prev = old_rule._s_tgt_prev[:, lo:hi].clone()
     # carry the full network's current state over (a freshly built network starts at rest like the reference)
     B = network.batch_size
     if Y.v.numel() == B * N:

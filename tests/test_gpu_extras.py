@@ -115,7 +115,9 @@ def test_conv2d_postpre_updates_and_run():
     net.run({"X": T_(sp).to(DEV)}, time=T3)
     assert net.last_plan == "generic"
     np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
-    np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-4)
+    # every single update is bit-exact against the oracle (above); against the REFERENCE the batch/position sums of its two
+    # torch.bmm calls run in BLAS order, and 30 updates accumulate that: the north star's 1e-5, relative to wmax = 4.0
+    np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-5 * 4.0)
 
 
 def test_mstdp_on_conv2d_connection_matches_oracle_and_reference():
@@ -181,8 +183,11 @@ def test_mstdp_on_conv2d_connection_matches_oracle_and_reference():
     np.testing.assert_array_equal(host(cc.w).view(np.uint32), W.view(np.uint32))
     np.testing.assert_array_equal(host(cc.update_rule.eligibility).view(np.uint32), E.view(np.uint32))
     np.testing.assert_array_equal(ras, unpack(g["run_sY"], (T3, 400)))
-    np.testing.assert_allclose(host(cc.w), g["run_W"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(host(cc.update_rule.eligibility), g["run_elig"], rtol=0, atol=1e-4)
+    # (bit-exact against the hand-stepped oracle above; the reference's eligibility comes out of two torch.bmm calls in
+    #  BLAS order: 1e-5 relative to wmax = 4.0 for the weights; the eligibility is a sum over up to 100 output positions
+    #  of products of O(1) traces, compared relative to its own magnitude)
+    np.testing.assert_allclose(host(cc.w), g["run_W"], rtol=0, atol=1e-5 * 4.0)
+    np.testing.assert_allclose(host(cc.update_rule.eligibility), g["run_elig"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(g["run_elig"]).max())))
     assert ras.sum() > 500 and np.abs(host(cc.w) - W0).max() > 1e-2
 
 

@@ -125,6 +125,54 @@ def test_column_shards_on_the_device_equal_the_full_network(kind):
     assert int(full[1][0].sum()) > 100
 
 
+def test_column_shards_of_a_network_in_mid_training_carry_the_rule_state():
+    """An MSTDP rule keeps p_plus / p_minus / the previous spikes across run() and reset_state_variables(); sharding a network
+    that has already run must carry them (advisor finding, round 2): input 0 on the full network, THEN shard, input 1 on the
+    shards -- weights, rasters and the rule's state equal the full network's second run bit for bit."""
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    from bindsnet_amd.parallel import column_shard
+    T, B, Nin, N = 40, 24, 784, 352
+
+    def make():
+        torch.manual_seed(0)
+        net = Network(dt=1.0)
+        net.add_layer(Input(n=Nin, traces=True), "X")
+        net.add_layer(LIFNodes(n=N, traces=True), "Y")
+        net.add_connection(Connection(net.layers["X"], net.layers["Y"], w=0.3 * torch.rand(Nin, N), wmin=0, wmax=1, update_rule=MSTDP,
+                                      nu=1e-1, norm=0.1 * Nin, reduction=torch.sum), "X", "Y")
+        return net.to(DEV)
+
+    inputs = [torch.from_numpy(synth.dense_spikes(50 + r, (T, B, Nin), 0.03)).to(DEV) for r in range(2)]
+    full = make()
+    mon = Monitor(full.layers["Y"], ["s"], time=T)
+    full.add_monitor(mon, "Y_s")
+    full.run({"X": inputs[0]}, time=T, reward=1.0)
+    full.reset_state_variables()
+    base = make()
+    base.run({"X": inputs[0]}, time=T, reward=1.0)
+    base.reset_state_variables()
+    assert float(base.connections[("X", "Y")].update_rule.p_plus.abs().sum()) > 0      # the rule holds state now
+    full.run({"X": inputs[1]}, time=T, reward=1.0)
+    parts = []
+    for r in range(3):
+        shard, lo, hi = column_shard(base, r, 3)
+        m = Monitor(shard.layers["Y"], ["s"], time=T)
+        shard.add_monitor(m, "Y_s")
+        shard.run({"X": inputs[1]}, time=T, reward=1.0)
+        rule = shard.connections[("X", "Y")].update_rule
+        parts.append((m.get("s").reshape(T, B, -1).clone(), shard.connections[("X", "Y")].w.detach().clone(), rule.p_minus.clone(), rule.p_plus.clone()))
+    fr = full.connections[("X", "Y")].update_rule
+    assert torch.equal(torch.cat([p[0] for p in parts], dim=-1), mon.get("s").reshape(T, B, -1)), "rasters"
+    assert torch.equal(torch.cat([p[1] for p in parts], dim=-1), full.connections[("X", "Y")].w.detach()), "weights"
+    assert torch.equal(torch.cat([p[2] for p in parts], dim=-1), fr.p_minus), "p_minus"
+    for p_ in parts:
+        assert torch.equal(p_[3], fr.p_plus), "p_plus"
+
+
 def test_native_rccl_communicator_single_rank():
     """include/snnhip.h snn_dist_*: the C ABI's own RCCL collectives (no torch.distributed), world size 1."""
     from bindsnet_amd.parallel import NativeComm
