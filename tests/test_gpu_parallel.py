@@ -150,19 +150,19 @@ def test_column_shards_of_a_network_in_mid_training_carry_the_rule_state():
     full = make()
     mon = Monitor(full.layers["Y"], ["s"], time=T)
     full.add_monitor(mon, "Y_s")
-    full.run({"X": inputs[0]}, time=T, reward=1.0)
+    full.run({"X": inputs[0].clone()}, time=T, reward=1.0)      # (clones: reset_state_variables() zeroes the last slice of the tensor Input.s aliases)
     full.reset_state_variables()
     base = make()
-    base.run({"X": inputs[0]}, time=T, reward=1.0)
+    base.run({"X": inputs[0].clone()}, time=T, reward=1.0)
     base.reset_state_variables()
     assert float(base.connections[("X", "Y")].update_rule.p_plus.abs().sum()) > 0      # the rule holds state now
-    full.run({"X": inputs[1]}, time=T, reward=1.0)
+    full.run({"X": inputs[1].clone()}, time=T, reward=1.0)
     parts = []
     for r in range(3):
         shard, lo, hi = column_shard(base, r, 3)
         m = Monitor(shard.layers["Y"], ["s"], time=T)
         shard.add_monitor(m, "Y_s")
-        shard.run({"X": inputs[1]}, time=T, reward=1.0)
+        shard.run({"X": inputs[1].clone()}, time=T, reward=1.0)
         rule = shard.connections[("X", "Y")].update_rule
         parts.append((m.get("s").reshape(T, B, -1).clone(), shard.connections[("X", "Y")].w.detach().clone(), rule.p_minus.clone(), rule.p_plus.clone()))
     fr = full.connections[("X", "Y")].update_rule
