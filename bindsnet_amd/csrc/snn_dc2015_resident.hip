@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
 //   barrier E
 // Bit-exactness: every value is produced by the same operations in the same order as in the first-generation kernel; a
 // column of the won branch is computed by the (row, column) form of the update (stdp_rows_lds) from the committed weights.
+constexpr int kSpecEarlyTwists = 2; // generator blocks refilled behind barrier R (the rest in the next window)
 constexpr int kSpecRing = 16;      // generator blocks resident (a step with up to 11 crossing samples stays on the fast path)
 constexpr size_t spec_fixed_lds() { return resident_fixed_lds(4) + (size_t)(kSpecRing - 8) * 624 * 4; }
 // behind the digests: wnew [Nin][4], wwin [Nin][4], second crossing-bit buffer, curXwin [32][4], xwin [2][4], arbdone [32]
@@ -1672,6 +1673,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
             return ow;
         };
 
+        int rng_early = 0;                                                // generator wave: blocks refilled behind barrier R of this iteration
         float curE = 0.f, curI = 0.f;                                     // currents of step t of this tile thread's pair
         if (fast) {
             if (wave < NTW) {
@@ -1713,9 +1715,20 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
                     }
                     part_barrier(&cnt[21], sub_o, NOW_);
                 }
-                clear_next(TT, NOT);
-                final_words(TT, NOT);
-                commit(TT, NOT, own_winners());
+                if (wave == W_RNG) {
+                    // the generator wave takes no share of the commit: the blocks this step's arbitration consumed are free
+                    // now, so it starts the refill here (up to kSpecEarlyTwists blocks, what fits before barrier E) instead
+                    // of doing all of it in the next window, where it was the last wave to reach barrier R
+                    if (!(c.spec_flags & 16)) {
+                        const int mbn = (mb + arb_ntw) & RMK, ah = ahead - arb_ntw;        // (fast iteration: arb_ntw <= ahead)
+                        for (int m = ah; m < RMK && rng_early < kSpecEarlyTwists; ++m, ++rng_early)
+                            mt_twist_block_wave(mt + ((mbn + m) & RMK) * 624, mt + ((mbn + m + 1) & RMK) * 624, lane);
+                    }
+                } else {
+                    clear_next(TT, NOT - 64);
+                    final_words(TT, NOT - 64);
+                    commit(TT, NOT - 64, own_winners());
+                }
             }
         } else {
             // ---- slow iteration (and t == 0): the first generation's order
@@ -1796,6 +1809,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
         }
         if (use_rng) {                                                    // generator bookkeeping (every thread, from the crossing mask alone)
             if (fast || arb_ntw <= RMK) ahead -= arb_ntw; else ahead = 0;
+            ahead += rng_early;                        // (generator wave only: blocks it has already put back behind barrier R)
             mb = (mb + arb_ntw) & RMK;
             rng_pos = arb_E - 624 * arb_ntw;
             rng_consumed += (long long)arb_rows * N;
