@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_spec(const DcCtx c) {
         target += nwaves;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { if (c.spec_flags & 32) __builtin_amdgcn_s_sleep(1); }
         asm volatile("" ::: "memory");
     };
     auto win_of = [&](int b) __attribute__((always_inline)) -> int { return (int)(0xFFFFFFFFu - (uint32_t)(keys[b] & 0xFFFFFFFFull)); };
