@@ -21,7 +21,8 @@ Input: the generator BASELINE.md section 2 states for this config -- per sample 
 Poisson-encoded (bindsnet.encoding.poisson, time=250, dt=1) from torch.manual_seed(1): ~1.17 % spike density; the first
 three batches are the trains tests/golden/full_cfg2_dc_n400_b32_poisson.npz holds from the REFERENCE encoder.
 
-Order of the legs (N = 1): CPU baseline first, then GPU warm-up + timed region, parity, roofline profile last.
+Order of the legs (N = 1): CPU baseline first (8-thread / 1-thread legs pinned to 8 CPUs = one CCD), then GPU warm-up +
+timed region, parity, roofline profile last.
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event-timed, vs HBM peak), "cpu_baseline"
 (oracle/torch_cpu_ref.py -- the reference's own ATen operator sequence on the host CPU -- 8 threads = `value`,
 median of 3 whole inputs; 1 thread; cpu_count()-1 threads [eth_mnist.py:77]; the scalar C port) and "parity" (the
@@ -92,7 +93,7 @@ def c_port_baseline(spikes, steps=100):
             "sample": f"first {steps} timesteps of input 0, oracle/snn_oracle.c ({dt:.1f} s)"}
 
 
-def cpu_baseline(host_inputs):
+def cpu_baseline(host_inputs, aff_all=None, pin=None):
     """The reference's CPU path restated operator for operator (oracle/torch_cpu_ref.py) on this host's cores, BEFORE
     the GPU leg.  Protocol (fixed, no best-of): 8 threads (SURVEY.md / BASELINE.md section 3's setting) = `value`,
     median over 3 WHOLE consecutive inputs from the fixture's start state (weights and theta carry over, reset between:
@@ -127,8 +128,10 @@ def cpu_baseline(host_inputs):
 
     v8, all8, recs = leg(min(8, ncpu), T, 0)
     v1, all1, _ = leg(1, 100, 0)
+    if aff_all is not None:
+        os.sched_setaffinity(0, aff_all)                   # the script's own setting is unpinned; so is everything after this leg
     vd, alld, _ = leg(max(1, ncpu - 1), 3, 1)
-    torch.set_num_threads(threads0)
+    torch.set_num_threads(min(threads0, ncpu))
     cpu = {"value": round(v8, 2), "unit": "timesteps/s", "cores": min(8, ncpu), "kind": "port",
            "sample": f"median of 3 whole consecutive inputs (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors, reset between) "
                      f"through oracle/torch_cpu_ref.py = the reference's ATen operator sequence, {min(8, ncpu)} threads; "
@@ -139,7 +142,8 @@ def cpu_baseline(host_inputs):
            "reference_default_threads": {"threads": max(1, ncpu - 1), "value": round(vd, 2), "per_sample": alld,
                                          "note": "torch.set_num_threads(os.cpu_count() - 1), eth_mnist.py:77; median of 3 samples "
                                                  "of 3 timesteps after 1 untimed one"},
-           "c_port": c_port_baseline(host_inputs[0]), "host_cpus": ncpu}
+           "c_port": c_port_baseline(host_inputs[0]), "host_cpus": ncpu,
+           "affinity": (f"8-thread and 1-thread legs pinned to CPUs {pin}" if pin else "not pinned (sched_setaffinity unavailable)")}
     return cpu, recs
 
 
@@ -204,7 +208,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # ---- inputs on the host, then the CPU leg -- BEFORE this process creates its HIP context (with the runtime's
-    #      threads alive the same operators ran 3-4x slower on the GPU box's EPYC: 21 vs 80 timesteps/s)
+    #      threads alive the same operators ran 3-4x slower on the GPU box's EPYC: 21 vs 80 timesteps/s).  The 8-thread and
+    #      1-thread legs run PINNED to the first 8 CPUs this process may use (one CCD of the EPYC: 8 cores, one L3): unpinned,
+    #      the 8-thread figure flipped between ~27 and ~170 timesteps/s from one input to the next on the same box.
+    cpu_leg = rank == 0 and world == 1 and not args.no_cpu_baseline
+    aff_all = pin = None
+    if cpu_leg and hasattr(os, "sched_setaffinity"):
+        try:
+            aff_all = os.sched_getaffinity(0)
+            pin = sorted(aff_all)[:8]
+            torch.set_num_threads(min(8, len(pin)))        # (before the first parallel operator creates the worker threads)
+            os.sched_setaffinity(0, pin)
+        except OSError:
+            aff_all = pin = None
     from bindsnet_amd import synth
     host_pool = synth.poisson_mnist_like(BATCH, T, 4, seed=1 + 17 * rank)
     per = np.stack([h.reshape(T, BATCH, N_IN).sum(2) for h in host_pool])
@@ -215,8 +231,8 @@ def main():
                    "matches_reference_encoded_fixture": (
                        [synth.sha(h.reshape(T, BATCH, N_IN)) for h in host_pool[:3]] == synth.POISSON_CFG2_SHA) if rank == 0 else None}
     cpu = recs = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # N = 1 only
-        cpu, recs = cpu_baseline(host_pool)
+    if cpu_leg:                                                 # N = 1 only
+        cpu, recs = cpu_baseline(host_pool, aff_all, pin)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
