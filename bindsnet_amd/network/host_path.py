@@ -200,7 +200,8 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
                 conn.w.data.masked_fill_(torch.as_tensor(mask).bool().view_as(conn.w), 0.0)
         for m in network.monitors.values():
             m.record()
-    normalize(network)
+    if not network.__dict__.get("_defer_norm", False):     # (parallel.sharded_run normalises the MERGED weights itself)
+        normalize(network)
 
 
 def normalize(network) -> None:

@@ -491,6 +491,10 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return t
 
     def _normalize_all(self):
+        if self._device().type != "cuda":          # a network on the host: plain PyTorch (network/host_path.py)
+            from . import host_path
+            host_path.normalize(self)
+            return
         for c in self.connections.values():
             c.normalize()
 

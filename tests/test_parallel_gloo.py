@@ -186,3 +186,86 @@ def test_column_shard_builds_the_slice_network():
     from bindsnet_amd.models import DiehlAndCook2015
     with pytest.raises(NotImplementedError):
         column_shard(DiehlAndCook2015(784, n_neurons=64), 0, 2)
+
+
+# ------------------------------------------------------------------------------------------------ the real thing on CPU
+def _real_worker(rank, world, port, q):
+    """One rank of the north-star schedule with NOTHING stubbed: its own batch shard of a D&C network on the host
+    (network/host_path.py), bindsnet_amd.parallel.sharded_run for two consecutive inputs, gloo all-reduce of the deltas."""
+    import os, sys
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from bindsnet_amd import parallel
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        N, per, T = 100, 3, 60
+        torch.manual_seed(0)
+        net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+        feat = net.connections[("X", "Ae")].pipeline[0]
+        feat.value.data.copy_(torch.from_numpy(synth.weights_q12(10, 784, N)))
+        mon = Monitor(net.layers["Ae"], ["s"], time=T)
+        net.add_monitor(mon, "Ae_s")
+        torch.manual_seed(2 + rank)
+        out = {}
+        for k in range(2):
+            shard = synth.spike_train(20 + k, T, per * world, 784, max_rate=0.25)[:, rank * per:(rank + 1) * per]
+            parallel.sharded_run(net, {"X": torch.from_numpy(np.ascontiguousarray(shard)).view(T, per, 1, 28, 28)}, T)
+            assert net.last_plan == "host-torch"
+            out[f"i{k}_sE"] = mon.get("s").numpy().reshape(T, per, N).astype(np.uint8).copy()
+            out[f"i{k}_W"] = feat.value.detach().numpy().copy()
+            out[f"i{k}_theta"] = net.layers["Ae"].theta.numpy().copy()
+            net.reset_state_variables()
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_run_world2_gloo_real_shards_vs_oracle():
+    """World size 2 over gloo with real shards (host path) and the real sharded_run: every rank's rasters equal the oracle
+    on its shard from the merged weights / theta of the previous input, the merged tensors equal the numpy merge -- the
+    CPU twin of tests/test_gpu_parallel.py::test_two_ranks_on_one_gpu_gloo."""
+    import sys
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import cases
+    import oracle
+    import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    N, per, T = 100, 3, 60
+    W = synth.weights_q12(10, 784, N)
+    theta = np.zeros(N, np.float32)
+    P = oracle.eth_mnist_dc_params(N, per, T)
+    P.norm = 0.0
+    Q = [oracle.exp_noise(2 + r, per * N * T * 2 + 16) for r in range(2)]
+    cur = [np.zeros(1, np.int64) for _ in range(2)]
+    for k in range(2):
+        Wg, thg = [], []
+        full = synth.spike_train(20 + k, T, per * 2, 784, max_rate=0.25)
+        for r in range(2):
+            st = oracle.eth_mnist_dc_state(N, per, W.copy())
+            st["theta"][:] = theta
+            rasE, _ = oracle.run_dc2015(P, st, np.ascontiguousarray(full[:, r * per:(r + 1) * per]), Q[r], cur[r])
+            np.testing.assert_array_equal(res[r][f"i{k}_sE"], rasE, err_msg=f"input {k} rank {r}")
+            Wg.append(st["W_xe"]); thg.append(st["theta"])
+        W = (W + ((Wg[0] - W) + (Wg[1] - W))).astype(np.float32)
+        np.clip(W, 0.0, 1.0, out=W)
+        oracle.normalize(W, 78.4, False)
+        theta = (theta + ((thg[0] - theta) + (thg[1] - theta))).astype(np.float32)
+        for r in range(2):
+            np.testing.assert_array_equal(res[r][f"i{k}_W"].view(np.uint32), W.view(np.uint32), err_msg=f"input {k}: merged weights, rank {r}")
+            np.testing.assert_array_equal(res[r][f"i{k}_theta"].view(np.uint32), theta.view(np.uint32), err_msg=f"input {k}: merged theta, rank {r}")
