@@ -1,7 +1,8 @@
 """Multi-process (gloo, world size 2, CPU) coverage of the batch-shard merge used at N > 1 GPUs:
-bindsnet_amd.parallel.merge_deltas / sharded_run.  The device run itself is stubbed (no GPU here); what
-is tested is the distributed logic: normalisation postponed until after the merge, weight and theta
-deltas summed over ranks with one all-reduce, clamp, then normalise -- identical on every rank."""
+bindsnet_amd.parallel.merge_deltas / sharded_run.  test_sharded_merge_world2_gloo stubs the run itself and checks the
+distributed logic (normalisation postponed until after the merge, weight and theta deltas summed over ranks with one
+all-reduce, clamp, then normalise -- identical on every rank); test_sharded_run_world2_gloo_real_shards_vs_oracle runs
+the real thing: host-path shards, the real sharded_run, the oracle per shard as the checker."""
 import os
 import socket
 
@@ -39,14 +40,7 @@ def _worker(rank, world, port, out):
             net.layers["Ae"].theta += 0.05 * (rank + 1)
             calls.append("run")
 
-        def fake_normalize():                             # CPU stand-in for snn_normalize (signed column sums)
-            calls.append("norm")
-            cs = feat.value.data.sum(0, keepdim=True)
-            cs[cs == 0] = 1.0
-            feat.value.data *= feat.norm / cs
-
-        net.run = fake_run
-        feat.normalize = fake_normalize
+        net.run = fake_run                                # (the normalisation after the merge is the host path's own)
         # 1) raw merge
         b = [torch.ones(3), torch.zeros(2, 2)]
         a = [torch.ones(3) + (rank + 1), torch.full((2, 2), float(rank))]
@@ -54,7 +48,7 @@ def _worker(rank, world, port, out):
         assert torch.equal(a[0], torch.ones(3) + 3.0) and torch.equal(a[1], torch.full((2, 2), 1.0))
         # 2) whole sharded step
         parallel.sharded_run(net, {"X": torch.zeros(2, 1, 1, 8, 8, dtype=torch.uint8)}, 2)
-        assert calls == ["run", "norm"] and feat.norm == 7.0 and net.__dict__.get("_defer_norm") is False
+        assert calls == ["run"] and feat.norm == 7.0 and net.__dict__.get("_defer_norm") is False
         exp = W0.clone()
         for r in range(world):
             g = torch.Generator().manual_seed(100 + r)
