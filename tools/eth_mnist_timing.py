@@ -75,7 +75,7 @@ def main():
     with open(path, "rb") as f:
         assert hashlib.sha256(f.read()).hexdigest() == REF_SHA, "not the reference's eth_mnist.py"
 
-    acc = {}
+    acc, per_call = {}, {}
     cuda = torch.cuda.is_available()
 
     def timed(key, fn, sync=False):
@@ -86,9 +86,11 @@ def main():
             out = fn(*a, **k)
             if sync and cuda:
                 torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
             e = acc.setdefault(key, [0.0, 0])
-            e[0] += time.perf_counter() - t0
+            e[0] += dt_
             e[1] += 1
+            per_call.setdefault(key, []).append(dt_)
             return out
         return wrapper
 
@@ -148,6 +150,9 @@ def main():
             "total": round(total / n_samples * 1e3, 3)},
         "calls": {k: v[1] for k, v in sorted(acc.items())},
         "run_only_timesteps_per_s": round(n_samples * 250 / acc["run"][0], 1),
+        "run_ms_first_call": round(per_call["run"][0] * 1e3, 3), "run_ms_median": round(sorted(per_call["run"])[len(per_call["run"]) // 2] * 1e3, 3),
+        "run_median_timesteps_per_s": round(250 / sorted(per_call["run"])[len(per_call["run"]) // 2], 1),
+        "encode_ms_median": round(sorted(per_call["encode"])[len(per_call["encode"]) // 2] * 1e3, 3),
         "accuracy": {k: float(v) for k, v in dict(g["accuracy"]).items()},
         "W_sha256": hashlib.sha256(W.tobytes()).hexdigest(),
         "plan": getattr(net, "last_plan", "reference torch CPU path"),
