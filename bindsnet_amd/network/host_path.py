@@ -5,8 +5,8 @@ package still constructs and runs where there is no GPU (SURVEY.md 8(b) fallback
 second, independent statement of the same semantics: tests/test_host_path.py pins it to the reference-generated fixtures
 the GPU tests use.  It is selected by Network.run only when the network's tensors are CPU tensors; it never touches
 libsnnhip and has nothing to do with oracle/ (test infrastructure).  Supported on this path: Input / LIFNodes /
-DiehlAndCookNodes; MulticompartmentConnection + Weight (no rule / PostPre), Connection (no rule / PostPre / MSTDP),
-Conv2dConnection (no rule); clamp / unclamp / injects_v / masks / one_step / reward; Monitor / NetworkMonitor.
+DiehlAndCookNodes; MulticompartmentConnection + Weight (no rule / PostPre), Connection (no rule / PostPre / MSTDP / Hebbian /
+WeightDependentPostPre), Conv2dConnection (no rule); clamp / unclamp / injects_v / masks / one_step / reward; Monitor / NetworkMonitor.
 
 What each function states (paths inside BindsNET): network.py:211-250,380-465 (loop, `zeros + c1 + c2` accumulation,
 normalise), nodes.py:96-107,211-221,500-529,1069-1111 (layers), topology.py:332-346,437-479,799-815 and
@@ -121,14 +121,47 @@ def _update_dense(conn, kwargs, mask) -> None:
         return
     B = conn.source.batch_size
     W = conn.w.data
-    if not isinstance(rule, rules.PostPre) or W.dim() != 2:
-        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on {type(conn).__name__} (supported: PostPre on Connection)")
+    if W.dim() != 2:
+        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on {type(conn).__name__} (learning on dense connections only)")
     rule._check_reduction()
     nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
-    if nu0:
+    src_s, tgt_s = conn.source.s.view(B, -1).float(), conn.target.s.view(B, -1).float()
+    if isinstance(rule, rules.MSTDP):
+        # learning.py:1504-1574: the update uses the PREVIOUS step's eligibility (kept as its two factors, like on the
+        # device: elig[b] = p_plus[b] (x) s_tgt_prev[b] + s_src_prev[b] (x) p_minus[b]), then the traces move on
+        rule._ensure_state()
+        reward = kwargs["reward"]
+        elig = torch.bmm(rule.p_plus.unsqueeze(2), rule._s_tgt_prev.float().unsqueeze(1)) + \
+            torch.bmm(rule._s_src_prev.float().unsqueeze(2), rule.p_minus.unsqueeze(1))
+        if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+            reward = reward.view(-1, 1, 1).float()
+        W += nu0 * _reduce(rule, reward * elig)
+        dp, dm = rule._decays()
+        rule.p_plus *= dp
+        rule.p_plus += torch.tensor(kwargs.get("a_plus", 1.0)) * src_s
+        rule.p_minus *= dm
+        rule.p_minus += torch.tensor(kwargs.get("a_minus", -1.0)) * tgt_s
+        rule._s_src_prev, rule._s_tgt_prev = conn.source.s.view(B, -1).to(torch.uint8).clone(), conn.target.s.view(B, -1).to(torch.uint8).clone()
+    elif isinstance(rule, (rules.Hebbian, rules.WeightDependentPostPre)):
+        # learning.py:1052-1135 / 562-653: raw outer products reduced over the batch, THEN scaled by nu
+        u1 = _reduce(rule, torch.bmm(src_s.unsqueeze(2), conn.target.x.view(B, -1).unsqueeze(1)))
+        u2 = _reduce(rule, torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), tgt_s.unsqueeze(1)))
+        if isinstance(rule, rules.Hebbian):
+            W += nu0 * u1
+            W += nu1 * u2
+        else:
+            update = 0
+            if nu0:
+                update = update - nu0 * u1 * (W - conn.wmin)
+            if nu1:
+                update = update + nu1 * u2 * (conn.wmax - W)
+            W += update
+    elif not isinstance(rule, rules.PostPre):
+        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} (supported: PostPre, MSTDP, Hebbian, WeightDependentPostPre)")
+    if isinstance(rule, rules.PostPre) and nu0:
         pre = torch.bmm(conn.source.s.view(B, -1).unsqueeze(2).float(), conn.target.x.view(B, -1).unsqueeze(1) * nu0)
         W -= _reduce(rule, pre)
-    if nu1:
+    if isinstance(rule, rules.PostPre) and nu1:
         post = torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), conn.target.s.view(B, -1).unsqueeze(1).float() * nu1)
         W += _reduce(rule, post)
     W *= float(rule.weight_decay)

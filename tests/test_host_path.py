@@ -106,3 +106,68 @@ def test_external_currents_and_one_step_clamp_on_the_host():
         net.run({"X": T_(sp)}, time=T, one_step=flag, clamp={"A": clampA}, unclamp={"A": unclampA})
         for l, n in (("A", nA), ("B", nB)):
             np.testing.assert_array_equal(mons[l].get("s").numpy().reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
+
+
+def test_mstdp_on_the_host_matches_reference():
+    """Input -> Connection(MSTDP) -> LIF (the cfg5 graph, small): rasters and the rule's traces identical to the reference,
+    weights within the dense family's tolerance (MKL propagation)."""
+    from bindsnet_amd.learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    g = gold("run_two_mstdp_b4")
+    Nin, N, B, T = int(g["Nin"]), int(g["N"]), int(g["B"]), int(g["T"])
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True), "Y")
+    conn = Connection(net.layers["X"], net.layers["Y"], w=T_(synth.weights_q12(11, Nin, N)).clone(), wmin=0, wmax=1, update_rule=MSTDP,
+                      nu=1e-1, norm=0.1 * Nin, reduction=torch.sum)
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    net.run({"X": T_(spikes)}, time=T, reward=1.0)
+    assert net.last_plan == "host-torch"
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), unpack(g["sY"], (T, B, N)))
+    np.testing.assert_allclose(conn.w.detach().numpy(), g["W"], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(bits(conn.update_rule.p_plus.numpy()), bits(g["p_plus"]))
+    np.testing.assert_array_equal(bits(conn.update_rule.p_minus.numpy()), bits(g["p_minus"]))
+
+
+@pytest.mark.parametrize("rule", ["hebbian", "wdpp"])
+def test_hebbian_and_wdpp_on_the_host_vs_oracle(rule):
+    """The two outer-product rules on the host path against the order-pinned oracle run (the checker of the MI355X
+    variants): rasters identical, weights within the dense family's tolerance."""
+    import oracle
+    from bindsnet_amd.learning import Hebbian, WeightDependentPostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    Nin, N, B, T = 196, 48, 6, 40
+    W0 = synth.weights_q12(11, Nin, N)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True), "Y")
+    conn = Connection(net.layers["X"], net.layers["Y"], w=T_(W0).clone(), wmin=0.0, wmax=1.0,
+                      update_rule={"hebbian": Hebbian, "wdpp": WeightDependentPostPre}[rule], nu=(1e-4, 1e-3), norm=0.1 * Nin, reduction=torch.sum)
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    net.run({"X": T_(spikes)}, time=T)
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T, P.dt = B, Nin, N, T, 1.0
+    P.rule = {"hebbian": 3, "wdpp": 4}[rule]
+    P.x_trace_decay = float(net.layers["X"].trace_decay); P.x_trace_scale = 1.0; P.x_traces = 1
+    P.decay = float(net.layers["Y"].decay); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.y_traces = 1; P.y_trace_decay = float(net.layers["Y"].trace_decay); P.y_trace_scale = 1.0
+    P.nu0, P.nu1 = 1e-4, 1e-3
+    P.has_min = P.has_max = 1; P.wmin, P.wmax = 0.0, 1.0; P.has_norm = 1; P.norm = 0.1 * Nin; P.learning = 1
+    st = dict(W=W0.copy(), sX=np.zeros((B, Nin), u8), xX=np.zeros((B, Nin), np.float32), vY=np.full((B, N), -65.0, np.float32),
+              rY=np.zeros((B, N), np.float32), sY=np.zeros((B, N), u8), xY=np.zeros((B, N), np.float32))
+    ras = oracle.run_two_layer(P, st, spikes)
+    assert ras.sum() > 20
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), ras)
+    np.testing.assert_allclose(conn.w.detach().numpy(), st["W"], rtol=0, atol=1e-5)
