@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -120,6 +120,7 @@ _SIGS = {
     "snn_input_step": ([_vp, _vp, _l, _f, _f, _i, _vp, _vp], _i),
     "snn_lif_step": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp], _i),
     "snn_dc_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp, _vp], _i),
+    "snn_dc_arbitrate": ([_vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp], _i),
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),
     "snn_conv2d_postpre": ([_vp] * 5 + [_i] * 9 + [_f, _f, _f, _i, _f, _i, _f, _vp, _vp], _i),
     "snn_stdp_hebbian": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _i, _f, _i, _f, _vp], _i),

@@ -323,6 +323,16 @@ extern "C" int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float 
     return snn_launch_dc_arbitrate(s, x, B, N, *h_p, noise_q, q_len, cursor, status, raster_s, (hipStream_t)stream);
 }
 
+extern "C" int snn_dc_arbitrate(uint8_t *s, float *x, int B, int N, const snn_dc_params *h_p, const float *noise_q,
+                                long long q_len, long long *cursor, int *status, uint8_t *raster_s,
+                                snn_stream_t stream) {
+    if (!s || !h_p || B <= 0 || N <= 0) return SNN_ERR_INVALID;
+    if (h_p->lif.traces && !x) return SNN_ERR_INVALID;
+    if (h_p->one_spike && (!noise_q || !cursor || !status)) return SNN_ERR_INVALID;
+    if (B > 1024) return SNN_ERR_UNSUPPORTED;
+    return snn_launch_dc_arbitrate(s, x, B, N, *h_p, noise_q, q_len, cursor, status, raster_s, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device-side noise for one_spike: materialise, for the rows that crossed threshold this step,
 // exactly the Exp(1) draws torch.multinomial would consume (row-major over [rows_with_crossing, N]),

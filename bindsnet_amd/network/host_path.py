@@ -19,14 +19,18 @@ import torch
 import torch.nn.functional as F
 
 
-def _trace(layer, s) -> None:
-    if not layer.traces:
-        return
-    layer.x *= layer.trace_decay
+def _trace_into(layer, s, x) -> None:
+    """nodes.py:96-107 on explicit tensors: the trace `x` (in place) after the spikes `s`."""
+    x *= layer.trace_decay
     if layer.traces_additive:
-        layer.x += layer.trace_scale * s.float()
+        x += layer.trace_scale * s.float()
     else:
-        layer.x.masked_fill_(s.bool(), float(layer.trace_scale))
+        x.masked_fill_(s.bool(), float(layer.trace_scale))
+
+
+def _trace(layer, s) -> None:
+    if layer.traces:
+        _trace_into(layer, s, layer.x)
 
 
 def _step_input(layer, x) -> None:
@@ -34,7 +38,8 @@ def _step_input(layer, x) -> None:
     _trace(layer, x)
 
 
-def _step_lif(layer, x) -> None:
+def _lif_membrane(layer, x) -> None:
+    """nodes.py:500-526: the LIF step without its trace."""
     layer.v = layer.decay * (layer.v - layer.rest) + layer.rest
     x.masked_fill_(layer.refrac_count > 0, 0.0)        # (in place on the summed input, as the reference does)
     layer.refrac_count -= layer.dt
@@ -44,11 +49,15 @@ def _step_lif(layer, x) -> None:
     layer.v.masked_fill_(layer.s, float(layer.reset))
     if layer.lbound is not None:
         layer.v.masked_fill_(layer.v < layer.lbound, float(layer.lbound))
+
+
+def _step_lif(layer, x) -> None:
+    _lif_membrane(layer, x)
     _trace(layer, layer.s)
 
 
-def _step_dc(layer, x) -> None:
-    B = x.shape[0]
+def _dc_membrane(layer, x) -> None:
+    """nodes.py:1069-1092: everything up to the threshold crossings (left in layer.s) and their reset."""
     layer.v = layer.decay * (layer.v - layer.rest) + layer.rest
     if layer.learning:
         layer.theta *= layer.theta_decay
@@ -57,14 +66,31 @@ def _step_dc(layer, x) -> None:
     layer.s = layer.v >= layer.thresh + layer.theta
     layer.refrac_count.masked_fill_(layer.s, float(layer.refrac))
     layer.v.masked_fill_(layer.s, float(layer.reset))
+
+
+def _dc_theta(layer, crossings) -> None:
+    """nodes.py:1093-1094: every neuron that crossed bumps the shared threshold, summed over the batch `crossings` spans."""
     if layer.learning:
-        layer.theta += layer.theta_plus * layer.s.float().sum(0)
-    if layer.one_spike and layer.s.any():              # one winner per sample with a crossing, drawn from the global generator
-        rows = layer.s.view(B, -1).any(1)
-        ind = torch.multinomial(layer.s.float().view(B, -1)[rows], 1)
+        layer.theta += layer.theta_plus * crossings.float().sum(0)
+
+
+def _one_spike(s2d) -> None:
+    """nodes.py:1097-1105 on a [B, N] bool matrix, in place: one winner per row with a crossing, drawn from the global
+    generator (rows in batch order)."""
+    if s2d.any():
+        rows = s2d.any(1)
+        ind = torch.multinomial(s2d.float()[rows], 1)
         rows = rows.nonzero()
-        layer.s.zero_()
-        layer.s.view(B, -1)[rows, ind] = 1
+        s2d.zero_()
+        s2d[rows, ind] = 1
+
+
+def _step_dc(layer, x) -> None:
+    B = x.shape[0]
+    _dc_membrane(layer, x)
+    _dc_theta(layer, layer.s)
+    if layer.one_spike:
+        _one_spike(layer.s.view(B, -1))
     if layer.lbound is not None:
         layer.v.masked_fill_(layer.v < layer.lbound, layer.lbound)
     _trace(layer, layer.s)
@@ -91,6 +117,21 @@ def _reduce(rule, t):
     return t.squeeze(0) if rule.reduction is torch.squeeze else rule.reduction(t, dim=0)
 
 
+def _postpre_mcc(rule, W, s_src, x_src, s_tgt, x_tgt, dt) -> None:
+    """MCC_learning.py:224-302 + :86-110 on explicit [B, n] factors (parallel.exact_run hands the GLOBAL batch's)."""
+    nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
+    if nu0:
+        pre = torch.bmm(s_src.unsqueeze(2).float(), x_tgt.unsqueeze(1) * nu0)
+        W -= _reduce(rule, pre) * dt
+    if nu1:
+        post = torch.bmm(x_src.unsqueeze(2), s_tgt.unsqueeze(1).float() * nu1)
+        W += _reduce(rule, post) * dt
+    W *= float(rule.decay)
+    lo, hi = rule._bounds()
+    if lo is not None or hi is not None:
+        W.clamp_(lo, hi)
+
+
 def _update_mcc(conn, dt) -> None:
     from ..learning import MCC_learning as rules
     feat = conn._weight()
@@ -100,18 +141,8 @@ def _update_mcc(conn, dt) -> None:
     if not isinstance(rule, rules.PostPre):
         raise NotImplementedError(f"bindsnet_amd host path: MCC rule {type(rule).__name__} (supported: PostPre)")
     B = conn.source.batch_size
-    W = feat.value.data
-    nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
-    if nu0:
-        pre = torch.bmm(conn.source.s.view(B, -1).unsqueeze(2).float(), conn.target.x.view(B, -1).unsqueeze(1) * nu0)
-        W -= _reduce(rule, pre) * dt
-    if nu1:
-        post = torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), conn.target.s.view(B, -1).unsqueeze(1).float() * nu1)
-        W += _reduce(rule, post) * dt
-    W *= float(rule.decay)
-    lo, hi = rule._bounds()
-    if lo is not None or hi is not None:
-        W.clamp_(lo, hi)
+    _postpre_mcc(rule, feat.value.data, conn.source.s.view(B, -1), conn.source.x.view(B, -1), conn.target.s.view(B, -1),
+                 conn.target.x.view(B, -1), dt)
 
 
 def _update_dense(conn, kwargs, mask) -> None:

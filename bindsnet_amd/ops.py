@@ -100,6 +100,18 @@ def dc_step(v, refrac, s, x, theta, I, p: DcParams, noise_q, cursor, status, ras
                             _ptr(raster_s, "spike", True), _ptr(raster_v, F32, True), _stream()), "dc_step")
 
 
+def dc_arbitrate(s, x, p: DcParams, noise_q, cursor, status, raster_s=None):
+    """The second half of dc_step on its own (nodes.py:1097-1111): one_spike winners on the crossings `s` [B,N] (in place),
+    trace, raster.  cursor[1] = offset of this step's first draw in noise_q (rng_fill_exponential leaves 0 and the draws
+    in its qbuf)."""
+    B = s.shape[0]
+    N = s.numel() // B
+    qlen = 0 if noise_q is None else noise_q.numel()
+    check(lib().snn_dc_arbitrate(_ptr(s, "spike"), _ptr(x, F32, True), B, N, C.byref(p), _ptr(noise_q, F32, True), qlen,
+                                 _ptr(cursor, torch.int64, True), _ptr(status, torch.int32, True),
+                                 _ptr(raster_s, "spike", True), _stream()), "dc_arbitrate")
+
+
 def stdp_postpre(W, s_src, x_src, s_tgt, x_tgt, nu0, nu1, use_dt, dt=1.0, decay=1.0, wmin=None, wmax=None,
                  assume_clamped=False):
     B = s_src.shape[0]

@@ -233,6 +233,339 @@ def gather_columns(local: torch.Tensor, n_columns: int, group=None) -> torch.Ten
 
 
 # =====================================================================================================
+# Exact multi-GPU mode for graphs whose batch IS coupled (DiehlAndCook2015): shard the batch, exchange the spikes of every
+# timestep (SURVEY.md 8(e) "exact").
+#
+# What couples the samples of a batch in the reference's step: theta += theta_plus * (crossings summed
+# over the batch, nodes.py:1093-1094), the one_spike draws consumed in batch-row order (nodes.py:1097-1105), and the
+# learning rule's sum over the batch (MCC_learning.py:260-263,296-299), whose result feeds the next step's propagation.
+# None of them needs more than the SPIKES of the other samples.  So per timestep every rank
+#   (1) propagates and advances the membrane state of ITS rows (currents, decay, refractory, crossings: per-sample work),
+#   (2) all-gathers the step's spike bytes of all non-input layers -- ONE collective of B_shard * sum(n) bytes,
+#   (3) applies the coupled operations to the GLOBAL batch, identically on every rank (replicated, like the weights):
+#       theta bump with the global crossing counts, the draws + arbitration of all rows (every rank's copy of the
+#       generator advances identically), the traces, and the learning rule over the global factors in ATen's batch order.
+# Every operation runs with exactly the operands the single-process global batch would hand it, so rasters, weights, theta,
+# membrane state and the position of the host generator equal the single-process run bit for bit, at any world size that
+# divides the batch.  The input spike trains are gathered once per run.  Cost: a collective and ~15 small launches per
+# timestep (the generic operators of the C ABI, not a fused plan), and (3) is replicated work -- this mode buys batches
+# beyond one device's, not speed (DESIGN.md section 6 has the numbers); `sharded_run` above is the fast, non-equivalent one.
+# On the host (CPU tensors, gloo) the same schedule runs on network/host_path.py's operators: tests/test_parallel_gloo.py.
+# =====================================================================================================
+def _exact_check(network):
+    from .learning import MCC_learning as mcc_rules
+    from .learning import learning as dense_rules
+    from .network.nodes import DiehlAndCookNodes, Input, LIFNodes
+    from .network.topology import Connection
+    for name, layer in network.layers.items():
+        if type(layer) not in (Input, LIFNodes, DiehlAndCookNodes):
+            raise NotImplementedError(f"exact_run: layer type {type(layer).__name__} ('{name}')")
+    learned = []
+    for key, conn in network.connections.items():
+        if isinstance(conn, MulticompartmentConnection):
+            rule = conn._weight().learning_rule
+            if isinstance(rule, mcc_rules.PostPre) and not conn.manual_update:
+                if not (conn.source.traces and conn.target.traces):
+                    raise AssertionError("PostPre needs traces on both layers")
+                learned.append(key)
+            elif not isinstance(rule, mcc_rules.NoOp) and not conn.manual_update:
+                raise NotImplementedError(f"exact_run: MCC rule {type(rule).__name__} (supported: PostPre)")
+        elif type(conn) is Connection:
+            if not isinstance(conn.update_rule, dense_rules.NoOp):
+                raise NotImplementedError("exact_run: learning on a dense Connection (Input -> Connection -> LIFNodes graphs shard "
+                                          "their columns exactly with column_shard, without any collective)")
+        else:
+            raise NotImplementedError(f"exact_run: connection type {type(conn).__name__}")
+        if isinstance(network.layers[key[1]], Input):
+            raise NotImplementedError("exact_run: a connection into an Input layer")
+    return learned
+
+
+class _ExactHost:
+    """The per-rank and the replicated operators of exact_run as plain PyTorch (network/host_path.py's statements)."""
+
+    def __init__(self, network, B, dev):
+        from .network import host_path
+        self.hp, self.net = host_path, network
+
+    def begin(self):
+        return self
+
+    def prop(self, conn, s_rows, cur, acc):
+        out = self.hp._propagate(conn, s_rows.view(s_rows.shape[0], *conn.source.shape))
+        if acc:
+            cur += out.view_as(cur)
+        else:
+            cur.copy_(torch.zeros_like(cur) + out.view_as(cur))          # zeros + c1 (network.py:240-248)
+
+    def trace(self, layer, s, x):
+        self.hp._trace_into(layer, s.view_as(x), x)
+
+    def lif(self, layer, cur, rv):
+        self.hp._lif_membrane(layer, cur.view(cur.shape[0], *layer.shape))
+        if rv is not None:
+            rv.copy_(layer.v)
+
+    def dc_membrane(self, layer, cur, rv):
+        self.hp._dc_membrane(layer, cur.view(cur.shape[0], *layer.shape))
+        if layer.lbound is not None:
+            layer.v.masked_fill_(layer.v < layer.lbound, layer.lbound)
+        if rv is not None:
+            rv.copy_(layer.v)
+
+    def dc_couple(self, layer, s_g):
+        """theta bump + one_spike on the global crossings `s_g` [B, n] u8, in place."""
+        sb = s_g.bool()
+        self.hp._dc_theta(layer, sb.view(sb.shape[0], *layer.shape))
+        if layer.one_spike:
+            self.hp._one_spike(sb)
+            s_g.copy_(sb)
+
+    def postpre(self, conn, s_src, x_src, s_tgt, x_tgt, t):
+        feat = conn._weight()
+        self.hp._postpre_mcc(feat.learning_rule, feat.value.data, s_src, x_src, s_tgt, x_tgt, float(self.net.dt))
+
+    def end(self, ok):
+        pass
+
+
+class _ExactDevice:
+    """The same on the MI355X: the C ABI's per-operator entry points (include/snnhip.h), torch for memory and streams."""
+
+    def __init__(self, network, B, dev):
+        from . import ops
+        from .network.nodes import DiehlAndCookNodes
+        from .rng import DeviceGenerator
+        self.ops, self.net = ops, network
+        draws = max([B * l.n for l in network.layers.values() if isinstance(l, DiehlAndCookNodes) and l.one_spike] or [0])
+        self.gen = DeviceGenerator(dev, draws)
+        self.params = {}
+
+    def begin(self):
+        self.gen.__enter__()
+        return self
+
+    def prop(self, conn, s_rows, cur, acc):
+        if isinstance(conn, MulticompartmentConnection):
+            self.ops.prop_cascade(conn._weight().value.data, s_rows, cur, accumulate=acc)
+        else:
+            self.ops.prop_dense(conn.w.data, s_rows, cur, bias=None if conn.b is None else conn.b.data, accumulate=acc)
+
+    def trace(self, layer, s, x):
+        from .network.nodes import _f
+        self.ops.input_step(s, x, _f(layer.trace_decay), _f(layer.trace_scale), layer.traces_additive)
+
+    def lif(self, layer, cur, rv):
+        p = self.params.get(id(layer))
+        if p is None:
+            p = self.params[id(layer)] = layer._lif_params()
+            p.traces = 0                                   # the trace is advanced on the global spikes (step 3)
+        self.ops.lif_step(layer.v, layer.refrac_count, layer.s, None, cur, p, None, rv)
+
+    def dc_membrane(self, layer, cur, rv):
+        p = self.params.get(id(layer))
+        if p is None:
+            full = layer._dc_params()
+            half = layer._dc_params()
+            half.lif.traces, half.one_spike, half.learning = 0, 0, 0     # membrane half only; theta is handled around it
+            full.lif.traces = 0
+            p = self.params[id(layer)] = (half, full)
+        if layer.learning:
+            layer.theta.mul_(layer.theta_decay)            # nodes.py:1078-1079 (one f32 multiply per neuron, as in k_dc_membrane)
+        self.ops.dc_step(layer.v, layer.refrac_count, layer.s, None, layer.theta, cur, p[0], None, None, None, None, rv)
+
+    def dc_couple(self, layer, s_g):
+        if layer.learning:                                 # nodes.py:1093-1094: counts are exact in f32; multiply, THEN add
+            bump = s_g.sum(0, dtype=torch.float32)
+            bump.mul_(layer.theta_plus)
+            layer.theta.view(-1).add_(bump)
+        if layer.one_spike:
+            self.ops.rng_fill_exponential(self.gen.state, s_g, self.gen.qbuf, self.gen.cursor)
+            self.ops.dc_arbitrate(s_g, None, self.params[id(layer)][1], self.gen.qbuf, self.gen.cursor, self.gen.status)
+
+    def postpre(self, conn, s_src, x_src, s_tgt, x_tgt, t):
+        rule = conn._weight().learning_rule
+        lo, hi = rule._bounds()
+        self.ops.stdp_postpre(conn._weight().value.data, s_src, x_src, s_tgt, x_tgt, float(rule.nu[0]), float(rule.nu[1]), True,
+                              float(self.net.dt), float(rule.decay), lo, hi, assume_clamped=t > 0)
+
+    def end(self, ok):
+        if ok:
+            self.gen.finish()
+        else:
+            self.gen.__exit__(RuntimeError, None, None)
+
+
+def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None) -> None:
+    """network.run() for a batch that is sharded over the ranks of `group`, EXACTLY: `inputs` holds this rank's rows
+    (rank r owns rows [r * B_shard, (r + 1) * B_shard) of the global batch), the network is this rank's replica with
+    batch size B_shard, and after the call weights, theta, the state of the own rows, monitors and the host generator
+    are what the single-process run of the global batch leaves (see the section comment).  Every rank must enter with the
+    same weights / theta and the same state of the global generator (torch.manual_seed)."""
+    from .network.monitors import Monitor
+    from .network.nodes import DiehlAndCookNodes, Input
+    assert type(inputs) == dict, "'inputs' must be a dict of names of layers (str) and relevant input tensors."
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    for key in inputs:                                        # network.py:329-353
+        if inputs[key].dim() == 1:
+            inputs[key] = inputs[key].unsqueeze(0).unsqueeze(0)
+        elif inputs[key].dim() == 2:
+            inputs[key] = inputs[key].unsqueeze(1)
+    for key in inputs:
+        if inputs[key].size(1) != network.batch_size:
+            network.batch_size = inputs[key].size(1)
+            for l in network.layers.values():
+                l.set_batch_size(network.batch_size)
+            for m in network.monitors.values():
+                m.reset_state_variables()
+        break
+    learned = _exact_check(network)
+    T, Bs = int(time / network.dt), network.batch_size
+    B, lo = Bs * world, rank * Bs
+    hi = lo + Bs
+    dev = network._device()
+    if T <= 0:
+        network._normalize_all()
+        return
+    if B > 256 and learned:
+        raise NotImplementedError("exact_run: the learning operators take global batches of up to 256 samples")
+    u8 = torch.uint8
+
+    def gather(own):
+        """[Bs, k] (any dtype) of every rank -> [B, k], rows in rank order."""
+        own = own.contiguous()
+        if world == 1:
+            return own.clone()
+        out = torch.empty(world, *own.shape, dtype=own.dtype, device=own.device)
+        dist.all_gather(list(out.unbind(0)), own, group=group)
+        return out.view(B, *own.shape[1:])
+
+    def bytes_of(t, n):
+        t = t.contiguous()
+        return (t.view(u8) if t.dtype == torch.bool else t.to(u8)).view(-1, n)
+
+    names = list(network.layers)
+    s_g, x_g, in_own, in_g, cur = {}, {}, {}, {}, {}
+    for name, layer in network.layers.items():
+        n = layer.n
+        if isinstance(layer, Input):
+            if name not in inputs:
+                raise NotImplementedError(f"bindsnet_amd: Input layer '{name}' needs an entry in `inputs`")
+            x = inputs[name]
+            if x.dtype not in (u8, torch.bool):
+                raise NotImplementedError(f"bindsnet_amd: input spike trains must be uint8 or bool (got {x.dtype})")
+            if x.shape[0] < T or x[0].numel() != Bs * n:
+                raise ValueError(f"inputs['{name}'] has shape {tuple(x.shape)}, expected [T >= {T}, {Bs}, {n}]")
+            x = inputs[name] = x.to(dev).contiguous()
+            in_own[name] = bytes_of(x[:T], Bs * n).view(T, Bs, n)
+            if world == 1:
+                in_g[name] = in_own[name]
+            else:                                            # the spike trains of all ranks, once per run: [T, B, n]
+                out = torch.empty(world, T, Bs, n, dtype=u8, device=dev)
+                dist.all_gather(list(out.unbind(0)), in_own[name], group=group)
+                in_g[name] = out.permute(1, 0, 2, 3).reshape(T, B, n).contiguous()
+            entry = layer.s
+            if entry.numel() != Bs * n or entry.device != dev:
+                entry = torch.zeros(Bs, n, dtype=u8, device=dev)
+        else:
+            if name in inputs:
+                raise NotImplementedError("exact_run: external currents into non-Input layers")
+            network._check_state(layer, Bs, dev)
+            cur[name] = torch.zeros(Bs, n, device=dev)
+            entry = layer.s
+        s_g[name] = gather(bytes_of(entry, n))              # the state the run starts from is the layers' own
+        if layer.traces:
+            x_g[name] = gather(layer.x.reshape(Bs, n).float())
+    others = [nm for nm in names if not isinstance(network.layers[nm], Input)]
+    width = sum(network.layers[nm].n for nm in others)
+    send = torch.empty(Bs, width, dtype=u8, device=dev)
+    recv = torch.empty(world, Bs, width, dtype=u8, device=dev)
+    # monitors: spikes and voltages of the OWN rows, [T, B_shard, *shape] like run()'s
+    ras_s, ras_v, appends = {}, {}, []
+    for m in network.monitors.values():
+        if not isinstance(m, Monitor) or not any(m.obj is l for l in network.layers.values()):
+            raise NotImplementedError("exact_run: Monitor objects on layers ('s', 'v') are supported")
+        name = next(nm for nm, l in network.layers.items() if l is m.obj)
+        for var in m.state_vars:
+            if var == "s":
+                if name not in ras_s:
+                    ras_s[name] = torch.empty(T, Bs, *m.obj.shape, dtype=torch.bool, device=dev)
+                appends.append((m, var, ras_s[name]))
+            elif var == "v" and hasattr(m.obj, "v"):
+                if name not in ras_v:
+                    ras_v[name] = torch.empty(T, Bs, *m.obj.shape, device=dev)
+                appends.append((m, var, ras_v[name]))
+            else:
+                raise NotImplementedError(f"exact_run: monitoring '{var}' of {type(m.obj).__name__}")
+
+    ops_ = (_ExactDevice if dev.type == "cuda" else _ExactHost)(network, B, dev).begin()
+    ok = False
+    try:
+        for t in range(T):
+            # (1a) network.py:384 _get_inputs(): previous-step spikes of the OWN rows through every connection, in order
+            fed = set()
+            for (src, dst), conn in network.connections.items():
+                ops_.prop(conn, s_g[src][lo:hi], cur[dst], dst in fed)
+                fed.add(dst)
+            # (1b) layers in insertion order: the per-sample half of every step
+            off = 0
+            for name, layer in network.layers.items():
+                if isinstance(layer, Input):
+                    s_g[name] = in_g[name][t]
+                    if layer.traces:
+                        ops_.trace(layer, s_g[name], x_g[name])
+                    continue
+                if name not in fed:
+                    cur[name].zero_()
+                rv = ras_v[name][t] if name in ras_v else None
+                if isinstance(layer, DiehlAndCookNodes):
+                    ops_.dc_membrane(layer, cur[name], rv)
+                else:
+                    ops_.lif(layer, cur[name], rv)
+                send[:, off:off + layer.n].copy_(bytes_of(layer.s, layer.n))
+                off += layer.n
+            # (2) the step's spikes of all ranks
+            if world > 1:
+                dist.all_gather(list(recv.unbind(0)), send, group=group)
+            else:
+                recv[0].copy_(send)
+            # (3) the coupled half, on the global batch, identically on every rank
+            off = 0
+            for name in others:
+                layer = network.layers[name]
+                s_g[name].view(world, Bs, layer.n).copy_(recv[:, :, off:off + layer.n])
+                off += layer.n
+                if isinstance(layer, DiehlAndCookNodes):
+                    ops_.dc_couple(layer, s_g[name])
+                if layer.traces:
+                    ops_.trace(layer, s_g[name], x_g[name])
+                if name in ras_s:
+                    ras_s[name][t].view(Bs, layer.n).copy_(s_g[name][lo:hi])
+            if network.learning:
+                for key in learned:
+                    ops_.postpre(network.connections[key], s_g[key[0]], x_g[key[0]], s_g[key[1]], x_g[key[1]], t)
+        ok = True
+    finally:
+        ops_.end(ok)
+    # hand the own rows back to the layers (what run() leaves): final spikes, traces; Input.s aliases the last input slice
+    for name, layer in network.layers.items():
+        if isinstance(layer, Input):
+            layer.s = inputs[name][T - 1]
+            if name in ras_s:
+                ras_s[name].view(T, Bs, layer.n).copy_(in_own[name])
+        else:
+            layer.s = s_g[name][lo:hi].bool().view(Bs, *layer.shape).clone()
+        if layer.traces:
+            layer.x = x_g[name][lo:hi].view(Bs, *layer.shape).clone()
+    for m, var, buf in appends:
+        m._append(var, buf)
+    network.__dict__["last_plan"] = "exact-sharded"
+    if not network.__dict__.get("_defer_norm", False):
+        network._normalize_all()
+
+
+# =====================================================================================================
 # The C ABI's own collectives (include/snnhip.h, snn_dist_*): RCCL without torch.distributed, for callers on the other
 # side of the boundary.  `rendezvous` hands rank 0's 128-byte id to everybody (here: through a torch.distributed
 # broadcast when a process group exists; any out-of-band channel does).

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 4
+#define SNN_ABI_VERSION 5
 
 typedef void *snn_stream_t;
 
@@ -122,6 +122,19 @@ int snn_dc_step(float *v, float *refrac, uint8_t *s, float *x, float *theta, con
                 int B, int N, const snn_dc_params *h_p,
                 const float *noise_q, long long q_len, long long *cursor, int *status,
                 uint8_t *raster_s, float *raster_v, snn_stream_t stream);
+
+/* The second half of snn_dc_step on its own: bindsnet/network/nodes.py:1097-1111 -- one_spike winner selection on the
+ * crossings `s` [B,N] (in: every neuron that crossed its threshold; out: one winner per row that had a crossing), then the
+ * trace update with the final spikes (nodes.py:96-107) and the raster slice.  For callers that put something between
+ * the membrane update and the arbitration: the exact batch-sharded multi-GPU mode runs the membrane half
+ * (snn_dc_step with one_spike = 0, traces = 0, learning = 0) on each rank's rows, gathers the crossings of all ranks, and
+ * then arbitrates the GLOBAL batch on every rank, so that the draws are consumed in the global row order.  noise_q /
+ * q_len as in snn_dc_step; cursor[1] must hold the offset of this step's first draw inside noise_q
+ * (snn_rng_fill_exponential leaves 0 there and the draws in qbuf); cursor[0] receives cursor[1] + rows_with_a_crossing * N.
+ * h_p->learning and theta are not used here (the adaptive threshold belongs to the membrane half).           */
+int snn_dc_arbitrate(uint8_t *s, float *x, int B, int N, const snn_dc_params *h_p,
+                     const float *noise_q, long long q_len, long long *cursor, int *status,
+                     uint8_t *raster_s, snn_stream_t stream);
 
 /* ---- device-resident emulation of torch's CPU generator --------------------------------------
  * Replaces the pre-drawn noise_q stream: the library reproduces the draws torch.multinomial

@@ -2,7 +2,9 @@
 bindsnet_amd.parallel.merge_deltas / sharded_run.  test_sharded_merge_world2_gloo stubs the run itself and checks the
 distributed logic (normalisation postponed until after the merge, weight and theta deltas summed over ranks with one
 all-reduce, clamp, then normalise -- identical on every rank); test_sharded_run_world2_gloo_real_shards_vs_oracle runs
-the real thing: host-path shards, the real sharded_run, the oracle per shard as the checker."""
+the real thing: host-path shards, the real sharded_run, the oracle per shard as the checker.
+test_exact_batch_sharded_mode_*: bindsnet_amd.parallel.exact_run (SURVEY 8(e) "exact": batch shards + one all-gather of the
+spikes per timestep) at world sizes 2 / 3 / 4 on the host operators == the REFERENCE's single-process global batch."""
 import os
 import socket
 
@@ -263,3 +265,33 @@ def test_sharded_run_world2_gloo_real_shards_vs_oracle():
         for r in range(2):
             np.testing.assert_array_equal(res[r][f"i{k}_W"].view(np.uint32), W.view(np.uint32), err_msg=f"input {k}: merged weights, rank {r}")
             np.testing.assert_array_equal(res[r][f"i{k}_theta"].view(np.uint32), theta.view(np.uint32), err_msg=f"input {k}: merged theta, rank {r}")
+
+
+# ------------------------------------------------------------------------------------------------ exact mode, D&C graph
+@pytest.mark.parametrize("world,fixture", [(2, "run_dc_n400_b4"), (4, "run_dc_n400_b4"), (3, "run_dc_n100_b3_busy")])
+def test_exact_batch_sharded_mode_equals_the_reference_global_batch(world, fixture, tmp_path):
+    """SURVEY 8(e) "exact" for the graph whose batch IS coupled (theta, one_spike row order, the PostPre batch sum):
+    `world` processes over gloo, each with ITS rows of the batch, parallel.exact_run for two consecutive inputs (reset
+    between) -- rows side by side == what the unmodified reference computed for the global batch in ONE process (fixtures of
+    tests/golden/make_golden.py): rasters, weights, theta, membrane state, traces bit for bit, and every rank's host
+    generator stands where the reference's does.  (`busy`: many crossings per step; world 3 = one sample per rank.)"""
+    import exact_harness as H
+    res = H.launch(world, fixture, "cpu", tmp_path)
+    H.check_against_reference(res, fixture)
+
+
+def test_exact_batch_sharded_mode_full_cfg2_world4(tmp_path):
+    """The same at BASELINE cfg2's full size on BASELINE.md's stated input: DiehlAndCook2015 784 -> 400, B = 32 = 4 ranks x 8,
+    T = 250, three consecutive inputs, against the reference's single-process run (full_cfg2_dc_n400_b32_poisson)."""
+    import exact_harness as H
+    name = "full_cfg2_dc_n400_b32_poisson"
+    res = H.launch(4, name, "cpu", tmp_path, timeout=1500)
+    H.check_against_reference(res, name)
+
+
+def test_exact_mode_refuses_what_it_does_not_implement():
+    from bindsnet_amd import parallel
+    from bindsnet_amd.models import TwoLayerNetwork
+    net = TwoLayerNetwork(n_inpt=64, n_neurons=32, reduction=torch.sum)
+    with pytest.raises(NotImplementedError):
+        parallel.exact_run(net, {"X": torch.zeros(3, 2, 64, dtype=torch.uint8)}, 3)
