@@ -269,23 +269,3 @@ def test_two_ranks_on_one_gpu_rccl(tmp_path):
         pytest.skip("RCCL did not form a 2-rank group on one device: " + tail.replace("\n", " | ")[-600:])
     _check_two_ranks(outs)
 
-
-# ---------------------------------------------------------------------------------------------------------------
-# The EXACT batch-sharded mode (parallel.exact_run: per-timestep all-gather of the spikes, coupled operations on the global
-# batch) on the device: the C ABI's per-operator entry points incl. snn_dc_arbitrate, against the REFERENCE's single-process
-# global batch.  tests/test_parallel_gloo.py runs the same schedule on the host operators at world 2 / 3 / 4.
-def test_exact_mode_single_rank_on_the_gpu(tmp_path):
-    """World size 1 (no process group): exact_run's operator sequence alone == the reference fixture, bit for bit."""
-    import exact_harness as H
-    res = H.launch(1, "run_dc_n400_b4", "cuda", tmp_path)
-    H.check_against_reference(res, "run_dc_n400_b4")
-
-
-def test_exact_mode_two_ranks_on_one_gpu(tmp_path):
-    """Two processes on the one GPU (gloo between them), 16 + 16 rows of BASELINE cfg2's stated input, three consecutive
-    inputs: rows side by side == the reference's single-process global batch of 32 -- rasters, weights, theta, membrane
-    state, traces bit for bit, and both host generators where the reference's stands."""
-    import exact_harness as H
-    name = "full_cfg2_dc_n400_b32_poisson"
-    res = H.launch(2, name, "cuda", tmp_path)
-    H.check_against_reference(res, name)

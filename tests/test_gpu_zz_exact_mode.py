@@ -1,0 +1,25 @@
+"""The EXACT batch-sharded mode (bindsnet_amd.parallel.exact_run: one all-gather of the spikes per timestep, the coupled
+operations -- theta bump, one_spike draws in global row order, PostPre's batch sum -- on the global batch, identically on
+every rank) ON THE DEVICE: the C ABI's per-operator entry points incl. snn_dc_arbitrate (ABI 5), against what the unmodified
+reference computed for the GLOBAL batch in one process.  tests/test_parallel_gloo.py runs the same schedule on the host
+operators at world 2 / 3 / 4.  (The file sorts last on purpose: these tests start extra processes that share the GPU.)"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_exact_mode_single_rank_on_the_gpu(tmp_path):
+    """World size 1 (no process group): exact_run's operator sequence alone == the reference fixture, bit for bit."""
+    import exact_harness as H
+    res = H.launch(1, "run_dc_n400_b4", "cuda", tmp_path, timeout=240)
+    H.check_against_reference(res, "run_dc_n400_b4")
+
+
+def test_exact_mode_two_ranks_on_one_gpu(tmp_path):
+    """Two processes on the one GPU (gloo between them), 16 + 16 rows of BASELINE cfg2's stated input, three consecutive
+    inputs: rows side by side == the reference's single-process global batch of 32 -- rasters, weights, theta, membrane
+    state, traces bit for bit, and both host generators where the reference's stands."""
+    import exact_harness as H
+    name = "full_cfg2_dc_n400_b32_poisson"
+    res = H.launch(2, name, "cuda", tmp_path, timeout=240)
+    H.check_against_reference(res, name)

@@ -3,7 +3,7 @@
 processes (gloo between them) on ONE device -- the only multi-rank arrangement a 1-GPU box offers -- each with B / world rows
 of the global batch of 32; every run is checked against the reference's single-process fixture before its time counts.
 
-    python tools/bench_exact.py --device cuda --worlds 1 2 4 > gpurun_out/exact_mode.json"""
+    python tools/bench_exact.py --device cuda --worlds 1 2 > gpurun_out/exact_mode.json"""
 import argparse
 import json
 import os
