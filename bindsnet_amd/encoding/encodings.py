@@ -13,9 +13,30 @@ per element -- without materialising the [time, n] probability tensor; `poisson`
 explicitly seeded counter-based stream instead: same distribution, NOT the reference's stream (see
 `poisson_device`).
 """
+import contextlib
 from typing import Optional
 
 import torch
+
+_ENCODER_THREADS = 4
+
+
+@contextlib.contextmanager
+def _few_threads():
+    """The host encoders work on [time, n] tensors of ~200 k elements through a dozen small ATen calls: with the
+    intra-op pool a script like eth_mnist.py asks for (`torch.set_num_threads(os.cpu_count() - 1)`, 255 on the GPU box) every
+    one of them pays a 255-way fork/join and one `poisson()` call took 1.6 s there against ~4 ms with a handful of threads
+    (DESIGN.md section 5).  The samplers themselves are serial in the generator (ATen's cpu_serial_kernel), so the thread
+    count changes nothing in the result: the encoders cap it for their own duration and put it back."""
+    n0 = torch.get_num_threads()
+    if n0 <= _ENCODER_THREADS:
+        yield
+        return
+    torch.set_num_threads(_ENCODER_THREADS)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(n0)
 
 
 def single(datum: torch.Tensor, time: int, dt: float = 1.0, sparsity: float = 0.5, device="cpu", **kwargs) -> torch.Tensor:
@@ -51,9 +72,10 @@ def bernoulli(datum: torch.Tensor, time: Optional[int] = None, dt: float = 1.0, 
     if torch.device(device).type == "cuda":
         from ..ops import encode_bernoulli
         return encode_bernoulli(flat, 1 if steps is None else steps, max_prob, device).view(*(() if steps is None else (steps,)), *shape)
-    if steps is None:
-        return torch.bernoulli(max_prob * flat).view(*shape).byte()
-    return torch.bernoulli(max_prob * flat.repeat([steps, 1])).view(steps, *shape).byte()
+    with _few_threads():
+        if steps is None:
+            return torch.bernoulli(max_prob * flat).view(*shape).byte()
+        return torch.bernoulli(max_prob * flat.repeat([steps, 1])).view(steps, *shape).byte()
 
 
 def poisson(datum: torch.Tensor, time: int, dt: float = 1.0, device="cpu", approx=False, **kwargs) -> torch.Tensor:
@@ -63,6 +85,11 @@ def poisson(datum: torch.Tensor, time: int, dt: float = 1.0, device="cpu", appro
     shape, size = datum.shape, datum.numel()
     if torch.device(device).type == "cuda":
         return poisson_device(datum, time, dt=dt, device=device, **kwargs)
+    with _few_threads():
+        return _poisson_host(datum, time, dt, device, approx, shape, size)
+
+
+def _poisson_host(datum, time, dt, device, approx, shape, size):
     flat = datum.flatten().to(device)
     steps = int(time / dt)
     if approx:      # the reference's "fast, less accurate" variant: |N(0,1)| ^ ((x * 0.11 + 5) / 50) < 0.6

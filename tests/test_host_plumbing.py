@@ -38,6 +38,33 @@ def test_encodings_match_reference_stream_for_stream():
         np.testing.assert_array_equal(x.numpy(), g[f"x_after{k}"], err_msg=f"{name} case {k}: in-place normalisation")
 
 
+def test_encoders_cap_their_thread_count_and_put_it_back():
+    """eth_mnist.py:77 asks for cpu_count() - 1 intra-op threads (255 on the GPU box), with which one poisson() call took
+    1.6 s; the host encoders run with a handful of threads for their own duration.  Same fixture, same generator position,
+    and the caller's setting is back afterwards."""
+    from make_golden_host_cases import ENC_CASES, datum_for
+    from bindsnet_amd.encoding import bernoulli, encodings, poisson
+    g = gold("op_encoding")
+    n0 = torch.get_num_threads()
+    seen = []
+    real = torch.poisson
+    try:
+        torch.set_num_threads(32)
+        torch.poisson = lambda *a, **k: (seen.append(torch.get_num_threads()), real(*a, **k))[1]
+        for k, (name, shape, scale, time, dt, kw) in enumerate(ENC_CASES):
+            if name not in ("poisson", "bernoulli"):
+                continue
+            torch.manual_seed(100 + k)
+            y = dict(poisson=poisson, bernoulli=bernoulli)[name](T_(datum_for(k, shape, scale)).clone(), time=time, dt=dt, **kw)
+            np.testing.assert_array_equal(np.packbits(y.numpy().astype(np.uint8)), g[f"y{k}"], err_msg=f"{name} case {k}")
+            np.testing.assert_array_equal(torch.rand(3).numpy(), g[f"probe{k}"], err_msg=f"{name} case {k}: generator position")
+            assert torch.get_num_threads() == 32
+    finally:
+        torch.poisson = real
+        torch.set_num_threads(n0)
+    assert seen and all(n == encodings._ENCODER_THREADS for n in seen)
+
+
 def test_encoder_objects():
     from make_golden_host_cases import datum_for
     from bindsnet_amd.encoding import BernoulliEncoder, NullEncoder, PoissonEncoder
