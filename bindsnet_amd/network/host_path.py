@@ -5,8 +5,9 @@ package still constructs and runs where there is no GPU (SURVEY.md 8(b) fallback
 second, independent statement of the same semantics: tests/test_host_path.py pins it to the reference-generated fixtures
 the GPU tests use.  It is selected by Network.run only when the network's tensors are CPU tensors; it never touches
 libsnnhip and has nothing to do with oracle/ (test infrastructure).  Supported on this path: Input / LIFNodes /
-DiehlAndCookNodes; MulticompartmentConnection + Weight (no rule / PostPre), Connection (no rule / PostPre / MSTDP / Hebbian /
-WeightDependentPostPre), Conv2dConnection (no rule); clamp / unclamp / injects_v / masks / one_step / reward; Monitor / NetworkMonitor.
+DiehlAndCookNodes; MulticompartmentConnection + Weight (no rule / PostPre / MSTDP / MSTDPET), Connection and LocalConnection (no
+rule / PostPre / MSTDP / Hebbian / WeightDependentPostPre / MSTDPET), Conv2dConnection (no rule / PostPre / MSTDP at batch 1);
+clamp / unclamp / injects_v / masks / one_step / reward; Monitor / NetworkMonitor.
 
 What each function states (paths inside BindsNET): network.py:211-250,380-465 (loop, `zeros + c1 + c2` accumulation,
 normalise), nodes.py:96-107,211-221,500-529,1069-1111 (layers), topology.py:332-346,437-479,799-815 and
@@ -117,6 +118,80 @@ def _reduce(rule, t):
     return t.squeeze(0) if rule.reduction is torch.squeeze else rule.reduction(t, dim=0)
 
 
+def _mstdp(rule, W, src_s, tgt_s, kwargs) -> None:
+    """learning.py:1504-1574 / MCC_learning.py:468-551 (the same arithmetic): the update uses the PREVIOUS step's eligibility
+    (kept as its two factors, like on the device: elig[b] = p_plus[b] (x) s_tgt_prev[b] + s_src_prev[b] (x) p_minus[b]),
+    then the traces move on.  src_s / tgt_s: [B, n] float spikes of this step."""
+    rule._ensure_state()
+    reward = kwargs["reward"]
+    elig = torch.bmm(rule.p_plus.unsqueeze(2), rule._s_tgt_prev.float().unsqueeze(1)) + \
+        torch.bmm(rule._s_src_prev.float().unsqueeze(2), rule.p_minus.unsqueeze(1))
+    if isinstance(reward, torch.Tensor) and reward.numel() > 1:
+        reward = reward.view(-1, 1, 1).float()
+    W += float(rule.nu[0]) * _reduce(rule, reward * elig)
+    dp, dm = rule._decays()
+    rule.p_plus *= dp
+    rule.p_plus += torch.tensor(kwargs.get("a_plus", 1.0)) * src_s
+    rule.p_minus *= dm
+    rule.p_minus += torch.tensor(kwargs.get("a_minus", -1.0)) * tgt_s
+    rule._s_src_prev, rule._s_tgt_prev = src_s.to(torch.uint8), tgt_s.to(torch.uint8)
+
+
+def _mstdpet(rule, W, dt, src_s, tgt_s, kwargs) -> None:
+    """learning.py:2187-2248 / MCC_learning.py:652-729 (batch 1; src_s / tgt_s flat float spikes): the eligibility TRACE
+    takes the previous step's point eligibility, the update is ((nu0 * dt) * reward) * trace, then P+ / P- move on."""
+    if rule.source.batch_size != 1:
+        raise NotImplementedError("MSTDPET is defined for batch size 1 (learning.py:2211-2212, MCC_learning.py:665-666)")
+    rule._ensure_state()
+    dp, dm, de = rule._decays()
+    rule.eligibility_trace *= de
+    rule.eligibility_trace += rule.eligibility / rule.tc_e_trace
+    W += rule.nu[0] * dt * kwargs["reward"] * rule.eligibility_trace
+    rule.p_plus *= dp
+    rule.p_plus += torch.tensor(kwargs.get("a_plus", 1.0)) * src_s
+    rule.p_minus *= dm
+    rule.p_minus += torch.tensor(kwargs.get("a_minus", -1.0)) * tgt_s
+    rule._s_src_prev, rule._s_tgt_prev = src_s.to(torch.uint8), tgt_s.to(torch.uint8)
+
+
+def _conv_postpre(conn, rule) -> None:
+    """learning.py:457-497: im2col of the source's spikes / traces, one bmm per term, reduced over the batch."""
+    from ..utils import im2col_indices
+    W = conn.w.data
+    Cout, _, kh, kw = W.shape
+    B = conn.source.batch_size
+    src_x = im2col_indices(conn.source.x.view(B, *conn.source.shape), kh, kw, padding=conn.padding, stride=conn.stride)
+    src_s = im2col_indices(conn.source.s.view(B, *conn.source.shape).float(), kh, kw, padding=conn.padding, stride=conn.stride)
+    tgt_x, tgt_s = conn.target.x.view(B, Cout, -1), conn.target.s.view(B, Cout, -1).float()
+    if rule.nu[0].any():
+        W -= rule.nu[0] * _reduce(rule, torch.bmm(tgt_x, src_s.permute(0, 2, 1))).view(W.shape)
+    if rule.nu[1].any():
+        W += rule.nu[1] * _reduce(rule, torch.bmm(tgt_s, src_x.permute(0, 2, 1))).view(W.shape)
+
+
+def _conv_mstdp(conn, rule, kwargs) -> None:
+    """learning.py:1942-2015 (batch 1).  From its second call on the reference's eligibility has the weight's shape, so its
+    torch.sum(update, dim=0) runs over the OUTPUT CHANNELS and is broadcast back (in the first call the eligibility is all
+    zeros either way); P+ is kept in input space here -- its im2col goes through the same elementwise operations."""
+    from ..utils import im2col_indices
+    if conn.source.batch_size != 1:
+        raise NotImplementedError("MSTDP on a Conv2dConnection is defined for batch size 1 (learning.py:2013)")
+    rule._ensure_state()
+    W = conn.w.data
+    Cout, _, kh, kw = W.shape
+    W += rule.nu[0] * torch.sum(kwargs["reward"] * rule._elig, dim=0)
+    dp, dm = rule._decays()
+    src_s = conn.source.s.view(1, *conn.source.shape).float()
+    tgt_s = conn.target.s.view(1, Cout, -1).float()
+    rule.p_plus *= dp
+    rule.p_plus += torch.tensor(kwargs.get("a_plus", 1.0)) * src_s[0]
+    rule.p_minus *= dm
+    rule.p_minus += torch.tensor(kwargs.get("a_minus", -1.0)) * tgt_s[0]
+    unf = lambda t: im2col_indices(t, kh, kw, padding=conn.padding, stride=conn.stride)      # noqa: E731
+    rule._elig = (torch.bmm(tgt_s, unf(rule.p_plus[None]).permute(0, 2, 1)) +
+                  torch.bmm(rule.p_minus[None], unf(src_s).permute(0, 2, 1))).view(W.shape)
+
+
 def _postpre_mcc(rule, W, s_src, x_src, s_tgt, x_tgt, dt) -> None:
     """MCC_learning.py:224-302 + :86-110 on explicit [B, n] factors (parallel.exact_run hands the GLOBAL batch's)."""
     nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
@@ -132,75 +207,87 @@ def _postpre_mcc(rule, W, s_src, x_src, s_tgt, x_tgt, dt) -> None:
         W.clamp_(lo, hi)
 
 
-def _update_mcc(conn, dt) -> None:
+def _update_mcc(conn, dt, kwargs) -> None:
     from ..learning import MCC_learning as rules
     feat = conn._weight()
     rule = feat.learning_rule
     if isinstance(rule, rules.NoOp) or conn.manual_update:
         return
-    if not isinstance(rule, rules.PostPre):
-        raise NotImplementedError(f"bindsnet_amd host path: MCC rule {type(rule).__name__} (supported: PostPre)")
     B = conn.source.batch_size
-    _postpre_mcc(rule, feat.value.data, conn.source.s.view(B, -1), conn.source.x.view(B, -1), conn.target.s.view(B, -1),
-                 conn.target.x.view(B, -1), dt)
+    W = feat.value.data
+    if rule.reduction is torch.squeeze and B != 1 and not isinstance(rule, rules.MSTDPET):
+        raise RuntimeError("reduction=torch.squeeze requires batch size 1")      # (the reference fails with a broadcast error here)
+    if isinstance(rule, rules.PostPre):
+        _postpre_mcc(rule, W, conn.source.s.view(B, -1), conn.source.x.view(B, -1), conn.target.s.view(B, -1),
+                     conn.target.x.view(B, -1), dt)
+        return
+    if isinstance(rule, rules.MSTDP):
+        _mstdp(rule, W, conn.source.s.view(B, -1).float(), conn.target.s.view(B, -1).float(), kwargs)
+    elif isinstance(rule, rules.MSTDPET):
+        _mstdpet(rule, W, dt, conn.source.s.view(-1).float(), conn.target.s.view(-1).float(), kwargs)
+    else:
+        raise NotImplementedError(f"bindsnet_amd host path: MCC rule {type(rule).__name__} (supported: PostPre, MSTDP, MSTDPET)")
+    W *= float(rule.decay)                               # MCC_learning.py:86-110
+    lo, hi = rule._bounds()
+    if lo is not None or hi is not None:
+        W.clamp_(lo, hi)
 
 
 def _update_dense(conn, kwargs, mask) -> None:
     from ..learning import learning as rules
+    from .topology import Conv2dConnection
     rule = conn.update_rule
     if rule is None or isinstance(rule, rules.NoOp):
         return
     B = conn.source.batch_size
     W = conn.w.data
-    if W.dim() != 2:
-        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on {type(conn).__name__} (learning on dense connections only)")
-    rule._check_reduction()
+    conv = isinstance(conn, Conv2dConnection)
+    if W.dim() != 2 and not conv:
+        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on {type(conn).__name__}")
     nu0, nu1 = float(rule.nu[0]), float(rule.nu[1])
-    src_s, tgt_s = conn.source.s.view(B, -1).float(), conn.target.s.view(B, -1).float()
-    if isinstance(rule, rules.MSTDP):
-        # learning.py:1504-1574: the update uses the PREVIOUS step's eligibility (kept as its two factors, like on the
-        # device: elig[b] = p_plus[b] (x) s_tgt_prev[b] + s_src_prev[b] (x) p_minus[b]), then the traces move on
-        rule._ensure_state()
-        reward = kwargs["reward"]
-        elig = torch.bmm(rule.p_plus.unsqueeze(2), rule._s_tgt_prev.float().unsqueeze(1)) + \
-            torch.bmm(rule._s_src_prev.float().unsqueeze(2), rule.p_minus.unsqueeze(1))
-        if isinstance(reward, torch.Tensor) and reward.numel() > 1:
-            reward = reward.view(-1, 1, 1).float()
-        W += nu0 * _reduce(rule, reward * elig)
-        dp, dm = rule._decays()
-        rule.p_plus *= dp
-        rule.p_plus += torch.tensor(kwargs.get("a_plus", 1.0)) * src_s
-        rule.p_minus *= dm
-        rule.p_minus += torch.tensor(kwargs.get("a_minus", -1.0)) * tgt_s
-        rule._s_src_prev, rule._s_tgt_prev = conn.source.s.view(B, -1).to(torch.uint8).clone(), conn.target.s.view(B, -1).to(torch.uint8).clone()
-    elif isinstance(rule, (rules.Hebbian, rules.WeightDependentPostPre)):
-        # learning.py:1052-1135 / 562-653: raw outer products reduced over the batch, THEN scaled by nu
-        u1 = _reduce(rule, torch.bmm(src_s.unsqueeze(2), conn.target.x.view(B, -1).unsqueeze(1)))
-        u2 = _reduce(rule, torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), tgt_s.unsqueeze(1)))
-        if isinstance(rule, rules.Hebbian):
-            W += nu0 * u1
-            W += nu1 * u2
+    if conv:
+        if isinstance(rule, rules.PostPre):
+            rule._check_reduction()
+            _conv_postpre(conn, rule)
+        elif isinstance(rule, rules.MSTDP):
+            _conv_mstdp(conn, rule, kwargs)
         else:
-            update = 0
+            raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} on a Conv2dConnection (supported: PostPre, MSTDP)")
+    elif isinstance(rule, rules.MSTDPET):
+        _mstdpet(rule, W, conn.dt, conn.source.s.view(-1).float(), conn.target.s.view(-1).float(), kwargs)
+    else:
+        rule._check_reduction()
+        src_s, tgt_s = conn.source.s.view(B, -1).float(), conn.target.s.view(B, -1).float()
+        if isinstance(rule, rules.MSTDP):
+            _mstdp(rule, W, src_s, tgt_s, kwargs)
+        elif isinstance(rule, (rules.Hebbian, rules.WeightDependentPostPre)):
+            # learning.py:1052-1135 / 562-653: raw outer products reduced over the batch, THEN scaled by nu
+            u1 = _reduce(rule, torch.bmm(src_s.unsqueeze(2), conn.target.x.view(B, -1).unsqueeze(1)))
+            u2 = _reduce(rule, torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), tgt_s.unsqueeze(1)))
+            if isinstance(rule, rules.Hebbian):
+                W += nu0 * u1
+                W += nu1 * u2
+            else:
+                update = 0
+                if nu0:
+                    update = update - nu0 * u1 * (W - conn.wmin)
+                if nu1:
+                    update = update + nu1 * u2 * (conn.wmax - W)
+                W += update
+        elif isinstance(rule, rules.PostPre):               # learning.py:390-420
             if nu0:
-                update = update - nu0 * u1 * (W - conn.wmin)
+                W -= _reduce(rule, torch.bmm(src_s.unsqueeze(2), conn.target.x.view(B, -1).unsqueeze(1) * nu0))
             if nu1:
-                update = update + nu1 * u2 * (conn.wmax - W)
-            W += update
-    elif not isinstance(rule, rules.PostPre):
-        raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} (supported: PostPre, MSTDP, Hebbian, WeightDependentPostPre)")
-    if isinstance(rule, rules.PostPre) and nu0:
-        pre = torch.bmm(conn.source.s.view(B, -1).unsqueeze(2).float(), conn.target.x.view(B, -1).unsqueeze(1) * nu0)
-        W -= _reduce(rule, pre)
-    if isinstance(rule, rules.PostPre) and nu1:
-        post = torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), conn.target.s.view(B, -1).unsqueeze(1).float() * nu1)
-        W += _reduce(rule, post)
-    W *= float(rule.weight_decay)
+                W += _reduce(rule, torch.bmm(conn.source.x.view(B, -1).unsqueeze(2), tgt_s.unsqueeze(1) * nu1))
+        else:
+            raise NotImplementedError(f"bindsnet_amd host path: rule {type(rule).__name__} (supported: PostPre, MSTDP, Hebbian, "
+                                      "WeightDependentPostPre, MSTDPET)")
+    W *= float(rule.weight_decay)                          # learning.py:87-104
     lo, hi = rule._bounds()
     if lo is not None or hi is not None:
         W.clamp_(lo, hi)
-    if mask is not None:
-        W.masked_fill_(mask.bool().view_as(W), 0.0)
+    if mask is not None and not conv:
+        W.masked_fill_(torch.as_tensor(mask).bool().view_as(W), 0.0)
 
 
 def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs) -> None:
@@ -255,12 +342,12 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
         if network.learning:
             for key, conn in network.connections.items():
                 if isinstance(conn, MulticompartmentConnection):
-                    _update_mcc(conn, dt)
+                    _update_mcc(conn, dt, kwargs)
                 else:
-                    _update_dense(conn, kwargs, masks.get(key))
-        for key, mask in masks.items():                                # masks apply every step, learning or not
-            conn = network.connections[key]
-            if hasattr(conn, "w"):
+                    _update_dense(conn, kwargs, _mask_of(conn, masks.get(key)))
+        for key, conn in network.connections.items():                  # masks apply every step, learning or not
+            mask = _mask_of(conn, masks.get(key))
+            if mask is not None and hasattr(conn, "w") and conn.w.dim() == 2:
                 conn.w.data.masked_fill_(torch.as_tensor(mask).bool().view_as(conn.w), 0.0)
         for m in network.monitors.values():
             m.record()
@@ -268,10 +355,16 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
         normalize(network)
 
 
+def _mask_of(conn, mask):
+    """run(..., masks={...}) entry of the connection, else a LocalConnection's structural mask (topology.py:1468-1470)."""
+    return mask if mask is not None else getattr(conn, "mask", None)
+
+
 def normalize(network) -> None:
     """network.py:463-465: every connection's normalisation -- Weight features by their SIGNED column sums
-    (topology_features.py:250-266), dense connections by the absolute ones (topology.py:383-392)."""
-    from .topology import MulticompartmentConnection
+    (topology_features.py:250-266), dense connections by the absolute ones (topology.py:383-392), a LocalConnection by the
+    signed ones again (topology.py:1475-1482)."""
+    from .topology import LocalConnection, MulticompartmentConnection
     for conn in network.connections.values():
         if isinstance(conn, MulticompartmentConnection):
             feat = conn._weight()
@@ -280,6 +373,6 @@ def normalize(network) -> None:
                 colsum[colsum == 0] = 1.0
                 feat.value.data *= feat.norm / colsum
         elif getattr(conn, "norm", None) is not None and hasattr(conn, "w") and conn.w.dim() == 2:
-            colsum = conn.w.data.abs().sum(0).unsqueeze(0)
+            colsum = (conn.w.data if isinstance(conn, LocalConnection) else conn.w.data.abs()).sum(0).unsqueeze(0)
             colsum[colsum == 0] = 1.0
             conn.w.data *= conn.norm / colsum

@@ -349,7 +349,8 @@ class _ExactDevice:
         if isinstance(conn, MulticompartmentConnection):
             self.ops.prop_cascade(conn._weight().value.data, s_rows, cur, accumulate=acc)
         else:
-            self.ops.prop_dense(conn.w.data, s_rows, cur, bias=None if conn.b is None else conn.b.data, accumulate=acc)
+            b = getattr(conn, "b", None)
+            self.ops.prop_dense(conn.w.data, s_rows, cur, bias=None if b is None else b.data, accumulate=acc)
 
     def trace(self, layer, s, x):
         from .network.nodes import _f

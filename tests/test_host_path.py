@@ -171,3 +171,159 @@ def test_hebbian_and_wdpp_on_the_host_vs_oracle(rule):
     assert ras.sum() > 20
     np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), ras)
     np.testing.assert_allclose(conn.w.detach().numpy(), st["W"], rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ the remaining rules
+@pytest.mark.parametrize("name", ["run_two_mcc_mstdp_b4", "run_two_mcc_mstdp_b20", "run_two_mcc_mstdp_n208"])
+def test_mcc_mstdp_on_the_host_matches_reference(name):
+    """MulticompartmentConnection + Weight with MCC_learning.MSTDP: two consecutive runs (scalar reward, then per-sample
+    rewards) bit for bit against the reference fixture the MI355X path is tested with."""
+    import cases
+    from bindsnet_amd.learning.MCC_learning import MSTDP
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    g = gold(name)
+    Nin, N, B, T = int(g["Nin"]), int(g["N"]), int(g["B"]), int(g["T"])
+    net = Network(dt=1.0)
+    X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    feat = Weight("weight", T_(synth.weights_q12(11, Nin, N)), range=[0.0, 1.0], norm=0.1 * Nin, nu=(1e-1, 1e-1), learning_rule=MSTDP)
+    conn = MulticompartmentConnection(X_, Y_, device="cpu", pipeline=[feat])      # (before the layers get a batch size: reduction = sum)
+    net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(Y_, ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    for r in range(2):
+        spikes = synth.spike_train(30 + r, T, B, Nin, active=0.3, max_rate=0.12)
+        reward = 1.0 if r == 0 else T_(synth.uniform_f32(17, (B,), -1.0, 1.0)).view(B, 1, 1)
+        net.run({"X": T_(spikes)}, time=T, reward=reward)
+        assert net.last_plan == "host-torch"
+        rule = feat.learning_rule
+        np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), unpack(g[f"r{r}_sY"], (T, B, N)))
+        for got, key in ((feat.value, "W"), (Y_.v, "vY"), (rule.p_plus, "p_plus"), (rule.p_minus, "p_minus")):
+            np.testing.assert_array_equal(bits(got.detach().numpy()), bits(g[f"r{r}_{key}"]), err_msg=f"run {r} {key}")
+        assert cases.sha(rule.eligibility.numpy()) == str(g[f"r{r}_elig_sha"])
+        net.reset_state_variables()
+
+
+def test_mcc_mstdpet_on_the_host_matches_reference():
+    """MCC_learning.MSTDPET (batch 1): two runs with different reward / a_plus, layers reset in between, the rule's state
+    kept -- everything bit for bit against the reference fixture."""
+    from bindsnet_amd.learning.MCC_learning import MSTDPET
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    g = gold("run_two_mcc_mstdpet_b1")
+    Nin, N, T = int(g["Nin"]), int(g["N"]), int(g["T"])
+    net = Network(dt=1.0)
+    X_, Y_ = Input(n=Nin, traces=True), LIFNodes(n=N, traces=True)
+    feat = Weight("weight", T_(synth.weights_q12(11, Nin, N)), range=[0.0, 1.0], norm=0.1 * Nin, nu=(1e-1, 1e-1), learning_rule=MSTDPET)
+    conn = MulticompartmentConnection(X_, Y_, device="cpu", pipeline=[feat], tc_e_trace=25.0)
+    net.add_layer(X_, "X"); net.add_layer(Y_, "Y")
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(Y_, ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    rule = feat.learning_rule
+    for r in range(2):
+        spikes = synth.spike_train(30 + r, T, 1, Nin, active=0.3, max_rate=0.12)
+        net.run({"X": T_(spikes)}, time=T, reward=0.8 if r == 0 else -0.5, a_plus=1.0 if r == 0 else 0.75)
+        np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, 1, N).astype(u8), unpack(g[f"r{r}_sY"], (T, 1, N)))
+        for got, key in ((feat.value, "W"), (Y_.v, "vY"), (rule.p_plus, "p_plus"), (rule.p_minus, "p_minus"), (rule.eligibility, "elig"),
+                         (rule.eligibility_trace, "e_trace")):
+            np.testing.assert_array_equal(bits(got.detach().numpy().reshape(-1)), bits(g[f"r{r}_{key}"].reshape(-1)), err_msg=f"run {r} {key}")
+        net.reset_state_variables()
+
+
+def test_dense_mstdpet_on_the_host_vs_oracle():
+    import oracle
+    from bindsnet_amd.learning import MSTDPET
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Connection
+    Nin, N, B, T = 196, 48, 1, 40
+    W0 = synth.weights_q12(11, Nin, N)
+    net = Network(dt=1.0)
+    net.add_layer(Input(n=Nin, traces=True), "X")
+    net.add_layer(LIFNodes(n=N, traces=True), "Y")
+    conn = Connection(net.layers["X"], net.layers["Y"], w=T_(W0).clone(), wmin=0.0, wmax=1.0, update_rule=MSTDPET, nu=(1e-1, 1e-1),
+                      norm=0.1 * Nin, reduction=torch.sum)
+    net.add_connection(conn, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T)
+    net.add_monitor(mon, "Y_s")
+    spikes = synth.spike_train(30, T, B, Nin, active=0.3, max_rate=0.12)
+    net.run({"X": T_(spikes)}, time=T, reward=0.8)
+    P = oracle.TwoParams()
+    P.B, P.Nin, P.N, P.T, P.dt, P.rule = B, Nin, N, T, 1.0, 5
+    P.x_trace_decay = float(net.layers["X"].trace_decay); P.x_trace_scale = 1.0; P.x_traces = 1
+    P.decay = float(net.layers["Y"].decay); P.rest, P.reset, P.thresh, P.refrac = -65.0, -65.0, -52.0, 5.0
+    P.y_traces = 1; P.y_trace_decay = float(net.layers["Y"].trace_decay); P.y_trace_scale = 1.0
+    P.nu0, P.nu1 = 1e-1, 1e-1
+    P.has_min = P.has_max = 1; P.wmin, P.wmax = 0.0, 1.0; P.has_norm = 1; P.norm = 0.1 * Nin; P.learning = 1
+    dp, dm, de = conn.update_rule._decays()
+    P.reward, P.a_plus, P.a_minus, P.decay_plus, P.decay_minus, P.decay_e, P.tc_e = 0.8, 1.0, -1.0, dp, dm, de, 25.0
+    st = dict(W=W0.copy(), sX=np.zeros((B, Nin), u8), xX=np.zeros((B, Nin), np.float32), vY=np.full((B, N), -65.0, np.float32),
+              rY=np.zeros((B, N), np.float32), sY=np.zeros((B, N), u8), xY=np.zeros((B, N), np.float32),
+              elig=np.zeros((Nin, N), np.float32), e_trace=np.zeros((Nin, N), np.float32), p_plus=np.zeros(Nin, np.float32),
+              p_minus=np.zeros(N, np.float32))
+    ras = oracle.run_two_layer(P, st, spikes)
+    assert ras.sum() > 20
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T, B, N).astype(u8), ras)
+    np.testing.assert_allclose(conn.w.detach().numpy(), st["W"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(conn.update_rule.eligibility_trace.numpy(), st["e_trace"], rtol=0, atol=1e-6)
+
+
+def test_local_connection_and_conv2d_learning_on_the_host_match_reference():
+    """LocalConnection + PostPre (structural mask, signed normalisation), Conv2dConnection + PostPre and + MSTDP (batch 1):
+    whole runs on the host against the reference fixtures of the MI355X tests -- rasters identical, weights within the
+    dense family's tolerance (the reference's matmuls / bmms run in BLAS order)."""
+    from bindsnet_amd.learning import MSTDP, PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection, LocalConnection
+    g = gold("run_extras")
+    np.random.seed(7)
+    T2 = 50
+    net = Network(dt=1.0)
+    X, Y = Input(n=144, traces=True), LIFNodes(n=4 * 16, traces=True)
+    lc = LocalConnection(X, Y, kernel_size=6, stride=2, n_filters=4, update_rule=PostPre, nu=(1e-4, 1e-2), wmin=0.0, wmax=1.0, norm=0.2)
+    net.add_layer(X, "X"); net.add_layer(Y, "Y"); net.add_connection(lc, "X", "Y")
+    mon = Monitor(Y, ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    net.run({"X": T_(synth.spike_train(31, T2, 1, 144, active=0.5, max_rate=0.25))}, time=T2)
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T2, 1, 64).astype(u8), unpack(g["lc_sY"], (T2, 1, 64)))
+    np.testing.assert_allclose(lc.w.detach().numpy(), g["lc_W"], rtol=0, atol=1e-5)
+    assert (lc.w.detach().numpy()[lc.mask.numpy()] == 0).all()
+
+    B, T3 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(1700, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T3)
+    net.add_monitor(mon, "s")
+    net.run({"X": T_(synth.dense_spikes(1701, (T3, B, 1, 12, 12), 0.2))}, time=T3)
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
+    np.testing.assert_allclose(cc.w.detach().numpy(), g["crun_W"], rtol=0, atol=1e-5 * 4.0)
+
+    g = gold("op_conv_mstdp")
+    T4 = 40
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cm = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(2290, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=MSTDP, nu=(2e-3, 1e-3), wmin=0.0, wmax=4.0)
+    net.add_connection(cm, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T4)
+    net.add_monitor(mon, "s")
+    net.run({"X": T_(synth.dense_spikes(2291, (T4, 1, 1, 12, 12), 0.2))}, time=T4, reward=0.6)
+    np.testing.assert_array_equal(mon.get("s").numpy().reshape(T4, 400).astype(u8), unpack(g["run_sY"], (T4, 400)))
+    np.testing.assert_allclose(cm.w.detach().numpy(), g["run_W"], rtol=0, atol=1e-5 * 4.0)
+    np.testing.assert_allclose(cm.update_rule.eligibility.numpy(), g["run_elig"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(g["run_elig"]).max())))
