@@ -20,6 +20,25 @@ import torch
 import torch.nn.functional as F
 
 
+def _sum(t, dim):
+    """ATen's sum in its SERIAL order, whatever the caller's thread setting.  The reference's own float sums are not
+    independent of the intra-op thread count: when the batch is smaller than the thread count, ATen splits the contiguous
+    (non-reduced) columns among the threads in chunks rounded to 32 columns, and a chunk that ends up holding only the last
+    N mod 32 < 8 columns is summed by another kernel (scalar_outer_sum: the cascade order of a full group) than the same
+    columns at the end of a longer chunk (vectorized_outer_sum's row_sum tail) -- e.g. N = 100, B = 1: columns 96-99 at 9 or
+    >= 12 threads (tools/probe_aten_sum_threads.py).  This package pins the SERIAL order (what the
+    reference computes with up to 8 threads at the sizes of BASELINE.md, and at any thread count once B >= threads): the
+    MI355X kernels, the oracle and, through this helper, the host path."""
+    n = torch.get_num_threads()
+    if n == 1:
+        return t.sum(dim)
+    torch.set_num_threads(1)
+    try:
+        return t.sum(dim)
+    finally:
+        torch.set_num_threads(n)
+
+
 def _trace_into(layer, s, x) -> None:
     """nodes.py:96-107 on explicit tensors: the trace `x` (in place) after the spikes `s`."""
     x *= layer.trace_decay
@@ -102,12 +121,12 @@ def _propagate(conn, s):
     B = s.shape[0]
     if isinstance(conn, MulticompartmentConnection):
         value = conn._weight().value
-        spikes = s.view(B, conn.source.n, 1).repeat(1, 1, conn.target.n)
-        return (value * spikes).sum(1).view(B, *conn.target.shape)
+        spikes = s.reshape(B, conn.source.n, 1).repeat(1, 1, conn.target.n)
+        return _sum(value * spikes, 1).view(B, *conn.target.shape)
     if isinstance(conn, Conv2dConnection):
         return F.conv2d(s.float(), conn.w, conn.b, stride=conn.stride, padding=conn.padding, dilation=conn.dilation)
     if isinstance(conn, (Connection, LocalConnection)):
-        post = s.view(B, -1).float() @ conn.w.view(conn.source.n, conn.target.n)
+        post = s.reshape(B, -1).float() @ conn.w.view(conn.source.n, conn.target.n)
         if getattr(conn, "b", None) is not None:
             post = post + conn.b
         return post.view(B, *conn.target.shape)
@@ -115,7 +134,9 @@ def _propagate(conn, s):
 
 
 def _reduce(rule, t):
-    return t.squeeze(0) if rule.reduction is torch.squeeze else rule.reduction(t, dim=0)
+    if rule.reduction is torch.squeeze:
+        return t.squeeze(0)
+    return _sum(t, 0) if rule.reduction is torch.sum else rule.reduction(t, dim=0)
 
 
 def _mstdp(rule, W, src_s, tgt_s, kwargs) -> None:
@@ -179,7 +200,7 @@ def _conv_mstdp(conn, rule, kwargs) -> None:
     rule._ensure_state()
     W = conn.w.data
     Cout, _, kh, kw = W.shape
-    W += rule.nu[0] * torch.sum(kwargs["reward"] * rule._elig, dim=0)
+    W += rule.nu[0] * _sum(kwargs["reward"] * rule._elig, 0)
     dp, dm = rule._decays()
     src_s = conn.source.s.view(1, *conn.source.shape).float()
     tgt_s = conn.target.s.view(1, Cout, -1).float()
@@ -360,19 +381,23 @@ def _mask_of(conn, mask):
     return mask if mask is not None else getattr(conn, "mask", None)
 
 
-def normalize(network) -> None:
-    """network.py:463-465: every connection's normalisation -- Weight features by their SIGNED column sums
-    (topology_features.py:250-266), dense connections by the absolute ones (topology.py:383-392), a LocalConnection by the
-    signed ones again (topology.py:1475-1482)."""
+def normalize_connection(conn) -> None:
+    """One connection's normalisation -- Weight features by their SIGNED column sums (topology_features.py:250-266), dense
+    connections by the absolute ones (topology.py:383-392), a LocalConnection by the signed ones again (topology.py:1475-1482)."""
     from .topology import LocalConnection, MulticompartmentConnection
-    for conn in network.connections.values():
-        if isinstance(conn, MulticompartmentConnection):
-            feat = conn._weight()
-            if feat.norm is not None:
-                colsum = feat.value.data.sum(0).unsqueeze(0)
-                colsum[colsum == 0] = 1.0
-                feat.value.data *= feat.norm / colsum
-        elif getattr(conn, "norm", None) is not None and hasattr(conn, "w") and conn.w.dim() == 2:
-            colsum = (conn.w.data if isinstance(conn, LocalConnection) else conn.w.data.abs()).sum(0).unsqueeze(0)
+    if isinstance(conn, MulticompartmentConnection):
+        feat = conn._weight()
+        if feat.norm is not None:
+            colsum = _sum(feat.value.data, 0).unsqueeze(0)
             colsum[colsum == 0] = 1.0
-            conn.w.data *= conn.norm / colsum
+            feat.value.data *= feat.norm / colsum
+    elif getattr(conn, "norm", None) is not None and hasattr(conn, "w") and conn.w.dim() == 2:
+        colsum = _sum(conn.w.data if isinstance(conn, LocalConnection) else conn.w.data.abs(), 0).unsqueeze(0)
+        colsum[colsum == 0] = 1.0
+        conn.w.data *= conn.norm / colsum
+
+
+def normalize(network) -> None:
+    """network.py:463-465: every connection's normalisation."""
+    for conn in network.connections.values():
+        normalize_connection(conn)

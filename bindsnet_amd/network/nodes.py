@@ -110,6 +110,9 @@ class Input(Nodes, AbstractInput):
                          trace_scale=trace_scale, sum_input=sum_input)
 
     def forward(self, x: torch.Tensor) -> None:
+        if not x.is_cuda:                                 # a layer on the host: plain PyTorch (network/host_path.py)
+            from . import host_path
+            return host_path._step_input(self, x)
         self.s = x
         if self.traces:
             ops.input_step(x.contiguous(), self.x, _f(self.trace_decay), _f(self.trace_scale), self.traces_additive)
@@ -160,6 +163,9 @@ class LIFNodes(Nodes):
 
     def forward(self, x: torch.Tensor) -> None:
         """One step (nodes.py:500-529); `x` is masked in place where refractory, as in the reference."""
+        if not self.v.is_cuda:                            # a layer on the host: plain PyTorch (network/host_path.py)
+            from . import host_path
+            return host_path._step_lif(self, x)
         if self.s.dtype != torch.bool or self.s.shape != self.v.shape:
             self.s = torch.zeros_like(self.v, dtype=torch.bool)
         ops.lif_step(self.v, self.refrac_count, self.s, self.x if self.traces else None, x, self._lif_params())
@@ -221,6 +227,9 @@ class DiehlAndCookNodes(Nodes):
     def forward(self, x: torch.Tensor) -> None:
         """One step (nodes.py:1069-1111).  The winner draw consumes the global CPU generator
         exactly like torch.multinomial does in the reference (see bindsnet_amd/rng.py)."""
+        if not self.v.is_cuda:                            # a layer on the host: plain PyTorch (network/host_path.py)
+            from . import host_path
+            return host_path._step_dc(self, x)
         from ..rng import NoiseStream
         if self.s.dtype != torch.bool or self.s.shape != self.v.shape:
             self.s = torch.zeros_like(self.v, dtype=torch.bool)

@@ -38,7 +38,11 @@ class AbstractConnection(_lib.TouchingModule, Module):
     def update(self, **kwargs) -> None:
         """Reference: topology.py:112-139."""
         if kwargs.get("learning", True):
-            self.update_rule.update(**kwargs)
+            if not self.w.is_cuda:                        # a connection on the host: plain PyTorch (network/host_path.py)
+                from . import host_path
+                host_path._update_dense(self, kwargs, None)
+            else:
+                self.update_rule.update(**kwargs)
         mask = kwargs.get("mask", None)
         if mask is not None:                       # topology.py:129-133
             self.w.masked_fill_(torch.as_tensor(mask, device=self.w.device).bool(), 0)
@@ -80,6 +84,9 @@ class Connection(AbstractConnection):
 
     def compute(self, s: torch.Tensor) -> torch.Tensor:
         """s.view(B,-1) @ w (+ b) in canonical ascending-source order (topology.py:332-346)."""
+        if not self.w.is_cuda:
+            from . import host_path
+            return host_path._propagate(self, s)
         B = s.size(0)
         out = torch.empty(B, self.target.n, device=self.w.device)
         ops.prop_dense(self.w.data, s.reshape(B, -1).contiguous(), out, bias=None if self.b is None else self.b.data)
@@ -88,6 +95,9 @@ class Connection(AbstractConnection):
     def normalize(self) -> None:
         """Reference: topology.py:383-392 (abs column sums)."""
         if self.norm is not None:
+            if not self.w.is_cuda:
+                from . import host_path
+                return host_path.normalize_connection(self)
             ops.normalize(self.w.data, float(self.norm), use_abs=True)
 
 
@@ -145,6 +155,10 @@ class LocalConnection(AbstractConnection):
 
     def compute(self, s: torch.Tensor) -> torch.Tensor:
         B = s.size(0)
+        if not self.w.is_cuda:
+            from . import host_path
+            out = host_path._propagate(self, s)
+            return out.view(*self.target.shape) if B == 1 else out
         out = torch.empty(B, self.target.n, device=self.w.device)
         ops.prop_dense(self.w.data, s.reshape(B, -1).contiguous(), out, bias=self.b.data)
         return out.view(*self.target.shape) if B == 1 else out.view(B, *self.target.shape)
@@ -157,6 +171,9 @@ class LocalConnection(AbstractConnection):
     def normalize(self) -> None:
         """Signed column sums (topology.py:1475-1482)."""
         if self.norm is not None:
+            if not self.w.is_cuda:
+                from . import host_path
+                return host_path.normalize_connection(self)
             ops.normalize(self.w.data.view(self.source.n, self.target.n), float(self.norm), use_abs=False)
 
 
@@ -202,6 +219,9 @@ class Conv2dConnection(AbstractConnection):
 
     def compute(self, s: torch.Tensor) -> torch.Tensor:
         B = s.size(0)
+        if not self.w.is_cuda:
+            from . import host_path
+            return host_path._propagate(self, s)
         out = torch.empty(B, *self.target.shape, device=self.w.device)
         ops.prop_conv2d(self.w.data, s.contiguous(), out, bias=self.b.data, stride=self.stride[0], pad=self.padding[0])
         return out
@@ -267,6 +287,9 @@ class MulticompartmentConnection(AbstractMulticompartmentConnection):
         """out[b,j] = sum_i value[i,j]*s[b,i] in the reference's ATen sum order (topology.py:437-479)."""
         w = self._weight().value
         B = s.size(0)
+        if not w.is_cuda:
+            from . import host_path
+            return host_path._propagate(self, s)
         out = torch.empty(B, self.target.n, device=w.device)
         ops.prop_cascade(w.data, s.reshape(B, -1).contiguous(), out)
         return out.view(B, *self.target.shape)
@@ -274,10 +297,16 @@ class MulticompartmentConnection(AbstractMulticompartmentConnection):
     def update(self, **kwargs) -> None:
         """Reference: topology.py:509-518 (note the default learning=False)."""
         if kwargs.get("learning", False) and not self.manual_update:
+            if len(self.pipeline) == 1 and isinstance(self.pipeline[0].value, torch.Tensor) and not self.pipeline[0].value.is_cuda:
+                from . import host_path                 # a connection on the host: plain PyTorch (network/host_path.py)
+                return host_path._update_mcc(self, float(self.dt), kwargs)
             for f in self.pipeline:
                 f.update(**kwargs)
 
     def normalize(self) -> None:
+        if len(self.pipeline) == 1 and isinstance(self.pipeline[0].value, torch.Tensor) and not self.pipeline[0].value.is_cuda:
+            from . import host_path
+            return host_path.normalize_connection(self)
         for f in self.pipeline:
             f.normalize()
 
