@@ -6,7 +6,9 @@
 // is load-bearing: the reference rounds after every multiply and every add.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/snnhip.h"
+#include "snn_conv_events.hpp"
 #include "snn_order.hpp"
 #include "snn_common.hpp"
 #include "snn_rng.hpp"
@@ -661,6 +663,42 @@ __global__ __launch_bounds__(256) void k_conv_pp_partial(const uint8_t *__restri
     part[(size_t)B * E + id] = p;
 }
 
+// The same partial sums from packed spike rows (snn_conv_events.hpp): a workgroup = one (sample, input channel, slice of 256
+// weight elements); it packs the sample's source rows of that channel and ALL its target rows into LDS words (one per image
+// row), then every thread walks the set bits its element reads.  Bit-identical to k_conv_pp_partial (checked body against body
+// on the host: tests/test_conv_events_host.py); rows wider than 32 pixels never get here, multi-valued spike bytes take the
+// dense body.  OPT-IN (SNN_CONV_PP_EVENTS=1) until it has run on an MI355X.
+__global__ __launch_bounds__(256) void k_conv_pp_partial_ev(const uint8_t *__restrict__ s_src, const float *__restrict__ x_src,
+                                                            const uint8_t *__restrict__ s_tgt, const float *__restrict__ x_tgt,
+                                                            float *__restrict__ part, int B, snn::ConvGeom g) {
+    extern __shared__ uint32_t ev_lds[];                 // srow[H] | trow[Cout * OH] | multi
+    uint32_t *srow = ev_lds, *trow = ev_lds + g.H;
+    int *multi = (int *)(trow + g.Cout * g.OH);
+    const int tid = threadIdx.x, b = blockIdx.x / g.Cin, ci = blockIdx.x - b * g.Cin;
+    if (tid == 0) *multi = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int r = tid; r < g.H; r += 256)
+        srow[r] = snn::conv_pack_row(s_src + (((size_t)b * g.Cin + ci) * g.H + r) * g.Wd, g.Wd, &mine);
+    for (int r = tid; r < g.Cout * g.OH; r += 256)
+        trow[r] = snn::conv_pack_row(s_tgt + ((size_t)b * g.Cout * g.OH + r) * g.OW, g.OW, &mine);
+    if (mine) atomicOr(multi, 1);
+    __syncthreads();
+    const bool dense = *multi != 0;
+    const int KK = g.KH * g.KW;
+    const long K = (long)g.Cin * KK, E = (long)g.Cout * K;
+    const int e = blockIdx.y * 256 + tid;
+    if (e >= g.Cout * KK) return;
+    const int co = e / KK, kk = e - co * KK, ky = kk / g.KW, kx = kk - ky * g.KW;
+    const size_t soff = ((size_t)b * g.Cin + ci) * g.H * g.Wd, toff = ((size_t)b * g.Cout + co) * g.OH * g.OW;
+    float a, p;
+    if (!dense) snn::conv_pp_events(g, ky, kx, srow, trow + co * g.OH, x_src + soff, x_tgt + toff, &a, &p);
+    else snn::conv_pp_dense(g, ky, kx, s_src + soff, x_src + soff, s_tgt + toff, x_tgt + toff, &a, &p);
+    const long id = (long)b * E + (long)co * K + (long)ci * KK + kk;
+    part[id] = a;
+    part[(size_t)B * E + id] = p;
+}
+
 __global__ __launch_bounds__(256) void k_conv_pp_apply(float *__restrict__ W, const float *__restrict__ part, int B, long E, float nu0,
                                                        float nu1, float decay, int has_min, float wmin, int has_max, float wmax) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -691,8 +729,15 @@ extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
     const long E = (long)Cout * Cin * KH * KW, n = (long)B * E;
-    hipLaunchKernelGGL(k_conv_pp_partial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws,
-                       B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW);
+    static const bool events = [] { const char *v = getenv("SNN_CONV_PP_EVENTS"); return v && v[0] == '1'; }();
+    const size_t ev_lds_bytes = ((size_t)H + (size_t)Cout * OH + 1) * sizeof(uint32_t);
+    if (events && Wd <= 32 && OW <= 32 && ev_lds_bytes <= 48 * 1024) {
+        const snn::ConvGeom g{Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW};
+        hipLaunchKernelGGL(k_conv_pp_partial_ev, dim3((unsigned)(B * Cin), (unsigned)((Cout * KH * KW + 255) / 256)), dim3(256), ev_lds_bytes,
+                           (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws, B, g);
+    } else
+        hipLaunchKernelGGL(k_conv_pp_partial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws,
+                           B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW);
     hipLaunchKernelGGL(k_conv_pp_apply, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ws, B, E, nu0, nu1, decay,
                        has_min, wmin, has_max, wmax);
     return snn_check_launch();
