@@ -78,6 +78,24 @@ f32, u8 = np.float32, np.uint8
 cf, ci, cl = C.c_float, C.c_int, C.c_long
 
 
+class reference_threads:
+    """`with oracle.reference_threads(16): ...` -- prop_mcc / normalize (and run_dc2015, run_two_layer's MCC form) follow the
+    reference AS IT RUNS WITH that many torch intra-op threads (ATen's thread-dependent order in the last N mod 32 < 8
+    columns: snn_oracle.c tail_isolated).  Outside the block: 1 = the serial order everything is pinned to."""
+
+    def __init__(self, threads: int):
+        self.threads = int(threads)
+
+    def __enter__(self):
+        self._old = int(lib().orc_get_reference_threads())
+        lib().orc_set_reference_threads(ci(self.threads))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_reference_threads(ci(self._old))
+        return False
+
+
 def prop_mcc(W, s, out=None, accumulate=False):
     B, Nin = s.shape
     N = W.shape[1]

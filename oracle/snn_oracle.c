@@ -14,6 +14,9 @@
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against
  * fixtures produced by running the unmodified reference (tests/golden/make_golden.py).
+ * The order pinned by default is the reference's SERIAL one (= its runs with up to 8 torch threads at BASELINE.md's sizes);
+ * orc_set_reference_threads(t) follows the reference as it sums with t threads (the last N mod 32 < 8 columns move to another
+ * kernel of SumKernel.cpp), pinned against torch itself and a 16-thread reference run by tests/test_aten_sum_threads.py.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -78,6 +81,37 @@ static float outer_sum(orc_term_fn f, const void *ctx, long n, long col, long nc
     return row_sum4(f, ctx, n);
 }
 
+/* The reference's sums are not independent of torch's intra-op thread count (DESIGN.md section 2,
+ * tools/probe_aten_sum_threads.py): a reduction of `outer` x n x ncols elements over n runs serially below
+ * at::internal::GRAIN_SIZE = 32768 elements; else it is split over the outermost non-reduced dimension that has at least
+ * `threads` entries (if neither has: the larger one, ties to the outer) -- and when that is the COLUMNS, cut into `threads`
+ * ranges of c = ceil(ncols / threads) whose ends are rounded down to multiples of 32, a last range that holds only the
+ * ncols mod 32 < 8 tail columns is summed by scalar_outer_sum: groups of FOUR columns in the cascade order of a full group,
+ * the rest row_sum.  orc_set_reference_threads(t) makes orc_prop_mcc / orc_normalize (and the runs built on them) follow
+ * the reference AS IT RUNS WITH t THREADS; the default, 1, is the serial order everything else in this repository pins. */
+static int g_ref_threads = 1;
+ORC_API void orc_set_reference_threads(int t) { g_ref_threads = t > 0 ? t : 1; }
+ORC_API int orc_get_reference_threads(void) { return g_ref_threads; }
+
+static int tail_isolated(long outer, long n, long ncols)
+{
+    const long t = g_ref_threads, tail = ncols % 32;
+    if (t <= 1 || tail == 0 || tail >= 8) return 0;
+    if (outer * n * ncols < 32768) return 0;
+    if (outer >= t) return 0;
+    if (ncols < t && ncols <= outer) return 0;
+    const long c = (ncols + t - 1) / t;
+    return c * ((ncols - 1) / c) >= ncols - tail;
+}
+
+static float outer_sum_threads(orc_term_fn f, const void *ctx, long n, long col, long ncols, long outer)
+{
+    const long full = (ncols / 32) * 32;
+    if (col >= full && tail_isolated(outer, n, ncols) && col - full < ((ncols - full) / 4) * 4)
+        return cascade_sum(f, ctx, 0, 1, n);
+    return outer_sum(f, ctx, n, col, ncols);
+}
+
 /* ------------------------------------------------------------------------------------------
  * a5: MulticompartmentConnection.compute + Weight.compute
  *     bindsnet/network/topology.py:437-479, bindsnet/network/topology_features.py:633-645
@@ -96,7 +130,7 @@ ORC_API void orc_prop_mcc(const float *W, const uint8_t *s, float *out,
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < N; ++j) {
             prop_ctx c = { W, s + (long)b * Nin, N, j };
-            float r = outer_sum(prop_term, &c, Nin, j, N);
+            float r = outer_sum_threads(prop_term, &c, Nin, j, N, B);
             /* network.py:240-248: inputs = zeros; inputs += compute(...) per connection */
             out[(long)b * N + j] = (accumulate ? out[(long)b * N + j] : 0.0f) + r;
         }
@@ -531,7 +565,7 @@ ORC_API void orc_normalize(float *W, int Nin, int N, float norm, int use_abs)
     float *scale = (float *)malloc(sizeof(float) * (size_t)N);
     for (int j = 0; j < N; ++j) {
         nm_ctx c = { W, N, j, use_abs };
-        float cs = outer_sum(nm_term, &c, Nin, j, N);
+        float cs = outer_sum_threads(nm_term, &c, Nin, j, N, 1);
         if (cs == 0.f) cs = 1.0f;
         const float rc = 1.0f / cs;
         scale[j] = rc * norm;

@@ -11,7 +11,8 @@ range are vectorized_outer_sum's leftover: row_sum order (SumKernel.cpp).  Diffe
 
 Model (this script checks it against torch for every thread count it is given):
     c = ceil(N / threads);   the tail [32*floor(N/32), N) is isolated  <=>  c * floor((N - 1) / c) >= 32 * floor(N / 32)
-    (and it matters only when the columns are what is split: B < threads, and 0 < N mod 32 < 8)
+    (and it matters only when the reduction runs in parallel at all -- B * Nin * N >= 32768 --, when the columns are what is split
+    -- B < threads, and N >= threads or N > B -- and when 0 < N mod 32 < 8)
 
     python tools/probe_aten_sum_threads.py [--threads 1 2 ... ] [--shapes B,Nin,N ...]"""
 import argparse
@@ -20,13 +21,17 @@ import numpy as np
 import torch
 
 
-def tail_isolated(B: int, N: int, threads: int) -> bool:
-    """True when torch.sum(dim=1) of a contiguous [B, Nin, N] float tensor at `threads` intra-op threads sums the last
-    N mod 32 columns in another order than it does serially."""
+def tail_isolated(B: int, N: int, threads: int, Nin: int = 1 << 20) -> bool:
+    """True when torch.sum(dim=1) of a contiguous [B, Nin, N] float tensor (B = 1: also sum(dim=0) of [Nin, N]) at `threads`
+    intra-op threads sums the last N mod 32 columns in another order than it does serially."""
     tail = N % 32
     if threads <= 1 or not 0 < tail < 8:
         return False
+    if B * Nin * N < 32768:              # at::internal::GRAIN_SIZE: small reductions run serially
+        return False
     if B >= threads:                     # the batch is split: every sample is summed serially
+        return False
+    if N < threads and N <= B:           # neither dimension has `threads` entries: the larger one is split (ties: the batch)
         return False
     c = -(-N // threads)
     return c * ((N - 1) // c) >= N - tail
@@ -55,7 +60,7 @@ def main():
             cols = sorted(set(np.nonzero(got != serial)[1].tolist()))
             if differs:
                 changed.append((t, cols))
-            if differs != tail_isolated(B, N, t) and not (tail_isolated(B, N, t) and not differs):
+            if differs != tail_isolated(B, N, t, Nin) and not (tail_isolated(B, N, t, Nin) and not differs):
                 wrong.append(t)                      # (an isolated tail may still round to the same bits: not a model error)
         print(f"[B={B}, Nin={Nin}, N={N}] differs from the serial order at threads {[t for t, _ in changed]} "
               f"in columns {sorted(set(c for _, cs in changed for c in cs))}; model wrong at: {wrong or 'none'}")
