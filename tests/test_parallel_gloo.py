@@ -295,3 +295,46 @@ def test_exact_mode_refuses_what_it_does_not_implement():
     net = TwoLayerNetwork(n_inpt=64, n_neurons=32, reduction=torch.sum)
     with pytest.raises(NotImplementedError):
         parallel.exact_run(net, {"X": torch.zeros(3, 2, 64, dtype=torch.uint8)}, 3)
+
+
+@pytest.mark.parametrize("learning", [True, False])
+def test_exact_run_single_rank_equals_run_on_the_host(learning):
+    """exact_run at world size 1 (no process group) against Network.run on the host, same seeds: voltage and spike monitors,
+    learning on and off (test mode: no theta adaptation, no PostPre), two consecutive inputs with a reset between."""
+    import synth
+    from bindsnet_amd import parallel
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    T, B, N = 40, 3, 64
+
+    def make():
+        torch.manual_seed(0)
+        net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=17.5, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+        net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(synth.weights_q12(10, 784, N)))
+        mons = {("Ae", "s"): Monitor(net.layers["Ae"], ["s", "v"], time=T), ("Ai", "s"): Monitor(net.layers["Ai"], ["s", "v"], time=T),
+                ("X", "s"): Monitor(net.layers["X"], ["s"], time=T)}
+        for (l, _), m in mons.items():
+            net.add_monitor(m, l)
+        net.train(learning)
+        return net, mons
+
+    a, ma = make()
+    b, mb = make()
+    for r in range(2):
+        sp = torch.from_numpy(synth.spike_train(40 + r, T, B, 784, max_rate=0.3)).view(T, B, 1, 28, 28)
+        torch.manual_seed(5 + r)
+        a.run({"X": sp.clone()}, time=T)
+        torch.manual_seed(5 + r)
+        parallel.exact_run(b, {"X": sp.clone()}, T)
+        for key in ma:
+            for var in ma[key].state_vars:
+                assert torch.equal(ma[key].get(var), mb[key].get(var)), (r, key, var)
+        assert int(ma[("Ae", "s")].get("s").sum()) > 5
+        for name in ("Ae", "Ai", "X"):
+            la, lb = a.layers[name], b.layers[name]
+            for attr in ("v", "refrac_count", "x", "theta", "s"):
+                if hasattr(la, attr) and isinstance(getattr(la, attr), torch.Tensor) and getattr(la, attr).numel():
+                    assert torch.equal(getattr(la, attr).reshape(-1).float(), getattr(lb, attr).reshape(-1).float()), (r, name, attr)
+        assert torch.equal(a.connections[("X", "Ae")].pipeline[0].value, b.connections[("X", "Ae")].pipeline[0].value)
+        a.reset_state_variables()
+        b.reset_state_variables()
