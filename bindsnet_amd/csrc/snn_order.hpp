@@ -12,6 +12,8 @@
 // Skipping a zero term is exact (x + 0.0f == x), but the block structure is defined on the term
 // INDEX, so the accumulators must still be flushed at the same index boundaries -- that is what
 // Cascade::advance() does.  Built with -ffp-contract=off: every add below is one rounding.
+// The accumulators are __host__ __device__: tests/hostcheck/order_rng_host.hip runs them on the CPU, term by term as the
+// kernels' threads do, against the oracle (tests/test_order_rng_host.py) -- the build container has no GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,13 +25,13 @@ struct Cascade {
     float a0, a1, a2, a3;
     int cb;  // index of the 16-term block whose partial sum sits in a0 (-1: none yet)
 
-    __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = 0.f; cb = -1; }
+    __host__ __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = 0.f; cb = -1; }
 
     // Close block `cb` and move to block nb > cb.  A level-1 flush happens at every block
     // boundary that is a multiple of 16 blocks inside (cb, nb], a level-2 flush at multiples of
     // 256; repeated flushes of an already-zero accumulator are no-ops, so one test per level
     // is enough.
-    __device__ __forceinline__ void advance(int nb) {
+    __host__ __device__ __forceinline__ void advance(int nb) {
         a1 += a0; a0 = 0.f;
         if ((nb >> 4) != (cb >> 4)) {
             a2 += a1; a1 = 0.f;
@@ -40,14 +42,14 @@ struct Cascade {
 
     // pos: index of the term in the full (dense) sequence; nfull: number of complete blocks
     // (n >> 4).  Terms past the last complete block all land in pseudo-block `nfull`.
-    __device__ __forceinline__ void add(int pos, float term, int nfull) {
+    __host__ __device__ __forceinline__ void add(int pos, float term, int nfull) {
         int blk = pos >> 4;
         blk = blk < nfull ? blk : nfull;
         if (blk != cb) advance(blk);
         a0 += term;
     }
 
-    __device__ __forceinline__ float finish(int nfull) {
+    __host__ __device__ __forceinline__ float finish(int nfull) {
         if (cb != nfull) advance(nfull);
         return ((a0 + a1) + a2) + a3;
     }
@@ -58,10 +60,10 @@ struct RowSum4 {
     float L0;
     bool closed0;
 
-    __device__ __forceinline__ void init() { l0.init(); l1.init(); l2.init(); l3.init(); L0 = 0.f; closed0 = false; }
+    __host__ __device__ __forceinline__ void init() { l0.init(); l1.init(); l2.init(); l3.init(); L0 = 0.f; closed0 = false; }
 
     // n: total number of terms of the dense sequence.
-    __device__ __forceinline__ void add(int pos, float term, int n) {
+    __host__ __device__ __forceinline__ void add(int pos, float term, int n) {
         const int n4 = n >> 2, nfull4 = n4 >> 4;
         if (pos >= (n4 << 2)) {  // leftovers: added to lane 0 after its cascade has been combined
             if (!closed0) { L0 = l0.finish(nfull4); closed0 = true; }
@@ -77,7 +79,7 @@ struct RowSum4 {
         }
     }
 
-    __device__ __forceinline__ float finish(int n) {
+    __host__ __device__ __forceinline__ float finish(int n) {
         const int nfull4 = (n >> 2) >> 4;
         if (!closed0) { L0 = l0.finish(nfull4); closed0 = true; }
         float r = L0 + l1.finish(nfull4);
@@ -93,8 +95,8 @@ struct RowSum4 {
 struct CascadeFlat {
     float a0, a1, a2;
     int cb;
-    __device__ __forceinline__ void init() { a0 = a1 = a2 = 0.f; cb = -1; }
-    __device__ __forceinline__ void add(int pos, float term, int n) {
+    __host__ __device__ __forceinline__ void init() { a0 = a1 = a2 = 0.f; cb = -1; }
+    __host__ __device__ __forceinline__ void add(int pos, float term, int n) {
         const int nfull = n >> 4;
         int blk = pos >> 4;
         blk = blk < nfull ? blk : nfull;
@@ -108,7 +110,7 @@ struct CascadeFlat {
         cb = blk;
         a0 += term;
     }
-    __device__ __forceinline__ float finish(int n) {
+    __host__ __device__ __forceinline__ float finish(int n) {
         const int nfull = n >> 4;
         if (cb != nfull) {
             a1 += a0; a0 = 0.f;
@@ -121,9 +123,9 @@ struct CascadeFlat {
 // Cascade with the (pos, term, n) interface of RowSum4, for code templated on the column class.
 struct CascadeN {
     Cascade c;
-    __device__ __forceinline__ void init() { c.init(); }
-    __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
-    __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
+    __host__ __device__ __forceinline__ void init() { c.init(); }
+    __host__ __device__ __forceinline__ void add(int pos, float term, int n) { c.add(pos, term, n >> 4); }
+    __host__ __device__ __forceinline__ float finish(int n) { return c.finish(n >> 4); }
 };
 
 // One output element's reduction; `tail` selects row_sum (column >= 32*floor(ncols/32)).
@@ -131,19 +133,19 @@ struct OuterSum {
     Cascade c;
     RowSum4 r;
     bool tail;
-    __device__ __forceinline__ void init(bool is_tail) { tail = is_tail; c.init(); if (is_tail) r.init(); }
-    __device__ __forceinline__ void add(int pos, float term, int n) {
+    __host__ __device__ __forceinline__ void init(bool is_tail) { tail = is_tail; c.init(); if (is_tail) r.init(); }
+    __host__ __device__ __forceinline__ void add(int pos, float term, int n) {
         if (!tail) c.add(pos, term, n >> 4); else r.add(pos, term, n);
     }
-    __device__ __forceinline__ float finish(int n) { return tail ? r.finish(n) : c.finish(n >> 4); }
+    __host__ __device__ __forceinline__ float finish(int n) { return tail ? r.finish(n) : c.finish(n >> 4); }
 };
 
 // Plain ascending sequential sum (canonical order of the dense Connection path).
 struct SeqSum {
     float a;
-    __device__ __forceinline__ void init(bool) { a = 0.f; }
-    __device__ __forceinline__ void add(int, float term, int) { a += term; }
-    __device__ __forceinline__ float finish(int) { return a; }
+    __host__ __device__ __forceinline__ void init(bool) { a = 0.f; }
+    __host__ __device__ __forceinline__ void add(int, float term, int) { a += term; }
+    __host__ __device__ __forceinline__ float finish(int) { return a; }
 };
 
 }  // namespace snn

@@ -20,7 +20,7 @@
 
 namespace snn {
 
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+__host__ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
@@ -28,7 +28,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
+__host__ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
     const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
@@ -73,15 +73,15 @@ __device__ __forceinline__ void mt_twist_block_wave(const uint32_t *src, uint32_
     }
 }
 
-__device__ __forceinline__ int32_t dbl_hi(double x) { return (int32_t)(__double_as_longlong(x) >> 32); }
-__device__ __forceinline__ double dbl_set_hi(double x, int32_t h) {
-    const uint64_t u = ((uint64_t)__double_as_longlong(x) & 0xffffffffull) | ((uint64_t)(uint32_t)h << 32);
-    return __longlong_as_double((long long)u);
+__host__ __device__ __forceinline__ int32_t dbl_hi(double x) { return (int32_t)(__builtin_bit_cast(long long, x) >> 32); }
+__host__ __device__ __forceinline__ double dbl_set_hi(double x, int32_t h) {
+    const uint64_t u = ((uint64_t)__builtin_bit_cast(long long, x) & 0xffffffffull) | ((uint64_t)(uint32_t)h << 32);
+    return __builtin_bit_cast(double, u);
 }
 
 // glibc 2.35 __log1p for -1 < x <= 0 ... the general algorithm, branches for NaN/inf dropped
 // because the argument is always -u with u in [0, 1).
-__device__ __forceinline__ double log1p_glibc(double x) {
+__host__ __device__ __forceinline__ double log1p_glibc(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                  Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
@@ -136,7 +136,7 @@ __device__ __forceinline__ double log1p_glibc(double x) {
 }
 
 // Exp(1) draw from two consecutive tempered mt19937 outputs (hi first), as torch does.
-__device__ __forceinline__ float exp1_from_words(uint32_t hi, uint32_t lo) {
+__host__ __device__ __forceinline__ float exp1_from_words(uint32_t hi, uint32_t lo) {
     const uint64_t r = ((uint64_t)hi << 32) | lo;
     const double u = (double)(long long)(r & ((1ull << 53) - 1ull)) * 0x1.0p-53;
     return (float)(-1.0 * log1p_glibc(-u));

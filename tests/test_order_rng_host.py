@@ -1,0 +1,112 @@
+"""The kernels' ordered-sum accumulators (csrc/snn_order.hpp: Cascade, RowSum4, OuterSum, CascadeFlat, CascadeN, SeqSum) and the
+device generator's arithmetic (csrc/snn_rng.hpp: mt19937 tempering / twist, the glibc log1p port, the Exp(1) draw) ON THE HOST:
+they are __host__ __device__, tests/hostcheck/order_rng_host.hip drives them the way the kernels' threads do (non-zero terms
+only, ascending index), and the results are compared bit for bit with the oracle (serial ATen order), with torch's own sums and
+with torch's CPU generator.  The device code is unchanged by the attribute (the gfx950 ISA of every kernel file is identical
+before and after, apart from the compilation-unit id)."""
+import ctypes as C
+import math
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+f32, u8 = np.float32, np.uint8
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc on this machine")
+    out = str(tmp_path_factory.mktemp("hostcheck") / "liborderhost.so")
+    src = os.path.join(ROOT, "tests", "hostcheck", "order_rng_host.hip")
+    subprocess.run([HIPCC, "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "--offload-arch=gfx950", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    lib = C.CDLL(out)
+    lib.hostcheck_log1p.argtypes, lib.hostcheck_log1p.restype = [C.c_double], C.c_double
+    return lib
+
+
+def p_(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("B,Nin,N,dens", [(3, 784, 100, 0.3), (2, 784, 400, 0.012), (2, 1000, 37, 0.4), (1, 5000, 70, 0.6), (2, 33, 15, 0.5),
+                                          (1, 70000, 33, 0.05), (2, 4099, 64, 0.5), (2, 400, 400, 0.01), (1, 20, 33, 0.9)])
+def test_outer_sum_accumulators_equal_the_oracle_and_torch(host, B, Nin, N, dens):
+    W = synth.uniform_f32(6000 + N, (Nin, N), -1.0, 1.0)
+    s = synth.dense_spikes(6100 + Nin, (B, Nin), dens)
+    out = np.empty((B, N), f32)
+    host.hostcheck_prop(p_(W), p_(s), B, Nin, N, 0, p_(out))
+    np.testing.assert_array_equal(bits(out), bits(oracle.prop_mcc(W, s)), err_msg="OuterSum vs the oracle")
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        t = (torch.from_numpy(s).view(B, Nin, 1).repeat(1, 1, N) * torch.from_numpy(W)).sum(1).numpy()
+    finally:
+        torch.set_num_threads(n0)
+    np.testing.assert_array_equal(bits(out), bits(t), err_msg="OuterSum vs torch (serial)")
+    # the other forms of the same sums: CascadeN == the cascade class everywhere; CascadeFlat likewise below 4096 terms;
+    # RowSum4 == the tail class everywhere; SeqSum == plain ascending order
+    full = (N // 32) * 32
+    host.hostcheck_prop(p_(W), p_(s), B, Nin, N, 3, p_(out))
+    np.testing.assert_array_equal(bits(out[:, :full]), bits(t[:, :full]), err_msg="CascadeN")
+    if Nin < 4096:
+        host.hostcheck_prop(p_(W), p_(s), B, Nin, N, 1, p_(out))
+        np.testing.assert_array_equal(bits(out[:, :full]), bits(t[:, :full]), err_msg="CascadeFlat")
+    host.hostcheck_prop(p_(W), p_(s), B, Nin, N, 4, p_(out))
+    np.testing.assert_array_equal(bits(out[:, full:]), bits(t[:, full:]), err_msg="RowSum4")
+    host.hostcheck_prop(p_(W), p_(s), B, Nin, N, 2, p_(out))
+    np.testing.assert_array_equal(bits(out), bits(oracle.prop_dense(W, s)), err_msg="SeqSum vs the oracle's canonical dense order")
+
+
+@pytest.mark.parametrize("B,E", [(1, 64), (16, 960), (17, 960), (32, 2400), (48, 784 * 4), (128, 640), (37, 63), (200, 96)])
+def test_batch_reduction_accumulator_equals_torch_sum_over_the_batch(host, B, E):
+    terms = synth.uniform_f32(6200 + B, (B, E), -1.0, 1.0) * synth.dense_spikes(6300 + E, (B, E), 0.4)
+    out = np.empty(E, f32)
+    host.hostcheck_batch_sum(p_(np.ascontiguousarray(terms)), B, E, p_(out))
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        want = torch.sum(torch.from_numpy(terms), dim=0).numpy()
+    finally:
+        torch.set_num_threads(n0)
+    np.testing.assert_array_equal(bits(out), bits(want))
+
+
+def test_device_generator_arithmetic_equals_torch_cpu_generator(host):
+    from bindsnet_amd.rng import torch_state_to_words
+    for seed, warm, n in ((0, 0, 5000), (7, 311, 3000), (123, 624 * 2 + 5, 2000)):
+        torch.manual_seed(seed)
+        if warm:
+            torch.rand(warm)
+        img = torch_state_to_words(torch.get_rng_state()).view(np.uint32).copy()
+        mt, pos = np.ascontiguousarray(img[:624]), C.c_int(int(img[624]))
+        want = torch.empty(n).exponential_(1).numpy()
+        out = np.empty(n, f32)
+        host.hostcheck_exponential(p_(mt), C.byref(pos), C.c_long(n), p_(out))
+        np.testing.assert_array_equal(bits(out), bits(want), err_msg=f"seed {seed}")
+        after = torch_state_to_words(torch.get_rng_state()).view(np.uint32)
+        np.testing.assert_array_equal(mt, after[:624])
+        assert pos.value == int(after[624])
+
+
+def test_log1p_port_equals_the_host_libm(host):
+    rs = np.random.RandomState(9)
+    xs = np.concatenate([-rs.uniform(0, 1, 200000), -np.ldexp(rs.uniform(0.5, 1, 50000), -rs.randint(1, 60, 50000)), [-0.0, -1e-300, -0.5, -0.2928932188134525,
+                                                                                                                         -(1 - 2.0 ** -53)]])
+    for x in xs:
+        got, want = host.hostcheck_log1p(float(x)), math.log1p(float(x))
+        assert got == want or (got != got and want != want), (x, got, want)
