@@ -12,7 +12,7 @@ int snn_check(hipError_t e);
 namespace snn {
 
 // Nodes.forward trace, bindsnet/network/nodes.py:96-103.
-__device__ __forceinline__ float trace_next(float x, uint8_t s, float decay, float scale, int additive) {
+__host__ __device__ __forceinline__ float trace_next(float x, uint8_t s, float decay, float scale, int additive) {
     float t = x * decay;
     if (additive) t = t + scale * (float)s;
     else if (s) t = scale;
@@ -21,7 +21,7 @@ __device__ __forceinline__ float trace_next(float x, uint8_t s, float decay, flo
 
 // LIFNodes.forward, bindsnet/network/nodes.py:508-527.  `cur` must already be zeroed by the
 // caller where rc > 0 (nodes.py:511 masks with the refractory counter BEFORE it is decremented).
-__device__ __forceinline__ uint8_t lif_update(float &v, float &rc, float cur, const snn_lif_params &p) {
+__host__ __device__ __forceinline__ uint8_t lif_update(float &v, float &rc, float cur, const snn_lif_params &p) {
     float vv = v - p.rest;              // :508  decay * (v - rest) + rest, three roundings
     vv = p.decay * vv;
     vv = vv + p.rest;
@@ -36,7 +36,7 @@ __device__ __forceinline__ uint8_t lif_update(float &v, float &rc, float cur, co
 
 // DiehlAndCookNodes.forward membrane part, bindsnet/network/nodes.py:1077-1092 (+ :1108-1109).
 // thr = thresh + theta[j] (already decayed), computed once per neuron by the caller.
-__device__ __forceinline__ uint8_t dc_update(float &v, float &rc, float cur, float thr, const snn_lif_params &p) {
+__host__ __device__ __forceinline__ uint8_t dc_update(float &v, float &rc, float cur, float thr, const snn_lif_params &p) {
     float vv = v - p.rest;              // :1077
     vv = p.decay * vv;
     vv = vv + p.rest;

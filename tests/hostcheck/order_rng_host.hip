@@ -77,3 +77,45 @@ extern "C" void hostcheck_exponential(uint32_t *mt, int *pos, long n, float *out
 }
 
 extern "C" double hostcheck_log1p(double x) { return log1p_glibc(x); }
+
+// ---- csrc/snn_common.hpp: the elementwise neuron updates, driven like k_lif / k_dc_membrane drive them -------------------
+#include "../../bindsnet_amd/csrc/snn_common.hpp"
+
+// T steps of LIFNodes.forward over [B*N] neurons: k_lif's loop body (the current is zeroed where the refractory counter is
+// positive BEFORE lif_update, nodes.py:511), trace, raster.
+extern "C" void hostcheck_lif_sequence(float *v, float *rc, uint8_t *s, float *x, const float *I, long n, int T, const snn_lif_params *p,
+                                       uint8_t *raster) {
+    for (int t = 0; t < T; ++t)
+        for (long k = 0; k < n; ++k) {
+            float vv = v[k], r = rc[k], cur = I[(size_t)t * n + k];
+            if (r > 0.f) cur = 0.f;
+            const uint8_t sp = lif_update(vv, r, cur, *p);
+            v[k] = vv; rc[k] = r; s[k] = sp;
+            if (p->traces) x[k] = trace_next(x[k], sp, p->trace_decay, p->trace_scale, p->traces_additive);
+            raster[(size_t)t * n + k] = sp;
+        }
+}
+
+// T steps of DiehlAndCookNodes.forward WITHOUT one_spike: k_dc_membrane's loop (theta decay, threshold, dc_update per sample,
+// crossing count, theta bump) + the trace of k_dc_arbitrate.
+extern "C" void hostcheck_dc_sequence(float *v, float *rc, uint8_t *s, float *x, float *theta, const float *I, int B, int N, int T,
+                                      const snn_dc_params *p, uint8_t *raster) {
+    for (int t = 0; t < T; ++t)
+        for (int j = 0; j < N; ++j) {
+            float th = theta[j];
+            if (p->learning) th = th * p->theta_decay;
+            const float thr = p->lif.thresh + th;
+            int cnt = 0;
+            for (int b = 0; b < B; ++b) {
+                const size_t k = (size_t)b * N + j;
+                float vv = v[k], r = rc[k];
+                const uint8_t sp = dc_update(vv, r, I[(size_t)t * B * N + k], thr, p->lif);
+                v[k] = vv; rc[k] = r; s[k] = sp;
+                cnt += sp;
+                if (p->lif.traces) x[k] = trace_next(x[k], sp, p->lif.trace_decay, p->lif.trace_scale, p->lif.traces_additive);
+                raster[(size_t)t * B * N + k] = sp;
+            }
+            if (p->learning) th = th + p->theta_plus * (float)cnt;
+            theta[j] = th;
+        }
+}

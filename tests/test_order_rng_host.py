@@ -110,3 +110,55 @@ def test_log1p_port_equals_the_host_libm(host):
     for x in xs:
         got, want = host.hostcheck_log1p(float(x)), math.log1p(float(x))
         assert got == want or (got != got and want != want), (x, got, want)
+
+
+def test_neuron_updates_equal_the_reference_fixture_and_the_oracle(host):
+    """csrc/snn_common.hpp (lif_update, dc_update, trace_next) on the host: the LIF sequences of the reference fixture op_nodes
+    (refractory masking, lower bound, overwrite and additive traces) bit for bit; the D&C membrane / adaptive-threshold sequence
+    (one_spike off) against the oracle."""
+    from cases import gold, unpack
+    from bindsnet_amd._lib import DcParams, LifParams
+    g = gold("op_nodes")
+    B, N, T = int(g["B"]), int(g["N"]), int(g["T"])
+    I = synth.uniform_f32(900, (T, B, N), -2.0, 6.0)
+    n = B * N
+
+    def lif(p, cur, v0):
+        v = np.full((B, N), v0, f32); r = np.zeros((B, N), f32); s = np.zeros((B, N), u8); x = np.zeros((B, N), f32)
+        ras = np.zeros((T, B, N), u8)
+        host.hostcheck_lif_sequence(p_(v), p_(r), p_(s), p_(x), p_(np.ascontiguousarray(cur)), C.c_long(n), T, C.byref(p), p_(ras))
+        return v, r, x, ras
+
+    p = LifParams()
+    p.decay, p.rest, p.reset, p.thresh, p.refrac, p.dt = float(g["lif_decay"]), -60.0, -45.0, -40.0, 2.0, 1.0
+    p.has_lbound, p.lbound, p.traces, p.trace_decay, p.trace_scale, p.traces_additive = 1, -62.0, 1, float(g["lif_trace_decay"]), 1.0, 0
+    v, r, x, ras = lif(p, I, -60.0)
+    np.testing.assert_array_equal(ras, unpack(g["lif_s"], (T, B, N)))
+    for a, key in ((v, "lif_v"), (x, "lif_x"), (r, "lif_r")):
+        np.testing.assert_array_equal(bits(a), bits(g[key]), err_msg=key)
+    p = LifParams()
+    p.decay, p.rest, p.reset, p.thresh, p.refrac, p.dt = float(g["lifadd_decay"]), -65.0, -65.0, -52.0, 5.0, 1.0
+    p.traces, p.trace_decay, p.trace_scale, p.traces_additive = 1, float(g["lifadd_trace_decay"]), 0.5, 1
+    v, r, x, ras = lif(p, I * f32(3), -65.0)
+    np.testing.assert_array_equal(bits(v), bits(g["lifadd_v"]))
+    np.testing.assert_array_equal(bits(x), bits(g["lifadd_x"]))
+    # D&C membrane + theta, one_spike off, against the oracle
+    d = DcParams()
+    d.lif.decay, d.lif.rest, d.lif.reset, d.lif.thresh, d.lif.refrac, d.lif.dt = float(g["dc_decay"]), -65.0, -60.0, -52.0, 5.0, 1.0
+    d.lif.traces, d.lif.trace_decay, d.lif.trace_scale = 1, float(g["dc_trace_decay"]), 1.0
+    d.theta_decay, d.theta_plus, d.learning, d.one_spike = float(g["dc_theta_decay"]), 0.05, 1, 0
+    cur = np.ascontiguousarray(I * f32(2.0))
+    v = np.full((B, N), -65.0, f32); r = np.zeros((B, N), f32); s = np.zeros((B, N), u8); x = np.zeros((B, N), f32); th = np.zeros(N, f32)
+    ras = np.zeros((T, B, N), u8)
+    host.hostcheck_dc_sequence(p_(v), p_(r), p_(s), p_(x), p_(th), p_(cur), B, N, T, C.byref(d), p_(ras))
+    v2 = np.full((B, N), -65.0, f32); r2 = np.zeros((B, N), f32); s2 = np.zeros((B, N), u8); x2 = np.zeros((B, N), f32); th2 = np.zeros(N, f32)
+    ras2 = np.zeros((T, B, N), u8)
+    Q, c0 = np.zeros(1, f32), np.zeros(1, np.int64)
+    for t in range(T):
+        oracle.dc_step(v2, r2, s2, x2, th2, cur[t].copy(), Q, c0, decay=float(g["dc_decay"]), rest=-65.0, reset=-60.0, thresh=-52.0, refrac0=5.0,
+                       theta_decay=float(g["dc_theta_decay"]), theta_plus=0.05, one_spike=False, trace_decay=float(g["dc_trace_decay"]))
+        ras2[t] = s2
+    assert ras.sum() > 50
+    np.testing.assert_array_equal(ras, ras2)
+    for a, b_, key in ((v, v2, "v"), (r, r2, "refrac"), (x, x2, "x"), (th, th2, "theta")):
+        np.testing.assert_array_equal(bits(a), bits(b_), err_msg=key)
