@@ -162,3 +162,30 @@ def test_neuron_updates_equal_the_reference_fixture_and_the_oracle(host):
     np.testing.assert_array_equal(ras, ras2)
     for a, b_, key in ((v, v2, "v"), (r, r2, "refrac"), (x, x2, "x"), (th, th2, "theta")):
         np.testing.assert_array_equal(bits(a), bits(b_), err_msg=key)
+
+
+def test_the_draw_comparison_margin_of_the_lean_arbitration_holds():
+    """The lean D&C kernels pick the one_spike winner by comparing the 53-bit draws m_j instead of evaluating fl32(1 / fl32(-log1p(-u_j)))
+    for every candidate (csrc/snn_dc2015_resident.hip: `zone = mmin + (mmin >> 19) + 1`): outside the zone the smaller draw must win
+    STRICTLY in the reference's arithmetic.  Checked here for draws right at the edge of the zone, over the whole range of m:
+    val(m) = fl32(1 / fl32(-log1p(-m * 2^-53))) is strictly larger than val(zone(m) + 1)."""
+    rs = np.random.RandomState(11)
+    ms = np.concatenate([np.arange(0, 4096, dtype=np.uint64), (rs.uniform(0, 1, 150000) * 2.0 ** 53).astype(np.uint64),
+                         np.exp2(rs.uniform(0, 53, 150000)).astype(np.uint64), (1 << 53) - 1 - np.exp2(rs.uniform(0, 50, 50000)).astype(np.uint64)])
+    top = (1 << 53) - 1
+
+    def val(m):
+        u = float(int(m)) * 2.0 ** -53
+        q = np.float32(-1.0 * math.log1p(-u))
+        with np.errstate(divide="ignore"):
+            return np.float32(1.0) / q
+
+    bad = 0
+    for m1 in ms:
+        m1 = int(m1)
+        m2 = m1 + (m1 >> 19) + 2                      # the first draw OUTSIDE the zone
+        if m2 > top:
+            continue
+        if not val(m1) > val(m2):
+            bad += 1
+    assert bad == 0
