@@ -20,18 +20,44 @@ import torch
 import torch.nn.functional as F
 
 
+def aten_sum_leaves_serial_order(outer: int, n_reduced: int, n_cols: int, threads: int) -> bool:
+    """True when torch.sum over the middle dimension of a contiguous float [outer, n_reduced, n_cols] tensor (outer = 1: also
+    sum(dim=0) of [n_reduced, n_cols]) at `threads` intra-op threads sums the last n_cols mod 32 columns in another order than it
+    does serially.  The reference's own float sums are not independent of the thread count: reductions of at least 32768
+    elements are split over the outermost non-reduced dimension that has `threads` entries (if neither has: the larger one,
+    ties to the outer) -- and when that is the COLUMNS, cut into `threads` ranges of c = ceil(n_cols / threads) whose ends are
+    rounded down to multiples of 32, a last range holding ONLY the n_cols mod 32 < 8 tail columns is summed by another kernel
+    of SumKernel.cpp (scalar_outer_sum: groups of four columns in the cascade order of a full group) than the same columns at
+    the end of a longer range (vectorized_outer_sum's row_sum leftover).  E.g. n_cols = 100, batch 1: columns 96-99 at 9 or
+    >= 12 threads.  Pinned against torch itself by tests/test_aten_sum_threads.py (tools/probe_aten_sum_threads.py prints it)."""
+    tail = n_cols % 32
+    if threads <= 1 or not 0 < tail < 8:
+        return False
+    if outer * n_reduced * n_cols < 32768:       # at::internal::GRAIN_SIZE: small reductions run serially
+        return False
+    if outer >= threads:                         # the outer dimension is split: every slice is summed serially
+        return False
+    if n_cols < threads and n_cols <= outer:
+        return False
+    c = -(-n_cols // threads)
+    return c * ((n_cols - 1) // c) >= n_cols - tail
+
+
 def _sum(t, dim):
-    """ATen's sum in its SERIAL order, whatever the caller's thread setting.  The reference's own float sums are not
-    independent of the intra-op thread count: when the batch is smaller than the thread count, ATen splits the contiguous
-    (non-reduced) columns among the threads in chunks rounded to 32 columns, and a chunk that ends up holding only the last
-    N mod 32 < 8 columns is summed by another kernel (scalar_outer_sum: the cascade order of a full group) than the same
-    columns at the end of a longer chunk (vectorized_outer_sum's row_sum tail) -- e.g. N = 100, B = 1: columns 96-99 at 9 or
-    >= 12 threads (tools/probe_aten_sum_threads.py).  This package pins the SERIAL order (what the
-    reference computes with up to 8 threads at the sizes of BASELINE.md, and at any thread count once B >= threads): the
-    MI355X kernels, the oracle and, through this helper, the host path."""
+    """ATen's sum in its SERIAL order, whatever the caller's thread setting: this package pins the serial order (what the
+    reference computes with up to 8 threads at the sizes of BASELINE.md, and at any thread count once the batch has at least
+    `threads` samples) -- the MI355X kernels, the oracle and, through this helper, the host path.  The thread count is only
+    taken down for the call when the model above says the order would change (or the shape is not one it covers)."""
     n = torch.get_num_threads()
     if n == 1:
         return t.sum(dim)
+    if t.is_contiguous() and t.dim() in (2, 3) and dim in (0, 1):
+        if dim == 0:                                 # [B, ...] over the batch: the trailing dimensions are one run of columns
+            shape = (1, t.shape[0], t[0].numel())
+        else:
+            shape = (t.shape[0], t.shape[1], t.shape[2]) if t.dim() == 3 else None
+        if shape is not None and not aten_sum_leaves_serial_order(*shape, n):
+            return t.sum(dim)
     torch.set_num_threads(1)
     try:
         return t.sum(dim)

@@ -22,19 +22,12 @@ import torch
 
 
 def tail_isolated(B: int, N: int, threads: int, Nin: int = 1 << 20) -> bool:
-    """True when torch.sum(dim=1) of a contiguous [B, Nin, N] float tensor (B = 1: also sum(dim=0) of [Nin, N]) at `threads`
-    intra-op threads sums the last N mod 32 columns in another order than it does serially."""
-    tail = N % 32
-    if threads <= 1 or not 0 < tail < 8:
-        return False
-    if B * Nin * N < 32768:              # at::internal::GRAIN_SIZE: small reductions run serially
-        return False
-    if B >= threads:                     # the batch is split: every sample is summed serially
-        return False
-    if N < threads and N <= B:           # neither dimension has `threads` entries: the larger one is split (ties: the batch)
-        return False
-    c = -(-N // threads)
-    return c * ((N - 1) // c) >= N - tail
+    """The model, as the host path uses it (bindsnet_amd/network/host_path.py::aten_sum_leaves_serial_order)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bindsnet_amd.network.host_path import aten_sum_leaves_serial_order
+    return aten_sum_leaves_serial_order(B, Nin, N, threads)
 
 
 def main():
