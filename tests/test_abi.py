@@ -165,3 +165,22 @@ def test_scalar_parameter_cache_and_cpu_reset():
     assert torch.all(Ae.theta == 0.3)
     net.run({"X": torch.zeros(5, 3, 1, 4, 4, dtype=torch.uint8)}, time=5)          # CPU tensors: the host path (test_host_path.py)
     assert net.last_plan == "host-torch"
+
+
+def test_bench_roofline_accounting():
+    """bench.py's byte figures: SURVEY.md 8(d)'s dense accounting (5.86 MB per timestep at cfg2, 1.03 MB at cfg1) and the
+    sparse-effective variant it reports separately (weight rows of spiking sources only) -- pure host arithmetic."""
+    import importlib.util
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes_per_timestep() == 5860480
+    assert bench.algorithmic_bytes_per_timestep(784, 100, 1) == 4 * (3 * 78400 + 2 * 10000) + (7840 + 2600 + 1800) + 800
+    rs = np.random.RandomState(0)
+    pool = [(rs.uniform(size=(250, 32, 1, 28, 28)) < 0.0117).astype(np.uint8)]
+    sb, rows = bench.sparse_effective_bytes_per_timestep(pool)
+    assert 150 < rows < 350 and sb < bench.algorithmic_bytes_per_timestep()
+    assert abs(sb - (4 * (rows * 400 + 2 * 784 * 400 + 2 * 32 * 400) + 32 * (7840 + 10400 + 7200) + 3200)) < 1
