@@ -132,3 +132,11 @@ def test_oracle_run_matches_the_reference_run_with_16_threads():
                 cases.dc_reset(st)
     for r in range(runs):
         np.testing.assert_array_equal(g16[f"r{r}_sE"], g8[f"r{r}_sE"])
+
+
+def test_selftest_host_part(threads):
+    """`python -m bindsnet_amd.selftest` ("ship a self-test that checks the summation rules against torch"):
+    its host checks pass on this torch; the device checks run where there is an MI355X (tests/test_gpu_zz_experimental.py)."""
+    from bindsnet_amd import selftest
+    msgs = []
+    assert selftest.host_checks(msgs.append), msgs

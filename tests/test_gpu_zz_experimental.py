@@ -21,3 +21,12 @@ def test_event_driven_conv_postpre_passes_the_conv_postpre_parity_tests():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_extras.py"), "-m", "gpu", "-q", "-k", "conv2d_postpre"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1500:]
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_selftest_device_part():
+    """bindsnet_amd.selftest's device checks: the propagation, normalisation and PostPre kernels against the torch expressions the
+    reference evaluates (1 thread), on random data, bit for bit."""
+    from bindsnet_amd import selftest
+    msgs = []
+    assert selftest.device_checks(msgs.append), msgs
