@@ -327,3 +327,58 @@ def test_local_connection_and_conv2d_learning_on_the_host_match_reference():
     np.testing.assert_array_equal(mon.get("s").numpy().reshape(T4, 400).astype(u8), unpack(g["run_sY"], (T4, 400)))
     np.testing.assert_allclose(cm.w.detach().numpy(), g["run_W"], rtol=0, atol=1e-5 * 4.0)
     np.testing.assert_allclose(cm.update_rule.eligibility.numpy(), g["run_elig"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(g["run_elig"]).max())))
+
+
+@pytest.mark.parametrize("N,B,T,Nin,inh,rate,learning,threads", [
+    (37, 2, 60, 196, 60.0, 0.35, True, 8), (68, 1, 80, 784, 120.0, 0.25, True, 16), (100, 3, 50, 784, 17.5, 0.3, True, 12),
+    (100, 1, 60, 784, 120.0, 0.3, False, 9), (64, 5, 40, 400, 30.0, 0.4, True, 1), (132, 2, 40, 784, 120.0, 0.25, True, 16)])
+def test_dc2015_on_the_host_vs_oracle_fuzz(N, B, T, Nin, inh, rate, learning, threads):
+    """D&C runs on the host at sizes the reference fixtures do not cover -- column tails of 4 / 5 columns (the shapes where ATen's
+    order depends on the thread count: the host path must stay on the serial one at any setting), test mode, small inputs --
+    against the oracle, two consecutive inputs: rasters, weights, theta, state and the number of draws, bit for bit."""
+    import oracle
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    side = int(round(Nin ** 0.5))
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(0)
+        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4 * Nin / 784, theta_plus=0.05, inpt_shape=(1, side, side))
+        W0 = synth.weights_q12(10, Nin, N)
+        feat = net.connections[("X", "Ae")].pipeline[0]
+        feat.value.data.copy_(T_(W0))
+        net.train(learning)
+        mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
+        for l, m in mons.items():
+            net.add_monitor(m, l)
+        P = oracle.eth_mnist_dc_params(N, B, T, Nin=Nin, learning=learning)
+        P.norm = 78.4 * Nin / 784
+        st = oracle.eth_mnist_dc_state(N, B, W0.copy(), Nin=Nin, inh=inh)
+        for r in range(2):
+            sp = synth.spike_train(60 + r, T, B, Nin, max_rate=rate)
+            Q = oracle.exp_noise(9 + r, B * N * T + 16)
+            cur = np.zeros(1, np.int64)
+            rasE, rasI = oracle.run_dc2015(P, st, sp, Q, cur)
+            torch.manual_seed(9 + r)
+            net.run({"X": T_(sp).view(T, B, 1, side, side)}, time=T)
+            got_probe = torch.rand(2)
+            np.testing.assert_array_equal(mons["Ae"].get("s").numpy().reshape(T, B, N).astype(u8), rasE, err_msg=f"input {r} Ae")
+            np.testing.assert_array_equal(mons["Ai"].get("s").numpy().reshape(T, B, N).astype(u8), rasI, err_msg=f"input {r} Ai")
+            np.testing.assert_array_equal(bits(feat.value.detach().numpy()), bits(st["W_xe"]), err_msg=f"input {r} weights")
+            for a, key in ((net.layers["Ae"].theta, "theta"), (net.layers["Ae"].v, "vE"), (net.layers["Ae"].x, "xE"), (net.layers["Ai"].v, "vI")):
+                np.testing.assert_array_equal(bits(a.numpy()), bits(st[key]), err_msg=f"input {r} {key}")
+            torch.manual_seed(9 + r)                                  # the host generator stands where `cur` draws leave it
+            if int(cur[0]):
+                torch.empty(int(cur[0])).exponential_(1)
+            assert torch.equal(got_probe, torch.rand(2)), f"input {r}: host generator position"
+            assert rasE.sum() > 3
+            if r == 0:
+                net.reset_state_variables()
+                for k in ("sX", "xX", "sE", "xE", "rE", "rI", "sI"):
+                    st[k][:] = 0
+                st["vE"][:] = -65.0
+                st["vI"][:] = -60.0
+        assert torch.get_num_threads() == threads
+    finally:
+        torch.set_num_threads(n0)
