@@ -1,6 +1,14 @@
-"""Batch sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL).
+"""Multi-GPU modes (one process per GPU, torch.distributed over RCCL; gloo on the host).  Three of them:
 
-Schedule (BASELINE.json north star): every rank holds a replica of the weights and simulates its
+  sharded_run     the north-star schedule: batch shards, ONE all-reduce of the weight / threshold deltas per input.  Fast, and
+                  NOT equivalent to the reference's single global batch (below).
+  column_shard    exact for graphs without coupling between target neurons (Input -> connection -> LIFNodes): 32-aligned column
+                  slices, no collective at all during the run.
+  exact_run       exact for graphs whose batch IS coupled every timestep (DiehlAndCook2015): batch shards, one all-gather of the
+                  spike bytes per timestep, the coupled operations on the global batch on every rank.  Bit-identical to the
+                  single-process global batch at any world size; per-operator launches (parity and capacity, not speed).
+
+Batch sharding across the GPUs of one node, the north-star schedule (BASELINE.json): every rank holds a replica of the weights and simulates its
 own shard of the batch for one input (`network.run`), then the weight and adaptive-threshold
 DELTAS of that input are summed over ranks (all-reduce over xGMI), clamped, and the weights are
 re-normalised -- one collective of Nin*N*4 + N*4 bytes per input, nothing per timestep.
