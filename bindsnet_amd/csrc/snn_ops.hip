@@ -735,9 +735,10 @@ extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x
         const snn::ConvGeom g{Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW};
         hipLaunchKernelGGL(k_conv_pp_partial_ev, dim3((unsigned)(B * Cin), (unsigned)((Cout * KH * KW + 255) / 256)), dim3(256), ev_lds_bytes,
                            (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws, B, g);
-    } else
+    } else {
         hipLaunchKernelGGL(k_conv_pp_partial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws,
                            B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW);
+    }
     hipLaunchKernelGGL(k_conv_pp_apply, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ws, B, E, nu0, nu1, decay,
                        has_min, wmin, has_max, wmax);
     return snn_check_launch();
