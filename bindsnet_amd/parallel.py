@@ -405,17 +405,32 @@ class _ExactDevice:
             self.gen.__exit__(RuntimeError, None, None)
 
 
-def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None) -> None:
+def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, comm=None) -> None:
     """network.run() for a batch that is sharded over the ranks of `group`, EXACTLY: `inputs` holds this rank's rows
     (rank r owns rows [r * B_shard, (r + 1) * B_shard) of the global batch), the network is this rank's replica with
     batch size B_shard, and after the call weights, theta, the state of the own rows, monitors and the host generator
     are what the single-process run of the global batch leaves (see the section comment).  Every rank must enter with the
-    same weights / theta and the same state of the global generator (torch.manual_seed)."""
+    same weights / theta and the same state of the global generator (torch.manual_seed).  The exchange goes through
+    torch.distributed (`group`; RCCL or gloo) or, with `comm` = a parallel.NativeComm, through the C ABI's own RCCL collective
+    snn_dist_allgather_step -- what a caller on the other side of the boundary would use (device tensors only)."""
     from .network.monitors import Monitor
     from .network.nodes import DiehlAndCookNodes, Input
     assert type(inputs) == dict, "'inputs' must be a dict of names of layers (str) and relevant input tensors."
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def exchange(recv, own):
+        """recv[r] <- rank r's `own` (recv: [world, *own.shape], contiguous)."""
+        if comm is not None:
+            recv.copy_(comm.allgather(own.contiguous()).view_as(recv))
+        elif world > 1:
+            dist.all_gather(list(recv.unbind(0)), own, group=group)
+        else:
+            recv[0].copy_(own)
+
     for key in inputs:                                        # network.py:329-353
         if inputs[key].dim() == 1:
             inputs[key] = inputs[key].unsqueeze(0).unsqueeze(0)
@@ -444,10 +459,8 @@ def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None) -
     def gather(own):
         """[Bs, k] (any dtype) of every rank -> [B, k], rows in rank order."""
         own = own.contiguous()
-        if world == 1:
-            return own.clone()
         out = torch.empty(world, *own.shape, dtype=own.dtype, device=own.device)
-        dist.all_gather(list(out.unbind(0)), own, group=group)
+        exchange(out, own)
         return out.view(B, *own.shape[1:])
 
     def bytes_of(t, n):
@@ -468,11 +481,11 @@ def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None) -
                 raise ValueError(f"inputs['{name}'] has shape {tuple(x.shape)}, expected [T >= {T}, {Bs}, {n}]")
             x = inputs[name] = x.to(dev).contiguous()
             in_own[name] = bytes_of(x[:T], Bs * n).view(T, Bs, n)
-            if world == 1:
+            if world == 1 and comm is None:
                 in_g[name] = in_own[name]
             else:                                            # the spike trains of all ranks, once per run: [T, B, n]
                 out = torch.empty(world, T, Bs, n, dtype=u8, device=dev)
-                dist.all_gather(list(out.unbind(0)), in_own[name], group=group)
+                exchange(out, in_own[name])
                 in_g[name] = out.permute(1, 0, 2, 3).reshape(T, B, n).contiguous()
             entry = layer.s
             if entry.numel() != Bs * n or entry.device != dev:
@@ -535,10 +548,7 @@ def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None) -
                 send[:, off:off + layer.n].copy_(bytes_of(layer.s, layer.n))
                 off += layer.n
             # (2) the step's spikes of all ranks
-            if world > 1:
-                dist.all_gather(list(recv.unbind(0)), send, group=group)
-            else:
-                recv[0].copy_(send)
+            exchange(recv, send)
             # (3) the coupled half, on the global batch, identically on every rank
             off = 0
             for name in others:

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--fixture", required=True)
     ap.add_argument("--runs", type=int, default=0)
     ap.add_argument("--threads", type=int, default=2)
+    ap.add_argument("--native", action="store_true", help="exchange through the C ABI's own RCCL communicator (parallel.NativeComm)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -60,6 +61,7 @@ def main():
         net.add_monitor(m, l + "_s")
     if a.device == "cuda":
         net.to("cuda")
+    comm = parallel.NativeComm(a.rank, a.world) if a.native else None
     host = lambda t: t.detach().cpu().numpy()                    # noqa: E731
     out = {"lo": lo, "hi": hi}
     if full:
@@ -74,7 +76,7 @@ def main():
         if a.device == "cuda":
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        parallel.exact_run(net, {"X": shard}, T)
+        parallel.exact_run(net, {"X": shard}, T, comm=comm)
         if a.device == "cuda":
             torch.cuda.synchronize()
         out[f"r{r}_seconds"] = time.perf_counter() - t0
@@ -93,6 +95,8 @@ def main():
     if a.world > 1:
         dist.barrier()
     np.savez_compressed(a.out, **out)
+    if comm is not None:
+        comm.close()
     if a.world > 1:
         dist.destroy_process_group()
 

@@ -30,3 +30,12 @@ def test_selftest_device_part():
     from bindsnet_amd import selftest
     msgs = []
     assert selftest.device_checks(msgs.append), msgs
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_exact_mode_through_the_native_rccl_communicator(tmp_path):
+    """parallel.exact_run(comm=NativeComm): the per-timestep exchange through the C ABI's own collective snn_dist_allgather_step
+    (world size 1 on a one-GPU box: RCCL refuses two ranks on one device) == the reference fixture."""
+    import exact_harness as H
+    res = H.launch(1, "run_dc_n400_b4", "cuda", tmp_path, timeout=240, native=True)
+    H.check_against_reference(res, "run_dc_n400_b4")
