@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -128,6 +128,7 @@ _SIGS = {
     "snn_mstdpet_step": ([_vp] * 8 + [_i, _i] + [_f] * 10 + [_i, _f, _i, _f, _vp], _i),
     "snn_mstdp_step": ([_vp] * 7 + [_i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _f, _i, _f, _vp], _i),
     "snn_normalize": ([_vp, _i, _i, _f, _i, _vp, _vp], _i),
+    "snn_normalize_conv2d": ([_vp, _i, _i, _f, _vp], _i),
     "snn_rng_fill_exponential": ([_vp, _vp, _i, _i, _vp, _vp, _vp], _i),
     "snn_encode_bernoulli": ([_vp, _vp, _i, _i, _f, _vp, _vp], _i),
     "snn_encode_poisson": ([_vp, _i, _i, _f, C.c_ulonglong, _vp, _vp], _i),

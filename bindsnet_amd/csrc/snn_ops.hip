@@ -999,6 +999,27 @@ extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, 
     return snn_check_launch();
 }
 
+// a11 for Conv2dConnection: normalize(), bindsnet/network/topology.py:824-837.  Every [KH*KW] filter of the [Cout*Cin, KH*KW] view
+// is scaled to sum `norm`: w[f] *= norm / w[f].sum(0), where the sum is ATen's vectorised INNER sum (snn_order.hpp inner_sum8) and
+// torch evaluates float / tensor as reciprocal(sum) * norm.  No zero guard (the reference has none).  One thread per filter: the
+// weights of a convolution are a few hundred floats.  The body is __host__ __device__ and checked on the host against the reference
+// fixture (tests/test_order_rng_host.py); NOT YET RUN ON AN MI355X (the round's GPU minutes were spent when it was written).
+__global__ __launch_bounds__(64) void k_normalize_filters(float *__restrict__ W, int F, int K, float norm) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= F) return;
+    float *w = W + (size_t)f * K;
+    const float sum = inner_sum8(w, K);
+    const float rc = 1.0f / sum;
+    const float scale = rc * norm;
+    for (int k = 0; k < K; ++k) w[k] = w[k] * scale;
+}
+
+extern "C" int snn_normalize_conv2d(float *W, int n_filters, int taps, float norm, snn_stream_t stream) {
+    if (!W || n_filters <= 0 || taps <= 0) return SNN_ERR_INVALID;
+    if (taps > kMaxTerms) return SNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_normalize_filters, dim3((unsigned)((n_filters + 63) / 64)), dim3(64), 0, (hipStream_t)stream, W, n_filters, taps, norm);
+    return snn_check_launch();
+}
 
 // =============================================================================================
 // Network.reset_state_variables(): every state tensor of every layer filled in ONE launch

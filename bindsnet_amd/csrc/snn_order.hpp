@@ -140,6 +140,32 @@ struct OuterSum {
     __host__ __device__ __forceinline__ float finish(int n) { return tail ? r.finish(n) : c.finish(n >> 4); }
 };
 
+// ATen's vectorised INNER sum of one contiguous row of n floats -- what `w[filter].sum(0)` of Conv2dConnection.normalize
+// (bindsnet/network/topology.py:824-837) runs: SumKernel.cpp's vectorized_inner_sum with 8-float vectors (torch 2.10 takes that
+// path under every ATEN_CPU_CAPABILITY; probed).  Lane l of 8 sums x[l], x[8 + l], ... through row_sum over the n / 8 vectors
+// (= RowSum4); then a fresh accumulator takes the n mod 8 leftover elements in order and after them the 8 lane sums in lane
+// order.  Rows shorter than one vector: scalar row_sum over the n terms.
+__host__ __device__ inline float inner_sum8(const float *x, int n) {
+    if (n < 8) {
+        RowSum4 r;
+        r.init();
+        for (int i = 0; i < n; ++i) r.add(i, x[i], n);
+        return r.finish(n);
+    }
+    const int vs = n >> 3;
+    float part[8];
+    for (int l = 0; l < 8; ++l) {
+        RowSum4 r;
+        r.init();
+        for (int i = 0; i < vs; ++i) r.add(i, x[i * 8 + l], vs);
+        part[l] = r.finish(vs);
+    }
+    float fin = 0.f;
+    for (int k = vs * 8; k < n; ++k) fin += x[k];
+    for (int l = 0; l < 8; ++l) fin += part[l];
+    return fin;
+}
+
 // Plain ascending sequential sum (canonical order of the dense Connection path).
 struct SeqSum {
     float a;

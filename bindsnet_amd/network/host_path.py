@@ -409,8 +409,15 @@ def _mask_of(conn, mask):
 
 def normalize_connection(conn) -> None:
     """One connection's normalisation -- Weight features by their SIGNED column sums (topology_features.py:250-266), dense
-    connections by the absolute ones (topology.py:383-392), a LocalConnection by the signed ones again (topology.py:1475-1482)."""
-    from .topology import LocalConnection, MulticompartmentConnection
+    connections by the absolute ones (topology.py:383-392), a LocalConnection by the signed ones again (topology.py:1475-1482),
+    a Conv2dConnection filter by filter (topology.py:824-837)."""
+    from .topology import Conv2dConnection, LocalConnection, MulticompartmentConnection
+    if isinstance(conn, Conv2dConnection):                       # topology.py:824-837: every [KH*KW] filter to sum `norm`
+        if conn.norm is not None:
+            w = conn.w.data.view(conn.w.shape[0] * conn.w.shape[1], conn.w.shape[2] * conn.w.shape[3])
+            for fltr in range(w.shape[0]):
+                w[fltr] *= conn.norm / w[fltr].sum(0)
+        return
     if isinstance(conn, MulticompartmentConnection):
         feat = conn._weight()
         if feat.norm is not None:

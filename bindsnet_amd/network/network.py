@@ -241,6 +241,10 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             else:
                 self.__dict__["resident_retries"] = self.__dict__.get("resident_retries", 0) + 1
                 R.plan = 2
+        if not self.__dict__.get("_defer_norm", False):     # network.py:463-465 for the connections snn_net_run does not normalise itself
+            for conn in self.connections.values():
+                if isinstance(conn, Conv2dConnection) and conn.norm is not None:
+                    conn.normalize()
         # Input.s aliases the last input slice, as in the reference (nodes.py:219)
         before = _lib.epoch()
         for i, name, layer, _ in built["inputs"]:
@@ -703,9 +707,12 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             raise NotImplementedError("bindsnet_amd: weight_decay on a connection without a learning rule is not supported")
         if conn.w.dtype != torch.float32 or not conn.w.is_contiguous():
             raise NotImplementedError("bindsnet_amd: connection weights must be contiguous float32")
-        if conn.norm is not None:
-            if isinstance(conn, Conv2dConnection):
-                raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not supported")
+        if conn.norm is not None and isinstance(conn, Conv2dConnection):
+            # Conv2dConnection.normalize (topology.py:824-837) scales every filter to sum `norm`: not a column normalisation, so
+            # not snn_net_run's post-loop step -- run() calls the connection's own normalize() (snn_normalize_conv2d) behind it
+            if isinstance(conn.norm, torch.Tensor):
+                raise NotImplementedError("bindsnet_amd: tensor norms are not supported")
+        elif conn.norm is not None:
             ws = self._scratch(f"norm_{src}_{dst}", (conn.target.n,), torch.float32, dev)
             # Connection.normalize sums |w| (topology.py:383-392), LocalConnection.normalize the signed weights (:1475-1482)
             d.has_norm, d.norm, d.norm_abs, d.norm_ws = 1, float(conn.norm), int(not isinstance(conn, LocalConnection)), _dptr(ws)

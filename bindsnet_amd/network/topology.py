@@ -227,8 +227,14 @@ class Conv2dConnection(AbstractConnection):
         return out
 
     def normalize(self) -> None:
+        """Every [KH*KW] filter scaled to sum `norm` (topology.py:824-837)."""
         if self.norm is not None:
-            raise NotImplementedError("bindsnet_amd: Conv2dConnection.normalize is not on the accelerated path")
+            if not self.w.is_cuda:
+                from . import host_path
+                return host_path.normalize_connection(self)
+            if isinstance(self.norm, torch.Tensor):
+                raise NotImplementedError("bindsnet_amd: tensor norms are not supported")
+            ops.normalize_conv2d(self.w.data, float(self.norm))
 
 
 class AbstractMulticompartmentConnection(_lib.TouchingModule, Module):

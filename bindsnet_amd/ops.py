@@ -185,6 +185,12 @@ def normalize(W, norm, use_abs, ws=None):
     check(lib().snn_normalize(_ptr(W, F32), Nin, N, norm, int(use_abs), _ptr(ws, F32), _stream()), "normalize")
 
 
+def normalize_conv2d(W, norm):
+    """Conv2dConnection.normalize (topology.py:824-837): every [KH*KW] filter of W [Cout, Cin, KH, KW] scaled to sum `norm`."""
+    Cout, Cin, KH, KW = W.shape
+    check(lib().snn_normalize_conv2d(_ptr(W, F32), Cout * Cin, KH * KW, float(norm), _stream()), "normalize_conv2d")
+
+
 def rng_fill_exponential(rng_state, crossings, qbuf, cursor):
     """Device generator: draws for the rows of `crossings` [B,N] that have a non-zero entry."""
     B = crossings.shape[0]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 5
+#define SNN_ABI_VERSION 6
 
 typedef void *snn_stream_t;
 
@@ -238,6 +238,10 @@ int snn_mstdpet_step(float *W, float *e_trace, float *p_plus, float *p_minus, ui
 int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, float *colsum_ws,
                   snn_stream_t stream);
 
+/* Conv2dConnection.normalize, bindsnet/network/topology.py:824-837: W viewed as [n_filters = Cout*Cin, taps = KH*KW]; every filter is
+ * scaled to sum `norm` -- w[f] *= norm * (1 / sum_k w[f,k]), the sum in ATen's vectorised inner-sum order (8 interleaved lanes of
+ * row_sum, leftovers, then the lanes), no zero guard like the reference.  (ABI 6)                                  */
+int snn_normalize_conv2d(float *W, int n_filters, int taps, float norm, snn_stream_t stream);
 
 /* ---- f2: spike encoders on the device ---------------------------------------------------------
  * bindsnet/encoding/encodings.py:51-98 (bernoulli): out [steps, n] u8 = what torch.bernoulli(max_prob *

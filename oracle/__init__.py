@@ -213,6 +213,19 @@ def normalize(W, norm, use_abs):
     lib().orc_normalize(_p(W, f32), ci(Nin), ci(N), cf(norm), ci(int(use_abs)))
 
 
+def normalize_conv2d(W, norm):
+    """Conv2dConnection.normalize (topology.py:824-837) in place on W [Cout, Cin, KH, KW]."""
+    Cout, Cin, KH, KW = W.shape
+    lib().orc_normalize_conv2d(_p(W, f32), ci(Cout * Cin), ci(KH * KW), cf(norm))
+
+
+def inner_sum(x):
+    """ATen's vectorised inner sum of one contiguous f32 row."""
+    f = lib().orc_inner_sum
+    f.restype = C.c_float
+    return float(f(_p(np.ascontiguousarray(x, f32), f32), cl(len(x))))
+
+
 def run_dc2015(P: DcParams, st: dict, inputs, Q, cursor, rasters=True):
     """st: dict of numpy state arrays (W_xe, W_ei, W_ie, sX, xX, vE, rE, sE, xE, theta, vI, rI, sI),
     all updated in place. inputs u8 [T,B,Nin]. Returns (rasterE, rasterI)."""

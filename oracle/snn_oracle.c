@@ -575,6 +575,42 @@ ORC_API void orc_normalize(float *W, int Nin, int N, float norm, int use_abs)
     free(scale);
 }
 
+/* a11 for Conv2dConnection: normalize(), bindsnet/network/topology.py:824-837 -- W viewed as [F = Cout*Cin, K = KH*KW]; every filter
+ * is scaled by norm / w[f].sum(0).  The 1-D sum of a contiguous row is SumKernel.cpp's vectorized_inner_sum with 8-float vectors
+ * (what torch 2.10 runs under every ATEN_CPU_CAPABILITY; probed): lane l of 8 takes x[l], x[8+l], ... through row_sum over the
+ * K / 8 vectors; a fresh accumulator then takes the K mod 8 leftover elements in order and after them the 8 lane sums in lane order;
+ * rows shorter than one vector take the scalar row_sum.  float / tensor is reciprocal(tensor) * float in torch; no zero guard. */
+typedef struct { const float *x; long stride, off; } lane_ctx;
+static float lane_term(const void *c, long i)
+{
+    const lane_ctx *p = (const lane_ctx *)c;
+    return p->x[i * p->stride + p->off];
+}
+
+static float inner_sum8(const float *x, long n)
+{
+    if (n < 8) { lane_ctx c = { x, 1, 0 }; return row_sum4(lane_term, &c, n); }
+    const long vs = n / 8;
+    float part[8];
+    for (int l = 0; l < 8; ++l) { lane_ctx c = { x, 8, l }; part[l] = row_sum4(lane_term, &c, vs); }
+    float fin = 0.f;
+    for (long k = vs * 8; k < n; ++k) fin += x[k];
+    for (int l = 0; l < 8; ++l) fin += part[l];
+    return fin;
+}
+
+ORC_API float orc_inner_sum(const float *x, long n) { return inner_sum8(x, n); }
+
+ORC_API void orc_normalize_conv2d(float *W, int F, int K, float norm)
+{
+    for (int f = 0; f < F; ++f) {
+        float *w = W + (long)f * K;
+        const float rc = 1.0f / inner_sum8(w, K);
+        const float scale = rc * norm;
+        for (int k = 0; k < K; ++k) w[k] = w[k] * scale;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * a1: Network.run for the DiehlAndCook2015 graph, bindsnet/network/network.py:380-465 with
  * the wiring of bindsnet/models/models.py:156-244 (layers X, Ae, Ai in that order;

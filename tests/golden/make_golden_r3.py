@@ -7,6 +7,9 @@
                          non-Input layers (network.py:386-392) on Input -> A -> B with MulticompartmentConnections
  run_one_step_clamp.npz  run(..., one_step=True, clamp=..., unclamp=...) -- a clamped layer's spikes feed the layers
                          behind it in the same timestep (network.py:388-429)
+ op_conv_normalize.npz   Conv2dConnection.normalize (topology.py:824-837): every [KH*KW] filter scaled to sum `norm` -- the 1-D
+                         sums run in ATen's vectorised INNER-sum order -- for kernels of 2x2 ... 16x16 taps; and a conv_mnist.py
+                         style run (Conv2d + PostPre + norm, two consecutive inputs: normalised after each)
 """
 import os
 import sys
@@ -68,6 +71,40 @@ def one_step_clamp_case():
     save("run_one_step_clamp", **out)
 
 
+CONV_NORM_CASES = [(4, 1, 3), (8, 3, 5), (25, 1, 16), (3, 2, 2), (6, 4, 7), (2, 1, 23)]      # (Cout, Cin, K): K*K = 9 ... 529 taps, 4 (< one vector)
+
+
+def conv_normalize_case():
+    from make_golden import Conv2dConnection
+    from bindsnet.learning import PostPre
+    out = {"cases": np.array(CONV_NORM_CASES)}
+    for k, (Cout, Cin, K) in enumerate(CONV_NORM_CASES):
+        H = K + 3
+        W = synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)
+        c = Conv2dConnection(Input(shape=(Cin, H, H)), LIFNodes(shape=(Cout, 4, 4)), kernel_size=K, w=T_(W).clone(), norm=0.4 * K * K)
+        c.normalize()
+        out[f"w{k}"] = c.w.detach().numpy().copy()
+    # a run: Input -> Conv2d(PostPre, norm) -> LIF, B = 2, two consecutive inputs (weights normalised after each run)
+    B2, T2 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(3390, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0, norm=9.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    for r in range(2):
+        net.run({"X": T_(synth.dense_spikes(3391 + r, (T2, B2, 1, 12, 12), 0.2))}, time=T2)
+        out[f"run{r}_sY"] = np.packbits(mon.get("s").numpy().astype(np.uint8))
+        out[f"run{r}_W"] = cc.w.detach().numpy().copy()
+        print(f"  conv normalize run {r}: spikes {int(mon.get('s').sum())}, filter sums {cc.w.detach().view(4, -1).sum(1).numpy()}")
+        net.reset_state_variables()
+    save("op_conv_normalize", **out)
+
+
 if __name__ == "__main__":
-    ext_current_case()
-    one_step_clamp_case()
+    import sys as _sys
+    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case}
+    for j in (_sys.argv[1:] or list(jobs)):
+        jobs[j]()

@@ -119,3 +119,16 @@ extern "C" void hostcheck_dc_sequence(float *v, float *rc, uint8_t *s, float *x,
             theta[j] = th;
         }
 }
+
+// ---- csrc/snn_order.hpp inner_sum8 + k_normalize_filters' thread body (Conv2dConnection.normalize) --------------------------------
+extern "C" float hostcheck_inner_sum8(const float *x, int n) { return inner_sum8(x, n); }
+
+extern "C" void hostcheck_normalize_filters(float *W, int F, int K, float norm) {
+    for (int f = 0; f < F; ++f) {                 // = one thread of k_normalize_filters
+        float *w = W + (size_t)f * K;
+        const float sum = inner_sum8(w, K);
+        const float rc = 1.0f / sum;
+        const float scale = rc * norm;
+        for (int k = 0; k < K; ++k) w[k] = w[k] * scale;
+    }
+}

@@ -39,3 +39,41 @@ def test_exact_mode_through_the_native_rccl_communicator(tmp_path):
     import exact_harness as H
     res = H.launch(1, "run_dc_n400_b4", "cuda", tmp_path, timeout=240, native=True)
     H.check_against_reference(res, "run_dc_n400_b4")
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_conv2d_normalize_on_the_device_matches_reference():
+    """snn_normalize_conv2d (ABI 6; Conv2dConnection.normalize, topology.py:824-837): the op-level reference fixture bit for bit, and a
+    conv_mnist.py style run (Conv2d + PostPre + norm, normalised after each of two inputs): rasters identical, weights <= 1e-5 * wmax."""
+    import numpy as np
+    import torch
+    import synth
+    from cases import gold
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))       # noqa: E731
+    g = gold("op_conv_normalize")
+    for k, (Cout, Cin, K) in enumerate(g["cases"]):
+        Cout, Cin, K = int(Cout), int(Cin), int(K)
+        c = Conv2dConnection(Input(shape=(Cin, K + 3, K + 3)), LIFNodes(shape=(Cout, 4, 4)), kernel_size=K,
+                             w=T_(synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)).clone(), norm=0.4 * K * K).to("cuda")
+        c.normalize()
+        np.testing.assert_array_equal(c.w.detach().cpu().numpy().view(np.uint32), g[f"w{k}"].view(np.uint32), err_msg=f"case {k}")
+    B2, T2 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(3390, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0, norm=9.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    net.to("cuda")
+    for r in range(2):
+        net.run({"X": T_(synth.dense_spikes(3391 + r, (T2, B2, 1, 12, 12), 0.2)).to("cuda")}, time=T2)
+        np.testing.assert_array_equal(np.packbits(mon.get("s").cpu().numpy().astype(np.uint8)), g[f"run{r}_sY"], err_msg=f"run {r} raster")
+        np.testing.assert_allclose(cc.w.detach().cpu().numpy(), g[f"run{r}_W"], rtol=0, atol=1e-5 * 4.0)
+        net.reset_state_variables()

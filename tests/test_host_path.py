@@ -382,3 +382,36 @@ def test_dc2015_on_the_host_vs_oracle_fuzz(N, B, T, Nin, inh, rate, learning, th
         assert torch.get_num_threads() == threads
     finally:
         torch.set_num_threads(n0)
+
+
+def test_conv2d_normalize_on_the_host_matches_reference():
+    """Conv2dConnection.normalize by hand and inside run() on the host: the op-level fixture bit for bit; a conv_mnist.py style run
+    (Conv2d + PostPre + norm, two consecutive inputs, normalised after each): rasters identical, weights within the dense
+    family's tolerance (the rule's bmm runs in BLAS order in the reference), every filter summing to norm."""
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import Conv2dConnection
+    g = gold("op_conv_normalize")
+    for k, (Cout, Cin, K) in enumerate(g["cases"]):
+        Cout, Cin, K = int(Cout), int(Cin), int(K)
+        c = Conv2dConnection(Input(shape=(Cin, K + 3, K + 3)), LIFNodes(shape=(Cout, 4, 4)), kernel_size=K,
+                             w=T_(synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)).clone(), norm=0.4 * K * K)
+        c.normalize()
+        np.testing.assert_array_equal(bits(c.w.detach().numpy()), bits(g[f"w{k}"]), err_msg=f"case {k}")
+    B2, T2 = 2, 30
+    net = Network(dt=1.0)
+    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(3390, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0, norm=9.0)
+    net.add_connection(cc, "X", "Y")
+    mon = Monitor(net.layers["Y"], ["s"], time=T2)
+    net.add_monitor(mon, "s")
+    for r in range(2):
+        net.run({"X": T_(synth.dense_spikes(3391 + r, (T2, B2, 1, 12, 12), 0.2))}, time=T2)
+        np.testing.assert_array_equal(np.packbits(mon.get("s").numpy().astype(u8)), g[f"run{r}_sY"], err_msg=f"run {r} raster")
+        np.testing.assert_allclose(cc.w.detach().numpy(), g[f"run{r}_W"], rtol=0, atol=1e-5 * 4.0)
+        np.testing.assert_allclose(cc.w.detach().view(4, -1).sum(1).numpy(), 9.0, rtol=1e-6)
+        net.reset_state_variables()

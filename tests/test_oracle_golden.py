@@ -529,3 +529,14 @@ def test_conv2d_postpre_matches_reference_within_blas_tolerance():
                               synth.dense_spikes(1500 + k, (B, Cout, OH, OH), 0.1), synth.uniform_f32(1600 + k, (B, Cout, OH, OH), 0.0, 1.0),
                               stride=stride, pad=pad, nu0=np.float32(1e-3), nu1=np.float32(1e-2), wmin=0.0, wmax=1.0)
         np.testing.assert_allclose(W, g[f"cpp{k}"], rtol=0, atol=1e-5, err_msg=f"case {k}")
+
+
+def test_conv2d_normalize_matches_reference():
+    """Conv2dConnection.normalize (topology.py:824-837): filters of 2x2 ... 23x23 taps scaled to sum norm -- the sums in ATen's
+    vectorised inner-sum order -- bit for bit against the reference (tests/golden/make_golden_r3.py convnorm)."""
+    g = gold("op_conv_normalize")
+    for k, (Cout, Cin, K) in enumerate(g["cases"]):
+        Cout, Cin, K = int(Cout), int(Cin), int(K)
+        W = synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)
+        oracle.normalize_conv2d(W, np.float32(0.4 * K * K))
+        np.testing.assert_array_equal(bits(W), bits(g[f"w{k}"]), err_msg=f"case {k}")

@@ -189,3 +189,23 @@ def test_the_draw_comparison_margin_of_the_lean_arbitration_holds():
         if not val(m1) > val(m2):
             bad += 1
     assert bad == 0
+
+
+def test_inner_sum_and_conv_normalize_equal_torch_the_oracle_and_the_reference(host):
+    """csrc/snn_order.hpp inner_sum8 (ATen's vectorised inner sum) and the thread body of k_normalize_filters
+    (Conv2dConnection.normalize, topology.py:824-837) on the host: == torch.sum of a contiguous row for 1 ... 9000 elements, == the
+    oracle, and the normalised filters == the reference fixture op_conv_normalize (2x2 ... 23x23 taps), bit for bit."""
+    from cases import gold
+    host.hostcheck_inner_sum8.restype = C.c_float
+    rs = np.random.RandomState(3)
+    for n in list(range(1, 70)) + [100, 127, 128, 129, 255, 256, 257, 511, 512, 513, 529, 1000, 2047, 2048, 4099, 9000]:
+        x = (rs.uniform(size=n) - 0.3).astype(f32)
+        got = np.float32(host.hostcheck_inner_sum8(p_(x), n))
+        assert got == np.float32(torch.from_numpy(x).sum(0).item()), n
+        assert got == np.float32(oracle.inner_sum(x)), n
+    g = gold("op_conv_normalize")
+    for k, (Cout, Cin, K) in enumerate(g["cases"]):
+        Cout, Cin, K = int(Cout), int(Cin), int(K)
+        W = synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)
+        host.hostcheck_normalize_filters(p_(W), Cout * Cin, K * K, C.c_float(0.4 * K * K))
+        np.testing.assert_array_equal(bits(W), bits(g[f"w{k}"]), err_msg=f"case {k}")
