@@ -103,8 +103,62 @@ def conv_normalize_case():
     save("op_conv_normalize", **out)
 
 
+def conv_mnist_graph(mod, n_filters=25, kernel_size=16, stride=4, seed=0):
+    """examples/mnist/conv_mnist.py:84-126 with the classes of `mod` (the reference here, the mirror in the tests): Input(1,28,28) ->
+    Conv2dConnection(PostPre, norm = 0.4 k^2, wmax = 1) -> DiehlAndCookNodes(n_filters, c, c) with the script's lateral inhibition
+    between filters at the same position (dense Connection, -100)."""
+    conv_size = int((28 - kernel_size) / stride) + 1
+    torch.manual_seed(seed)
+    network = mod.Network()
+    input_layer = mod.Input(n=784, shape=(1, 28, 28), traces=True)
+    conv_layer = mod.DiehlAndCookNodes(n=n_filters * conv_size * conv_size, shape=(n_filters, conv_size, conv_size), traces=True)
+    conv_conn = mod.Conv2dConnection(input_layer, conv_layer, kernel_size=kernel_size, stride=stride, update_rule=mod.PostPre,
+                                     norm=0.4 * kernel_size ** 2, nu=[1e-4, 1e-2], wmax=1.0)
+    w = torch.zeros(n_filters, conv_size, conv_size, n_filters, conv_size, conv_size)
+    for f1 in range(n_filters):
+        for f2 in range(n_filters):
+            if f1 != f2:
+                for i in range(conv_size):
+                    for j in range(conv_size):
+                        w[f1, i, j, f2, i, j] = -100.0
+    w = w.view(n_filters * conv_size * conv_size, n_filters * conv_size * conv_size)
+    recurrent_conn = mod.Connection(conv_layer, conv_layer, w=w)
+    network.add_layer(input_layer, name="X")
+    network.add_layer(conv_layer, name="Y")
+    network.add_connection(conv_conn, source="X", target="Y")
+    network.add_connection(recurrent_conn, source="Y", target="Y")
+    mons = {"v": mod.Monitor(network.layers["Y"], ["v"], time=60), "s": mod.Monitor(network.layers["Y"], ["s"], time=60)}
+    network.add_monitor(mons["v"], name="output_voltage")
+    network.add_monitor(mons["s"], name="output_spikes")
+    return network, mons, conv_conn
+
+
+def conv_mnist_case():
+    """The conv_mnist.py training graph, batch 1 (the script's), two consecutive inputs of 60 timesteps with a reset between."""
+    import types
+    from make_golden import Conv2dConnection, Connection, DiehlAndCookNodes
+    from bindsnet.learning import PostPre
+    mod = types.SimpleNamespace(Network=Network, Input=Input, DiehlAndCookNodes=DiehlAndCookNodes, Conv2dConnection=Conv2dConnection,
+                                Connection=Connection, PostPre=PostPre, Monitor=Monitor)
+    net, mons, cc = conv_mnist_graph(mod)
+    out = {"W0": cc.w.detach().numpy().copy()}
+    T3 = 60
+    torch.manual_seed(2)
+    for r in range(2):
+        sp = synth.spike_train(3400 + r, T3, 1, 784, active=0.5, max_rate=0.35)
+        net.run({"X": T_(sp).view(T3, 1, 1, 28, 28)}, time=T3)
+        out[f"r{r}_sY"] = np.packbits(mons["s"].get("s").numpy().astype(np.uint8))
+        out[f"r{r}_vY"] = mons["v"].get("v").numpy().copy()
+        out[f"r{r}_W"] = cc.w.detach().numpy().copy()
+        out[f"r{r}_theta"] = net.layers["Y"].theta.numpy().copy()
+        print(f"  conv_mnist graph run {r}: spikes {int(mons['s'].get('s').sum())}, filter sums {cc.w.detach().view(25, -1).sum(1)[:3].numpy()}")
+        net.reset_state_variables()
+    out["probe_after"] = torch.rand(4).numpy()
+    save("run_conv_mnist_graph", **out)
+
+
 if __name__ == "__main__":
     import sys as _sys
-    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case}
+    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case, "convmnist": conv_mnist_case}
     for j in (_sys.argv[1:] or list(jobs)):
         jobs[j]()

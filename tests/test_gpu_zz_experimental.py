@@ -77,3 +77,14 @@ def test_conv2d_normalize_on_the_device_matches_reference():
         np.testing.assert_array_equal(np.packbits(mon.get("s").cpu().numpy().astype(np.uint8)), g[f"run{r}_sY"], err_msg=f"run {r} raster")
         np.testing.assert_allclose(cc.w.detach().cpu().numpy(), g[f"run{r}_W"], rtol=0, atol=1e-5 * 4.0)
         net.reset_state_variables()
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_conv_mnist_training_graph_on_the_device_matches_reference():
+    """examples/mnist/conv_mnist.py's training graph (Conv2d 16x16 stride 4 + PostPre + norm -> D&C nodes (25, 4, 4) with lateral
+    inhibition, batch 1) on the generic plan against the reference fixture: tests/test_host_path.py has the host twin."""
+    from test_host_path import _conv_mnist_net, check_conv_mnist_graph
+    net, mons, cc = _conv_mnist_net()
+    net.to("cuda")
+    check_conv_mnist_graph(net, mons, cc, dev="cuda")
+    assert net.last_plan == "generic"

@@ -415,3 +415,48 @@ def test_conv2d_normalize_on_the_host_matches_reference():
         np.testing.assert_allclose(cc.w.detach().numpy(), g[f"run{r}_W"], rtol=0, atol=1e-5 * 4.0)
         np.testing.assert_allclose(cc.w.detach().view(4, -1).sum(1).numpy(), 9.0, rtol=1e-6)
         net.reset_state_variables()
+
+
+def _conv_mnist_net():
+    """examples/mnist/conv_mnist.py:84-126 through the mirror (the graph builder the reference fixture was made with)."""
+    import importlib.util
+    import os
+    import types
+    from bindsnet_amd.learning import PostPre
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import DiehlAndCookNodes, Input
+    from bindsnet_amd.network.topology import Connection, Conv2dConnection
+    mod = types.SimpleNamespace(Network=Network, Input=Input, DiehlAndCookNodes=DiehlAndCookNodes, Conv2dConnection=Conv2dConnection,
+                                Connection=Connection, PostPre=PostPre, Monitor=Monitor)
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_r3.py")).read()
+    body = src[src.index("def conv_mnist_graph("):src.index("def conv_mnist_case(")]
+    ns = {"torch": torch}
+    exec(body, ns)                                                  # (the generator module itself imports the reference at import time)
+    return ns["conv_mnist_graph"](mod)
+
+
+def check_conv_mnist_graph(net, mons, cc, dev="cpu"):
+    g = gold("run_conv_mnist_graph")
+    host = lambda t: t.detach().cpu().numpy()                      # noqa: E731
+    np.testing.assert_array_equal(bits(host(cc.w)), bits(g["W0"]), err_msg="construction draws")
+    T3 = 60
+    torch.manual_seed(2)
+    for r in range(2):
+        sp = synth.spike_train(3400 + r, T3, 1, 784, active=0.5, max_rate=0.35)
+        net.run({"X": T_(sp).view(T3, 1, 1, 28, 28).to(dev)}, time=T3)
+        np.testing.assert_array_equal(np.packbits(host(mons["s"].get("s")).astype(u8)), g[f"r{r}_sY"], err_msg=f"run {r} raster")
+        np.testing.assert_allclose(host(mons["v"].get("v")), g[f"r{r}_vY"], rtol=0, atol=2e-4, err_msg=f"run {r} voltages")
+        np.testing.assert_allclose(host(cc.w), g[f"r{r}_W"], rtol=0, atol=1e-5, err_msg=f"run {r} weights")
+        np.testing.assert_array_equal(bits(host(net.layers["Y"].theta)), bits(g[f"r{r}_theta"]), err_msg=f"run {r} theta")
+        net.reset_state_variables()
+    np.testing.assert_array_equal(torch.rand(4).numpy(), g["probe_after"], err_msg="host generator position")
+
+
+def test_conv_mnist_training_graph_on_the_host_matches_reference():
+    """The graph examples/mnist/conv_mnist.py trains -- Input -> Conv2dConnection(PostPre, norm, wmax) -> DiehlAndCookNodes(25, 4, 4)
+    with lateral inhibition between the filters (dense recurrent Connection), one_spike arbitration from the host generator --
+    at the script's sizes and batch 1, two consecutive inputs: rasters, theta and the generator position exact, voltages and
+    weights within the convolution's tolerance (oneDNN / BLAS order in the reference)."""
+    net, mons, cc = _conv_mnist_net()
+    check_conv_mnist_graph(net, mons, cc)
