@@ -79,6 +79,23 @@ def _trace(layer, s) -> None:
         _trace_into(layer, s, layer.x)
 
 
+def clamp_mask(spec, n: int) -> torch.Tensor:
+    """run(..., clamp= / unclamp=): the reference assigns `s[:, spec] = 1` (network.py:416-429), so `spec` is whatever indexes the
+    neuron dimension -- a boolean (or byte) MASK of n entries, or an integer tensor of neuron INDICES (supervised_mnist.py:201-207
+    clamps `per_class * label + choice`) -- optionally one row per timestep.  Returns the boolean mask, [n] or [T, n]."""
+    m = torch.as_tensor(spec)
+    if m.dtype in (torch.bool, torch.uint8) or m.is_floating_point():
+        return m.ne(0)
+    idx = m.long()
+    if idx.dim() <= 1:
+        out = torch.zeros(n, dtype=torch.bool, device=idx.device)
+        out[idx.reshape(-1)] = True
+        return out
+    out = torch.zeros(idx.shape[0], n, dtype=torch.bool, device=idx.device)
+    out.scatter_(1, idx.reshape(idx.shape[0], -1), True)
+    return out
+
+
 def _step_input(layer, x) -> None:
     layer.s = x                                        # aliases the caller's tensor, like the reference
     _trace(layer, x)
@@ -383,8 +400,8 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
                 for table, value in ((clamps, 1), (unclamps, 0)):
                     m = table.get(name)
                     if m is not None:
-                        m = torch.as_tensor(m)
-                        m = (m[t] if m.dim() >= 2 else m).bool()
+                        m = clamp_mask(m, layer.n)
+                        m = m[t] if m.dim() >= 2 else m
                         layer.s[:, m.view(*layer.shape)] = bool(value)
         if network.learning:
             for key, conn in network.connections.items():

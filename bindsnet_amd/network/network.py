@@ -318,7 +318,8 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 for key, table in (("clamp", clamps), ("unclamp", unclamps)):
                     m = table.get(name)
                     if m is not None:
-                        m = torch.as_tensor(m).to(dev)
+                        from .host_path import clamp_mask      # boolean masks, or neuron INDICES like supervised_mnist.py:201-207
+                        m = clamp_mask(m, layer.n).to(dev)
                         per_step = m.dim() >= 2
                         if m.numel() != (T if per_step else 1) * layer.n and not (per_step and m.shape[0] >= T and m[0].numel() == layer.n):
                             raise ValueError(f"{key}['{name}'] must have {layer.n} entries (optionally one row per timestep)")

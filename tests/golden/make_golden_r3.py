@@ -157,8 +157,39 @@ def conv_mnist_case():
     save("run_conv_mnist_graph", **out)
 
 
+def clamp_index_case():
+    """supervised_mnist.py:201-207: run(..., clamp={"Ae": LongTensor of neuron INDICES}) on DiehlAndCook2015 -- the reference's
+    `s[:, clamp] = 1` takes an index tensor as well as a boolean mask (network.py:416-421); plus an index unclamp and a per-step
+    [T, k] index clamp."""
+    from make_golden import DiehlAndCook2015
+    N, B, T4 = 100, 2, 60
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+    feat = net.connections[("X", "Ae")].pipeline[0]
+    feat.value.data.copy_(T_(synth.weights_q12(10, 784, N)))
+    mons = {l: Monitor(net.layers[l], ["s"], time=T4) for l in ("Ae", "Ai")}
+    for l, m in mons.items():
+        net.add_monitor(m, l + "_s")
+    out = {}
+    specs = [dict(clamp={"Ae": torch.tensor([37])}), dict(clamp={"Ae": torch.tensor([3, 64, 99])}, unclamp={"Ae": torch.tensor([5, 6, 7, 64])}),
+             dict(clamp={"Ae": T_(np.stack([np.array([t % N, (7 * t + 3) % N]) for t in range(T4)]))})]
+    for r, kw in enumerate(specs):
+        sp = synth.spike_train(3500 + r, T4, B, 784, max_rate=0.25)
+        torch.manual_seed(2 + r)
+        net.run({"X": T_(sp).view(T4, B, 1, 28, 28)}, time=T4, **kw)
+        out[f"r{r}_sE"] = np.packbits(mons["Ae"].get("s").numpy().astype(np.uint8))
+        out[f"r{r}_sI"] = np.packbits(mons["Ai"].get("s").numpy().astype(np.uint8))
+        mg.pack(out, f"r{r}_W", feat.value.detach().numpy().copy())
+        out[f"r{r}_theta"] = net.layers["Ae"].theta.numpy().copy()
+        print(f"  index clamp run {r}: Ae spikes {int(mons['Ae'].get('s').sum())}, Ai {int(mons['Ai'].get('s').sum())}")
+        net.reset_state_variables()
+    out["probe_after"] = torch.rand(4).numpy()
+    save("run_clamp_indices", **out)
+
+
 if __name__ == "__main__":
     import sys as _sys
-    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case, "convmnist": conv_mnist_case}
+    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case, "convmnist": conv_mnist_case,
+            "clampidx": clamp_index_case}
     for j in (_sys.argv[1:] or list(jobs)):
         jobs[j]()

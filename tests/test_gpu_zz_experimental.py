@@ -96,3 +96,11 @@ def test_conv_mnist_script_itself_on_the_device():
     script's default is --gpu): the reference's CPU run of the same file -- rasters, theta, weights <= 1e-5."""
     from test_conv_mnist_script import run_and_check
     run_and_check("generic")
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_index_tensor_clamps_on_the_device_match_reference():
+    """supervised_mnist.py:201-207 clamps with an integer tensor of neuron INDICES (the reference's `s[:, clamp] = 1` takes masks and
+    indices alike): D&C graph on the generic plan, index clamp / index unclamp / per-step index rows, against the reference fixture."""
+    from test_host_path import clamp_index_runs
+    clamp_index_runs("cuda")

@@ -460,3 +460,38 @@ def test_conv_mnist_training_graph_on_the_host_matches_reference():
     weights within the convolution's tolerance (oneDNN / BLAS order in the reference)."""
     net, mons, cc = _conv_mnist_net()
     check_conv_mnist_graph(net, mons, cc)
+
+
+def clamp_index_runs(dev="cpu"):
+    """supervised_mnist.py's way of clamping -- an integer tensor of neuron INDICES -- against the reference fixture."""
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    from cases import check_packed
+    g = gold("run_clamp_indices")
+    N, B, T4 = 100, 2, 60
+    torch.manual_seed(0)
+    net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+    feat = net.connections[("X", "Ae")].pipeline[0]
+    feat.value.data.copy_(T_(synth.weights_q12(10, 784, N)))
+    mons = {l: Monitor(net.layers[l], ["s"], time=T4) for l in ("Ae", "Ai")}
+    for l, m in mons.items():
+        net.add_monitor(m, l + "_s")
+    if dev != "cpu":
+        net.to(dev)
+    specs = [dict(clamp={"Ae": torch.tensor([37])}), dict(clamp={"Ae": torch.tensor([3, 64, 99])}, unclamp={"Ae": torch.tensor([5, 6, 7, 64])}),
+             dict(clamp={"Ae": T_(np.stack([np.array([t % N, (7 * t + 3) % N]) for t in range(T4)]))})]
+    for r, kw in enumerate(specs):
+        sp = synth.spike_train(3500 + r, T4, B, 784, max_rate=0.25)
+        torch.manual_seed(2 + r)
+        net.run({"X": T_(sp).view(T4, B, 1, 28, 28).to(dev)}, time=T4, **kw)
+        for l in ("Ae", "Ai"):
+            got = np.packbits(mons[l].get("s").cpu().numpy().astype(u8))
+            np.testing.assert_array_equal(got, g[f"r{r}_s{'E' if l == 'Ae' else 'I'}"], err_msg=f"run {r} {l} raster")
+        check_packed(g, f"r{r}_W", feat.value.detach().cpu().numpy())
+        np.testing.assert_array_equal(bits(net.layers["Ae"].theta.cpu().numpy()), bits(g[f"r{r}_theta"]), err_msg=f"run {r} theta")
+        net.reset_state_variables()
+    np.testing.assert_array_equal(torch.rand(4).numpy(), g["probe_after"], err_msg="host generator position")
+
+
+def test_index_tensor_clamps_on_the_host_match_reference():
+    clamp_index_runs()
