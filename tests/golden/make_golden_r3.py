@@ -187,9 +187,42 @@ def clamp_index_case():
     save("run_clamp_indices", **out)
 
 
+def guide_example(mod, time=500, seed=0):
+    """docs/source/guide/guide_part_i.rst, "Running Simulations": the guide's end-to-end example, statement for statement, with the
+    classes of `mod`; returns (network, source_monitor, target_monitor, input_data)."""
+    torch.manual_seed(seed)
+    network = mod.Network()
+    source_layer = mod.Input(n=100)
+    target_layer = mod.LIFNodes(n=1000)
+    network.add_layer(layer=source_layer, name="A")
+    network.add_layer(layer=target_layer, name="B")
+    forward_connection = mod.Connection(source=source_layer, target=target_layer, w=0.05 + 0.1 * torch.randn(source_layer.n, target_layer.n))
+    network.add_connection(connection=forward_connection, source="A", target="B")
+    recurrent_connection = mod.Connection(source=target_layer, target=target_layer, w=0.025 * (torch.eye(target_layer.n) - 1))
+    network.add_connection(connection=recurrent_connection, source="B", target="B")
+    source_monitor = mod.Monitor(obj=source_layer, state_vars=("s",), time=time)
+    target_monitor = mod.Monitor(obj=target_layer, state_vars=("s", "v"), time=time)
+    network.add_monitor(monitor=source_monitor, name="A")
+    network.add_monitor(monitor=target_monitor, name="B")
+    input_data = torch.bernoulli(0.1 * torch.ones(time, source_layer.n)).byte()
+    return network, source_monitor, target_monitor, input_data
+
+
+def guide_case():
+    import types
+    from make_golden import Connection
+    mod = types.SimpleNamespace(Network=Network, Input=Input, LIFNodes=LIFNodes, Connection=Connection, Monitor=Monitor)
+    net, sm, tm, x = guide_example(mod)
+    net.run(inputs={"A": x}, time=500)
+    s, v = tm.get("s").numpy(), tm.get("v").numpy()
+    print("  guide example: B spikes", int(s.sum()), "shapes", sm.get("s").shape, s.shape, v.shape)
+    save("run_guide_example", x=np.packbits(x.numpy()), sA=np.packbits(sm.get("s").numpy().astype(np.uint8)), sB=np.packbits(s.astype(np.uint8)),
+         shapes=np.array([list(sm.get("s").shape), list(s.shape), list(v.shape)]), v_sample=v.reshape(-1)[::997].copy(), v_last=v[-1].copy())
+
+
 if __name__ == "__main__":
     import sys as _sys
-    jobs = {"ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case, "convmnist": conv_mnist_case,
+    jobs = {"guide": guide_case, "ext": ext_current_case, "clamp": one_step_clamp_case, "convnorm": conv_normalize_case, "convmnist": conv_mnist_case,
             "clampidx": clamp_index_case}
     for j in (_sys.argv[1:] or list(jobs)):
         jobs[j]()

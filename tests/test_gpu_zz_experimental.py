@@ -104,3 +104,12 @@ def test_index_tensor_clamps_on_the_device_match_reference():
     indices alike): D&C graph on the generic plan, index clamp / index unclamp / per-step index rows, against the reference fixture."""
     from test_host_path import clamp_index_runs
     clamp_index_runs("cuda")
+
+
+@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
+def test_user_guide_example_on_the_device():
+    """docs/source/guide/guide_part_i.rst's end-to-end example on the MI355X (generic plan: dense feed-forward + recurrent
+    Connection, LIF, s / v monitors, a 2-D input): voltages within the dense family's tolerance of the reference, at most a
+    handful of threshold-edge spike flips among 5 321 spikes."""
+    from test_host_path import guide_example_check
+    guide_example_check("cuda")
