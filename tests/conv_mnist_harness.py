@@ -1,4 +1,4 @@
-"""Run the reference's examples/mnist/conv_mnist.py ITSELF (unmodified, through runpy) with: the torchvision stand-in installed, a
+"""Run one of the reference's example scripts (examples/mnist/conv_mnist.py, reservoir.py) ITSELF (unmodified, through runpy) with: the torchvision stand-in installed, a
 non-interactive matplotlib backend whose plt.pause does not sleep, a seeded CPU generator, and `Network.run` wrapped so that every
 input's Y raster is recorded.  `bindsnet` is whatever the caller put into sys.modules: the reference (fixture generator) or this
 package's alias (tests)."""
@@ -20,7 +20,7 @@ def sha(a) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def run_script(path, network_module, argv, seed=0):
+def run_script(path, network_module, argv, seed=0, monitor="Y_spikes", result=None):
     os.environ["MPLBACKEND"] = "Agg"
     import matplotlib
     matplotlib.use("Agg", force=True)
@@ -32,7 +32,7 @@ def run_script(path, network_module, argv, seed=0):
 
     def recording_run(self, inputs, time, *a, **k):
         out = orig_run(self, inputs, time, *a, **k)
-        mon = self.monitors.get("Y_spikes")
+        mon = self.monitors.get(monitor)
         if mon is not None:
             s = mon.get("s").detach().cpu().numpy().astype(np.uint8)
             records.append((sha(np.packbits(s)), int(s.sum())))
@@ -53,5 +53,7 @@ def run_script(path, network_module, argv, seed=0):
         os.chdir(old_cwd)
         plt.close("all")
     net = g["network"]
+    if result is not None:
+        return dict(raster_sha=[r[0] for r in records], raster_sum=[r[1] for r in records], plan=getattr(net, "last_plan", None), **result(g))
     return dict(raster_sha=[r[0] for r in records], raster_sum=[r[1] for r in records], W=g["conv_conn"].w.detach().cpu().numpy().copy(),
                 theta=net.layers["Y"].theta.detach().cpu().numpy().copy(), plan=getattr(net, "last_plan", None))

@@ -94,7 +94,7 @@ def test_conv_mnist_training_graph_on_the_device_matches_reference():
 def test_conv_mnist_script_itself_on_the_device():
     """The LITERAL examples/mnist/conv_mnist.py (staged byte copy, sha256-checked) with `bindsnet` = this package on the MI355X (the
     script's default is --gpu): the reference's CPU run of the same file -- rasters, theta, weights <= 1e-5."""
-    from test_conv_mnist_script import run_and_check
+    from test_example_scripts import run_and_check
     run_and_check("generic")
 
 
