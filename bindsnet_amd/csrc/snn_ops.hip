@@ -667,7 +667,8 @@ __global__ __launch_bounds__(256) void k_conv_pp_partial(const uint8_t *__restri
 // weight elements); it packs the sample's source rows of that channel and ALL its target rows into LDS words (one per image
 // row), then every thread walks the set bits its element reads.  Bit-identical to k_conv_pp_partial (checked body against body
 // on the host: tests/test_conv_events_host.py); rows wider than 32 pixels never get here, multi-valued spike bytes take the
-// dense body.  OPT-IN (SNN_CONV_PP_EVENTS=1) until it has run on an MI355X.
+// dense body.  The default since round 4 (first run on an MI355X: parity tests green, 8 879 vs 4 361 timesteps/s on the
+// Conv2d 5x5x32 PostPre graph at B = 16, profiles/r04_conv_postpre_dense_vs_events.jsonl); SNN_CONV_PP_EVENTS=0 selects the dense body.
 __global__ __launch_bounds__(256) void k_conv_pp_partial_ev(const uint8_t *__restrict__ s_src, const float *__restrict__ x_src,
                                                             const uint8_t *__restrict__ s_tgt, const float *__restrict__ x_tgt,
                                                             float *__restrict__ part, int B, snn::ConvGeom g) {
@@ -729,7 +730,7 @@ extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
     const long E = (long)Cout * Cin * KH * KW, n = (long)B * E;
-    static const bool events = [] { const char *v = getenv("SNN_CONV_PP_EVENTS"); return v && v[0] == '1'; }();
+    static const bool events = [] { const char *v = getenv("SNN_CONV_PP_EVENTS"); return !(v && v[0] == '0'); }();
     const size_t ev_lds_bytes = ((size_t)H + (size_t)Cout * OH + 1) * sizeof(uint32_t);
     if (events && Wd <= 32 && OW <= 32 && ev_lds_bytes <= 48 * 1024) {
         const snn::ConvGeom g{Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW};
@@ -1003,7 +1004,7 @@ extern "C" int snn_normalize(float *W, int Nin, int N, float norm, int use_abs, 
 // is scaled to sum `norm`: w[f] *= norm / w[f].sum(0), where the sum is ATen's vectorised INNER sum (snn_order.hpp inner_sum8) and
 // torch evaluates float / tensor as reciprocal(sum) * norm.  No zero guard (the reference has none).  One thread per filter: the
 // weights of a convolution are a few hundred floats.  The body is __host__ __device__ and checked on the host against the reference
-// fixture (tests/test_order_rng_host.py); NOT YET RUN ON AN MI355X (the round's GPU minutes were spent when it was written).
+// fixture (tests/test_order_rng_host.py); first run on an MI355X in round 4 (reference fixture bit for bit, profiles/r04_experimental_suite_mi355x.log).
 __global__ __launch_bounds__(64) void k_normalize_filters(float *__restrict__ W, int F, int K, float norm) {
     const int f = blockIdx.x * 64 + threadIdx.x;
     if (f >= F) return;

@@ -180,7 +180,11 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 continue;
             }
             if (!fed[l]) TRY(snn_check(hipMemsetAsync(d.current, 0, sizeof(float) * (size_t)B * d.n, st)));  // :409-413
-            if (d.ext_current)                     // an external current for this layer: added behind the connections' sums (:386-392)
+            // an external current for this layer: added behind the connections' sums (:386-392).  With one_step the reference
+            // OVERWRITES it for a layer that has an incoming connection: `current_inputs[l] = inputs[l][t]` is followed by
+            // `current_inputs.update(self._get_inputs(layers=[l]))` (:388-393), which replaces the entry -- the current survives
+            // only where no connection feeds the layer
+            if (d.ext_current && !(R->one_step && fed[l]))
                 hipLaunchKernelGGL(k_add_current, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.current, d.ext_current + off, (long)B * d.n);
             if (d.inject_v) {
                 const int len = d.inject_len > 0 ? d.inject_len : d.n;

@@ -14,6 +14,7 @@ explicitly seeded counter-based stream instead: same distribution, NOT the refer
 `poisson_device`).
 """
 import contextlib
+import threading
 from typing import Optional
 
 import torch
@@ -21,22 +22,43 @@ import torch
 _ENCODER_THREADS = 4
 
 
+_cap_lock = threading.Lock()
+_cap_depth = 0          # encoder calls currently inside the cap (main thread only)
+_cap_saved = None       # the caller's setting, taken by the outermost call
+
+
 @contextlib.contextmanager
 def _few_threads():
     """The host encoders work on [time, n] tensors of ~200 k elements through a dozen small ATen calls: with the
     intra-op pool a script like eth_mnist.py asks for (`torch.set_num_threads(os.cpu_count() - 1)`, 255 on the GPU box) every
     one of them pays a 255-way fork/join and one `poisson()` call took 1.6 s there against ~4 ms with a handful of threads
-    (DESIGN.md section 5).  The samplers themselves are serial in the generator (ATen's cpu_serial_kernel), so the thread
-    count changes nothing in the result: the encoders cap it for their own duration and put it back."""
-    n0 = torch.get_num_threads()
-    if n0 <= _ENCODER_THREADS:
+    (measured on the MI355X box in round 4: 5.6 ms per sample).  The samplers themselves are serial in
+    the generator (ATen's cpu_serial_kernel), so the thread count changes nothing in the result: the encoders cap it for their
+    own duration and put it back.
+
+    `torch.set_num_threads` is PROCESS-global, so the cap is only applied from the main thread (a DataLoader worker thread or
+    any other thread that encodes concurrently with ATen work elsewhere leaves the setting alone and just runs at the caller's
+    count), and nested / re-entrant calls share one save / restore through a depth counter under a lock: the value put back is
+    always the one the OUTERMOST call found."""
+    global _cap_depth, _cap_saved
+    if threading.current_thread() is not threading.main_thread():
         yield
         return
-    torch.set_num_threads(_ENCODER_THREADS)
+    with _cap_lock:
+        if _cap_depth == 0:
+            n0 = torch.get_num_threads()
+            _cap_saved = n0 if n0 > _ENCODER_THREADS else None
+            if _cap_saved is not None:
+                torch.set_num_threads(_ENCODER_THREADS)
+        _cap_depth += 1
     try:
         yield
     finally:
-        torch.set_num_threads(n0)
+        with _cap_lock:
+            _cap_depth -= 1
+            if _cap_depth == 0 and _cap_saved is not None:
+                torch.set_num_threads(_cap_saved)
+                _cap_saved = None
 
 
 def single(datum: torch.Tensor, time: int, dt: float = 1.0, sparsity: float = 0.5, device="cpu", **kwargs) -> torch.Tensor:

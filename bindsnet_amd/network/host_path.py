@@ -360,6 +360,10 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
     clamps, unclamps = kwargs.get("clamp", {}) or {}, kwargs.get("unclamp", {}) or {}
     injects_v, masks = kwargs.get("injects_v", {}) or {}, kwargs.get("masks", {}) or {}
     dt = float(network.dt)
+    if isinstance(kwargs.get("a_plus"), dict) or isinstance(kwargs.get("a_minus"), dict):
+        # network.py:356-378, 432-447 also takes {connection key: value} tables; like the MI355X path (network.py::_fill_conn)
+        # this one does not, and says so instead of failing inside torch.tensor(dict)
+        raise NotImplementedError("bindsnet_amd: per-connection a_plus/a_minus dicts are not supported")
     for name, layer in network.layers.items():
         if not isinstance(layer, (Input, LIFNodes, DiehlAndCookNodes)):
             raise NotImplementedError(f"bindsnet_amd host path: layer type {type(layer).__name__}")
@@ -384,10 +388,16 @@ def run(network, inputs: Dict[str, torch.Tensor], T: int, one_step: bool, kwargs
             if isinstance(layer, Input):
                 _step_input(layer, inputs[name][t])
             else:
+                fed_now = False
                 if one_step:
-                    cur.update(currents(name))
+                    own = currents(name)
+                    fed_now = name in own
+                    cur.update(own)
                 x = cur.get(name)
-                if name in inputs:                                     # an external current for a non-Input layer
+                # an external current for a non-Input layer (network.py:386-392).  With one_step the reference's
+                # `current_inputs.update(self._get_inputs(layers=[l]))` (:388-393) REPLACES the entry it has just set for a
+                # layer with an incoming connection: the current survives only where no connection feeds the layer
+                if name in inputs and not fed_now:
                     ext = inputs[name][t].float().view(network.batch_size, *layer.shape)
                     x = ext.clone() if x is None else x + ext
                 if x is None:

@@ -351,41 +351,40 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             _nodes._SCALARS = None
             raise
 
-        for table, what in ((clamps, "clamp"), (unclamps, "unclamp"), (injects_v, "injects_v")):
-            for lname in table:
-                if lname not in self.layers or isinstance(self.layers[lname], Input):
-                    _nodes._SCALARS = None
-                    raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
-        Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
-        lists, dyn_conns = [], []
-        for k, ((src, dst), conn) in enumerate(self.connections.items()):
-            try:                                   # (the collector stays on: clamp bounds are read through _f() as well)
-                self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)
-            except BaseException:
-                _nodes._SCALARS = None
-                raise
-            if self.__dict__.get("_defer_norm", False):    # parallel.sharded_run normalises the MERGED weights itself
-                Cn[k].has_norm = 0
-            wanted = self._conn_monitor_requests(conn, (src, dst))
-            if wanted:
-                dyn_conns.append((k, conn, wanted))
-            rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else getattr(conn, "update_rule", None)
-            nu = getattr(rule, "nu", None)
-            if isinstance(nu, torch.Tensor):
-                lists.append((nu, nu._version))
-            elif isinstance(nu, (list, tuple)):
-                lists.append((nu, tuple(nu)))
-            mask = masks.get((src, dst))
-            if mask is None:
-                mask = getattr(conn, "mask", None)         # LocalConnection's structural mask (topology.py:1468-1470)
-            if mask is not None:
-                if not hasattr(conn, "w") or isinstance(conn, Conv2dConnection):
-                    raise NotImplementedError("bindsnet_amd: weight masks are supported on dense connections")
-                m = torch.as_tensor(mask).to(dev).ne(0).to(torch.uint8).contiguous()
-                if m.numel() != conn.w.numel():
-                    raise ValueError(f"mask of connection {(src, dst)} must have the shape of its weights")
-                keep.append(m)
-                Cn[k].mask = _dptr(m)
+        try:           # ONE guard from here to the end of the collection: whatever raises in between must not leave a stale collector behind
+            for table, what in ((clamps, "clamp"), (unclamps, "unclamp"), (injects_v, "injects_v")):
+                for lname in table:
+                    if lname not in self.layers or isinstance(self.layers[lname], Input):
+                        raise NotImplementedError(f"bindsnet_amd: {what}['{lname}'] must name a non-Input layer of the network")
+            Cn = (_lib.ConnDesc * max(1, len(self.connections)))()
+            lists, dyn_conns = [], []
+            for k, ((src, dst), conn) in enumerate(self.connections.items()):
+                self._fill_conn(Cn[k], conn, index[src], index[dst], B, dev, keep, kwargs)   # (the collector stays on: clamp bounds are read through _f() as well)
+                if self.__dict__.get("_defer_norm", False):    # parallel.sharded_run normalises the MERGED weights itself
+                    Cn[k].has_norm = 0
+                wanted = self._conn_monitor_requests(conn, (src, dst))
+                if wanted:
+                    dyn_conns.append((k, conn, wanted))
+                rule = conn._weight().learning_rule if isinstance(conn, MulticompartmentConnection) else getattr(conn, "update_rule", None)
+                nu = getattr(rule, "nu", None)
+                if isinstance(nu, torch.Tensor):
+                    lists.append((nu, nu._version))
+                elif isinstance(nu, (list, tuple)):
+                    lists.append((nu, tuple(nu)))
+                mask = masks.get((src, dst))
+                if mask is None:
+                    mask = getattr(conn, "mask", None)         # LocalConnection's structural mask (topology.py:1468-1470)
+                if mask is not None:
+                    if not hasattr(conn, "w") or isinstance(conn, Conv2dConnection):
+                        raise NotImplementedError("bindsnet_amd: weight masks are supported on dense connections")
+                    m = torch.as_tensor(mask).to(dev).ne(0).to(torch.uint8).contiguous()
+                    if m.numel() != conn.w.numel():
+                        raise ValueError(f"mask of connection {(src, dst)} must have the shape of its weights")
+                    keep.append(m)
+                    Cn[k].mask = _dptr(m)
+        except BaseException:
+            _nodes._SCALARS = None
+            raise
 
         _nodes._SCALARS = None
         # every tensor whose ADDRESS went into the descriptors: `t.data = other`, set_() or resize_() re-home a tensor

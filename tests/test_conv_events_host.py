@@ -2,7 +2,7 @@
 spike rows) against the dense body (every output position), element by element as the kernel's threads call them, and -- at
 batch 1, where the batch reduction is the identity -- the resulting update against the oracle.  The bodies are
 __host__ __device__; tests/hostcheck/conv_events_host.hip is compiled by hipcc (no GPU needed) and run on the CPU.  The device
-kernel k_conv_pp_partial_ev is opt-in (SNN_CONV_PP_EVENTS=1) until it has run on an MI355X."""
+kernel k_conv_pp_partial_ev is the default since it ran on an MI355X (round 4); SNN_CONV_PP_EVENTS=0 selects the dense body."""
 import ctypes as C
 import os
 import shutil

@@ -276,3 +276,10 @@ def test_one_step_with_clamp_matches_reference():
         for l, n in (("A", nA), ("B", nB)):
             np.testing.assert_array_equal(host(mons[l].get("s")).reshape(T, B, n).astype(u8), unpack(g[f"{tag}_{l}"], (T, B, n)), err_msg=f"{tag} {l}")
     assert not np.array_equal(g["one_B"], g["sync_B"])
+
+
+def test_one_step_drops_the_external_current_of_fed_layers_like_the_reference():
+    """one_step=True + external currents into non-Input layers on the generic plan (csrc/snn_run.hip): the reference replaces the
+    current of a layer that a connection feeds (network.py:386-393); the host twin is tests/test_host_path.py."""
+    from test_host_path import one_step_ext_current_runs
+    one_step_ext_current_runs(DEV)

@@ -1,10 +1,10 @@
-"""Kernels that compile and whose arithmetic is checked on the host (tests/test_conv_events_host.py) but that have not run on an
-MI355X yet: opt-in in the library (environment switch), and their device tests only run when SNN_EXPERIMENTAL=1.
+"""Device paths that round 3's second session prepared and checked on the host only (they were gated behind SNN_EXPERIMENTAL=1
+until they had run on an MI355X).  Round 4's first GPU call ran all eight green (profiles/r04_experimental_suite_mi355x.log);
+the gate is gone and the file name is historical.
 
-    SNN_EXPERIMENTAL=1 python -m pytest tests/test_gpu_zz_experimental.py -m gpu -q
-
-conv PostPre from packed spike rows (csrc/snn_conv_events.hpp, k_conv_pp_partial_ev, SNN_CONV_PP_EVENTS=1): the existing parity
-tests of Conv2d PostPre (bit-exact against the oracle, reference fixtures) are re-run in a process that has the switch on."""
+conv PostPre from packed spike rows (csrc/snn_conv_events.hpp, k_conv_pp_partial_ev) is now the library's default; the existing
+parity tests of Conv2d PostPre (bit-exact against the oracle, reference fixtures) are re-run with the DENSE body selected
+(SNN_CONV_PP_EVENTS=0) so that both bodies stay covered."""
 import os
 import subprocess
 import sys
@@ -15,15 +15,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="experimental kernels: set SNN_EXPERIMENTAL=1")
-def test_event_driven_conv_postpre_passes_the_conv_postpre_parity_tests():
-    env = dict(os.environ, SNN_CONV_PP_EVENTS="1")
+def test_dense_conv_postpre_body_still_passes_the_conv_postpre_parity_tests():
+    env = dict(os.environ, SNN_CONV_PP_EVENTS="0")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_extras.py"), "-m", "gpu", "-q", "-k", "conv2d_postpre"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-1500:]
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_selftest_device_part():
     """bindsnet_amd.selftest's device checks: the propagation, normalisation and PostPre kernels against the torch expressions the
     reference evaluates (1 thread), on random data, bit for bit."""
@@ -32,7 +30,6 @@ def test_selftest_device_part():
     assert selftest.device_checks(msgs.append), msgs
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_exact_mode_through_the_native_rccl_communicator(tmp_path):
     """parallel.exact_run(comm=NativeComm): the per-timestep exchange through the C ABI's own collective snn_dist_allgather_step
     (world size 1 on a one-GPU box: RCCL refuses two ranks on one device) == the reference fixture."""
@@ -41,7 +38,6 @@ def test_exact_mode_through_the_native_rccl_communicator(tmp_path):
     H.check_against_reference(res, "run_dc_n400_b4")
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_conv2d_normalize_on_the_device_matches_reference():
     """snn_normalize_conv2d (ABI 6; Conv2dConnection.normalize, topology.py:824-837): the op-level reference fixture bit for bit, and a
     conv_mnist.py style run (Conv2d + PostPre + norm, normalised after each of two inputs): rasters identical, weights <= 1e-5 * wmax."""
@@ -79,7 +75,6 @@ def test_conv2d_normalize_on_the_device_matches_reference():
         net.reset_state_variables()
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_conv_mnist_training_graph_on_the_device_matches_reference():
     """examples/mnist/conv_mnist.py's training graph (Conv2d 16x16 stride 4 + PostPre + norm -> D&C nodes (25, 4, 4) with lateral
     inhibition, batch 1) on the generic plan against the reference fixture: tests/test_host_path.py has the host twin."""
@@ -90,7 +85,6 @@ def test_conv_mnist_training_graph_on_the_device_matches_reference():
     assert net.last_plan == "generic"
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_conv_mnist_script_itself_on_the_device():
     """The LITERAL examples/mnist/conv_mnist.py (staged byte copy, sha256-checked) with `bindsnet` = this package on the MI355X (the
     script's default is --gpu): the reference's CPU run of the same file -- rasters, theta, weights <= 1e-5."""
@@ -98,7 +92,6 @@ def test_conv_mnist_script_itself_on_the_device():
     run_and_check("generic")
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_index_tensor_clamps_on_the_device_match_reference():
     """supervised_mnist.py:201-207 clamps with an integer tensor of neuron INDICES (the reference's `s[:, clamp] = 1` takes masks and
     indices alike): D&C graph on the generic plan, index clamp / index unclamp / per-step index rows, against the reference fixture."""
@@ -106,7 +99,6 @@ def test_index_tensor_clamps_on_the_device_match_reference():
     clamp_index_runs("cuda")
 
 
-@pytest.mark.skipif(os.environ.get("SNN_EXPERIMENTAL") != "1", reason="not yet run on an MI355X: set SNN_EXPERIMENTAL=1")
 def test_user_guide_example_on_the_device():
     """docs/source/guide/guide_part_i.rst's end-to-end example on the MI355X (generic plan: dense feed-forward + recurrent
     Connection, LIF, s / v monitors, a 2-D input): voltages within the dense family's tolerance of the reference, at most a

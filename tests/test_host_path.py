@@ -533,3 +533,79 @@ def guide_example_check(dev="cpu"):
 
 def test_user_guide_example_on_the_host_matches_reference():
     assert guide_example_check() == 0          # same torch, same MKL on the host: identical here
+
+
+def _r4_chain(dev="cpu"):
+    from bindsnet_amd.network import Network
+    from bindsnet_amd.network.monitors import Monitor
+    from bindsnet_amd.network.nodes import Input, LIFNodes
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    nX, nA, nB, nC, T = 64, 40, 24, 16, 30
+    net = Network(dt=1.0, learning=False)
+    net.add_layer(Input(n=nX), "X"); net.add_layer(LIFNodes(n=nA, thresh=-60.0), "A")
+    net.add_layer(LIFNodes(n=nC, thresh=-58.0), "C"); net.add_layer(LIFNodes(n=nB, thresh=-61.0), "B")
+    for k, (src, dst, ns, nd, sc) in enumerate((("X", "A", nX, nA, 0.6), ("A", "B", nA, nB, 0.5), ("B", "A", nB, nA, -1.0), ("C", "B", nC, nB, 1.0))):
+        w = (synth.uniform_f32(3400 + k, (ns, nd), 0.0, abs(sc)) * np.sign(sc)).astype(np.float32)
+        net.add_connection(MulticompartmentConnection(net.layers[src], net.layers[dst], device="cpu", pipeline=[Weight("weight", T_(w).clone())]), src, dst)
+    mons = {l: Monitor(net.layers[l], ["s", "v"], time=T) for l in ("A", "B", "C")}
+    for l, m in mons.items():
+        net.add_monitor(m, l)
+    if dev != "cpu":
+        net.to(dev)
+    return net, mons
+
+
+def one_step_ext_current_runs(dev="cpu"):
+    """run(..., one_step=True) with external currents into non-Input layers: the reference REPLACES the current of every layer a
+    connection feeds by that layer's own `_get_inputs` (network.py:386-393): A's and B's are dropped, C's (no incoming connection)
+    survives; the synchronous run of the same inputs adds all three.  Rasters and membrane potentials bit for bit
+    (tests/golden/make_golden_r4.py).  Shared by the host test and the MI355X test."""
+    g = gold("run_one_step_ext_current")
+    nX, nA, nB, nC, B, T = 64, 40, 24, 16, 3, 30
+    net, mons = _r4_chain(dev)
+    sp = synth.dense_spikes(3410, (T, B, nX), 0.12)
+    cur = {"A": synth.uniform_f32(3411, (T, B, nA), -1.0, 2.0), "B": synth.uniform_f32(3412, (T, B, nB), 0.0, 1.5),
+           "C": synth.uniform_f32(3413, (T, B, nC), 0.0, 3.0)}
+    for tag, flag in (("one", True), ("sync", False)):
+        net.reset_state_variables()
+        net.run({"X": T_(sp).to(dev), **{k: T_(v).to(dev) for k, v in cur.items()}}, time=T, one_step=flag)
+        for l, n in (("A", nA), ("B", nB), ("C", nC)):
+            np.testing.assert_array_equal(mons[l].get("s").cpu().numpy().reshape(T, B, n).astype(u8), unpack(g[f"{tag}_s_{l}"], (T, B, n)), err_msg=f"{tag} raster {l}")
+            np.testing.assert_array_equal(bits(mons[l].get("v").cpu().numpy().reshape(T, B, n)), bits(g[f"{tag}_v_{l}"].reshape(T, B, n)), err_msg=f"{tag} v {l}")
+
+
+def test_one_step_drops_the_external_current_of_fed_layers_like_the_reference():
+    one_step_ext_current_runs("cpu")
+
+
+def test_per_connection_a_plus_tables_are_refused_explicitly():
+    """network.py:356-378 also accepts {connection: value} tables for a_plus / a_minus; neither path of this package does, and
+    both say so (the host path used to fail inside torch.tensor(dict))."""
+    net, _ = _r4_chain()
+    with pytest.raises(NotImplementedError, match="a_plus/a_minus dicts"):
+        net.run({"X": torch.zeros(2, 3, 64, dtype=torch.uint8)}, time=2, a_plus={("X", "A"): 1.0})
+
+
+def test_encoder_thread_cap_is_reentrant_and_skips_worker_threads():
+    """encodings._few_threads changes a PROCESS-global setting: nested calls restore what the outermost one found, and a call from a
+    thread other than the main one leaves the setting alone."""
+    import threading
+    from bindsnet_amd.encoding import encodings as E
+    n0 = torch.get_num_threads()
+    try:
+        torch.set_num_threads(8)
+        with E._few_threads():
+            inner = torch.get_num_threads()
+            with E._few_threads():
+                assert torch.get_num_threads() == inner
+            assert torch.get_num_threads() == inner
+        assert inner == min(8, E._ENCODER_THREADS) and torch.get_num_threads() == 8
+        seen = []
+        def worker():
+            with E._few_threads():
+                seen.append(torch.get_num_threads())
+        th = threading.Thread(target=worker); th.start(); th.join()
+        assert torch.get_num_threads() == 8 and E._cap_depth == 0
+    finally:
+        torch.set_num_threads(n0)
