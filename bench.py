@@ -313,6 +313,8 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "traffic": pmc_traffic(plan_timed),
                     "frac_of_measured_copy_bandwidth_6290": round(ach / 6290.0, 5)}
+            if "resident_form" in prof:
+                roof["resident_form"] = prof["resident_form"]
             try:                                           # the sparse-effective variant, never mixed with the dense one
                 sb, rows = sparse_effective_bytes_per_timestep(host_pool)
                 sach = sb * prof["timesteps_per_launch"] / (prof["avg_ms"] * 1e-3) / 1e9

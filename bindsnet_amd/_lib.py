@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -142,6 +142,7 @@ _SIGS = {
     "snn_net_run": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc), _vp], _i),
     "snn_net_workspace_bytes": ([C.POINTER(LayerDesc), _i, C.POINTER(ConnDesc), _i, C.POINTER(RunDesc)], C.c_ulonglong),
     "snn_plan_name": ([], C.c_char_p),
+    "snn_dc2015_last_form": ([], C.c_int),
     "snn_set_plan_mode": ([_i], None),
     "snn_graph_stats": ([C.POINTER(C.c_int)] * 3, None),
     "snn_profile_enable": ([_i], None),
@@ -202,8 +203,10 @@ def profile_run(net, inputs, time, stride=4, repeats=5):
         return None
     plan = net.last_plan
     if plan.startswith("dc2015-resident"):
-        spec = plan.endswith("lean") and os.environ.get("SNN_DC_SPEC", "1") != "0"
-        return {"kernel": ("k_dc2015_spec [lean form, second generation]" if spec else "k_dc2015_run%s" % (" [lean form]" if plan.endswith("lean") else "")) + " (one launch per network.run())", "avg_ms": s.value / n.value, "n": n.value,
+        form = L.snn_dc2015_last_form()
+        kname = {3: "k_dc2015_async [lean form, third generation: compute workgroups + arbiter + raster writers]", 2: "k_dc2015_spec [lean form, second generation]",
+                 1: "k_dc2015_run [lean form]"}.get(form, "k_dc2015_run")
+        return {"kernel": kname + " (one launch per network.run())", "resident_form": form, "avg_ms": s.value / n.value, "n": n.value,
                 "timesteps_per_launch": int(round(time / net.dt))}
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}

@@ -224,7 +224,10 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
         if (i < Nin) D_rm[i] = rowmask[i];
     }
     __syncthreads();
-    if (tid == 0) { D_meta[32] = (uint32_t)misc[0]; D_meta[33] = (uint32_t)misc[1]; }
+    if (tid == 0) {
+        D_meta[32] = (uint32_t)misc[0]; D_meta[33] = (uint32_t)misc[1];
+        if (c.tbad && (misc[1] & 5)) atomicMin(c.tbad, e);     // first entry the lean resident forms give up on (third generation: refused up front)
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
@@ -733,13 +736,17 @@ static size_t fused_workspace(int B, int Nin, int N) {
     return 4 * al((size_t)B * NW * 4) + al((size_t)B * Nin * 4) + al(sizeof(snn_rng_state));
 }
 
-// lean form: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2
-static size_t resident_summary_bytes(int N) { return (size_t)2 * ((N + 1) / 2) * 4 * 8; }
+// lean forms: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2; the third generation keeps FOUR steps of both kinds of
+// granules in flight (rings of 4), plus its winners granules [8][11], 16 progress words of the raster writers and the tbad word
+static int g_last_form = -1;          // resident form of the last D&C run: 0 general, 1 / 2 / 3 lean generations, -1 per-step
+constexpr int kAsyncDefault = 0;      // third-generation lean form on by default?  (SNN_DC_ASYNC overrides)
+static size_t resident_summary_bytes(int N) { return (size_t)4 * ((N + 1) / 2) * 4 * 8; }
+static size_t resident_gran_bytes(int B, int N) { return (size_t)4 * ((N + 1) / 2) * ((B + 1) / 2) * 8; }   // >= 4 * G * KB * 8 for every tile width
+constexpr size_t kAsyncCtlBytes = 8 * 11 * 8 + 16 * 4 + 64;
 
 static size_t resident_extra(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t gran = (size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8;      // >= 2 * G * KB * 8 for every tile width
-    return al(gran) + al(resident_summary_bytes(N)) + al((size_t)(T + 1) * B * Nin * 4);
+    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N)) + al(kAsyncCtlBytes) + al((size_t)(T + 1) * B * Nin * 4);
 }
 
 // The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
@@ -772,6 +779,8 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
     if (digest_lds_words(R->B, L[0].n) > 4 * NT) return false;
     return true;
 }
+
+extern "C" int snn_dc2015_last_form(void) { return g_last_form; }
 
 extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
                                           const snn_run_desc *R) {
@@ -830,8 +839,12 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         auto al2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
         unsigned char *p = (unsigned char *)c.dig + al2((size_t)(R->T + 1) * c.DW * 4);
         c.ex = (unsigned long long *)p;
-        c.exs = (unsigned long long *)(p + al2((size_t)2 * ((N + 1) / 2) * ((B + 1) / 2) * 8));
-        c.xtr = (float *)((unsigned char *)c.exs + al2(resident_summary_bytes(N)));
+        c.exs = (unsigned long long *)(p + al2(resident_gran_bytes(B, N)));
+        unsigned char *actl = (unsigned char *)c.exs + al2(resident_summary_bytes(N));      // third generation: winners granules, raster progress, tbad
+        c.wing = (unsigned long long *)actl;
+        c.rprog = (int *)(actl + 8 * 11 * 8);
+        c.tbad = nullptr;                                                                  // (set below when that form is chosen)
+        c.xtr = (float *)(actl + al2(kAsyncCtlBytes));
         c.status = R->status;
         c.rows4 = !(getenv("SNN_DC_ROWS4") && atoi(getenv("SNN_DC_ROWS4")) == 0);
         c.spec_flags = getenv("SNN_DC_SPECFLAGS") ? atoi(getenv("SNN_DC_SPECFLAGS")) : 0;
@@ -868,7 +881,22 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     // ... and its second generation (k_dc2015_spec, "speculate, then repair"): the default wherever the lean form applies
     // and the extra weight copy fits (developer switch SNN_DC_SPEC=0: first generation)
     static const bool spec_on = !(getenv("SNN_DC_SPEC") && atoi(getenv("SNN_DC_SPEC")) == 0);
-    const int lean = !lean1 ? 0 : (spec_on && snn_dc2015_spec_lds(B, Nin, N) <= 150 * 1024 ? 2 : 1);
+    int lean = !lean1 ? 0 : (spec_on && snn_dc2015_spec_lds(B, Nin, N) <= 150 * 1024 ? 2 : 1);
+    // ... and the third generation (k_dc2015_async, snn_dc2015_async.hip: compute workgroups that do not wait for each other, one
+    // arbiter workgroup, raster writers): wherever the lean form applies, its grid (G + 1 + raster writers) is co-resident and the
+    // columns fit the winners' 11-bit field.  SNN_DC_ASYNC=0 / 1 forces it off / on.
+    {
+        static const int async_env = getenv("SNN_DC_ASYNC") ? atoi(getenv("SNN_DC_ASYNC")) : kAsyncDefault;
+        if (lean && async_env && N <= 1024 && B <= MAXB) {
+            const size_t alds = snn_dc2015_async_lds(B, Nin, N);
+            const int nrw = (c.rasE || c.rasI) ? 4 : 0;
+            if (alds <= 150 * 1024 && rG + 1 + nrw <= snn_dc2015_async_capacity(alds)) {
+                lean = 3;
+                c.NRW = nrw;
+                c.tbad = (int *)((unsigned char *)c.rprog + 16 * 4);
+            }
+        }
+    }
     if (resident) { c.G = rG; c.KB = rKB; }
     static long long *dbg = nullptr;
     static int dbg_T = 0;
@@ -894,10 +922,12 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         if (resident) {
             // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
             if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex), qs)))) return rc0;
+            if (c.tbad && (rc0 = snn_check(hipMemsetAsync(c.tbad, 0x7F, sizeof(int), qs)))) return rc0;
             hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
-            const int rcl = snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
+            const int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs)
+                                      : snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
             if (prof) snn_prof_end(qs);
             return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
@@ -980,6 +1010,39 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         }
     }
     if (rc) return rc;
+    g_last_form = resident ? lean : -1;
+    if (c.dbg && resident && lean == 3) {   // developer aid, third-generation lean kernel
+        (void)hipStreamSynchronize(st);
+        const int T_ = R->T;
+        std::vector<long long> h((size_t)24 * (T_ + 1)), hw((size_t)(T_ + 1) * 256 * 4);
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hw.data(), dbg + (size_t)24 * (T_ + 1), hw.size() * 8, hipMemcpyDeviceToHost);
+        double a[9] = {0}, step = 0; int n = 0;
+        for (int t = 3; t + 1 < T_; ++t, ++n) {
+            const long long *r = &h[(size_t)t * 24];
+            for (int k = 1; k < 9; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
+            step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
+        }
+        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] (a) resolution+trace %.2f | barrier 1 %.2f | PostPre %.2f | barrier 2 %.2f | "
+                        "X currents %.2f | barrier 3 %.2f | winners(t-2) read %.2f | published %.2f || iteration %.2f us\n",
+                c.dbg_wg, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, step / n);
+        // per step: first / last publish over the compute workgroups, arbiter: all granules seen, winners out
+        double spread = 0, seen = 0, out = 0, period = 0, lastx = 0; int m = 0, nx = 0; long long prev_last = 0;
+        std::vector<int> lastcnt(c.G, 0);
+        for (int t = 3; t + 1 < T_; ++t) {
+            long long p0 = hw[((size_t)t * 256) * 4 + 1], p1 = p0; int gl = 0;
+            for (int gq = 1; gq < c.G; ++gq) { const long long v = hw[((size_t)t * 256 + gq) * 4 + 1]; if (v < p0) p0 = v; if (v > p1) { p1 = v; gl = gq; } }
+            const long long s0 = hw[((size_t)t * 256 + 255) * 4], s1 = hw[((size_t)t * 256 + 255) * 4 + 1];
+            spread += (double)(p1 - p0) / 100.0; seen += (double)(s0 - p1) / 100.0; out += (double)(s1 - s0) / 100.0;
+            if (prev_last) period += (double)(p1 - prev_last) / 100.0;
+            prev_last = p1; ++m; lastcnt[gl]++;
+            if (t >= 1 && hw[((size_t)(t - 1) * 256 + gl) * 4 + 2] > 0) { lastx += 1; }
+            (void)nx;
+        }
+        fprintf(stderr, "[dc2015 async per step] last publish - first publish %.2f us | arbiter: last publish -> all granules seen %.2f us, -> winners out +%.2f us | "
+                        "period of the last publisher %.2f us | the last publisher had crossed the step before in %.0f %% of the steps\n",
+                spread / m, seen / m, out / m, period / (m - 1), 100.0 * lastx / m);
+    } else
     if (c.dbg && resident && lean == 2) {   // developer aid, second-generation lean kernel: its own marks (us since the iteration's start)
         (void)hipStreamSynchronize(st);
         std::vector<long long> h((size_t)24 * (R->T + 1));

@@ -55,6 +55,13 @@ struct DcCtx {
                                 // exits at once, as if it had never been scheduled -> every other one times out
     int dbg_wg;
     long long *dbg;             // developer aid (SNN_DC_TIMING=1): per-launch phase timestamps of workgroup 0
+    // third-generation lean form (k_dc2015_async, snn_dc2015_async.hip): winners granules [kWinRing][kWinGr] written by the arbiter
+    // workgroup, progress words of the raster workgroups, number of raster workgroups, and the first digest entry the lean forms do
+    // not handle (k_dc2015_prep: meta[33] & 5; INT_MAX when none) -- its exchange granules ex / exs are rings of FOUR steps
+    unsigned long long *wing;
+    int *rprog;
+    int NRW;
+    int *tbad;
 };
 
 namespace {
@@ -273,3 +280,7 @@ int snn_dc2015_resident_cw(int N);
 int snn_dc2015_resident_nt();
 int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, int lean, hipStream_t st);
 int snn_dc2015_resident_capacity(int cw, int nt, size_t lds_bytes);
+// third-generation lean form (snn_dc2015_async.hip)
+size_t snn_dc2015_async_lds(int B, int Nin, int N);
+int snn_dc2015_async_capacity(size_t lds_bytes);
+int snn_dc2015_async_launch(const DcCtx &c, size_t lds_bytes, hipStream_t st);

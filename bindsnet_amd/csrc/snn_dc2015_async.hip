@@ -1,0 +1,788 @@
+// snn_dc2015_async.hip -- third-generation lean form of the resident DiehlAndCook2015 plan (k_dc2015_async).
+//
+// Same graph (bindsnet/models/models.py:156-244), same arithmetic, same order of every floating-point operation as the kernels in
+// snn_dc2015_resident.hip (read that file's header first); what changed is WHO WAITS FOR WHOM.
+//
+// The first two generations run all workgroups in lock step: every timestep ends with an all-to-all spike exchange that everybody
+// waits for (5.5 / 7.0 us per step at cfg2).  But of "finish step t-1, start step t" almost nothing needs the other workgroups'
+// spikes of step t-1:
+//   * membrane potential, refractory counter and theta of an Ae neuron follow its PRE-arbitration crossings (nodes.py:1088-1097: the
+//     reset, the refractory period and theta are applied before torch.multinomial picks the one spike) -- local;
+//   * the inhibitory current of step t comes from the Ai spikes of step t-1, which are the Ae WINNERS of step t-2 (Ai_j is driven by
+//     Ae_j alone: own slice of the Ae -> Ai weights diagonal; an Ai neuron that does not follow its Ae partner ends the launch with
+//     SNN_ERR_RETRY) -- known one whole step earlier;
+//   * only a pair that crossed at step t-1 has to know whether it WON (Ae trace, the post-synaptic PostPre term of its column, its
+//     Ae -> Ai current).
+// So a workgroup publishes its crossings of step t and goes on with step t+1; the winners of step t are needed by everybody only for
+// the membrane update of step t+2, and at once only by the few workgroups (~6 of 100 per step at cfg2) that crossed.
+//
+// Roles (one cooperative launch, one workgroup per CU, 512 threads = 8 waves: 256 VGPRs per lane, nothing spills):
+//   workgroups 0 .. G-1   COMPUTE: 4 columns x 32 samples each, weights / state in LDS as before.  No generator, no polling waves,
+//                         no software barriers: three s_barrier per step (probe: 88-140 cycles each against 312-448 for an LDS-counter
+//                         barrier among a subset of the waves, tools/probe_latency.hip).  Per step: [own crossing at t-1: wait for the
+//                         winners of t-1] trace | PostPre(t-1) in place | X currents of step t | membrane update (inhibition from the
+//                         winners of t-2), publish the crossings of step t as ONE summary granule per tile wave (ring of four steps).
+//   workgroup G           ARBITER: one wave polls all crossing granules of a step, decodes them, decides every sample's winner -- a
+//                         sample with one crossing needs no draw; the others take the draw-comparison arbitration of the lean forms on
+//                         the ONE generator copy of the launch (a second wave twists ahead into a 32-block ring; 0.375 us per block) --
+//                         and publishes the winners as tagged 8-byte granules (3 {sample, column} entries each; ring of eight steps).
+//                         It owns the generator position and writes the generator back.
+//   workgroups G+1 ..     RASTER writers (when spike monitors are attached): read the winners granules, write whole [N]-byte raster
+//                         rows of both layers; the arbiter does not overrun them (progress words).
+// Hand-offs are the 8-byte {tag, data} granules of the earlier forms (one relaxed agent-scope store / load each; the data is the
+// flag).  Ring depths: a compute workgroup publishes step t+4 only after the winners of t+2 exist, i.e. after the arbiter has read
+// every granule of step t+2 >= t; the arbiter publishes step e+8 only after every raster writer has reported step e+2 done.
+//
+// State is written back only after the winners of the LAST step have arrived without an abort mark: by then no workgroup can give up
+// any more, so a launch that ends with SNN_ERR_RETRY / SNN_ERR_TIMEOUT has left every state tensor untouched, as before.
+// Inputs the lean forms do not take (multi-valued spike bytes, > 63 events in a sample: k_dc2015_prep's tbad word), more than one
+// entry spike per sample, off-diagonal Ae -> Ai weights: refused up front / on first sight with SNN_ERR_RETRY.
+#include <limits.h>
+#include <stdlib.h>
+#include "snn_dc2015.hpp"
+#include "snn_dc2015_tile.hpp"
+
+namespace {
+
+constexpr int ACW = 4;                 // columns per compute workgroup
+constexpr int ANT = 512;               // threads per workgroup (all roles)
+constexpr int kCrossRing = 4;          // steps of crossing granules in flight (ex / exs)
+constexpr int kWinRing = 8;            // steps of winners granules in flight
+constexpr int kWinGr = 11;             // winners granules per step: ceil(MAXB / 3)
+constexpr int kArbRing = 32;           // generator blocks resident in the arbiter's LDS
+constexpr unsigned kAPoll = 400000u;   // bounded polls (~0.5 s), then SNN_ERR_TIMEOUT
+constexpr unsigned kAbortPay = 0xFFFFFFFEu;   // crossing-granule payload of a workgroup that gives up
+
+__device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 1023u; }
+
+// ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
+constexpr int AT = MAXB * ACW;         // tile threads
+constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_CURX = OC_XNU0 + AT * 4, OC_ST = OC_CURX + AT * 4, OC_THC = OC_ST + 7 * AT * 4,
+                 OC_COLM = OC_THC + 32, OC_W0 = OC_COLM + 32, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
+static_assert(OC_WT % 16 == 0, "weights 16-byte aligned");
+size_t async_compute_lds(int B, int Nin, int N) {
+    const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
+    return OC_WT + (size_t)Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4;
+}
+// ---- ... of the arbiter: ctl[32] | cntc[32] | colc[32] | winlist[32] | keys[32] u64 | entry winners [2][32] | crs [B*NW] | mt ring
+constexpr size_t OA_CTL = 0, OA_CNT = 128, OA_COL = 256, OA_WL = 384, OA_KEY = 512, OA_W0 = 768, OA_C0 = 1024, OA_CRS = 1280;
+size_t async_arbiter_lds(int B, int N) {
+    const int BW = (B * ((N + 31) / 32) + 3) & ~3;
+    return OA_CRS + (size_t)BW * 4 + (size_t)kArbRing * 624 * 4;
+}
+
+// The X -> Ae part of the Ae current of (sample pb, column pq) from the X spikes in the digest `dg` and the weights ws[Nin][4], by
+// lane pL of the pair's four threads (k_dc2015_spec's x_current, statement for statement): the value, valid in lane pL == 0.
+__device__ __forceinline__ float x_current4(const float *ws, const uint32_t *dg, int B, int Nin, int pb, int pq, int pL, bool tailcol) {
+    constexpr int CW = ACW;
+    constexpr uint32_t GM = (1u << GCB) - 1u;
+    const uint16_t *lstX = (const uint16_t *)dg;
+    const uint32_t *rowmask = dg + B * (LX / 2) + 40;
+    const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
+    const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);
+    const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
+    const uint32_t *gqn = gcnt + B;
+    if (tailcol) {
+        const uint32_t gc = gcnt[pb];
+        const int st = (pL > 0 ? (int)(gc & GM) : 0) + (pL > 1 ? (int)((gc >> GCB) & GM) : 0) + (pL > 2 ? (int)((gc >> (2 * GCB)) & GM) : 0);
+        const int nL = (int)((gc >> (GCB * pL)) & GM);
+        const uint16_t *l2 = lst2 + pb * LX;
+        const int n4 = Nin >> 2;
+        int ix[8]; float wx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
+        CascadeFlat a; a.init();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u] >> 2, wx[u] * 1.0f, n4);
+        for (int u = 8; u < nL; ++u) {
+            const int i = (int)l2[st + u];
+            a.add(i >> 2, ws[i * CW + pq] * 1.0f, n4);
+        }
+        float v = a.finish(n4);
+        if (pL == 0) {
+            const int s4 = (int)(gc & GM) + (int)((gc >> GCB) & GM) + (int)((gc >> (2 * GCB)) & GM) + (int)((gc >> (3 * GCB)) & GM);
+            const int n5 = (int)((gc >> (4 * GCB)) & GM);
+            for (int u = 0; u < n5; ++u) {
+                const int i = (int)l2[s4 + u];
+                v += ws[i * CW + pq] * 1.0f;
+            }
+        }
+        const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
+        const float e1 = ((v + v1) + v2) + v3;
+        return 0.0f + e1;
+    }
+    const uint32_t gq = gqn[pb];
+    const int st = (pL > 0 ? (int)(gq & GM) : 0) + (pL > 1 ? (int)((gq >> GCB) & GM) : 0) + (pL > 2 ? (int)((gq >> (2 * GCB)) & GM) : 0);
+    const int nL = (int)((gq >> (GCB * pL)) & GM);
+    const uint16_t *lx = lstX + pb * LX;
+    int ix[8]; float wx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ix[u] = min((int)lx[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
+    CascadeFlat a; a.init();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u], wx[u] * 1.0f, Nin);
+    for (int u = 8; u < nL; ++u) {
+        const int ii2 = (int)lx[st + u];
+        a.add(ii2, ws[ii2 * CW + pq] * 1.0f, Nin);
+    }
+    const float G = a.a1 + a.a0;
+    const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
+    const int GL = (Nin >> 4) >> 4;
+    const float Gs[4] = {G, G1, G2, G3};
+    float A2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
+    float Gl = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
+    const float res = ((0.0f + Gl) + A2) + 0.0f;
+    return 0.0f + res;
+}
+
+// Entry spikes of both layers (the step before the run): per sample the column of its Ae spike -> w0[b] (the "winners of step -1":
+// they drive Ai at step 0 and are what inhibits at step 1) and of its Ai spike -> w0[MAXB + b] ("step -2": what inhibits at step 0);
+// -1 = none.  cnt0 counts them: more than one spike in a sample of either layer is outside the lean forms.  All threads of the
+// workgroup call it; a barrier behind it.
+__device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, int tid) {
+    const int B = c.B, N = c.N;
+    if (tid < 2 * MAXB) { w0[tid] = -1; cnt0[tid] = 0; }
+    __syncthreads();
+    for (int k = tid; k < B * N; k += ANT) {
+        if (c.sE[k]) { const int b = k / N; atomicAdd(&cnt0[b], 1); w0[b] = k - b * N; }
+        if (c.sI[k]) { const int b = k / N; atomicAdd(&cnt0[MAXB + b], 1); w0[MAXB + b] = k - b * N; }
+    }
+    __syncthreads();
+}
+
+// Winner column of sample `myb` at step e (-1: none) from the arbiter's granules; every lane of the wave polls the same words.
+// e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.
+__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad) {
+    if (e < 0) return w0[(e == -1 ? 0 : MAXB) + myb];
+    const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
+    const uint32_t tag = win_tag(e);
+    int res = -1, nw = 0;
+    for (int k = 0; k == 0 || 3 * k < nw; ++k) {
+        unsigned long long x = 0;
+        for (unsigned spins = 0;; ++spins) {
+            x = granule_load(gr + k);
+            if ((uint32_t)(x >> 54) == tag) break;
+            if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (k == 0) { nw = (int)((x >> 48) & 63u); if (nw == 63) { bad = true; return -1; } }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const uint32_t w = (uint32_t)(x >> (16 * u)) & 0xFFFFu;
+            if (w != 0xFFFFu && (int)(w >> 11) == myb) res = (int)(w & 0x7FFu);
+        }
+    }
+    return res;
+}
+
+// developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup's thread 0 per step, [T+1][24]; behind
+// them [T+1][256][4] per workgroup: [1] published, [2] own crossings; slot 255: the arbiter ([0] all granules seen, [1] winners out)
+#define AMARK(k) do { if (c.dbg && g == c.dbg_wg && tid == 0) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } while (0)
+
+// ===================================================================================================================== compute
+__device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
+    constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NWV = NT / 64;
+    const int B = c.B, Nin = c.Nin, N = c.N, T = c.T;
+    int *ctl = (int *)(smem + OC_CTL);                       // [0] abort seen (any wave), [1] commit seen
+    float *xnu0 = (float *)(smem + OC_XNU0);                 // [B][CW] x_tgt * nu0 of the step whose PostPre is next
+    float *curX = (float *)(smem + OC_CURX);                 // [B][CW] X -> Ae part of the Ae current of step t
+    float *stl = (float *)(smem + OC_ST);                    // [7][TT] vE rE vI rI xE xI theta
+    int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta)
+    uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [CW] samples with a FINAL spike per own column at step t-1 (PostPre)
+    int *w0 = (int *)(smem + OC_W0), *cnt0 = (int *)(smem + OC_C0);
+    float *wtile = (float *)(smem + OC_WT);                  // [Nin][CW] learned weights, updated in place
+    float *wieT = wtile + (size_t)Nin * CW;
+    float *weiT = wieT + (size_t)N * CW;
+    const int DGS = (c.DGW + 63) & ~63;
+    uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = (int)blockIdx.x, c0 = g * CW;
+    const int jj = tid % CW, bl = tid / CW, j = c0 + jj;
+    const bool colv = j < N, tailcol = c0 >= (N / 32) * 32;
+    const bool mine = tid < TT && bl < B && colv;
+    const unsigned kst = (unsigned)(bl * N + j);
+    const int KB = c.KB, NG = c.G * KB, NGS = c.G * NTW;
+    const int Emain = (int)(((long long)Nin * N / 32) * 32);
+
+    if (tid < 32) ctl[tid] = 0;
+    if (tid < 2 * CW) { thc[tid] = 0; colmask[tid & 3] = 0; }
+    scan_entry(c, w0, cnt0, tid);
+    bool offdiag = false, multi0 = false;
+    for (int k = tid; k < Nin * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wtile[k] = (c0 + q < N) ? c.Wxe[i * N + c0 + q] : 0.f;
+    }
+    for (int k = tid; k < N * CW; k += NT) {
+        const int i = k / CW, q = k % CW;
+        wieT[k] = (c0 + q < N) ? c.Wie[i * N + c0 + q] : 0.f;
+        const float we = (c0 + q < N) ? c.Wei[i * N + c0 + q] : 0.f;
+        weiT[k] = we;
+        offdiag = offdiag || (i != c0 + q && we != 0.f);
+    }
+    if (tid < 2 * MAXB) multi0 = cnt0[tid] > 1;
+    if (offdiag || multi0) ctl[0] = 1;                        // (benign race: everybody writes 1)
+    auto fetch_digest = [&](int e) __attribute__((always_inline)) {
+        const uint32_t *Dg = c.dig + (size_t)e * c.DW;
+        uint32_t *dst = dgbuf + (e & 1) * DGS;
+        for (int base = wave * 256; base < c.DGW; base += NWV * 256) {
+            const int ub = __builtin_amdgcn_readfirstlane(base);
+            if (ub + lane * 4 < c.DGW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(dst + ub), 16, 0, 0);
+        }
+    };
+    fetch_digest(0);
+    bool last_sE = false, last_sI = false;
+    if (mine) {
+        stl[0 * TT + tid] = c.vE[kst]; stl[1 * TT + tid] = c.rE[kst]; stl[2 * TT + tid] = c.vI[kst]; stl[3 * TT + tid] = c.rI[kst];
+        stl[4 * TT + tid] = c.pE.lif.traces ? c.xE[kst] : 0.f;
+        stl[5 * TT + tid] = c.pI.traces ? c.xI[kst] : 0.f;
+        stl[6 * TT + tid] = c.theta[j];
+        last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
+    }
+    if (tid < TT) { xnu0[tid] = 0.f; curX[tid] = 0.f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
+    if (bad && tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool sp_prev = last_sE;                                   // final Ae spike of this pair at the previous step
+    bool crossed_prev = false;                                // ... and its crossing
+    unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
+    int published = 0;                                        // steps this (tile) wave has published
+
+    for (int t = 0; t <= T; ++t) {
+        const bool phaseA = t >= 1, phaseB = t < T;
+        const int par = t & 1;
+        const uint32_t *dg = dgbuf + par * DGS;                           // digest of the X spikes of step t-1
+        const int *meta = (const int *)(dg + B * (LX / 2));
+        const uint32_t *rowmask = dg + B * (LX / 2) + 40;
+        const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
+        const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
+        const bool stdp_full = t == 1;
+        const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
+        AMARK(0);
+        if (phaseB) fetch_digest(t + 1);                                  // (its buffer was last read before barrier 3 of the previous iteration)
+        // ---- (a) tile waves: which of the own crossings of step t-1 won (only a wave that had one waits), Ae trace of step t-1
+        if (phaseA && wave < NTW) {
+            bool sp = false;
+            if (prevE != 0ull && !bad) {
+                const int jw = sample_winner(c, w0, t - 1, min(bl, B - 1), bad);
+                sp = crossed_prev && jw == j;
+            }
+            if (bl < B) {
+                float xn = 0.f;
+                if (colv) {
+                    if (c.pE.lif.traces) { xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); stl[4 * TT + tid] = xn; }
+                    last_sE = sp;
+                }
+                xnu0[bl * CW + jj] = xn * c.nu0;
+                if (sp) atomicOr(&colmask[jj], 1u << bl);
+                sp_prev = sp;
+            }
+            if (bad) ctl[0] = 1;
+        }
+        AMARK(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of digest t+1 has landed (visible behind the next barrier)
+        lds_barrier();                                                    // ---- 1
+        AMARK(2);
+        if (ctl[0]) { bad = true; break; }
+        if (tid < CW) thc[par * CW + tid] = 0;                            // (its readers -- the membrane update of step t-1 -- are behind us)
+        // ---- (c) PostPre of step t-1 on the own slice, in place (learning.py / MCC_learning.py:224-302)
+        if (do_stdp) {
+            const float *xsrc = c.xtr + (size_t)t * B * Nin;              // X trace after step t-1
+            if (stdp_full) {
+                stdp_rows_lds<CascadeT, true, CW, NT>(c, Nin, arows, rowmask, colmask, nullptr, xnu0, xsrc, wtile, c0, tid, Emain);
+            } else {
+                uint32_t acols = 0;
+                if (c.nu1 != 0.f) {
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
+                }
+                stdp_rows4<NT>(c, nact, arows, rowmask, colmask, xnu0, xsrc, wtile, c0, tid);
+                stdp_cols_lds<CascadeT, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
+            }
+        }
+        if (!phaseB) break;
+        AMARK(3);
+        lds_barrier();                                                    // ---- 2
+        AMARK(4);
+        if (tid < CW) colmask[tid] = 0;
+        // ---- (e) X -> Ae currents of step t: four threads per (sample, column) pair
+        for (int qt = tid; qt < B * CW * 4; qt += NT) {
+            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+            const float v = x_current4(wtile, dg, B, Nin, pb, pq, pL, tailcol);
+            if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
+        }
+        AMARK(5);
+        lds_barrier();                                                    // ---- 3
+        AMARK(6);
+        // ---- (g) tile waves: membrane update of step t, publish its crossings
+        if (wave < NTW) {
+            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
+            AMARK(7);
+            bool spE = false, spIn = false, mismatch = false;
+            float r_vE = 0.f, r_vI = 0.f;
+            if (mine) {
+                const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
+                const float e3 = sp_prev ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;   // (own slice diagonal: only Ae_j feeds Ai_j)
+                const float curE = curX[bl * CW + jj] + e2;                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
+                const float curI = 0.0f + e3;                              // zeros + Ae->Ai
+                float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
+                r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
+                if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)thc[(par ^ 1) * CW + jj];
+                if (c.pE.learning) th = th * c.pE.theta_decay;
+                spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
+                if (spE) atomicAdd(&thc[par * CW + jj], 1);
+                float ci = curI;
+                if (r_rI > 0.f) ci = 0.f;
+                spIn = lif_update(r_vI, r_rI, ci, c.pI);
+                last_sI = spIn;
+                mismatch = spIn != sp_prev;                                // Ai_j must fire exactly when Ae_j won the step before
+                stl[0 * TT + tid] = r_vE; stl[1 * TT + tid] = r_rE; stl[2 * TT + tid] = r_vI; stl[3 * TT + tid] = r_rI; stl[6 * TT + tid] = th;
+                if (c.pI.traces) stl[5 * TT + tid] = trace_next(stl[5 * TT + tid], spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
+            }
+            if (__any(mismatch)) {
+                bad = true;
+                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint64_t mE = __ballot(spE);
+            const int slot = t & (kCrossRing - 1);
+            uint32_t pay;
+            if (bad) pay = kAbortPay;
+            else {
+                const int nev = __popcll(mE);
+                if (nev <= 3) {
+                    pay = (uint32_t)nev << 30;
+                    int sh = 0;
+                    for (uint64_t m = mE; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
+                } else {
+                    const int sidx = lane / CW, b = wave * SPW + sidx;
+                    const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull);
+                    if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
+                        granule_store(c.ex + (size_t)slot * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pay = 0xC0FFFFFFu;
+                }
+            }
+            if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            AMARK(8);
+            if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); }
+            published = t + 1;
+            prevE = mE; crossed_prev = spE;
+            if (bad) ctl[0] = 1;
+            if (mine) {
+                if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
+                if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
+            }
+        }
+    }
+    // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
+    if (bad && wave < NTW && published <= T - 1 && lane == 0)
+        granule_store(c.exs + (size_t)(published & (kCrossRing - 1)) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(published + 1) << 32) | kAbortPay);
+    // ---- commit: the winners of the LAST step have arrived without an abort mark -> nobody can give up any more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0 && !bad) {
+        bool b2 = false;
+        (void)sample_winner(c, w0, T - 1, 0, b2);
+        if (!b2 && lane == 0) ctl[1] = 1;
+    }
+    __syncthreads();
+    if (ctl[0] != 0 || ctl[1] == 0) return;
+    if (c.x_traces) {
+        const float *src = c.xtr + (size_t)T * B * Nin;
+        for (int k = g * NT + tid; k < B * Nin; k += c.G * NT) c.xX[1][k] = src[k];
+    }
+    if (mine) {
+        float th = stl[6 * TT + tid];
+        if (c.pE.learning) th = th + c.pE.theta_plus * (float)thc[((T - 1) & 1) * CW + jj];
+        c.vE[kst] = stl[0 * TT + tid]; c.rE[kst] = stl[1 * TT + tid]; c.vI[kst] = stl[2 * TT + tid]; c.rI[kst] = stl[3 * TT + tid];
+        if (bl == 0) c.theta[j] = th;
+        if (c.pI.traces) c.xI[kst] = stl[5 * TT + tid];
+        if (c.pE.lif.traces) c.xE[kst] = stl[4 * TT + tid];
+        c.sE[kst] = last_sE; c.sI[kst] = last_sI;
+    }
+    if (c.has_norm) {          // topology_features.py:250-266 on the own columns, ATen's column-sum order (k_dc2015_spec's epilogue)
+        float *bsum = (float *)dgbuf;
+        float *sc = xnu0;
+        const int nfull = Nin >> 4;
+        __syncthreads();
+        if (!tailcol) {
+            for (int item = tid; item < nfull * CW; item += NT) {
+                const int blk = item / CW, q = item % CW;
+                float a0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const float w = wtile[(blk * 16 + k) * CW + q]; a0 += c.norm_abs ? fabsf(w) : w; }
+                bsum[item] = a0;
+            }
+            __syncthreads();
+            if (tid < CW) {
+                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int blk = 0; blk < nfull; ++blk) {
+                    a1 += bsum[blk * CW + tid];
+                    const int m = blk + 1;
+                    if ((m & 15) == 0) { a2 += a1; a1 = 0.f; if ((m & 255) == 0) { a3 += a2; a2 = 0.f; } }
+                }
+                float a0 = 0.f;
+                for (int i = nfull * 16; i < Nin; ++i) { const float w = wtile[i * CW + tid]; a0 += c.norm_abs ? fabsf(w) : w; }
+                float cs = ((a0 + a1) + a2) + a3;
+                if (cs == 0.f) cs = 1.0f;
+                sc[tid] = (1.0f / cs) * c.norm;
+            }
+        } else {
+            __syncthreads();
+            if (tid < CW * 4) {
+                const int q = tid >> 2, s4 = tid & 3, n4 = Nin >> 2, nf4 = n4 >> 4;
+                Cascade cc; cc.init();
+                for (int p_ = 0; p_ < n4; ++p_) { const float w = wtile[(4 * p_ + s4) * CW + q]; cc.add(p_, c.norm_abs ? fabsf(w) : w, nf4); }
+                float lsum = cc.finish(nf4);
+                if (s4 == 0)
+                    for (int i = n4 * 4; i < Nin; ++i) { const float w = wtile[i * CW + q]; lsum += c.norm_abs ? fabsf(w) : w; }
+                const float l1 = __shfl_down(lsum, 1, 4), l2 = __shfl_down(lsum, 2, 4), l3 = __shfl_down(lsum, 3, 4);
+                float cs = ((lsum + l1) + l2) + l3;
+                if (cs == 0.f) cs = 1.0f;
+                if (s4 == 0) sc[q] = (1.0f / cs) * c.norm;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k] * sc[q];
+        }
+    } else if (c.learning && c.rule == SNN_RULE_POSTPRE) {
+        for (int k = tid; k < Nin * CW; k += NT) {
+            const int i = k / CW, q = k % CW;
+            if (c0 + q < N) c.Wxe[i * N + c0 + q] = wtile[k];
+        }
+    }
+}
+
+// ===================================================================================================================== arbiter
+// One sample's one_spike arbitration by one wave: the lean forms' draw comparison (k_dc2015_spec's arbitrate_sample) on the ring
+// of generator blocks.  tb / off: ring-absolute block and offset of the step's first word; r = the sample's rank among the crossing
+// ones.  Returns the winning column (wave-uniform).
+__device__ __forceinline__ int arb_sample(const DcCtx &c, const uint32_t *mt, int tb, int off, int r, const uint32_t *crsrow,
+                                          unsigned long long *key, int lane) {
+    constexpr int RMK = kArbRing - 1;
+    const int N = c.N, NW = c.NW;
+    const uint32_t bits = lane < NW ? crsrow[lane] : 0u;
+    unsigned long long k1 = ~0ull, k2 = ~0ull;
+    for (uint32_t bb = bits; bb; bb &= bb - 1) {
+        const int jx = lane * 32 + __ffs(bb) - 1;
+        const int w0 = off + 2 * (r * N + jx), w1 = w0 + 1;
+        const int m0 = w0 / 624, m1 = w1 / 624;
+        const uint32_t hi = mt_temper(mt[((tb + m0) & RMK) * 624 + w0 - 624 * m0]);
+        const uint32_t lo = mt_temper(mt[((tb + m1) & RMK) * 624 + w1 - 624 * m1]);
+        const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << 53) - 1ull);
+        const unsigned long long kk = (m << 10) | (unsigned long long)jx;
+        if (kk < k1) { k2 = k1; k1 = kk; } else if (kk < k2) k2 = kk;
+    }
+    if (lane == 0) *key = ~0ull;
+    if (bits) atomicMin(key, k1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long kmin = *(volatile unsigned long long *)key;
+    const unsigned long long mmin = kmin >> 10, zone = mmin + (mmin >> c.zone_shift) + 1ull;
+    const bool close = (k1 != ~0ull && k1 != kmin && (k1 >> 10) <= zone) || (k2 != ~0ull && (k2 >> 10) <= zone);
+    int win = (int)(kmin & 1023ull);
+    if (__any(close)) {
+        if (lane == 0) *key = 0ull;
+        for (uint32_t bb = bits; bb; bb &= bb - 1) {
+            const int jx = lane * 32 + __ffs(bb) - 1;
+            const int w0 = off + 2 * (r * N + jx), w1 = w0 + 1;
+            const int m0 = w0 / 624, m1 = w1 / 624;
+            const float q = exp1_from_words(mt_temper(mt[((tb + m0) & RMK) * 624 + w0 - 624 * m0]),
+                                            mt_temper(mt[((tb + m1) & RMK) * 624 + w1 - 624 * m1]));
+            const float val = 1.0f / q;
+            atomicMax(key, ((unsigned long long)__float_as_uint(val) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)jx));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        win = (int)(0xFFFFFFFFu - (uint32_t)(*(volatile unsigned long long *)key & 0xFFFFFFFFull));
+    }
+    return win;
+}
+
+__device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *smem) {
+    constexpr int CW = ACW, NTW = AT / 64, SPW = 64 / CW, SPG = 16 / CW, RB = kArbRing, RMK = RB - 1;
+    const int B = c.B, N = c.N, NW = c.NW, T = c.T, G = c.G;
+    int *ctl = (int *)(smem + OA_CTL);                       // [0] generator head (last block produced), [1] tail (first block still needed), [2] stop
+    int *cntc = (int *)(smem + OA_CNT), *colc = (int *)(smem + OA_COL), *winlist = (int *)(smem + OA_WL);
+    unsigned long long *keys = (unsigned long long *)(smem + OA_KEY);
+    uint32_t *crs = (uint32_t *)(smem + OA_CRS);
+    const int BW = B * NW, BWp = (BW + 3) & ~3;
+    uint32_t *mt = crs + BWp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KB = c.KB, NG = G * KB, NGS = G * NTW;
+
+    if (tid < 32) { ctl[tid] = 0; cntc[tid] = 0; colc[tid] = 0; }
+    for (int k = tid; k < BW; k += ANT) crs[k] = 0;
+    for (int k = tid; k < 624; k += ANT) mt[k] = c.rng[0]->mt[k];
+    __syncthreads();
+    if (wave == 1) {
+        // ---- generator: block k (ring slot k & RMK) from block k-1, as far ahead as the ring allows
+        for (int k = 1;; ++k) {
+            bool stop = false;
+            for (unsigned spins = 0;; ++spins) {
+                if (k - __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RB) break;
+                if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stop || __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            asm volatile("" ::: "memory");
+            mt_twist_block_wave(mt + ((k - 1) & RMK) * 624, mt + (k & RMK) * 624, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&ctl[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (wave == 0) {
+        int pos = __builtin_amdgcn_readfirstlane(c.rng[0]->pos);         // offset of the next word in block tb (0 .. 624)
+        int tb = 0;
+        long long consumed;
+        {
+            const long long c0_ = c.rng[0]->consumed;
+            consumed = ((long long)__builtin_amdgcn_readfirstlane((int)(c0_ >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c0_);
+        }
+        bool failed = false;
+        auto wait_block = [&](int need) __attribute__((always_inline)) -> bool {        // generator head >= need
+            for (unsigned spins = 0; __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+                if (spins > 40000000u) return false;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            return true;
+        };
+        // an abort mark for step e AND the two behind it: a compute workgroup reads at most two steps past the one everybody
+        // is waiting for (its own resolution of e+1 in front of the inhibition of e), and their ring slots are free (the raster
+        // writers are done with step e-6 when step e is published)
+        auto publish_abort = [&](int e0) __attribute__((always_inline)) {
+            if (lane < 3)
+                granule_store(c.wing + (size_t)((e0 + lane) & (kWinRing - 1)) * kWinGr,
+                              ((unsigned long long)win_tag(e0 + lane) << 54) | (63ull << 48) | 0xFFFFFFFFFFFFull);
+        };
+        int e = 0;
+        for (; e < T && !failed; ++e) {
+            const int slot = e & (kCrossRing - 1);
+            const unsigned long long *sums = c.exs + (size_t)slot * NGS;
+            const unsigned long long *exr = c.ex + (size_t)slot * NG;
+            bool abortseen = false;
+            // ---- every crossing granule of step e: poll, decode into bit words / per-sample count / a crossing column
+            for (int gi = lane; gi < NGS; gi += 64) {
+                unsigned long long x = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    x = granule_load(sums + gi);
+                    if ((uint32_t)(x >> 32) == (uint32_t)(e + 1)) break;
+                    if (spins > kAPoll) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (failed) break;
+                const uint32_t pay = (uint32_t)x;
+                if (!pay) continue;
+                if (pay == kAbortPay) { abortseen = true; continue; }
+                auto event = [&](int bsm, int jx) __attribute__((always_inline)) {
+                    if (bsm >= B || jx >= N) return;
+                    atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31));
+                    atomicAdd(&cntc[bsm], 1);
+                    colc[bsm] = jx;
+                };
+                const int gsrc = gi / NTW, w = gi - gsrc * NTW;
+                if ((pay & 0xFFu) == 0xFFu) {                            // more than three crossings in that tile wave: its bit granules
+                    for (int q = 0; q < SPW / SPG; ++q) {
+                        const int k = w * (SPW / SPG) + q;
+                        if (k >= KB) break;
+                        unsigned long long d = 0;
+                        for (unsigned sp2 = 0;; ++sp2) {
+                            d = granule_load(exr + gsrc * KB + k);
+                            if ((uint32_t)(d >> 32) == (uint32_t)(e + 1)) break;
+                            if (sp2 > kAPoll) { failed = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (failed) break;
+                        uint32_t be = (uint32_t)d & 0xFFFFu;
+                        while (be) { const int p_ = __ffs(be) - 1; be &= be - 1; event(k * SPG + p_ / CW, gsrc * CW + p_ % CW); }
+                    }
+                } else {
+                    const int ne = (int)(pay >> 30);
+                    for (int e2 = 0; e2 < ne; ++e2) {
+                        const uint32_t ev = (pay >> (8 * e2)) & 0xFFu;
+                        const int p_ = (int)(ev & 0x3Fu);
+                        event(w * SPW + p_ / CW, gsrc * CW + p_ % CW);
+                    }
+                }
+            }
+            failed = __any(failed);
+            abortseen = __any(abortseen);
+            if (c.dbg && lane == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 0] = (long long)wall_clock64();
+            if (failed) { if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (failed || abortseen) {
+                // pass the abort on: every reader of this step's (and any later) winners sees the mark
+                publish_abort(e);
+                failed = true;
+                break;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- winners: lane b <-> sample b
+            const int myc = lane < B ? cntc[lane] : 0;
+            int mywin = (lane < B && myc == 1) ? colc[lane] : -1;
+            const uint32_t anym = (uint32_t)__ballot(myc > 0);
+            const uint32_t multim = (uint32_t)__ballot(myc > 1);
+            const int arb_rows = __popc(anym);
+            for (uint32_t rem = multim; rem; rem &= rem - 1) {
+                const int bsm = __ffs(rem) - 1;
+                const int r = __popc(anym & ((1u << bsm) - 1u));
+                // blocks in front of this sample's words are done with; its own words must be resident
+                const int first = tb + (pos + 2 * r * N) / 624, lastb = tb + (pos + 2 * (r + 1) * N - 1) / 624;
+                if (lane == 0) __hip_atomic_store(&ctl[1], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!wait_block(lastb)) { failed = true; break; }
+                const int wcol = arb_sample(c, mt, tb, pos, r, crs + bsm * NW, &keys[bsm], lane);
+                if (lane == bsm) mywin = wcol;
+            }
+            if (failed) {
+                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish_abort(e);
+                break;
+            }
+            // ---- pack: entry r of the list = (sample << 11) | column of the r-th crossing sample
+            if (lane < B && myc > 0) winlist[__popc(anym & ((1u << lane) - 1u))] = (lane << 11) | (mywin & 0x7FF);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int ngr = arb_rows > 3 ? (arb_rows + 2) / 3 : 1;
+            // the raster writers must be done with the step whose ring slot this one takes
+            if (c.NRW > 0 && e >= kWinRing - 2) {
+                bool late = false;
+                if (lane < c.NRW) {
+                    for (unsigned spins = 0; __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e - (kWinRing - 2) + 1; ++spins) {
+                        if (spins > kAPoll) { late = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (__any(late)) {
+                    if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    publish_abort(e);
+                    failed = true;
+                    break;
+                }
+            }
+            if (lane < ngr) {
+                unsigned long long pl = 0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int idx = 3 * lane + u;
+                    const unsigned long long wv = idx < arb_rows ? (unsigned long long)(uint32_t)winlist[idx] : 0xFFFFull;
+                    pl |= wv << (16 * u);
+                }
+                granule_store(c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr + lane,
+                              ((unsigned long long)win_tag(e) << 54) | ((unsigned long long)arb_rows << 48) | pl);
+            }
+            if (c.dbg && lane == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 2] = arb_rows + 100 * __popc(multim); }
+            // ---- the generator moves on by 2 N words per crossing sample (nodes.py:1100-1105: one multinomial row each); clean up
+            if (arb_rows) {
+                const int endw = pos + 2 * arb_rows * N;                 // offset (from block tb) behind the step's last word
+                const int adv = (endw - 1) / 624;
+                tb += adv; pos = endw - 624 * adv;                        // pos in 1 .. 624, as the reference leaves it
+                consumed += (long long)arb_rows * N;
+                if (lane == 0) __hip_atomic_store(&ctl[1], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = lane; k < BW; k += 64) crs[k] = 0;
+                if (lane < 32) cntc[lane] = 0;
+            }
+        }
+        // ---- the generator as the reference leaves it (workgroup-wide copy of the launch: there is only this one)
+        if (!failed) {
+            if (wait_block(tb)) {
+                snn_rng_state *wr = c.rng[0];
+                for (int k = lane; k < 624; k += 64) wr->mt[k] = mt[(tb & RMK) * 624 + k];
+                if (lane == 0) { wr->pos = pos; wr->consumed = consumed; }
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// ===================================================================================================================== raster
+// Raster rows of both layers (monitors.py:94-111: one [B, N] byte slice per step): row r of the 2 B rows of a step by raster
+// workgroup r mod NRW, wave by wave.  Ae row (step e, sample b): the winner's byte; Ai row (step e, sample b): the winner of step
+// e-1 (the arbiter's winners ARE the Ai spikes one step later; compute workgroups end the launch where that fails).
+__device__ __forceinline__ void async_raster(const DcCtx &c, unsigned char *smem, int rid) {
+    const int B = c.B, N = c.N, T = c.T;
+    int *w0 = (int *)smem, *cnt0 = w0 + 2 * MAXB;            // entry winners
+    int *wcur = cnt0 + 2 * MAXB;                              // [2][MAXB] winners by step parity
+    int *flag = wcur + 2 * MAXB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = ANT / 64;
+    scan_entry(c, w0, cnt0, tid);
+    if (tid < MAXB) { wcur[MAXB + tid] = w0[tid]; wcur[tid] = -1; }   // "step -1" sits in the odd slot
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    for (int e = 0; e < T; ++e) {
+        const int par = e & 1;
+        if (wave == 0) {
+            bool bad = false;
+            const int wv = sample_winner(c, w0, e, min(lane, B - 1), bad);
+            if (lane < MAXB) wcur[par * MAXB + lane] = lane < B ? wv : -1;
+            if (bad && lane == 0) flag[0] = 1;
+        }
+        lds_barrier();
+        if (flag[0]) break;
+        for (int r = rid + c.NRW * wave; r < 2 * B; r += c.NRW * NWV) {
+            const int b = r < B ? r : r - B;
+            uint8_t *ras = r < B ? c.rasE : c.rasI;
+            const int jw = r < B ? wcur[par * MAXB + b] : wcur[(par ^ 1) * MAXB + b];
+            if (ras) { uint8_t *row = ras + ((size_t)e * B + b) * N; for (int jx = lane; jx < N; jx += 64) row[jx] = (uint8_t)(jx == jw); }
+        }
+        lds_barrier();
+        if (tid == 0) __hip_atomic_store(&c.rprog[rid], e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int blk = (int)blockIdx.x;
+    if (blk == c.stall_wg) return;
+    if (*c.tbad <= c.T) {             // an input the lean forms do not take: refused before anything has happened
+        if (blk == 0 && threadIdx.x == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (blk < c.G) async_compute(c, smem);
+    else if (blk == c.G) async_arbiter(c, smem);
+    else async_raster(c, smem, blk - c.G - 1);
+}
+
+}  // namespace
+
+size_t snn_dc2015_async_lds(int B, int Nin, int N) {
+    const size_t a = async_compute_lds(B, Nin, N), b = async_arbiter_lds(B, N);
+    return a > b ? a : b;
+}
+
+static bool async_attr_once() {
+    static int state = 0;
+    if (!state) state = snn_check(hipFuncSetAttribute((const void *)k_dc2015_async, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ? -1 : 1;
+    return state == 1;
+}
+
+int snn_dc2015_async_capacity(size_t lds) {
+    if (!async_attr_once()) return 0;
+    int dev = 0, cus = 0, coop = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (getenv("SNN_DC_FAKE_CUS")) cus = atoi(getenv("SNN_DC_FAKE_CUS"));
+    return coop ? cus * per_cu : 0;
+}
+
+// grid = G compute workgroups + the arbiter + c.NRW raster writers, all co-resident (cooperative launch)
+int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st) {
+    if (!async_attr_once()) return SNN_ERR_LAUNCH;
+    static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    DcCtx arg = c;
+    void *args[1] = {(void *)&arg};
+    const unsigned grid = (unsigned)(c.G + 1 + c.NRW);
+    if (!coop) return snn_check(hipLaunchKernel((const void *)k_dc2015_async, dim3(grid), dim3(ANT), args, lds, st));
+    const hipError_t e = hipLaunchCooperativeKernel((const void *)k_dc2015_async, dim3(grid), dim3(ANT), args, (unsigned)lds, st);
+    if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }
+    return snn_check(e);
+}

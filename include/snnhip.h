@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 6
+#define SNN_ABI_VERSION 7
 
 typedef void *snn_stream_t;
 
@@ -355,6 +355,10 @@ unsigned long long snn_net_workspace_bytes(const snn_layer_desc *h_layers, int n
                                            int n_conns, const snn_run_desc *h_run);
 /* Name of the plan the last snn_net_run on this thread used ("generic", "dc2015-fused", ...). */
 const char *snn_plan_name(void);
+/* Which resident form of the DiehlAndCook2015 plan the last such run of this process took: 0 = general form, 1 / 2 / 3 = first /
+ * second / third generation of the lean form (csrc/snn_dc2015_resident.hip, snn_dc2015_async.hip), -1 = one launch per timestep or no
+ * such run yet.  ABI 7; a diagnostic for bench.py and the tests (the plan NAME stays "dc2015-resident-lean" for all lean forms). */
+int snn_dc2015_last_form(void);
 /* Profiling aid (bench.py roofline): when stride > 0, snn_net_run brackets the launches of every
  * stride-th timestep with hipEvents recorded on the run's stream (at most 64 samples per run).
  * snn_profile_collect (call after synchronising the stream) returns the summed elapsed
