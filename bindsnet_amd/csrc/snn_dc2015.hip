@@ -1023,9 +1023,9 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             for (int k = 1; k < 9; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
         }
-        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] (a) resolution+trace %.2f | barrier 1 %.2f | PostPre %.2f | barrier 2 %.2f | "
-                        "X currents %.2f | barrier 3 %.2f | winners(t-2) read %.2f | published %.2f || iteration %.2f us\n",
-                c.dbg_wg, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n, a[8] / n, step / n);
+        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] front (resolution, trace) %.2f | barrier A %.2f | tile waves: winners(t-2) read %.2f, "
+                        "published %.2f | other waves: PostPre done %.2f | barrier M %.2f | X currents %.2f | won branch %.2f || iteration %.2f us\n",
+                c.dbg_wg, a[1] / n, a[2] / n, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, step / n);
         // per step: first / last publish over the compute workgroups, arbiter: all granules seen, winners out
         double spread = 0, seen = 0, out = 0, period = 0, lastx = 0; int m = 0, nx = 0; long long prev_last = 0;
         std::vector<int> lastcnt(c.G, 0);

@@ -57,15 +57,17 @@ __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 
 
 // ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
 constexpr int AT = MAXB * ACW;         // tile threads
-constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_CURX = OC_XNU0 + AT * 4, OC_ST = OC_CURX + AT * 4, OC_THC = OC_ST + 7 * AT * 4,
-                 OC_COLM = OC_THC + 32, OC_W0 = OC_COLM + 32, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
-static_assert(OC_WT % 16 == 0, "weights 16-byte aligned");
+constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
+                 OC_ST = OC_CURXW + AT * 4, OC_THC = OC_ST + 7 * AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 16, OC_COLRES = OC_COLX + 32,
+                 OC_XWINV = OC_COLRES + 16, OC_W0 = OC_XWINV + 16 + 16, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
+static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
+// ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
 size_t async_compute_lds(int B, int Nin, int N) {
     const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
-    return OC_WT + (size_t)Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4;
+    return OC_WT + (size_t)3 * Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4;
 }
 // ---- ... of the arbiter: ctl[32] | cntc[32] | colc[32] | winlist[32] | keys[32] u64 | entry winners [2][32] | crs [B*NW] | mt ring
-constexpr size_t OA_CTL = 0, OA_CNT = 128, OA_COL = 256, OA_WL = 384, OA_KEY = 512, OA_W0 = 768, OA_C0 = 1024, OA_CRS = 1280;
+constexpr size_t OA_CTL = 0, OA_CNT = 128, OA_COL = 256, OA_WL = 384, OA_KEY = 512, OA_CRS = 1280;
 size_t async_arbiter_lds(int B, int N) {
     const int BW = (B * ((N + 31) / 32) + 3) & ~3;
     return OA_CRS + (size_t)BW * 4 + (size_t)kArbRing * 624 * 4;
@@ -160,7 +162,8 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 
 // Winner column of sample `myb` at step e (-1: none) from the arbiter's granules; every lane of the wave polls the same words.
 // e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.
-__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad) {
+__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad, bool have_pre = false,
+                                             unsigned long long pre = 0ull) {
     if (e < 0) return w0[(e == -1 ? 0 : MAXB) + myb];
     const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
     const uint32_t tag = win_tag(e);
@@ -168,7 +171,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     for (int k = 0; k == 0 || 3 * k < nw; ++k) {
         unsigned long long x = 0;
         for (unsigned spins = 0;; ++spins) {
-            x = granule_load(gr + k);
+            x = (k == 0 && have_pre && spins == 0) ? pre : granule_load(gr + k);   // (a first granule the caller loaded earlier: valid if its tag is)
             if ((uint32_t)(x >> 54) == tag) break;
             if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
             __builtin_amdgcn_s_sleep(1);
@@ -186,23 +189,122 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
 // developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup's thread 0 per step, [T+1][24]; behind
 // them [T+1][256][4] per workgroup: [1] published, [2] own crossings; slot 255: the arbiter ([0] all granules seen, [1] winners out)
 #define AMARK(k) do { if (c.dbg && g == c.dbg_wg && tid == 0) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } while (0)
+#define AMARKW(k, th) do { if (c.dbg && g == c.dbg_wg && tid == (th)) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } while (0)
+
+// The pre-synaptic PostPre term of one row (its four columns) when no own pair has a FINAL spike: spec_rows4's body
+// (snn_dc2015_tile.hpp), statement for statement.  m: samples whose source spiked; xnu0[b][4] = x_tgt * nu0.
+__device__ __forceinline__ float4 postpre_row_nowin(const DcCtx &c, float4 w4, uint32_t m, const float *xnu0) {
+    float w[4] = {w4.x, w4.y, w4.z, w4.w};
+    if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+        float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+        int cblk = 0;
+        while (m) {
+            const int b = __ffs(m) - 1; m &= m - 1;
+            const float4 xn = *(const float4 *)(xnu0 + b * 4);
+            const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+            const float same = (b >> 4) == cblk ? 1.f : 0.f, diff = 1.f - same;
+            cblk = b >> 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+                a0[q] = __builtin_fmaf(a0[q], same, 1.0f * xv[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+            if (c.use_dt) uu = uu * c.dt;
+            w[q] = w[q] - uu;
+        }
+    }
+    if (c.nu1 != 0.f) {                                      // + dt * (empty sum): what the update adds without a post-synaptic spike
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float uu = 0.f;
+            if (c.use_dt) uu = uu * c.dt;
+            w[q] = w[q] + uu;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (c.has_min && w[q] < c.wmin) w[q] = c.wmin;
+        if (c.has_max && w[q] > c.wmax) w[q] = c.wmax;
+    }
+    return make_float4(w[0], w[1], w[2], w[3]);
+}
+
+// One element of PostPre in its (row, column) form (k_dc2015_spec's postpre_elem = stdp_rows_lds's update; lean form: no tail
+// elements, 0/1 spikes): row i, column q, pre-synaptic samples m, post-synaptic samples cm; sample bst's x_tgt*nu0 replaced by xw
+// when bst >= 0; have_x: one post-synaptic sample, its X trace passed in.
+__device__ __forceinline__ float postpre_elem(const DcCtx &c, const float *xnu0, float w, int i, int q, uint32_t m, uint32_t cm, int bst,
+                                              float xw, const float *xs, bool have_x, float xval) {
+    constexpr int CW = ACW;
+    const int B = c.B, Nin = c.Nin;
+    if (c.nu0 != 0.f) {
+        float uu = 0.f;
+        if (m) {
+            CascadeT acc; acc.init(false);
+            while (m) {
+                const int b = __ffs(m) - 1; m &= m - 1;
+                acc.add(b, 1.0f * (b == bst ? xw : xnu0[b * CW + q]), B);
+            }
+            uu = acc.finish(B);
+        }
+        if (c.use_dt) uu = uu * c.dt;
+        w = w - uu;
+    }
+    if (c.nu1 != 0.f) {
+        float uu = 0.f;
+        if (cm) {
+            CascadeT acc; acc.init(false);
+            while (cm) {
+                const int b = __ffs(cm) - 1; cm &= cm - 1;
+                acc.add(b, (have_x ? xval : xs[b * Nin + i]) * (1.0f * c.nu1), B);
+            }
+            uu = acc.finish(B);
+        }
+        if (c.use_dt) uu = uu * c.dt;
+        w = w + uu;
+    }
+    if (c.has_min && w < c.wmin) w = c.wmin;
+    if (c.has_max && w > c.wmax) w = c.wmax;
+    return w;
+}
 
 // ===================================================================================================================== compute
+// Iteration t (three s_barrier: A, M, B):
+//   in front of A   tile waves: a wave that crossed at step t-1 waits for that step's winners; a winner redoes its Ae trace and
+//                   marks its column (colmask); then the trace of step t and x_tgt*nu0 as they are WITHOUT a final spike at step t
+//                   (the trace just decays: known before the step is simulated)
+//   A .. M          tile waves: membrane update of step t (X currents prepared one iteration earlier -- the won branch's for a
+//                   column that won at t-1 --, inhibition from the winners of t-2), publish the crossings of step t
+//                   other waves: PostPre of step t on the own slice under "no own final spike at t" (a column that won at t-1
+//                   starts from its won branch; the old rows are kept in wbak)
+//   M .. B          all waves: X currents of step t+1 from the new weights; a workgroup that crossed at step t prepares the won
+//                   branch of every crossing column (whole column from the old weights + its X currents) while the arbiter works --
+//                   a column with more than one crossing sample waits for the winners and is redone exactly
 __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
-    constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NWV = NT / 64;
+    constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NWV = NT / 64, NBC = NT - TT;
     const int B = c.B, Nin = c.Nin, N = c.N, T = c.T;
     int *ctl = (int *)(smem + OC_CTL);                       // [0] abort seen (any wave), [1] commit seen
-    float *xnu0 = (float *)(smem + OC_XNU0);                 // [B][CW] x_tgt * nu0 of the step whose PostPre is next
-    float *curX = (float *)(smem + OC_CURX);                 // [B][CW] X -> Ae part of the Ae current of step t
+    float *xnu0 = (float *)(smem + OC_XNU0);                 // [B][CW] x_tgt * nu0 of step t without an own final spike
+    float *xnu0s = (float *)(smem + OC_XNU0S);               // [B][CW] ... with the winners of a slow column put in
+    float *curX = (float *)(smem + OC_CURX);                 // [2][B][CW] X -> Ae part of the Ae current, by step parity
+    float *curXwin = (float *)(smem + OC_CURXW);             // [B][CW] ... of column q in its won branch
     float *stl = (float *)(smem + OC_ST);                    // [7][TT] vE rE vI rI xE xI theta
     int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta)
-    uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [CW] samples with a FINAL spike per own column at step t-1 (PostPre)
+    uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [CW] samples with a FINAL spike per own column at step t-1
+    uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity
+    uint32_t *colres = (uint32_t *)(smem + OC_COLRES);       // [CW] slow columns: their winners of this step
+    float *xwinv = (float *)(smem + OC_XWINV);               // [CW] x_tgt*nu0 of the crossing pair of column q if it wins
     int *w0 = (int *)(smem + OC_W0), *cnt0 = (int *)(smem + OC_C0);
-    float *wtile = (float *)(smem + OC_WT);                  // [Nin][CW] learned weights, updated in place
+    float *wtile = (float *)(smem + OC_WT);                  // [Nin][CW] learned weights
     float *wieT = wtile + (size_t)Nin * CW;
     float *weiT = wieT + (size_t)N * CW;
     const int DGS = (c.DGW + 63) & ~63;
     uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
+    float *wbak = (float *)(dgbuf + 2 * DGS);                // [Nin][CW] rows PostPre touched: their weights before
+    float *wwin = wbak + (size_t)Nin * CW;                   // [Nin][CW] column q: the whole column with its final spikes of this step
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)blockIdx.x, c0 = g * CW;
@@ -211,15 +313,15 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     const bool mine = tid < TT && bl < B && colv;
     const unsigned kst = (unsigned)(bl * N + j);
     const int KB = c.KB, NG = c.G * KB, NGS = c.G * NTW;
-    const int Emain = (int)(((long long)Nin * N / 32) * 32);
 
     if (tid < 32) ctl[tid] = 0;
-    if (tid < 2 * CW) { thc[tid] = 0; colmask[tid & 3] = 0; }
+    if (tid < 2 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid & 3] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
     scan_entry(c, w0, cnt0, tid);
     bool offdiag = false, multi0 = false;
     for (int k = tid; k < Nin * CW; k += NT) {
         const int i = k / CW, q = k % CW;
         wtile[k] = (c0 + q < N) ? c.Wxe[i * N + c0 + q] : 0.f;
+        wbak[k] = 0.f; wwin[k] = 0.f;
     }
     for (int k = tid; k < N * CW; k += NT) {
         const int i = k / CW, q = k % CW;
@@ -241,6 +343,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         }
     };
     fetch_digest(0);
+    if (T >= 1) fetch_digest(1);
     bool last_sE = false, last_sI = false;
     if (mine) {
         stl[0 * TT + tid] = c.vE[kst]; stl[1 * TT + tid] = c.rE[kst]; stl[2 * TT + tid] = c.vI[kst]; stl[3 * TT + tid] = c.rI[kst];
@@ -249,92 +352,97 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         stl[6 * TT + tid] = c.theta[j];
         last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
     }
-    if (tid < TT) { xnu0[tid] = 0.f; curX[tid] = 0.f; }
+    if (tid < TT) { xnu0[tid] = 0.f; xnu0s[tid] = 0.f; curX[tid] = 0.f; curX[TT + tid] = 0.f; curXwin[tid] = 0.f; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
     if (bad && tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // X -> Ae currents of step 0 (from the layer's spikes at entry, digest entry 0)
+    for (int qt = tid; qt < B * CW * 4; qt += NT) {
+        const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+        const float v = x_current4(wtile, dgbuf, B, Nin, pb, pq, pL, tailcol);
+        if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
+    }
+    lds_barrier();                                            // (digest buffer 0 is refilled at the top of the first iteration)
     bool sp_prev = last_sE;                                   // final Ae spike of this pair at the previous step
     bool crossed_prev = false;                                // ... and its crossing
+    float x_before = 0.f;                                     // Ae trace of this pair behind the previous step (final)
     unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
     int published = 0;                                        // steps this (tile) wave has published
+    const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
 
     for (int t = 0; t <= T; ++t) {
-        const bool phaseA = t >= 1, phaseB = t < T;
+        const bool phaseB = t < T;
         const int par = t & 1;
-        const uint32_t *dg = dgbuf + par * DGS;                           // digest of the X spikes of step t-1
-        const int *meta = (const int *)(dg + B * (LX / 2));
-        const uint32_t *rowmask = dg + B * (LX / 2) + 40;
+        const uint32_t *dgn = dgbuf + (par ^ 1) * DGS;                    // digest entry t+1: the X spikes of step t
+        const int *meta = (const int *)(dgn + B * (LX / 2));
+        const uint32_t *rowmask = dgn + B * (LX / 2) + 40;
         const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
-        const bool do_stdp = phaseA && c.learning && c.rule == SNN_RULE_POSTPRE;
-        const bool stdp_full = t == 1;
-        const int nact = stdp_full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
+        const bool do_stdp = phaseB && learn_pp;
+        const bool full = t == 0;                                         // the first update of a run clamps every element
+        const int nact = !phaseB ? 0 : (full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]));
         AMARK(0);
-        if (phaseB) fetch_digest(t + 1);                                  // (its buffer was last read before barrier 3 of the previous iteration)
-        // ---- (a) tile waves: which of the own crossings of step t-1 won (only a wave that had one waits), Ae trace of step t-1
-        if (phaseA && wave < NTW) {
-            bool sp = false;
-            if (prevE != 0ull && !bad) {
+        // the first winners granule of step t-2 (the membrane stage wants it): on its way while the rest of the iteration's front runs
+        unsigned long long pre_w = 0ull;
+        const bool have_pre = phaseB && t >= 2 && wave < NTW;
+        if (have_pre) pre_w = granule_load(c.wing + (size_t)((t - 2) & (kWinRing - 1)) * kWinGr);
+        if (t + 2 <= T) fetch_digest(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+        // ---- tile waves, in front of A
+        if (wave < NTW) {
+            if (t >= 1 && prevE != 0ull && !bad) {
                 const int jw = sample_winner(c, w0, t - 1, min(bl, B - 1), bad);
-                sp = crossed_prev && jw == j;
+                const bool sp = crossed_prev && jw == j && bl < B && colv;
+                if (sp) {
+                    if (c.pE.lif.traces) stl[4 * TT + tid] = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    atomicOr(&colmask[jj], 1u << bl);
+                    last_sE = true; sp_prev = true;
+                }
             }
-            if (bl < B) {
+            if (phaseB && bl < B) {
                 float xn = 0.f;
-                if (colv) {
-                    if (c.pE.lif.traces) { xn = trace_next(stl[4 * TT + tid], sp, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive); stl[4 * TT + tid] = xn; }
-                    last_sE = sp;
+                if (colv && c.pE.lif.traces) {
+                    x_before = stl[4 * TT + tid];
+                    xn = trace_next(x_before, 0, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    stl[4 * TT + tid] = xn;
                 }
                 xnu0[bl * CW + jj] = xn * c.nu0;
-                if (sp) atomicOr(&colmask[jj], 1u << bl);
-                sp_prev = sp;
             }
             if (bad) ctl[0] = 1;
         }
         AMARK(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of digest t+1 has landed (visible behind the next barrier)
-        lds_barrier();                                                    // ---- 1
+        lds_barrier();                                                    // ---- A
         AMARK(2);
         if (ctl[0]) { bad = true; break; }
-        if (tid < CW) thc[par * CW + tid] = 0;                            // (its readers -- the membrane update of step t-1 -- are behind us)
-        // ---- (c) PostPre of step t-1 on the own slice, in place (learning.py / MCC_learning.py:224-302)
-        if (do_stdp) {
-            const float *xsrc = c.xtr + (size_t)t * B * Nin;              // X trace after step t-1
-            if (stdp_full) {
-                stdp_rows_lds<CascadeT, true, CW, NT>(c, Nin, arows, rowmask, colmask, nullptr, xnu0, xsrc, wtile, c0, tid, Emain);
-            } else {
-                uint32_t acols = 0;
-                if (c.nu1 != 0.f) {
+        uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
+        if (learn_pp) {
 #pragma unroll
-                    for (int q = 0; q < CW; ++q) acols |= (colmask[q] != 0 ? 1u : 0u) << q;
+            for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[q]) != 0 ? 1u : 0u) << q;
+        }
+        if (!phaseB) {                                                    // behind the last step: only its winners' columns are left to commit
+            if (wonm)
+                for (int i = tid; i < Nin; i += NT) {
+                    float4 v = *(const float4 *)(wtile + i * 4);
+                    const float4 ww = *(const float4 *)(wwin + i * 4);
+                    if (wonm & 1u) v.x = ww.x;
+                    if (wonm & 2u) v.y = ww.y;
+                    if (wonm & 4u) v.z = ww.z;
+                    if (wonm & 8u) v.w = ww.w;
+                    *(float4 *)(wtile + i * 4) = v;
                 }
-                stdp_rows4<NT>(c, nact, arows, rowmask, colmask, xnu0, xsrc, wtile, c0, tid);
-                stdp_cols_lds<CascadeT, CW, NT>(c, acols, rowmask, colmask, xsrc, wtile, c0, tid, Emain);
-            }
+            break;
         }
-        if (!phaseB) break;
-        AMARK(3);
-        lds_barrier();                                                    // ---- 2
-        AMARK(4);
-        if (tid < CW) colmask[tid] = 0;
-        // ---- (e) X -> Ae currents of step t: four threads per (sample, column) pair
-        for (int qt = tid; qt < B * CW * 4; qt += NT) {
-            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-            const float v = x_current4(wtile, dg, B, Nin, pb, pq, pL, tailcol);
-            if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
-        }
-        AMARK(5);
-        lds_barrier();                                                    // ---- 3
-        AMARK(6);
-        // ---- (g) tile waves: membrane update of step t, publish its crossings
         if (wave < NTW) {
-            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
+            // ---- membrane update of step t, publish its crossings
+            float cx = 0.f;
+            if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
+            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, have_pre, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
             AMARK(7);
             bool spE = false, spIn = false, mismatch = false;
             float r_vE = 0.f, r_vI = 0.f;
             if (mine) {
                 const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
                 const float e3 = sp_prev ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;   // (own slice diagonal: only Ae_j feeds Ai_j)
-                const float curE = curX[bl * CW + jj] + e2;                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
+                const float curE = cx + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
                 const float curI = 0.0f + e3;                              // zeros + Ae->Ai
                 float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
                 r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
@@ -378,12 +486,120 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); }
             published = t + 1;
             prevE = mE; crossed_prev = spE;
+            if (mine) { last_sE = false; sp_prev = false; }               // (a winner of step t is put back in front of A of the next iteration)
+            if (spE) {
+                atomicOr(&colx[par * CW + jj], 1u << bl);
+                if (c.pE.lif.traces) xwinv[jj] = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive) * c.nu0;
+            }
             if (bad) ctl[0] = 1;
             if (mine) {
                 if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
                 if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
             }
+        } else if (do_stdp) {
+            // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
+            //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
+            const int ptid = tid - TT;
+            for (int k = ptid; k < nact; k += NBC) {
+                const int i = full ? k : (int)arows[k];
+                const uint32_t m = rowmask[i];
+                float4 v = *(const float4 *)(wtile + i * 4);
+                if (wonm) {
+                    const float4 ww = *(const float4 *)(wwin + i * 4);
+                    if (wonm & 1u) v.x = ww.x;
+                    if (wonm & 2u) v.y = ww.y;
+                    if (wonm & 4u) v.z = ww.z;
+                    if (wonm & 8u) v.w = ww.w;
+                }
+                *(float4 *)(wbak + i * 4) = v;
+                *(float4 *)(wtile + i * 4) = postpre_row_nowin(c, v, m, xnu0);
+            }
+            if (wonm && !full)                                            // ... and the rows this step does not touch take the won column as it is
+                for (int i = ptid; i < Nin; i += NBC) {
+                    if (rowmask[i] != 0) continue;
+                    float4 v = *(const float4 *)(wtile + i * 4);
+                    const float4 ww = *(const float4 *)(wwin + i * 4);
+                    if (wonm & 1u) v.x = ww.x;
+                    if (wonm & 2u) v.y = ww.y;
+                    if (wonm & 4u) v.z = ww.z;
+                    if (wonm & 8u) v.w = ww.w;
+                    *(float4 *)(wtile + i * 4) = v;
+                }
+            AMARKW(3, TT);
         }
+        lds_barrier();                                                    // ---- M
+        AMARK(4);
+        if (tid < CW) { colmask[tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
+        // ---- X -> Ae currents of step t+1 ("nobody of this workgroup won step t"): four threads per (sample, column) pair
+        for (int qt = tid; qt < B * CW * 4; qt += NT) {
+            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+            const float v = x_current4(wtile, dgn, B, Nin, pb, pq, pL, tailcol);
+            if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
+        }
+        AMARK(5);
+        // ---- a workgroup that crossed at step t: the won branch of its crossing columns
+        uint32_t xq[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
+        if (do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u) {
+            const float *xsrc = c.xtr + (size_t)(t + 1) * B * Nin;        // X trace after step t
+            const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
+            uint32_t cmq[CW];
+#pragma unroll
+            for (int q = 0; q < CW; ++q) cmq[q] = xq[q];
+            if (slow) {
+                // a column with several crossing samples: no single "it won" outcome to prepare -- wait for the winners of this step
+                if (wave == 0) {
+                    bool b2 = bad;
+                    const int jw = b2 ? -1 : sample_winner(c, w0, t, min(lane, B - 1), b2);
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        const uint64_t mm = __ballot(lane < B && jw == c0 + q && jw >= 0);
+                        if (lane == 0) colres[q] = (uint32_t)mm;
+                    }
+                    if (b2) { bad = true; ctl[0] = 1; }
+                }
+                lds_barrier();                                            // ---- S1
+#pragma unroll
+                for (int q = 0; q < CW; ++q) if (__popc(xq[q]) > 1) cmq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colres[q]);
+                if (tid < TT) {
+                    float v = xnu0[tid];
+                    const uint32_t xj = jj == 0 ? xq[0] : (jj == 1 ? xq[1] : (jj == 2 ? xq[2] : xq[3]));
+                    const uint32_t cj = jj == 0 ? cmq[0] : (jj == 1 ? cmq[1] : (jj == 2 ? cmq[2] : cmq[3]));
+                    if (bl < B && colv && __popc(xj) > 1 && ((cj >> bl) & 1u) && c.pE.lif.traces)
+                        v = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive) * c.nu0;
+                    xnu0s[tid] = v;
+                }
+                lds_barrier();                                            // ---- S2
+            }
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                if (!cmq[q] || c0 + q >= N) continue;
+                const bool single = __popc(xq[q]) == 1;
+                const int bst = single ? __ffs(cmq[q]) - 1 : -1;
+                const float xw = xwinv[q];
+                for (int i = tid; i < Nin; i += NT) {
+                    const uint32_t m = rowmask[i];
+                    const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
+                    float wn;
+                    if (single) wn = postpre_elem(c, xnu0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, xsrc[bst * Nin + i]);
+                    else wn = postpre_elem(c, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
+                    wwin[i * CW + q] = wn;
+                }
+            }
+            lds_barrier();                                                // ---- P
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                if (!cmq[q] || c0 + q >= N) continue;
+                for (int qt = tid; qt < B * 4; qt += NT) {
+                    const float v = x_current4(wwin, dgn, B, Nin, qt >> 2, q, qt & 3, tailcol);
+                    if ((qt & 3) == 0) curXwin[(qt >> 2) * CW + q] = v;
+                }
+            }
+        }
+        AMARK(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of digest t+2 has landed (visible behind the barrier)
+        lds_barrier();                                                    // ---- B
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
     if (bad && wave < NTW && published <= T - 1 && lane == 0)
@@ -529,7 +745,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
         // ---- generator: block k (ring slot k & RMK) from block k-1, as far ahead as the ring allows
         for (int k = 1;; ++k) {
             bool stop = false;
-            for (unsigned spins = 0;; ++spins) {
+            for (;;) {
                 if (k - __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RB) break;
                 if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; break; }
                 __builtin_amdgcn_s_sleep(2);
@@ -571,25 +787,36 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             const unsigned long long *sums = c.exs + (size_t)slot * NGS;
             const unsigned long long *exr = c.ex + (size_t)slot * NG;
             bool abortseen = false;
-            // ---- every crossing granule of step e: poll, decode into bit words / per-sample count / a crossing column
-            for (int gi = lane; gi < NGS; gi += 64) {
-                unsigned long long x = 0;
-                for (unsigned spins = 0;; ++spins) {
-                    x = granule_load(sums + gi);
-                    if ((uint32_t)(x >> 32) == (uint32_t)(e + 1)) break;
-                    if (spins > kAPoll) { failed = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (failed) break;
-                const uint32_t pay = (uint32_t)x;
+            // ---- every crossing granule of step e: lane l takes granules l, l + 64, ... (all its loads in flight at once, the missing
+            //      ones asked for again), then decodes them into bit words / per-sample count / a crossing column
+            int rp = INT_MAX;                                             // raster writers' progress, read early (used at publish time)
+            if (c.NRW > 0 && lane < c.NRW) rp = __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            constexpr int PG = 8;                                         // granules per lane: NGS <= 512
+            unsigned long long xs[PG];
+            uint32_t need = 0;
+#pragma unroll
+            for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+            for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
+#pragma unroll
+                for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(e + 1)) need &= ~(1u << u);
+                if (!__any(need != 0u)) break;
+                if (spins > kAPoll) { failed = true; break; }
+            }
+            auto event = [&](int bsm, int jx) __attribute__((always_inline)) {
+                if (bsm >= B || jx >= N) return;
+                atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31));
+                atomicAdd(&cntc[bsm], 1);
+                colc[bsm] = jx;
+            };
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                const int gi = lane + 64 * u;
+                if (failed || gi >= NGS) continue;
+                const uint32_t pay = (uint32_t)xs[u];
                 if (!pay) continue;
                 if (pay == kAbortPay) { abortseen = true; continue; }
-                auto event = [&](int bsm, int jx) __attribute__((always_inline)) {
-                    if (bsm >= B || jx >= N) return;
-                    atomicOr((unsigned int *)&crs[bsm * NW + (jx >> 5)], 1u << (jx & 31));
-                    atomicAdd(&cntc[bsm], 1);
-                    colc[bsm] = jx;
-                };
                 const int gsrc = gi / NTW, w = gi - gsrc * NTW;
                 if ((pay & 0xFFu) == 0xFFu) {                            // more than three crossings in that tile wave: its bit granules
                     for (int q = 0; q < SPW / SPG; ++q) {
@@ -651,13 +878,14 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             if (lane < B && myc > 0) winlist[__popc(anym & ((1u << lane) - 1u))] = (lane << 11) | (mywin & 0x7FF);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int ngr = arb_rows > 3 ? (arb_rows + 2) / 3 : 1;
-            // the raster writers must be done with the step whose ring slot this one takes
+            // the raster writers must be done with the step whose ring slot this one takes (progress read at the start of the step)
             if (c.NRW > 0 && e >= kWinRing - 2) {
                 bool late = false;
                 if (lane < c.NRW) {
-                    for (unsigned spins = 0; __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e - (kWinRing - 2) + 1; ++spins) {
+                    for (unsigned spins = 0; rp < e - (kWinRing - 2) + 1; ++spins) {
                         if (spins > kAPoll) { late = true; break; }
                         __builtin_amdgcn_s_sleep(1);
+                        rp = __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 if (__any(late)) {
