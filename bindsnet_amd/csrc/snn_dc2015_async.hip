@@ -57,8 +57,8 @@ __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 
 
 // ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
 constexpr int AT = MAXB * ACW;         // tile threads
-constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
-                 OC_ST = OC_CURXW + AT * 4, OC_THC = OC_ST + 7 * AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 16, OC_COLRES = OC_COLX + 32,
+constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
+                 OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 16, OC_COLRES = OC_COLX + 32,
                  OC_XWINV = OC_COLRES + 16, OC_W0 = OC_XWINV + 16 + 16, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
@@ -186,14 +186,25 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     return res;
 }
 
-// developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup's thread 0 per step, [T+1][24]; behind
+// developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup per step, [T+1][24]; behind
 // them [T+1][256][4] per workgroup: [1] published, [2] own crossings; slot 255: the arbiter ([0] all granules seen, [1] winners out)
-#define AMARK(k) do { if (c.dbg && g == c.dbg_wg && tid == 0) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } while (0)
-#define AMARKW(k, th) do { if (c.dbg && g == c.dbg_wg && tid == (th)) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } while (0)
+#define AMARKW(k, th) do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == (th)) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } } while (0)
+#define AMARK(k) AMARKW(k, 0)
+
+// A loop-invariant float parameter into a VECTOR register: kernel arguments are uniform, so the compiler keeps them in scalar
+// registers -- of which the compute loop needs far more than the 102 a wave has: the first versions re-read 226 spilled scalars per
+// iteration with v_readlane.  These values are operands of vector instructions anyway.
+__device__ __forceinline__ float vgpr(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+__device__ __forceinline__ snn_lif_params vgpr_params(snn_lif_params p) {
+    p.decay = vgpr(p.decay); p.rest = vgpr(p.rest); p.reset = vgpr(p.reset); p.thresh = vgpr(p.thresh); p.refrac = vgpr(p.refrac);
+    p.dt = vgpr(p.dt); p.lbound = vgpr(p.lbound); p.trace_decay = vgpr(p.trace_decay); p.trace_scale = vgpr(p.trace_scale);
+    return p;
+}
+struct PPar { float nu0, nu1, dt, wmin, wmax; int use_dt, has_min, has_max; };   // PostPre's parameters (floats in vector registers)
 
 // The pre-synaptic PostPre term of one row (its four columns) when no own pair has a FINAL spike: spec_rows4's body
 // (snn_dc2015_tile.hpp), statement for statement.  m: samples whose source spiked; xnu0[b][4] = x_tgt * nu0.
-__device__ __forceinline__ float4 postpre_row_nowin(const DcCtx &c, float4 w4, uint32_t m, const float *xnu0) {
+__device__ __forceinline__ float4 postpre_row_nowin(const PPar &c, float4 w4, uint32_t m, const float *xnu0) {
     float w[4] = {w4.x, w4.y, w4.z, w4.w};
     if (c.nu0 != 0.f) {                                      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
         float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -236,10 +247,9 @@ __device__ __forceinline__ float4 postpre_row_nowin(const DcCtx &c, float4 w4, u
 // One element of PostPre in its (row, column) form (k_dc2015_spec's postpre_elem = stdp_rows_lds's update; lean form: no tail
 // elements, 0/1 spikes): row i, column q, pre-synaptic samples m, post-synaptic samples cm; sample bst's x_tgt*nu0 replaced by xw
 // when bst >= 0; have_x: one post-synaptic sample, its X trace passed in.
-__device__ __forceinline__ float postpre_elem(const DcCtx &c, const float *xnu0, float w, int i, int q, uint32_t m, uint32_t cm, int bst,
-                                              float xw, const float *xs, bool have_x, float xval) {
+__device__ __forceinline__ float postpre_elem(const PPar &c, int B, int Nin, const float *xnu0, float w, int i, int q, uint32_t m, uint32_t cm,
+                                              int bst, float xw, const float *xs, bool have_x, float xval) {
     constexpr int CW = ACW;
-    const int B = c.B, Nin = c.Nin;
     if (c.nu0 != 0.f) {
         float uu = 0.f;
         if (m) {
@@ -272,26 +282,29 @@ __device__ __forceinline__ float postpre_elem(const DcCtx &c, const float *xnu0,
 }
 
 // ===================================================================================================================== compute
+// Threads: tile threads 0..127 <-> (sample tid / 4, column tid % 4): the Ae neuron of the pair, its state in registers; threads
+// 384..511 <-> the same pairs: the Ai neuron (its only input is the pair's own final Ae spike); threads 128..383 + 384..511: PostPre.
 // Iteration t (three s_barrier: A, M, B):
 //   in front of A   tile waves: a wave that crossed at step t-1 waits for that step's winners; a winner redoes its Ae trace and
-//                   marks its column (colmask); then the trace of step t and x_tgt*nu0 as they are WITHOUT a final spike at step t
-//                   (the trace just decays: known before the step is simulated)
+//                   x_tgt*nu0 and marks its column (colmask); every pair leaves its final spike of step t-1 for its Ai thread
 //   A .. M          tile waves: membrane update of step t (X currents prepared one iteration earlier -- the won branch's for a
-//                   column that won at t-1 --, inhibition from the winners of t-2), publish the crossings of step t
-//                   other waves: PostPre of step t on the own slice under "no own final spike at t" (a column that won at t-1
-//                   starts from its won branch; the old rows are kept in wbak)
+//                   column that won at t-1 --, inhibition from the winners of t-2), publish the crossings of step t, then the Ae
+//                   trace of step t and x_tgt*nu0 of step t+1 as they are WITHOUT a final spike (the trace just decays)
+//                   waves 2..5: PostPre of step t on the own slice under "no own final spike at t" (a column that won at t-1
+//                   starts from its won branch; the old rows are kept in wbak); waves 6..7: Ai membrane update of step t
 //   M .. B          all waves: X currents of step t+1 from the new weights; a workgroup that crossed at step t prepares the won
 //                   branch of every crossing column (whole column from the old weights + its X currents) while the arbiter works --
 //                   a column with more than one crossing sample waits for the winners and is redone exactly
+template <bool TIMING>
 __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
-    constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NWV = NT / 64, NBC = NT - TT;
+    constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NBC = NT - TT, TI0 = NT - TT;
     const int B = c.B, Nin = c.Nin, N = c.N, T = c.T;
     int *ctl = (int *)(smem + OC_CTL);                       // [0] abort seen (any wave), [1] commit seen
-    float *xnu0 = (float *)(smem + OC_XNU0);                 // [B][CW] x_tgt * nu0 of step t without an own final spike
+    float *xnu0 = (float *)(smem + OC_XNU0);                 // [2][B][CW] x_tgt * nu0 of a step without an own final spike, by step parity
     float *xnu0s = (float *)(smem + OC_XNU0S);               // [B][CW] ... with the winners of a slow column put in
     float *curX = (float *)(smem + OC_CURX);                 // [2][B][CW] X -> Ae part of the Ae current, by step parity
     float *curXwin = (float *)(smem + OC_CURXW);             // [B][CW] ... of column q in its won branch
-    float *stl = (float *)(smem + OC_ST);                    // [7][TT] vE rE vI rI xE xI theta
+    int *spfin = (int *)(smem + OC_SPFIN);                   // [TT] final Ae spike of the pair at step t-1 (for its Ai thread)
     int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta)
     uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [CW] samples with a FINAL spike per own column at step t-1
     uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity
@@ -308,11 +321,19 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)blockIdx.x, c0 = g * CW;
-    const int jj = tid % CW, bl = tid / CW, j = c0 + jj;
+    const bool is_ai = tid >= TI0;                            // Ai thread of pair tid - TI0
+    const int ptile = is_ai ? tid - TI0 : tid;                // pair of a tile / Ai thread
+    const int jj = ptile % CW, bl = ptile / CW, j = c0 + jj;
     const bool colv = j < N, tailcol = c0 >= (N / 32) * 32;
-    const bool mine = tid < TT && bl < B && colv;
+    const bool mine = tid < TT && bl < B && colv;             // owns the Ae neuron of a pair
+    const bool mine_i = is_ai && bl < B && colv;              // owns the Ai neuron of a pair
     const unsigned kst = (unsigned)(bl * N + j);
     const int KB = c.KB, NG = c.G * KB, NGS = c.G * NTW;
+    // loop-invariant parameters: floats in vector registers (see vgpr())
+    const snn_lif_params pE = vgpr_params(c.pE.lif), pI = vgpr_params(c.pI);
+    const float theta_plus = vgpr(c.pE.theta_plus), theta_decay = vgpr(c.pE.theta_decay);
+    const PPar pp = {vgpr(c.nu0), vgpr(c.nu1), vgpr(c.dt), vgpr(c.wmin), vgpr(c.wmax), c.use_dt, c.has_min, c.has_max};
+    const bool e_learning = c.pE.learning != 0;
 
     if (tid < 32) ctl[tid] = 0;
     if (tid < 2 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid & 3] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
@@ -332,27 +353,38 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     if (tid < 2 * MAXB) multi0 = cnt0[tid] > 1;
     if (offdiag || multi0) ctl[0] = 1;                        // (benign race: everybody writes 1)
-    auto fetch_digest = [&](int e) __attribute__((always_inline)) {
-        const uint32_t *Dg = c.dig + (size_t)e * c.DW;
-        uint32_t *dst = dgbuf + (e & 1) * DGS;
-        for (int base = wave * 256; base < c.DGW; base += NWV * 256) {
-            const int ub = __builtin_amdgcn_readfirstlane(base);
-            if (ub + lane * 4 < c.DGW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Dg + ub + lane * 4),
-                                                 (__attribute__((address_space(3))) void *)(dst + ub), 16, 0, 0);
-        }
-    };
-    fetch_digest(0);
-    if (T >= 1) fetch_digest(1);
-    bool last_sE = false, last_sI = false;
+    // The digest of a step travels global memory -> registers (at the top of an iteration) -> LDS (at its end): an LDS-DMA fetch
+    // (global_load_lds) makes the compiler drain vmcnt in front of EVERY later LDS read of the issuing wave -- it cannot tell which
+    // LDS bytes the transfer writes --, which put the transfer's whole latency in front of the step (0.6 us per iteration measured)
+    // (three named 16-byte registers per thread, loads unconditional with clamped indices: an array captured by a lambda went to scratch)
+    const int nchunk = c.DGW >> 2;                                        // 16-byte pieces of a digest entry: <= 3 * 512 (Nin <= 1024)
+    uint4 dg0 = make_uint4(0, 0, 0, 0), dg1 = dg0, dg2 = dg0;
+#define DIGEST_LOAD(e) do { const uint4 *src_ = (const uint4 *)(c.dig + (size_t)(e) * c.DW); dg0 = src_[min(tid, nchunk - 1)]; \
+                            dg1 = src_[min(tid + NT, nchunk - 1)]; dg2 = src_[min(tid + 2 * NT, nchunk - 1)]; } while (0)
+#define DIGEST_STORE(e) do { uint4 *dst_ = (uint4 *)(dgbuf + ((e) & 1) * DGS); if (tid < nchunk) dst_[tid] = dg0; \
+                             if (tid + NT < nchunk) dst_[tid + NT] = dg1; if (tid + 2 * NT < nchunk) dst_[tid + 2 * NT] = dg2; } while (0)
+    DIGEST_LOAD(0); DIGEST_STORE(0);
+    if (T >= 1) { DIGEST_LOAD(1); DIGEST_STORE(1); }
+    // state of the own neuron in registers: tile thread -> Ae (v, refractory counter, theta, trace), Ai thread -> Ai (v, counter, trace)
+    float r_v = 0.f, r_r = 0.f, r_th = 0.f, x_cur = 0.f, x_before = 0.f;
+    bool last_s = false;                                      // last final spike of the own neuron (Ae: redone by a winner; Ai)
     if (mine) {
-        stl[0 * TT + tid] = c.vE[kst]; stl[1 * TT + tid] = c.rE[kst]; stl[2 * TT + tid] = c.vI[kst]; stl[3 * TT + tid] = c.rI[kst];
-        stl[4 * TT + tid] = c.pE.lif.traces ? c.xE[kst] : 0.f;
-        stl[5 * TT + tid] = c.pI.traces ? c.xI[kst] : 0.f;
-        stl[6 * TT + tid] = c.theta[j];
-        last_sE = c.sE[kst] != 0; last_sI = c.sI[kst] != 0;
+        r_v = c.vE[kst]; r_r = c.rE[kst]; r_th = c.theta[j];
+        x_cur = pE.traces ? c.xE[kst] : 0.f;
+        last_s = c.sE[kst] != 0;
     }
-    if (tid < TT) { xnu0[tid] = 0.f; xnu0s[tid] = 0.f; curX[tid] = 0.f; curX[TT + tid] = 0.f; curXwin[tid] = 0.f; }
+    if (mine_i) {
+        r_v = c.vI[kst]; r_r = c.rI[kst];
+        x_cur = pI.traces ? c.xI[kst] : 0.f;
+        last_s = c.sI[kst] != 0;
+    }
+    if (tid < TT) {
+        // x_tgt*nu0 of step 0 without an own final spike: the entry trace, decayed once
+        float xn = 0.f;
+        if (bl < B && colv && pE.traces) xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+        xnu0[tid] = xn * pp.nu0; xnu0[TT + tid] = 0.f; xnu0s[tid] = 0.f;
+        curX[tid] = 0.f; curX[TT + tid] = 0.f; curXwin[tid] = 0.f; spfin[tid] = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
@@ -363,10 +395,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const float v = x_current4(wtile, dgbuf, B, Nin, pb, pq, pL, tailcol);
         if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
     }
-    lds_barrier();                                            // (digest buffer 0 is refilled at the top of the first iteration)
-    bool sp_prev = last_sE;                                   // final Ae spike of this pair at the previous step
+    lds_barrier();                                            // (digest buffer 0 is refilled at the end of the first iteration)
+    bool sp_prev = last_s;                                    // tile thread: final Ae spike of this pair at the previous step
     bool crossed_prev = false;                                // ... and its crossing
-    float x_before = 0.f;                                     // Ae trace of this pair behind the previous step (final)
     unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
     int published = 0;                                        // steps this (tile) wave has published
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
@@ -380,33 +411,29 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
         const bool do_stdp = phaseB && learn_pp;
         const bool full = t == 0;                                         // the first update of a run clamps every element
-        const int nact = !phaseB ? 0 : (full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]));
         AMARK(0);
-        // the first winners granule of step t-2 (the membrane stage wants it): on its way while the rest of the iteration's front runs
+        // the first winners granule of step t-2 (the membrane stage wants it): on its way while the front of the iteration runs
         unsigned long long pre_w = 0ull;
         const bool have_pre = phaseB && t >= 2 && wave < NTW;
         if (have_pre) pre_w = granule_load(c.wing + (size_t)((t - 2) & (kWinRing - 1)) * kWinGr);
-        if (t + 2 <= T) fetch_digest(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+        if (t + 2 <= T) DIGEST_LOAD(t + 2);                               // digest entry t+2 -> registers (into LDS at the end of the iteration)
         // ---- tile waves, in front of A
         if (wave < NTW) {
+            if (t >= 1) sp_prev = false;
             if (t >= 1 && prevE != 0ull && !bad) {
                 const int jw = sample_winner(c, w0, t - 1, min(bl, B - 1), bad);
                 const bool sp = crossed_prev && jw == j && bl < B && colv;
                 if (sp) {
-                    if (c.pE.lif.traces) stl[4 * TT + tid] = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
+                    // the pair won step t-1: its trace of that step, and x_tgt*nu0 of step t, with the spike in
+                    if (pE.traces) {
+                        x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                        if (phaseB) xnu0[par * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
+                    }
                     atomicOr(&colmask[jj], 1u << bl);
-                    last_sE = true; sp_prev = true;
+                    last_s = true; sp_prev = true;
                 }
             }
-            if (phaseB && bl < B) {
-                float xn = 0.f;
-                if (colv && c.pE.lif.traces) {
-                    x_before = stl[4 * TT + tid];
-                    xn = trace_next(x_before, 0, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive);
-                    stl[4 * TT + tid] = xn;
-                }
-                xnu0[bl * CW + jj] = xn * c.nu0;
-            }
+            spfin[tid] = sp_prev ? 1 : 0;
             if (bad) ctl[0] = 1;
         }
         AMARK(1);
@@ -432,35 +459,19 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             break;
         }
         if (wave < NTW) {
-            // ---- membrane update of step t, publish its crossings
+            // ---- Ae membrane update of step t, publish its crossings
             float cx = 0.f;
             if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
             const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, have_pre, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
             AMARK(7);
-            bool spE = false, spIn = false, mismatch = false;
-            float r_vE = 0.f, r_vI = 0.f;
+            bool spE = false;
             if (mine) {
                 const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
-                const float e3 = sp_prev ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;   // (own slice diagonal: only Ae_j feeds Ai_j)
                 const float curE = cx + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
-                const float curI = 0.0f + e3;                              // zeros + Ae->Ai
-                float r_rE = stl[1 * TT + tid], r_rI = stl[3 * TT + tid], th = stl[6 * TT + tid];
-                r_vE = stl[0 * TT + tid]; r_vI = stl[2 * TT + tid];
-                if (c.pE.learning && t >= 1) th = th + c.pE.theta_plus * (float)thc[(par ^ 1) * CW + jj];
-                if (c.pE.learning) th = th * c.pE.theta_decay;
-                spE = dc_update(r_vE, r_rE, curE, c.pE.lif.thresh + th, c.pE.lif);
+                if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[(par ^ 1) * CW + jj];
+                if (e_learning) r_th = r_th * theta_decay;
+                spE = dc_update(r_v, r_r, curE, pE.thresh + r_th, pE);
                 if (spE) atomicAdd(&thc[par * CW + jj], 1);
-                float ci = curI;
-                if (r_rI > 0.f) ci = 0.f;
-                spIn = lif_update(r_vI, r_rI, ci, c.pI);
-                last_sI = spIn;
-                mismatch = spIn != sp_prev;                                // Ai_j must fire exactly when Ae_j won the step before
-                stl[0 * TT + tid] = r_vE; stl[1 * TT + tid] = r_rE; stl[2 * TT + tid] = r_vI; stl[3 * TT + tid] = r_rI; stl[6 * TT + tid] = th;
-                if (c.pI.traces) stl[5 * TT + tid] = trace_next(stl[5 * TT + tid], spIn, c.pI.trace_decay, c.pI.trace_scale, c.pI.traces_additive);
-            }
-            if (__any(mismatch)) {
-                bad = true;
-                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const uint64_t mE = __ballot(spE);
             const int slot = t & (kCrossRing - 1);
@@ -483,23 +494,52 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
             if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
             AMARK(8);
-            if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); }
+            if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
             published = t + 1;
             prevE = mE; crossed_prev = spE;
-            if (mine) { last_sE = false; sp_prev = false; }               // (a winner of step t is put back in front of A of the next iteration)
+            // Ae trace of step t as it is without a final spike (nodes.py:96-103), x_tgt*nu0 of step t+1 likewise (the front of the
+            // next iteration redoes both for a winner of step t)
+            if (bl < B) {
+                float xn = 0.f;
+                if (colv && pE.traces) {
+                    x_before = x_cur;
+                    x_cur = trace_next(x_before, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                    xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                }
+                xnu0[(par ^ 1) * TT + tid] = xn * pp.nu0;
+            }
+            if (mine) last_s = false;                                      // (a winner of step t is put back in front of A of the next iteration)
             if (spE) {
                 atomicOr(&colx[par * CW + jj], 1u << bl);
-                if (c.pE.lif.traces) xwinv[jj] = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive) * c.nu0;
+                if (pE.traces) xwinv[jj] = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
             }
             if (bad) ctl[0] = 1;
-            if (mine) {
-                if (c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_vE;
-                if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_vI;
+            if (mine && c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_v;
+        } else if (wave >= NT / 64 - NTW) {
+            // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
+            //      weights diagonal); it must fire exactly when that spike was there -- what everybody's inhibition assumes
+            if (mine_i) {
+                const bool spA = spfin[ptile] != 0;
+                const float e3 = spA ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;
+                float ci = 0.0f + e3;                                      // zeros + Ae->Ai
+                if (r_r > 0.f) ci = 0.f;
+                const bool spIn = lif_update(r_v, r_r, ci, pI);
+                last_s = spIn;
+                if (pI.traces) x_cur = trace_next(x_cur, spIn, pI.trace_decay, pI.trace_scale, pI.traces_additive);
+                if (spIn != spA) {
+                    ctl[0] = 1;
+                    if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_v;
             }
-        } else if (do_stdp) {
+        }
+        if (wave >= NTW && do_stdp) {
             // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
             //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
+            //      (the Ai waves join behind their own update: rows beyond the 256 of waves 2..5)
+            const int nact = full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
             const int ptid = tid - TT;
+            const float *xn0 = xnu0 + par * TT;
             for (int k = ptid; k < nact; k += NBC) {
                 const int i = full ? k : (int)arows[k];
                 const uint32_t m = rowmask[i];
@@ -512,7 +552,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     if (wonm & 8u) v.w = ww.w;
                 }
                 *(float4 *)(wbak + i * 4) = v;
-                *(float4 *)(wtile + i * 4) = postpre_row_nowin(c, v, m, xnu0);
+                *(float4 *)(wtile + i * 4) = postpre_row_nowin(pp, v, m, xn0);
             }
             if (wonm && !full)                                            // ... and the rows this step does not touch take the won column as it is
                 for (int i = ptid; i < Nin; i += NBC) {
@@ -530,6 +570,25 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         lds_barrier();                                                    // ---- M
         AMARK(4);
         if (tid < CW) { colmask[tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
+        // ---- a workgroup that crossed at step t prepares the won branch of its crossing columns: their X-trace values first
+        //      (global memory; they arrive while the X currents are computed)
+        uint32_t xq[CW];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
+        const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
+        const float *xsrc = c.xtr + (size_t)(t + 1) * B * Nin;            // X trace after step t
+        float xv0[CW], xv1[CW];                                           // X trace of the crossing sample of column q at rows tid, tid + NT
+#pragma unroll
+        for (int q = 0; q < CW; ++q) { xv0[q] = 0.f; xv1[q] = 0.f; }
+        if (crossed_wg) {
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                if (__popc(xq[q]) != 1) continue;
+                const int bst = __ffs(xq[q]) - 1;
+                xv0[q] = xsrc[bst * Nin + min(tid, Nin - 1)];
+                xv1[q] = xsrc[bst * Nin + min(tid + NT, Nin - 1)];
+            }
+        }
         // ---- X -> Ae currents of step t+1 ("nobody of this workgroup won step t"): four threads per (sample, column) pair
         for (int qt = tid; qt < B * CW * 4; qt += NT) {
             const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
@@ -537,12 +596,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
         }
         AMARK(5);
-        // ---- a workgroup that crossed at step t: the won branch of its crossing columns
-        uint32_t xq[CW];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
-        if (do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u) {
-            const float *xsrc = c.xtr + (size_t)(t + 1) * B * Nin;        // X trace after step t
+        if (crossed_wg) {
+            const float *xn0 = xnu0 + par * TT;
             const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
             uint32_t cmq[CW];
 #pragma unroll
@@ -563,11 +618,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
                 for (int q = 0; q < CW; ++q) if (__popc(xq[q]) > 1) cmq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colres[q]);
                 if (tid < TT) {
-                    float v = xnu0[tid];
+                    float v = xn0[tid];
                     const uint32_t xj = jj == 0 ? xq[0] : (jj == 1 ? xq[1] : (jj == 2 ? xq[2] : xq[3]));
                     const uint32_t cj = jj == 0 ? cmq[0] : (jj == 1 ? cmq[1] : (jj == 2 ? cmq[2] : cmq[3]));
-                    if (bl < B && colv && __popc(xj) > 1 && ((cj >> bl) & 1u) && c.pE.lif.traces)
-                        v = trace_next(x_before, 1, c.pE.lif.trace_decay, c.pE.lif.trace_scale, c.pE.lif.traces_additive) * c.nu0;
+                    if (bl < B && colv && __popc(xj) > 1 && ((cj >> bl) & 1u) && pE.traces)
+                        v = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
                     xnu0s[tid] = v;
                 }
                 lds_barrier();                                            // ---- S2
@@ -578,13 +633,22 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 const bool single = __popc(xq[q]) == 1;
                 const int bst = single ? __ffs(cmq[q]) - 1 : -1;
                 const float xw = xwinv[q];
-                for (int i = tid; i < Nin; i += NT) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = tid + r * NT;
+                    if (i >= Nin) continue;
                     const uint32_t m = rowmask[i];
                     const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
                     float wn;
-                    if (single) wn = postpre_elem(c, xnu0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, xsrc[bst * Nin + i]);
-                    else wn = postpre_elem(c, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
+                    if (single) wn = postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, r == 0 ? xv0[q] : xv1[q]);
+                    else wn = postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
                     wwin[i * CW + q] = wn;
+                }
+                for (int i = tid + 2 * NT; i < Nin; i += NT) {            // (Nin > 1024 never gets here: kept for completeness)
+                    const uint32_t m = rowmask[i];
+                    const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
+                    wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, xsrc[bst * Nin + i])
+                                              : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
                 }
             }
             lds_barrier();                                                // ---- P
@@ -598,7 +662,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         AMARK(6);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of digest t+2 has landed (visible behind the barrier)
+        if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
         lds_barrier();                                                    // ---- B
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
@@ -618,13 +682,17 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         for (int k = g * NT + tid; k < B * Nin; k += c.G * NT) c.xX[1][k] = src[k];
     }
     if (mine) {
-        float th = stl[6 * TT + tid];
-        if (c.pE.learning) th = th + c.pE.theta_plus * (float)thc[((T - 1) & 1) * CW + jj];
-        c.vE[kst] = stl[0 * TT + tid]; c.rE[kst] = stl[1 * TT + tid]; c.vI[kst] = stl[2 * TT + tid]; c.rI[kst] = stl[3 * TT + tid];
+        float th = r_th;
+        if (e_learning) th = th + theta_plus * (float)thc[((T - 1) & 1) * CW + jj];
+        c.vE[kst] = r_v; c.rE[kst] = r_r;
         if (bl == 0) c.theta[j] = th;
-        if (c.pI.traces) c.xI[kst] = stl[5 * TT + tid];
-        if (c.pE.lif.traces) c.xE[kst] = stl[4 * TT + tid];
-        c.sE[kst] = last_sE; c.sI[kst] = last_sI;
+        if (pE.traces) c.xE[kst] = x_cur;
+        c.sE[kst] = last_s;
+    }
+    if (mine_i) {
+        c.vI[kst] = r_v; c.rI[kst] = r_r;
+        if (pI.traces) c.xI[kst] = x_cur;
+        c.sI[kst] = last_s;
     }
     if (c.has_norm) {          // topology_features.py:250-266 on the own columns, ATen's column-sum order (k_dc2015_spec's epilogue)
         float *bsum = (float *)dgbuf;
@@ -681,6 +749,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
 }
 
+
 // ===================================================================================================================== arbiter
 // One sample's one_spike arbitration by one wave: the lean forms' draw comparison (k_dc2015_spec's arbitrate_sample) on the ring
 // of generator blocks.  tb / off: ring-absolute block and offset of the step's first word; r = the sample's rank among the crossing
@@ -725,6 +794,7 @@ __device__ __forceinline__ int arb_sample(const DcCtx &c, const uint32_t *mt, in
     return win;
 }
 
+template <bool TIMING>
 __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *smem) {
     constexpr int CW = ACW, NTW = AT / 64, SPW = 64 / CW, SPG = 16 / CW, RB = kArbRing, RMK = RB - 1;
     const int B = c.B, N = c.N, NW = c.NW, T = c.T, G = c.G;
@@ -844,7 +914,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             }
             failed = __any(failed);
             abortseen = __any(abortseen);
-            if (c.dbg && lane == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 0] = (long long)wall_clock64();
+            if constexpr (TIMING) { if (c.dbg && lane == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 0] = (long long)wall_clock64(); }
             if (failed) { if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (failed || abortseen) {
                 // pass the abort on: every reader of this step's (and any later) winners sees the mark
@@ -906,7 +976,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 granule_store(c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr + lane,
                               ((unsigned long long)win_tag(e) << 54) | ((unsigned long long)arb_rows << 48) | pl);
             }
-            if (c.dbg && lane == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 2] = arb_rows + 100 * __popc(multim); }
+            if constexpr (TIMING) { if (c.dbg && lane == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 2] = arb_rows + 100 * __popc(multim); } }
             // ---- the generator moves on by 2 N words per crossing sample (nodes.py:1100-1105: one multinomial row each); clean up
             if (arb_rows) {
                 const int endw = pos + 2 * arb_rows * N;                 // offset (from block tb) behind the step's last word
@@ -965,6 +1035,7 @@ __device__ __forceinline__ void async_raster(const DcCtx &c, unsigned char *smem
     }
 }
 
+template <bool TIMING>
 __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int blk = (int)blockIdx.x;
@@ -973,8 +1044,8 @@ __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
         if (blk == 0 && threadIdx.x == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (blk < c.G) async_compute(c, smem);
-    else if (blk == c.G) async_arbiter(c, smem);
+    if (blk < c.G) async_compute<TIMING>(c, smem);
+    else if (blk == c.G) async_arbiter<TIMING>(c, smem);
     else async_raster(c, smem, blk - c.G - 1);
 }
 
@@ -987,7 +1058,8 @@ size_t snn_dc2015_async_lds(int B, int Nin, int N) {
 
 static bool async_attr_once() {
     static int state = 0;
-    if (!state) state = snn_check(hipFuncSetAttribute((const void *)k_dc2015_async, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ? -1 : 1;
+    if (!state) state = (snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
+                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) ? -1 : 1;
     return state == 1;
 }
 
@@ -997,7 +1069,7 @@ int snn_dc2015_async_capacity(size_t lds) {
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (getenv("SNN_DC_FAKE_CUS")) cus = atoi(getenv("SNN_DC_FAKE_CUS"));
     return coop ? cus * per_cu : 0;
 }
@@ -1009,8 +1081,9 @@ int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st) {
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
     const unsigned grid = (unsigned)(c.G + 1 + c.NRW);
-    if (!coop) return snn_check(hipLaunchKernel((const void *)k_dc2015_async, dim3(grid), dim3(ANT), args, lds, st));
-    const hipError_t e = hipLaunchCooperativeKernel((const void *)k_dc2015_async, dim3(grid), dim3(ANT), args, (unsigned)lds, st);
+    const void *fn = c.dbg ? (const void *)k_dc2015_async<true> : (const void *)k_dc2015_async<false>;     // (the timing marks are compiled out of the ordinary instance)
+    if (!coop) return snn_check(hipLaunchKernel(fn, dim3(grid), dim3(ANT), args, lds, st));
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(ANT), args, (unsigned)lds, st);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }
     return snn_check(e);
 }
