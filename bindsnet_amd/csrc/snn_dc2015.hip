@@ -739,7 +739,7 @@ static size_t fused_workspace(int B, int Nin, int N) {
 // lean forms: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2; the third generation keeps FOUR steps of both kinds of
 // granules in flight (rings of 4), plus its winners granules [8][11], 16 progress words of the raster writers and the tbad word
 static int g_last_form = -1;          // resident form of the last D&C run: 0 general, 1 / 2 / 3 lean generations, -1 per-step
-constexpr int kAsyncDefault = 0;      // third-generation lean form on by default?  (SNN_DC_ASYNC overrides)
+constexpr int kAsyncDefault = 1;      // third-generation lean form on by default?  (SNN_DC_ASYNC overrides)
 static size_t resident_summary_bytes(int N) { return (size_t)4 * ((N + 1) / 2) * 4 * 8; }
 static size_t resident_gran_bytes(int B, int N) { return (size_t)4 * ((N + 1) / 2) * ((B + 1) / 2) * 8; }   // >= 4 * G * KB * 8 for every tile width
 constexpr size_t kAsyncCtlBytes = 8 * 11 * 8 + 16 * 4 + 64;
@@ -886,7 +886,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     // arbiter workgroup, raster writers): wherever the lean form applies, its grid (G + 1 + raster writers) is co-resident and the
     // columns fit the winners' 11-bit field.  SNN_DC_ASYNC=0 / 1 forces it off / on.
     {
-        static const int async_env = getenv("SNN_DC_ASYNC") ? atoi(getenv("SNN_DC_ASYNC")) : kAsyncDefault;
+        const int async_env = getenv("SNN_DC_ASYNC") ? atoi(getenv("SNN_DC_ASYNC")) : kAsyncDefault;   // (read per run: the tests switch it)
         if (lean && async_env && N <= 1024 && B <= MAXB) {
             const size_t alds = snn_dc2015_async_lds(B, Nin, N);
             const int nrw = (c.rasE || c.rasI) ? 4 : 0;

@@ -15,20 +15,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False, nu=(1e-4, 1e-2)):
+def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False, nu=(1e-4, 1e-2), exc=22.5,
+        tweak=None):
     from bindsnet_amd import _lib
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
     _lib.lib().snn_set_plan_mode(int(mode))          # 0 auto (resident kernel), 1 generic, 2 one launch per timestep
     try:
         torch.manual_seed(0)
-        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=22.5, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape, nu=nu)
+        net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=exc, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape, nu=nu)
         W0 = synth.uniform_f32(3, (Nin, N), 0.0, w_scale)
         net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(W0, 1.0)))
         mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
         for l, m in mons.items():
             net.add_monitor(m, l)
         net.train(learning)
+        if tweak is not None:                        # e.g. other recurrent weights
+            tweak(net)
         if additive:                                 # nodes.py:96-103: x = x * decay + trace_scale * s instead of x <- trace_scale on a spike
             for l in net.layers.values():
                 l.traces_additive = True
@@ -47,6 +50,7 @@ def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, 
                 xE=net.layers["Ae"].x.cpu().numpy().copy(), xX=net.layers["X"].x.cpu().numpy().copy(),
                 vI=net.layers["Ai"].v.cpu().numpy().copy(), probe=probe))
             plan = net.last_plan
+            run.last_net = net
             if r % 2 == 0:
                 net.reset_state_variables()
         return out, plan
