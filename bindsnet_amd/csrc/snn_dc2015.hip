@@ -1017,15 +1017,18 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         std::vector<long long> h((size_t)24 * (T_ + 1)), hw((size_t)(T_ + 1) * 256 * 4);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hw.data(), dbg + (size_t)24 * (T_ + 1), hw.size() * 8, hipMemcpyDeviceToHost);
+        if (const char *dump = getenv("SNN_DC_TIMING_DUMP")) {       // raw marks for offline analysis: [T+1][24] then [T+1][256][4] int64
+            if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), 8, h.size(), f); fwrite(hw.data(), 8, hw.size(), f); fclose(f); }
+        }
         double a[9] = {0}, step = 0; int n = 0;
         for (int t = 3; t + 1 < T_; ++t, ++n) {
             const long long *r = &h[(size_t)t * 24];
             for (int k = 1; k < 9; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
         }
-        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] front (resolution, trace) %.2f | barrier A %.2f | tile waves: winners(t-2) read %.2f, "
-                        "published %.2f | other waves: PostPre done %.2f | barrier M %.2f | X currents %.2f | won branch %.2f || iteration %.2f us\n",
-                c.dbg_wg, a[1] / n, a[2] / n, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, step / n);
+        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f | other waves: PostPre done %.2f | "
+                        "barrier M %.2f | X currents %.2f | won branch %.2f | resolution of step t %.2f | barrier B %.2f || iteration %.2f us\n",
+                c.dbg_wg, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[1] / n, a[2] / n, step / n);
         // per step: first / last publish over the compute workgroups, arbiter: all granules seen, winners out
         double spread = 0, seen = 0, out = 0, period = 0, lastx = 0; int m = 0, nx = 0; long long prev_last = 0;
         std::vector<int> lastcnt(c.G, 0);
@@ -1038,6 +1041,22 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             prev_last = p1; ++m; lastcnt[gl]++;
             if (t >= 1 && hw[((size_t)(t - 1) * 256 + gl) * 4 + 2] > 0) { lastx += 1; }
             (void)nx;
+        }
+        {
+            std::vector<std::pair<int, int>> top;
+            for (int gq = 0; gq < c.G; ++gq) top.push_back({lastcnt[gq], gq});
+            std::sort(top.begin(), top.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+            fprintf(stderr, "[dc2015 async] workgroups most often the last publisher of a step (of %d steps):", m);
+            for (int k = 0; k < 8 && k < (int)top.size(); ++k) fprintf(stderr, " wg%d x%d", top[k].second, top[k].first);
+            // how long the last publisher's own iteration was (its publish to its next publish), crossing or not
+            double itc = 0, itn = 0; int nc = 0, nn2 = 0;
+            for (int t = 4; t + 1 < T_; ++t) {
+                long long p1 = 0; int gl = 0;
+                for (int gq = 0; gq < c.G; ++gq) { const long long v = hw[((size_t)t * 256 + gq) * 4 + 1]; if (v > p1) { p1 = v; gl = gq; } }
+                const double own = (double)(p1 - hw[((size_t)(t - 1) * 256 + gl) * 4 + 1]) / 100.0;
+                if (hw[((size_t)(t - 1) * 256 + gl) * 4 + 2] > 0) { itc += own; ++nc; } else { itn += own; ++nn2; }
+            }
+            fprintf(stderr, " | the last publisher's own step took %.2f us when it had crossed the step before (%d), %.2f us otherwise (%d)\n", nc ? itc / nc : 0.0, nc, nn2 ? itn / nn2 : 0.0, nn2);
         }
         fprintf(stderr, "[dc2015 async per step] last publish - first publish %.2f us | arbiter: last publish -> all granules seen %.2f us, -> winners out +%.2f us | "
                         "period of the last publisher %.2f us | the last publisher had crossed the step before in %.0f %% of the steps\n",

@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 
 // ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
 constexpr int AT = MAXB * ACW;         // tile threads
 constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
-                 OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 16, OC_COLRES = OC_COLX + 32,
+                 OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 32, OC_COLRES = OC_COLX + 32,
                  OC_XWINV = OC_COLRES + 16, OC_W0 = OC_XWINV + 16 + 16, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
@@ -284,17 +284,17 @@ __device__ __forceinline__ float postpre_elem(const PPar &c, int B, int Nin, con
 // ===================================================================================================================== compute
 // Threads: tile threads 0..127 <-> (sample tid / 4, column tid % 4): the Ae neuron of the pair, its state in registers; threads
 // 384..511 <-> the same pairs: the Ai neuron (its only input is the pair's own final Ae spike); threads 128..383 + 384..511: PostPre.
-// Iteration t (three s_barrier: A, M, B):
-//   in front of A   tile waves: a wave that crossed at step t-1 waits for that step's winners; a winner redoes its Ae trace and
-//                   x_tgt*nu0 and marks its column (colmask); every pair leaves its final spike of step t-1 for its Ai thread
-//   A .. M          tile waves: membrane update of step t (X currents prepared one iteration earlier -- the won branch's for a
+// Iteration t (two s_barrier: M in the middle, B at the end):
+//   B .. M          tile waves: membrane update of step t (X currents prepared one iteration earlier -- the won branch's for a
 //                   column that won at t-1 --, inhibition from the winners of t-2), publish the crossings of step t, then the Ae
 //                   trace of step t and x_tgt*nu0 of step t+1 as they are WITHOUT a final spike (the trace just decays)
 //                   waves 2..5: PostPre of step t on the own slice under "no own final spike at t" (a column that won at t-1
 //                   starts from its won branch; the old rows are kept in wbak); waves 6..7: Ai membrane update of step t
 //   M .. B          all waves: X currents of step t+1 from the new weights; a workgroup that crossed at step t prepares the won
 //                   branch of every crossing column (whole column from the old weights + its X currents) while the arbiter works --
-//                   a column with more than one crossing sample waits for the winners and is redone exactly
+//                   a column with more than one crossing sample waits for the winners and is redone exactly;
+//                   then the tile waves: a wave that crossed at step t waits for that step's winners; a winner redoes its Ae trace
+//                   and x_tgt*nu0 and marks its column (colmask); every pair leaves its final spike of step t for its Ai thread
 template <bool TIMING>
 __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
     constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NBC = NT - TT, TI0 = NT - TT;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     float *curXwin = (float *)(smem + OC_CURXW);             // [B][CW] ... of column q in its won branch
     int *spfin = (int *)(smem + OC_SPFIN);                   // [TT] final Ae spike of the pair at step t-1 (for its Ai thread)
     int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta)
-    uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [CW] samples with a FINAL spike per own column at step t-1
+    uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [2][CW] samples with a FINAL spike per own column at step t-1, by the parity of t
     uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity
     uint32_t *colres = (uint32_t *)(smem + OC_COLRES);       // [CW] slow columns: their winners of this step
     float *xwinv = (float *)(smem + OC_XWINV);               // [CW] x_tgt*nu0 of the crossing pair of column q if it wins
@@ -336,7 +336,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     const bool e_learning = c.pE.learning != 0;
 
     if (tid < 32) ctl[tid] = 0;
-    if (tid < 2 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid & 3] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
+    if (tid < 2 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
     scan_entry(c, w0, cnt0, tid);
     bool offdiag = false, multi0 = false;
     for (int k = tid; k < Nin * CW; k += NT) {
@@ -383,7 +383,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         float xn = 0.f;
         if (bl < B && colv && pE.traces) xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
         xnu0[tid] = xn * pp.nu0; xnu0[TT + tid] = 0.f; xnu0s[tid] = 0.f;
-        curX[tid] = 0.f; curX[TT + tid] = 0.f; curXwin[tid] = 0.f; spfin[tid] = 0;
+        curX[tid] = 0.f; curX[TT + tid] = 0.f; curXwin[tid] = 0.f;
+        spfin[tid] = (mine && last_s) ? 1 : 0;                // the pair's final Ae spike of the step before the run, for its Ai thread
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -396,7 +397,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
     }
     lds_barrier();                                            // (digest buffer 0 is refilled at the end of the first iteration)
-    bool sp_prev = last_s;                                    // tile thread: final Ae spike of this pair at the previous step
+    bool sp_prev = false;                                     // tile thread: final Ae spike of this pair at the previous step
     bool crossed_prev = false;                                // ... and its crossing
     unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
     int published = 0;                                        // steps this (tile) wave has published
@@ -416,34 +417,14 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         unsigned long long pre_w = 0ull;
         const bool have_pre = phaseB && t >= 2 && wave < NTW;
         if (have_pre) pre_w = granule_load(c.wing + (size_t)((t - 2) & (kWinRing - 1)) * kWinGr);
-        if (t + 2 <= T) DIGEST_LOAD(t + 2);                               // digest entry t+2 -> registers (into LDS at the end of the iteration)
-        // ---- tile waves, in front of A
-        if (wave < NTW) {
-            if (t >= 1) sp_prev = false;
-            if (t >= 1 && prevE != 0ull && !bad) {
-                const int jw = sample_winner(c, w0, t - 1, min(bl, B - 1), bad);
-                const bool sp = crossed_prev && jw == j && bl < B && colv;
-                if (sp) {
-                    // the pair won step t-1: its trace of that step, and x_tgt*nu0 of step t, with the spike in
-                    if (pE.traces) {
-                        x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                        if (phaseB) xnu0[par * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-                    }
-                    atomicOr(&colmask[jj], 1u << bl);
-                    last_s = true; sp_prev = true;
-                }
-            }
-            spfin[tid] = sp_prev ? 1 : 0;
-            if (bad) ctl[0] = 1;
-        }
-        AMARK(1);
-        lds_barrier();                                                    // ---- A
-        AMARK(2);
-        if (ctl[0]) { bad = true; break; }
+        // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
+        // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
+        if (t + 2 <= T && wave >= NTW) DIGEST_LOAD(t + 2);
+        if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
         if (learn_pp) {
 #pragma unroll
-            for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[q]) != 0 ? 1u : 0u) << q;
+            for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
         }
         if (!phaseB) {                                                    // behind the last step: only its winners' columns are left to commit
             if (wonm)
@@ -493,6 +474,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             }
             if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            if (t + 2 <= T) DIGEST_LOAD(t + 2);
             AMARK(8);
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
             published = t + 1;
@@ -569,7 +551,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         }
         lds_barrier();                                                    // ---- M
         AMARK(4);
-        if (tid < CW) { colmask[tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
+        if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
         // ---- a workgroup that crossed at step t prepares the won branch of its crossing columns: their X-trace values first
         //      (global memory; they arrive while the X currents are computed)
         uint32_t xq[CW];
@@ -662,8 +644,29 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         AMARK(6);
+        // ---- tile waves: which of the own crossings of step t won -- only a wave that had one waits for the arbiter.  A winner redoes
+        //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
+        if (wave < NTW) {
+            sp_prev = false;
+            if (prevE != 0ull && !bad) {
+                const int jw = sample_winner(c, w0, t, min(bl, B - 1), bad);
+                const bool sp = crossed_prev && jw == j && bl < B && colv;
+                if (sp) {
+                    if (pE.traces) {
+                        x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                        if (t + 1 < T) xnu0[(par ^ 1) * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
+                    }
+                    atomicOr(&colmask[(par ^ 1) * CW + jj], 1u << bl);
+                    last_s = true; sp_prev = true;
+                }
+            }
+            spfin[tid] = sp_prev ? 1 : 0;
+            if (bad) ctl[0] = 1;
+        }
+        AMARK(1);
         if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
         lds_barrier();                                                    // ---- B
+        AMARK(2);
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
     if (bad && wave < NTW && published <= T - 1 && lane == 0)
