@@ -161,27 +161,45 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 }
 
 // Winner column of sample `myb` at step e (-1: none) from the arbiter's granules; every lane of the wave polls the same words.
-// e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.
-__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad, bool have_pre = false,
-                                             unsigned long long pre = 0ull) {
+// e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.  The first TWO granules (six
+// winners: all of them in 97 % of the steps at cfg2) are asked for together -- a second round trip only beyond that --, and the
+// caller may have loaded them earlier (pre: valid if the tag is).
+struct WinPre { unsigned long long g0, g1; bool have; };
+__device__ __forceinline__ WinPre win_prefetch(const DcCtx &c, int e) {
+    const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
+    WinPre p; p.g0 = granule_load(gr); p.g1 = granule_load(gr + 1); p.have = true;
+    return p;
+}
+__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad, WinPre pre = WinPre{0ull, 0ull, false}) {
     if (e < 0) return w0[(e == -1 ? 0 : MAXB) + myb];
     const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
     const uint32_t tag = win_tag(e);
-    int res = -1, nw = 0;
-    for (int k = 0; k == 0 || 3 * k < nw; ++k) {
-        unsigned long long x = 0;
-        for (unsigned spins = 0;; ++spins) {
-            x = (k == 0 && have_pre && spins == 0) ? pre : granule_load(gr + k);   // (a first granule the caller loaded earlier: valid if its tag is)
-            if ((uint32_t)(x >> 54) == tag) break;
-            if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (k == 0) { nw = (int)((x >> 48) & 63u); if (nw == 63) { bad = true; return -1; } }
+    unsigned long long x0, x1;
+    if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
+    for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
+        if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+        __builtin_amdgcn_s_sleep(1);
+        x0 = granule_load(gr); x1 = granule_load(gr + 1);
+    }
+    const int nw = (int)((x0 >> 48) & 63u);
+    if (nw == 63) { bad = true; return -1; }
+    int res = -1;
+    auto entries = [&](unsigned long long x) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const uint32_t w = (uint32_t)(x >> (16 * u)) & 0xFFFFu;
             if (w != 0xFFFFu && (int)(w >> 11) == myb) res = (int)(w & 0x7FFu);
         }
+    };
+    entries(x0);
+    for (int k = 1; 3 * k < nw; ++k) {
+        unsigned long long x = k == 1 ? x1 : granule_load(gr + k);
+        for (unsigned spins = 0; (uint32_t)(x >> 54) != tag; ++spins) {
+            if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+            __builtin_amdgcn_s_sleep(1);
+            x = granule_load(gr + k);
+        }
+        entries(x);
     }
     return res;
 }
@@ -401,6 +419,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     bool crossed_prev = false;                                // ... and its crossing
     unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
     int published = 0;                                        // steps this (tile) wave has published
+    WinPre pre_w = WinPre{0ull, 0ull, false};                 // tile waves: winners granules asked for ahead of their use
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
 
     for (int t = 0; t <= T; ++t) {
@@ -413,10 +432,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const bool do_stdp = phaseB && learn_pp;
         const bool full = t == 0;                                         // the first update of a run clamps every element
         AMARK(0);
-        // the first winners granule of step t-2 (the membrane stage wants it): on its way while the front of the iteration runs
-        unsigned long long pre_w = 0ull;
-        const bool have_pre = phaseB && t >= 2 && wave < NTW;
-        if (have_pre) pre_w = granule_load(c.wing + (size_t)((t - 2) & (kWinRing - 1)) * kWinGr);
+        // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
         if (t + 2 <= T && wave >= NTW) DIGEST_LOAD(t + 2);
@@ -443,7 +459,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             // ---- Ae membrane update of step t, publish its crossings
             float cx = 0.f;
             if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
-            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, have_pre, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
+            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
             AMARK(7);
             bool spE = false;
             if (mine) {
@@ -648,6 +664,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
         if (wave < NTW) {
             sp_prev = false;
+            // the winners of step t-1, for the membrane stage of the next iteration: asked for now, used behind barrier B
+            pre_w.have = false;
+            if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1);
             if (prevE != 0ull && !bad) {
                 const int jw = sample_winner(c, w0, t, min(bl, B - 1), bad);
                 const bool sp = crossed_prev && jw == j && bl < B && colv;
