@@ -74,7 +74,7 @@ def build_network(device):
 def pmc_traffic(plan):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
     command (profiles/*_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
-    names = {"dc2015-resident-lean": ["r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
+    names = {"dc2015-resident-lean": ["r04_lean_pmc_hbm_traffic.json", "r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
              "dc2015-resident": ["r01_resident_pmc_hbm_traffic.json"], "dc2015-fused": ["r01_pmc_hbm_traffic.json"]}.get(plan, [])
     for name in names:
         path = os.path.join(ROOT, "profiles", name)

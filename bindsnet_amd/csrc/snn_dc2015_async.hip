@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 
 constexpr int AT = MAXB * ACW;         // tile threads
 constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
                  OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 32, OC_COLRES = OC_COLX + 32,
-                 OC_XWINV = OC_COLRES + 16, OC_W0 = OC_XWINV + 16 + 16, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
+                 OC_XWINV = OC_COLRES + 16, OC_XCNT = OC_XWINV + 16 + 16, OC_W0 = OC_XCNT + 2 * MAXB * 4, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
 size_t async_compute_lds(int B, int Nin, int N) {
@@ -328,6 +328,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity
     uint32_t *colres = (uint32_t *)(smem + OC_COLRES);       // [CW] slow columns: their winners of this step
     float *xwinv = (float *)(smem + OC_XWINV);               // [CW] x_tgt*nu0 of the crossing pair of column q if it wins
+    int *xcnt = (int *)(smem + OC_XCNT);                     // [NTW][MAXB] a crossing tile wave's own count of the step's crossings per sample
     int *w0 = (int *)(smem + OC_W0), *cnt0 = (int *)(smem + OC_C0);
     float *wtile = (float *)(smem + OC_WT);                  // [Nin][CW] learned weights
     float *wieT = wtile + (size_t)Nin * CW;
@@ -668,8 +669,55 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             pre_w.have = false;
             if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1);
             if (prevE != 0ull && !bad) {
-                const int jw = sample_winner(c, w0, t, min(bl, B - 1), bad);
-                const bool sp = crossed_prev && jw == j && bl < B && colv;
+                // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
+                // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
+                // instead of two.  Only a sample with several crossings waits for the arbiter's draw comparison.
+                int *xc = xcnt + wave * MAXB;
+                if (lane < MAXB) xc[lane] = 0;
+                {
+                    constexpr int PG = 8;                                 // granules per lane: NGS <= 512
+                    const unsigned long long *sums = c.exs + (size_t)(t & (kCrossRing - 1)) * NGS;
+                    unsigned long long xs[PG];
+                    uint32_t need = 0;
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+                    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                        for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
+#pragma unroll
+                        for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(t + 1)) need &= ~(1u << u);
+                        if (!__any(need != 0u)) break;
+                        if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    bool ab = false;
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) {
+                        const int gi = lane + 64 * u;
+                        if (bad || gi >= NGS) continue;
+                        const uint32_t pay = (uint32_t)xs[u];
+                        if (!pay) continue;
+                        if (pay == kAbortPay) { ab = true; continue; }
+                        const int w = gi % NTW;
+                        if ((pay & 0xFFu) == 0xFFu) {                    // that tile wave sent bit granules (> 3 crossings): any of its samples may have one
+                            for (int bs = 0; bs < SPW; ++bs) if (w * SPW + bs < B) atomicAdd(&xc[w * SPW + bs], 2);
+                        } else {
+                            const int ne = (int)(pay >> 30);
+                            for (int e2 = 0; e2 < ne; ++e2) {
+                                const int bsm = w * SPW + (int)((pay >> (8 * e2)) & 0x3Fu) / CW;
+                                if (bsm < B) atomicAdd(&xc[bsm], 1);
+                            }
+                        }
+                    }
+                    if (__any(ab)) bad = true;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int mycnt = (crossed_prev && bl < B) ? xc[bl] : 0;
+                int jw = (crossed_prev && mycnt == 1) ? j : -1;
+                if (!bad && __any(crossed_prev && mycnt > 1)) {
+                    const int ja = sample_winner(c, w0, t, min(bl, B - 1), bad);
+                    if (mycnt > 1) jw = ja;
+                }
+                const bool sp = !bad && crossed_prev && jw == j && bl < B && colv;
                 if (sp) {
                     if (pE.traces) {
                         x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);

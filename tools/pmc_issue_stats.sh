@@ -11,7 +11,7 @@ R=os.environ['GRAFT_REPO_ROOT']
 acc=collections.defaultdict(list)
 for path in glob.glob(R+'/gpurun_out/pmcx/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(path)):
-        if 'k_dc2015_spec' in row['Kernel_Name']:
+        if 'k_dc2015_async' in row['Kernel_Name']:
             acc[row['Counter_Name']].append(float(row['Counter_Value']))
 for k,v in sorted(acc.items()):
     print(k, sum(v)/len(v), len(v))

@@ -7,7 +7,7 @@ import os
 import shutil
 import sys
 
-KERNEL = "k_dc2015_spec"     # the default plan's kernel (second-generation lean form; first generation: k_dc2015_run)
+KERNEL = "k_dc2015_async"    # the default plan's kernel (third-generation lean form; second: k_dc2015_spec, first: k_dc2015_run)
 T, ALGO_PER_STEP = 250, 5_860_480          # bench.py: timesteps per launch, SURVEY 8(d) bytes per timestep (cfg2)
 
 

@@ -10,8 +10,8 @@ import sys
 
 # config -> (kernel name fragment, timesteps per launch, algorithmic bytes per timestep [SURVEY 8(d)])
 CFG = {
-    "cfg1": ("k_dc2015_spec", 250, 1_030_000),
-    "cfg2": ("k_dc2015_spec", 250, 5_860_480),
+    "cfg1": ("k_dc2015_async", 250, 1_030_000),
+    "cfg2": ("k_dc2015_async", 250, 5_860_480),
     "cfg3_shard": ("k_two_run", 100, 4 * 3 * 784 * 1600 + 16 * (784 * 10 + 1600 * 26)),
     "cfg3_b32": ("k_two_run", 100, 4 * 3 * 784 * 1600 + 32 * (784 * 10 + 1600 * 26)),
     "cfg3": ("k_two_run", 100, 21_400_000),
