@@ -423,6 +423,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     WinPre pre_w = WinPre{0ull, 0ull, false};                 // tile waves: winners granules asked for ahead of their use
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
 
+    if constexpr (TIMING) {      // where this workgroup runs: XCC_ID, HW_ID (wave / simd / cu / sh / se) -> the row behind the last step
+        if (c.dbg && tid == 0) {
+            c.dbg[(size_t)24 * (T + 1) + ((size_t)T * 256 + g) * 4 + 2] = (long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF);
+            c.dbg[(size_t)24 * (T + 1) + ((size_t)T * 256 + g) * 4 + 3] = (long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);
+        }
+    }
     for (int t = 0; t <= T; ++t) {
         const bool phaseB = t < T;
         const int par = t & 1;
@@ -433,6 +439,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const bool do_stdp = phaseB && learn_pp;
         const bool full = t == 0;                                         // the first update of a run clamps every element
         AMARK(0);
+        if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
@@ -568,7 +575,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         }
         lds_barrier();                                                    // ---- M
         AMARK(4);
+        if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
         if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
+        // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
+        // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front
+        // of the digest's LDS stores, which wait for every outstanding load: 0.4 us per iteration, more on some workgroups)
+        if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1); }
         // ---- a workgroup that crossed at step t prepares the won branch of its crossing columns: their X-trace values first
         //      (global memory; they arrive while the X currents are computed)
         uint32_t xq[CW];
@@ -665,9 +677,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
         if (wave < NTW) {
             sp_prev = false;
-            // the winners of step t-1, for the membrane stage of the next iteration: asked for now, used behind barrier B
-            pre_w.have = false;
-            if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1);
             if (prevE != 0ull && !bad) {
                 // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
                 // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
