@@ -120,18 +120,35 @@ __device__ __forceinline__ float x_current4(const float *ws, const uint32_t *dg,
     const int nL = (int)((gq >> (GCB * pL)) & GM);
     const uint16_t *lx = lstX + pb * LX;
     int ix[8]; float wx[8];
+    // (no clamp to Nin - 1: the slots behind a sample's events hold 0 -- k_dc2015_prep fills the whole row -- and the slot index
+    //  stays inside the row)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ix[u] = min((int)lx[min(st + u, LX - 1)], Nin - 1);
+    for (int u = 0; u < 8; ++u) ix[u] = (int)lx[min(st + u, LX - 1)];
 #pragma unroll
     for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
-    CascadeFlat a; a.init();
+    // This lane's events all lie in ONE 256-position group of the cascade, so CascadeFlat's third level never closes on them and its
+    // result here is a1 + a0: the same additions in the same order with the (value-neutral: 0 + 0) group bookkeeping left out --
+    // block cb closes into a1 when the next event's 16-position block differs, then the event is added to a0.
+    float a0 = 0.f, a1 = 0.f;
+    int cb = -1;
+    const int nfull = Nin >> 4;
+    auto add = [&](int pos, float term) __attribute__((always_inline)) {
+        int blk = pos >> 4;
+        blk = blk < nfull ? blk : nfull;
+        const bool nb = blk != cb;
+        const float s1 = a1 + a0;
+        a1 = nb ? s1 : a1;
+        a0 = nb ? 0.f : a0;
+        cb = blk;
+        a0 += term;
+    };
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u], wx[u] * 1.0f, Nin);
+    for (int u = 0; u < 8; ++u) if (u < nL) add(ix[u], wx[u] * 1.0f);
     for (int u = 8; u < nL; ++u) {
         const int ii2 = (int)lx[st + u];
-        a.add(ii2, ws[ii2 * CW + pq] * 1.0f, Nin);
+        add(ii2, ws[ii2 * CW + pq] * 1.0f);
     }
-    const float G = a.a1 + a.a0;
+    const float G = a1 + a0;
     const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
     const int GL = (Nin >> 4) >> 4;
     const float Gs[4] = {G, G1, G2, G3};
