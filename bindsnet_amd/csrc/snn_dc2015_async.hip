@@ -75,7 +75,11 @@ size_t async_arbiter_lds(int B, int N) {
 
 // The X -> Ae part of the Ae current of (sample pb, column pq) from the X spikes in the digest `dg` and the weights ws[Nin][4], by
 // lane pL of the pair's four threads (k_dc2015_spec's x_current, statement for statement): the value, valid in lane pL == 0.
-__device__ __forceinline__ float x_current4(const float *ws, const uint32_t *dg, int B, int Nin, int pb, int pq, int pL, bool tailcol) {
+// DUAL: the same sum over a second weight array ws2 (the won branch of a crossing column) in the same pass -> out2: the event
+// lists are read once, only the weight reads and the additions double.
+template <bool DUAL>
+__device__ __forceinline__ float x_current4(const float *ws, const float *ws2, float &out2, const uint32_t *dg, int B, int Nin, int pb, int pq,
+                                            int pL, bool tailcol) {
     constexpr int CW = ACW;
     constexpr uint32_t GM = (1u << GCB) - 1u;
     const uint16_t *lstX = (const uint16_t *)dg;
@@ -90,76 +94,91 @@ __device__ __forceinline__ float x_current4(const float *ws, const uint32_t *dg,
         const int nL = (int)((gc >> (GCB * pL)) & GM);
         const uint16_t *l2 = lst2 + pb * LX;
         const int n4 = Nin >> 2;
-        int ix[8]; float wx[8];
+        int ix[8]; float wx[8], wy[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
-        CascadeFlat a; a.init();
+        for (int u = 0; u < 8; ++u) { wx[u] = ws[ix[u] * CW + pq]; wy[u] = DUAL ? ws2[ix[u] * CW + pq] : 0.f; }
+        CascadeFlat a, a2; a.init(); a2.init();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (u < nL) a.add(ix[u] >> 2, wx[u] * 1.0f, n4);
+        for (int u = 0; u < 8; ++u) if (u < nL) { a.add(ix[u] >> 2, wx[u] * 1.0f, n4); if (DUAL) a2.add(ix[u] >> 2, wy[u] * 1.0f, n4); }
         for (int u = 8; u < nL; ++u) {
             const int i = (int)l2[st + u];
             a.add(i >> 2, ws[i * CW + pq] * 1.0f, n4);
+            if (DUAL) a2.add(i >> 2, ws2[i * CW + pq] * 1.0f, n4);
         }
-        float v = a.finish(n4);
+        float v = a.finish(n4), vb = DUAL ? a2.finish(n4) : 0.f;
         if (pL == 0) {
             const int s4 = (int)(gc & GM) + (int)((gc >> GCB) & GM) + (int)((gc >> (2 * GCB)) & GM) + (int)((gc >> (3 * GCB)) & GM);
             const int n5 = (int)((gc >> (4 * GCB)) & GM);
             for (int u = 0; u < n5; ++u) {
                 const int i = (int)l2[s4 + u];
                 v += ws[i * CW + pq] * 1.0f;
+                if (DUAL) vb += ws2[i * CW + pq] * 1.0f;
             }
         }
         const float v1 = __shfl_down(v, 1, 4), v2 = __shfl_down(v, 2, 4), v3 = __shfl_down(v, 3, 4);
         const float e1 = ((v + v1) + v2) + v3;
+        if (DUAL) {
+            const float b1 = __shfl_down(vb, 1, 4), b2 = __shfl_down(vb, 2, 4), b3 = __shfl_down(vb, 3, 4);
+            out2 = 0.0f + (((vb + b1) + b2) + b3);
+        }
         return 0.0f + e1;
     }
     const uint32_t gq = gqn[pb];
     const int st = (pL > 0 ? (int)(gq & GM) : 0) + (pL > 1 ? (int)((gq >> GCB) & GM) : 0) + (pL > 2 ? (int)((gq >> (2 * GCB)) & GM) : 0);
     const int nL = (int)((gq >> (GCB * pL)) & GM);
     const uint16_t *lx = lstX + pb * LX;
-    int ix[8]; float wx[8];
+    int ix[8]; float wx[8], wy[8];
     // (no clamp to Nin - 1: the slots behind a sample's events hold 0 -- k_dc2015_prep fills the whole row -- and the slot index
     //  stays inside the row)
 #pragma unroll
     for (int u = 0; u < 8; ++u) ix[u] = (int)lx[min(st + u, LX - 1)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wx[u] = ws[ix[u] * CW + pq];
+    for (int u = 0; u < 8; ++u) { wx[u] = ws[ix[u] * CW + pq]; wy[u] = DUAL ? ws2[ix[u] * CW + pq] : 0.f; }
     // This lane's events all lie in ONE 256-position group of the cascade, so CascadeFlat's third level never closes on them and its
     // result here is a1 + a0: the same additions in the same order with the (value-neutral: 0 + 0) group bookkeeping left out --
     // block cb closes into a1 when the next event's 16-position block differs, then the event is added to a0.
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, c0_ = 0.f, c1_ = 0.f;
     int cb = -1;
     const int nfull = Nin >> 4;
-    auto add = [&](int pos, float term) __attribute__((always_inline)) {
+    auto add = [&](int pos, float term, float term2) __attribute__((always_inline)) {
         int blk = pos >> 4;
         blk = blk < nfull ? blk : nfull;
         const bool nb = blk != cb;
         const float s1 = a1 + a0;
         a1 = nb ? s1 : a1;
         a0 = nb ? 0.f : a0;
-        cb = blk;
         a0 += term;
+        if (DUAL) {
+            const float t1 = c1_ + c0_;
+            c1_ = nb ? t1 : c1_;
+            c0_ = nb ? 0.f : c0_;
+            c0_ += term2;
+        }
+        cb = blk;
     };
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (u < nL) add(ix[u], wx[u] * 1.0f);
+    for (int u = 0; u < 8; ++u) if (u < nL) add(ix[u], wx[u] * 1.0f, wy[u] * 1.0f);
     for (int u = 8; u < nL; ++u) {
         const int ii2 = (int)lx[st + u];
-        add(ii2, ws[ii2 * CW + pq] * 1.0f);
+        add(ii2, ws[ii2 * CW + pq] * 1.0f, DUAL ? ws2[ii2 * CW + pq] * 1.0f : 0.f);
     }
-    const float G = a1 + a0;
-    const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
     const int GL = (Nin >> 4) >> 4;
-    const float Gs[4] = {G, G1, G2, G3};
-    float A2 = 0.0f;
+    auto combine = [&](float G) __attribute__((always_inline)) -> float {
+        const float G1 = __shfl_down(G, 1, 4), G2 = __shfl_down(G, 2, 4), G3 = __shfl_down(G, 3, 4);
+        const float Gs[4] = {G, G1, G2, G3};
+        float A2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
-    float Gl = 0.0f;
+        for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
+        float Gl = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
-    const float res = ((0.0f + Gl) + A2) + 0.0f;
-    return 0.0f + res;
+        for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
+        const float res = ((0.0f + Gl) + A2) + 0.0f;
+        return 0.0f + res;
+    };
+    if (DUAL) out2 = combine(c1_ + c0_);
+    return combine(a1 + a0);
 }
 
 // Entry spikes of both layers (the step before the run): per sample the column of its Ae spike -> w0[b] (the "winners of step -1":
@@ -429,7 +448,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     // X -> Ae currents of step 0 (from the layer's spikes at entry, digest entry 0)
     for (int qt = tid; qt < B * CW * 4; qt += NT) {
         const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-        const float v = x_current4(wtile, dgbuf, B, Nin, pb, pq, pL, tailcol);
+        float unused = 0.f;
+        const float v = x_current4<false>(wtile, wtile, unused, dgbuf, B, Nin, pb, pq, pL, tailcol);
         if (pL == 0 && c0 + pq < N) curX[pb * CW + pq] = v;
     }
     lds_barrier();                                            // (digest buffer 0 is refilled at the end of the first iteration)
@@ -598,40 +618,33 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front
         // of the digest's LDS stores, which wait for every outstanding load: 0.4 us per iteration, more on some workgroups)
         if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1); }
-        // ---- a workgroup that crossed at step t prepares the won branch of its crossing columns: their X-trace values first
-        //      (global memory; they arrive while the X currents are computed)
+        // ---- a workgroup that crossed at step t prepares the WON BRANCH of its crossing columns while the arbiter works: each such column
+        //      as it is with its final spike(s) of step t, every row from the old weights.  First the rows this step's X spikes touch --
+        //      the only rows the X currents of step t+1 read --, then the currents of both branches in ONE pass, then (waves 2..7,
+        //      while the tile waves look after the resolution) the other rows.  A column with several crossing samples has no single
+        //      "it won" outcome: it waits for the winners of this step and is done exactly.
         uint32_t xq[CW];
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
         const float *xsrc = c.xtr + (size_t)(t + 1) * B * Nin;            // X trace after step t
-        float xv0[CW], xv1[CW];                                           // X trace of the crossing sample of column q at rows tid, tid + NT
+        const float *xn0 = xnu0 + par * TT;
+        uint32_t cmq[CW];
 #pragma unroll
-        for (int q = 0; q < CW; ++q) { xv0[q] = 0.f; xv1[q] = 0.f; }
+        for (int q = 0; q < CW; ++q) cmq[q] = crossed_wg ? xq[q] : 0u;
+        const int nact = !phaseB ? 0 : (full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]));
+        // one element of the won branch: row i of column q
+        auto won_elem = [&](int i, int q) __attribute__((always_inline)) {
+            const bool single = __popc(xq[q]) == 1;
+            const int bst = single ? __ffs(cmq[q]) - 1 : -1;
+            const uint32_t m = rowmask[i];
+            const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
+            wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xsrc[bst * Nin + i])
+                                      : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
+        };
         if (crossed_wg) {
-#pragma unroll
-            for (int q = 0; q < CW; ++q) {
-                if (__popc(xq[q]) != 1) continue;
-                const int bst = __ffs(xq[q]) - 1;
-                xv0[q] = xsrc[bst * Nin + min(tid, Nin - 1)];
-                xv1[q] = xsrc[bst * Nin + min(tid + NT, Nin - 1)];
-            }
-        }
-        // ---- X -> Ae currents of step t+1 ("nobody of this workgroup won step t"): four threads per (sample, column) pair
-        for (int qt = tid; qt < B * CW * 4; qt += NT) {
-            const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-            const float v = x_current4(wtile, dgn, B, Nin, pb, pq, pL, tailcol);
-            if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
-        }
-        AMARK(5);
-        if (crossed_wg) {
-            const float *xn0 = xnu0 + par * TT;
             const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
-            uint32_t cmq[CW];
-#pragma unroll
-            for (int q = 0; q < CW; ++q) cmq[q] = xq[q];
             if (slow) {
-                // a column with several crossing samples: no single "it won" outcome to prepare -- wait for the winners of this step
                 if (wave == 0) {
                     bool b2 = bad;
                     const int jw = b2 ? -1 : sample_winner(c, w0, t, min(lane, B - 1), b2);
@@ -655,38 +668,41 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
                 lds_barrier();                                            // ---- S2
             }
+            for (int k = tid; k < nact; k += NT) {                        // the rows the X currents of step t+1 read
+                const int i = full ? k : (int)arows[k];
 #pragma unroll
-            for (int q = 0; q < CW; ++q) {
-                if (!cmq[q] || c0 + q >= N) continue;
-                const bool single = __popc(xq[q]) == 1;
-                const int bst = single ? __ffs(cmq[q]) - 1 : -1;
-                const float xw = xwinv[q];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int i = tid + r * NT;
-                    if (i >= Nin) continue;
-                    const uint32_t m = rowmask[i];
-                    const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
-                    float wn;
-                    if (single) wn = postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, r == 0 ? xv0[q] : xv1[q]);
-                    else wn = postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
-                    wwin[i * CW + q] = wn;
-                }
-                for (int i = tid + 2 * NT; i < Nin; i += NT) {            // (Nin > 1024 never gets here: kept for completeness)
-                    const uint32_t m = rowmask[i];
-                    const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
-                    wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xw, xsrc, true, xsrc[bst * Nin + i])
-                                              : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
-                }
+                for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
             }
             lds_barrier();                                                // ---- P
-#pragma unroll
-            for (int q = 0; q < CW; ++q) {
-                if (!cmq[q] || c0 + q >= N) continue;
-                for (int qt = tid; qt < B * 4; qt += NT) {
-                    const float v = x_current4(wwin, dgn, B, Nin, qt >> 2, q, qt & 3, tailcol);
-                    if ((qt & 3) == 0) curXwin[(qt >> 2) * CW + q] = v;
+        }
+        // ---- X -> Ae currents of step t+1: four threads per (sample, column) pair; "nobody of this workgroup won step t" from wtile and,
+        //      for a workgroup that crossed, the won branch of its crossing columns from wwin in the same pass
+        if (crossed_wg) {
+            for (int qt = tid; qt < B * CW * 4; qt += NT) {
+                const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+                float vw = 0.f;
+                const float v = x_current4<true>(wtile, wwin, vw, dgn, B, Nin, pb, pq, pL, tailcol);
+                if (pL == 0 && c0 + pq < N) {
+                    curX[(par ^ 1) * TT + pb * CW + pq] = v;
+                    const uint32_t cj = pq == 0 ? cmq[0] : (pq == 1 ? cmq[1] : (pq == 2 ? cmq[2] : cmq[3]));
+                    if (cj) curXwin[pb * CW + pq] = vw;
                 }
+            }
+        } else {
+            for (int qt = tid; qt < B * CW * 4; qt += NT) {
+                const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
+                float unused = 0.f;
+                const float v = x_current4<false>(wtile, wtile, unused, dgn, B, Nin, pb, pq, pL, tailcol);
+                if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
+            }
+        }
+        AMARK(5);
+        if (crossed_wg && wave >= NTW && !full) {
+            // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
+            for (int i = tid - TT; i < Nin; i += NBC) {
+                if (rowmask[i] != 0) continue;
+#pragma unroll
+                for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
             }
         }
         AMARK(6);
