@@ -55,6 +55,17 @@ constexpr unsigned kAbortPay = 0xFFFFFFFEu;   // crossing-granule payload of a w
 
 __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 1023u; }
 
+// The kernel context for a RARELY taken path: the same struct through a pointer the compiler cannot see through, so that the fields
+// read through it are loaded where they are used (scalar loads from the kernel-argument segment) instead of being kept -- spilled --
+// in scalar registers across the whole step loop.
+// (DcCtx is the kernel's only argument: it sits at offset 0 of the kernel-argument segment; taking &c instead made the compiler keep a
+//  568-byte private copy.)
+__device__ __forceinline__ const DcCtx &cold(const DcCtx &) {
+    const __attribute__((address_space(4))) DcCtx *p = (const __attribute__((address_space(4))) DcCtx *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const DcCtx *)p;
+}
+
 // ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
 constexpr int AT = MAXB * ACW;         // tile threads
 constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
@@ -213,7 +224,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     unsigned long long x0, x1;
     if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
     for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
-        if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+        if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
         __builtin_amdgcn_s_sleep(1);
         x0 = granule_load(gr); x1 = granule_load(gr + 1);
     }
@@ -231,7 +242,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     for (int k = 1; 3 * k < nw; ++k) {
         unsigned long long x = k == 1 ? x1 : granule_load(gr + k);
         for (unsigned spins = 0; (uint32_t)(x >> 54) != tag; ++spins) {
-            if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+            if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
             __builtin_amdgcn_s_sleep(1);
             x = granule_load(gr + k);
         }
@@ -529,7 +540,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     const int sidx = lane / CW, b = wave * SPW + sidx;
                     const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull);
                     if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
-                        granule_store(c.ex + (size_t)slot * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                        granule_store(cold(c).ex + (size_t)slot * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     pay = 0xC0FFFFFFu;
                 }
@@ -557,7 +568,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 if (pE.traces) xwinv[jj] = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
             }
             if (bad) ctl[0] = 1;
-            if (mine && c.rasVE) (c.rasVE + (size_t)t * B * N)[kst] = r_v;
+            if (mine && c.rasVE) (cold(c).rasVE + (size_t)t * B * N)[kst] = r_v;
         } else if (wave >= NT / 64 - NTW) {
             // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
             //      weights diagonal); it must fire exactly when that spike was there -- what everybody's inhibition assumes
@@ -571,9 +582,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 if (pI.traces) x_cur = trace_next(x_cur, spIn, pI.trace_decay, pI.trace_scale, pI.traces_additive);
                 if (spIn != spA) {
                     ctl[0] = 1;
-                    if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (c.rasVI) (c.rasVI + (size_t)t * B * N)[kst] = r_v;
+                if (c.rasVI) (cold(c).rasVI + (size_t)t * B * N)[kst] = r_v;
             }
         }
         if (wave >= NTW && do_stdp) {
@@ -627,7 +638,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
-        const float *xsrc = c.xtr + (size_t)(t + 1) * B * Nin;            // X trace after step t
+        const float *xsrc = crossed_wg ? cold(c).xtr + (size_t)(t + 1) * B * Nin : nullptr;   // X trace after step t
         const float *xn0 = xnu0 + par * TT;
         uint32_t cmq[CW];
 #pragma unroll
@@ -729,7 +740,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
                         for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(t + 1)) need &= ~(1u << u);
                         if (!__any(need != 0u)) break;
-                        if (spins > kAPoll) { bad = true; if (c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     }
                     bool ab = false;
 #pragma unroll

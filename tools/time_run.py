@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from bindsnet_amd import _lib  # noqa: E402
 
+if os.environ.get("SNN_LIB_OVERRIDE"):          # A/B of two builds on one box (developer aid)
+    _lib.LIB_PATH = os.environ["SNN_LIB_OVERRIDE"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda", 0)
 net = bench.build_network(dev)
@@ -21,5 +23,5 @@ for k in range(6):
     net.run({"X": pool[k % len(pool)]}, time=bench.T)
     net.reset_state_variables()
 prof = _lib.profile_run(net, {"X": pool[0].clone()}, bench.T, repeats=n)
-print(f"flags {os.environ.get('SNN_DC_SPECFLAGS', '0')}: {prof['avg_ms'] * 1e3:.1f} us per launch over {prof['n']} launches, form {prof.get('resident_form')}, "
+print(f"{os.path.basename(_lib.LIB_PATH)} flags {os.environ.get('SNN_DC_SPECFLAGS', '0')}: {prof['avg_ms'] * 1e3:.1f} us per launch over {prof['n']} launches, form {prof.get('resident_form')}, "
       f"{1e3 * prof['avg_ms'] / bench.T:.3f} us per timestep")
