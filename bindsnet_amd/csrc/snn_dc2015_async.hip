@@ -394,7 +394,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     const bool mine = tid < TT && bl < B && colv;             // owns the Ae neuron of a pair
     const bool mine_i = is_ai && bl < B && colv;              // owns the Ai neuron of a pair
     const unsigned kst = (unsigned)(bl * N + j);
-    const int KB = c.KB, NG = c.G * KB, NGS = c.G * NTW;
+    const int NGS = c.G * NTW;
     // loop-invariant parameters: floats in vector registers (see vgpr())
     const snn_lif_params pE = vgpr_params(c.pE.lif), pI = vgpr_params(c.pI);
     const float theta_plus = vgpr(c.pE.theta_plus), theta_decay = vgpr(c.pE.theta_decay);
@@ -540,7 +540,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     const int sidx = lane / CW, b = wave * SPW + sidx;
                     const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull);
                     if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
-                        granule_store(cold(c).ex + (size_t)slot * NG + g * KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                        granule_store(cold(c).ex + (size_t)slot * (cold(c).G * cold(c).KB) + g * cold(c).KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     pay = 0xC0FFFFFFu;
                 }
@@ -729,7 +729,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 if (lane < MAXB) xc[lane] = 0;
                 {
                     constexpr int PG = 8;                                 // granules per lane: NGS <= 512
-                    const unsigned long long *sums = c.exs + (size_t)(t & (kCrossRing - 1)) * NGS;
+                    const unsigned long long *sums = cold(c).exs + (size_t)(t & (kCrossRing - 1)) * NGS;
                     unsigned long long xs[PG];
                     uint32_t need = 0;
 #pragma unroll
