@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
+LIB_PATH = os.environ.get("SNN_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libsnnhip.so")   # (developer switch: A/B of two builds)
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
 ABI_VERSION = 7
