@@ -80,3 +80,34 @@ def test_missing_arbiter_or_raster_writer_times_out_state_untouched(monkeypatch,
     monkeypatch.delenv("SNN_DC_TEST_STALL")
     net, plans = safety.run_cfg2_inputs(1)
     assert plans == ["dc2015-resident-lean"] and getattr(net, "resident_retries", 0) == 0 and form() == 3
+
+
+def test_no_spike_monitors_means_no_raster_writers():
+    """Without a spike monitor on Ae / Ai the launch has no raster-writer workgroups (and the arbiter nothing to wait for): state,
+    weights, theta and the generator position still equal the generic plan's."""
+    from bindsnet_amd.models import DiehlAndCook2015
+    N, B, T = 100, 16, 60
+    spikes = [synth.dense_spikes(4400 + r, (T, B, 784), 0.04) for r in range(2)]
+
+    def go(mode):
+        _lib.lib().snn_set_plan_mode(mode)
+        try:
+            torch.manual_seed(0)
+            net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+            net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(synth.uniform_f32(3, (784, N), 0.0, 0.6), 1.0)))
+            net.to("cuda")
+            out = []
+            for r in range(2):
+                torch.manual_seed(11 + r)
+                net.run({"X": torch.from_numpy(spikes[r]).view(T, B, 1, 28, 28).to("cuda")}, time=T)
+                out.append(dict(W=net.connections[("X", "Ae")].pipeline[0].value.cpu().numpy().copy(), theta=net.layers["Ae"].theta.cpu().numpy().copy(),
+                                vE=net.layers["Ae"].v.cpu().numpy().copy(), vI=net.layers["Ai"].v.cpu().numpy().copy(),
+                                sE=net.layers["Ae"].s.cpu().numpy().copy(), probe=torch.rand(3).numpy()))
+            return out, net.last_plan
+        finally:
+            _lib.lib().snn_set_plan_mode(0)
+    res, plan = go(0)
+    assert plan == "dc2015-resident-lean" and form() == 3
+    gen, _ = go(1)
+    assert float(np.abs(gen[1]["theta"]).sum()) > 0, "the run must have spiked"
+    dc.same(res, gen)
