@@ -33,8 +33,9 @@
 // flag).  Ring depths: a compute workgroup publishes step t+4 only after the winners of t+2 exist, i.e. after the arbiter has read
 // every granule of step t+2 >= t; the arbiter publishes step e+8 only after every raster writer has reported step e+2 done.
 //
-// State is written back only after the winners of the LAST step have arrived without an abort mark: by then no workgroup can give up
-// any more, so a launch that ends with SNN_ERR_RETRY / SNN_ERR_TIMEOUT has left every state tensor untouched, as before.
+// State is written back only behind the arbiter's COMMIT granule ("step T"): every step published without an abort mark, every raster
+// writer through its last step -- by then nobody can give up any more, so a launch that ends with SNN_ERR_RETRY / SNN_ERR_TIMEOUT has left
+// every state tensor (and the generator) untouched, as before.
 // Inputs the lean forms do not take (multi-valued spike bytes, > 63 events in a sample: k_dc2015_prep's tbad word), more than one
 // entry spike per sample, off-diagonal Ae -> Ai weights: refused up front / on first sight with SNN_ERR_RETRY.
 #include <limits.h>
@@ -791,11 +792,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
     if (bad && wave < NTW && published <= T - 1 && lane == 0)
         granule_store(c.exs + (size_t)(published & (kCrossRing - 1)) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(published + 1) << 32) | kAbortPay);
-    // ---- commit: the winners of the LAST step have arrived without an abort mark -> nobody can give up any more
+    // ---- commit: the arbiter's commit granule ("step T") has arrived -> every step was published without an abort mark and the raster
+    //      writers are through: nobody can give up any more
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 0 && !bad) {
         bool b2 = false;
-        (void)sample_winner(c, w0, T - 1, 0, b2);
+        (void)sample_winner(c, w0, T, 0, b2);
         if (!b2 && lane == 0) ctl[1] = 1;
     }
     __syncthreads();
@@ -1111,9 +1113,26 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 if (lane < 32) cntc[lane] = 0;
             }
         }
-        // ---- the generator as the reference leaves it (workgroup-wide copy of the launch: there is only this one)
-        if (!failed) {
-            if (wait_block(tb)) {
+        // ---- COMMIT.  Every step has been published without an abort mark, so no compute workgroup can give up any more; when the raster
+        //      writers have reported their last step too (none of them ran into a bounded poll) and the generator block the launch ends
+        //      in is there, the arbiter publishes the commit granule -- "step T": the tag, no winners -- and only behind it do the
+        //      compute workgroups write their state back and the arbiter the generator.  Whatever fails before that leaves an abort mark
+        //      instead: nobody writes anything.
+        if (!failed && e == T) {
+            bool late = false;
+            if (c.NRW > 0 && lane < c.NRW) {
+                for (unsigned spins = 0; __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T; ++spins) {
+                    if (spins > kAPoll) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (__any(late) || !wait_block(tb)) {
+                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish_abort(T);
+            } else {
+                if (lane == 0)
+                    granule_store(c.wing + (size_t)(T & (kWinRing - 1)) * kWinGr, ((unsigned long long)win_tag(T) << 54) | 0xFFFFFFFFFFFFull);
+                // the generator as the reference leaves it (the one copy of the launch)
                 snn_rng_state *wr = c.rng[0];
                 for (int k = lane; k < 624; k += 64) wr->mt[k] = mt[(tb & RMK) * 624 + k];
                 if (lane == 0) { wr->pos = pos; wr->consumed = consumed; }
