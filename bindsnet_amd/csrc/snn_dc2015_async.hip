@@ -255,7 +255,22 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
 // developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup per step, [T+1][24]; behind
 // them [T+1][256][4] per workgroup: [1] published, [2] own crossings; slot 255: the arbiter ([0] all granules seen, [1] winners out)
 #define AMARKW(k, th) do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == (th)) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } } while (0)
-#define AMARK(k) AMARKW(k, 0)
+// wave 0's marks are kept in registers and written once per iteration, behind barrier B: a store per mark sat in front of the next
+// vmcnt wait (the winners granules) and was measured as part of it
+#define AMARK(k) do { if constexpr (TIMING) { if (wave == 0) mk[k] = (long long)wall_clock64(); } } while (0)
+// (flushed behind the winners decode of the NEXT iteration: marks 0, 9, 10, 7 are that iteration's by then, the others the previous one's)
+#define AMARK_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 20; ++k_) { \
+        const bool early_ = k_ == 0 || k_ == 9 || k_ == 10 || k_ == 7 || k_ == 11 || k_ == 18; \
+        if (k_ != 3 && k_ != 17 && (early_ || t >= 1)) c.dbg[(size_t)(early_ ? t : t - 1) * 24 + k_] = mk[k_]; } } } } while (0)
+
+// developer aid (-DSNN_WHATIF=<k>, tools/r04_sensitivity.sh; never in the product build): a known delay (s_sleep 8 = 512 clocks) at
+// point k of the compute loop.  The change of the period per unit of delay is that point's weight on the path that bounds the period:
+// 1 = everything behind it waits for it, 0 = slack.  Results stay exact (a delay changes no value).
+#ifdef SNN_WHATIF
+#define WHATIF_DELAY(k) do { if (SNN_WHATIF == (k)) __builtin_amdgcn_s_sleep(8); } while (0)
+#else
+#define WHATIF_DELAY(k) do { } while (0)
+#endif
 
 // A loop-invariant float parameter into a VECTOR register: kernel arguments are uniform, so the compiler keeps them in scalar
 // registers -- of which the compute loop needs far more than the 102 a wave has: the first versions re-read 226 spilled scalars per
@@ -478,6 +493,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             c.dbg[(size_t)24 * (T + 1) + ((size_t)T * 256 + g) * 4 + 3] = (long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);
         }
     }
+    long long mk[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
+    (void)mk;
     for (int t = 0; t <= T; ++t) {
         const bool phaseB = t < T;
         const int par = t & 1;
@@ -488,17 +505,23 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const bool do_stdp = phaseB && learn_pp;
         const bool full = t == 0;                                         // the first update of a run clamps every element
         AMARK(0);
+#ifdef SNN_TIMING_SPLIT
+        // (developer build) what a wave still has in flight from the previous iteration: everything older than the winners prefetch, then the prefetch itself
+        if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); AMARK(11); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AMARK(18); }
+#endif
         if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
         if (t + 2 <= T && wave >= NTW) DIGEST_LOAD(t + 2);
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
+        AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
         if (learn_pp) {
 #pragma unroll
             for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
         }
+        AMARK(10);
         if (!phaseB) {                                                    // behind the last step: only its winners' columns are left to commit
             if (wonm)
                 for (int i = tid; i < Nin; i += NT) {
@@ -513,21 +536,29 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             break;
         }
         if (wave < NTW) {
+            WHATIF_DELAY(1);
             // ---- Ae membrane update of step t, publish its crossings
             float cx = 0.f;
             if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
+            if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) c.dbg[(size_t)t * 24 + 17] = !pre_w.have ? 2 : ((uint32_t)(pre_w.g0 >> 54) != win_tag(t - 2) ? 1 : 0); }
             const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
             AMARK(7);
+            AMARK_FLUSH();
             bool spE = false;
             if (mine) {
                 const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
                 const float curE = cx + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
                 if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[(par ^ 1) * CW + jj];
                 if (e_learning) r_th = r_th * theta_decay;
+#if defined(SNN_WHATIF) && SNN_WHATIF == 22
+                { float sv = r_v, sr = r_r; asm volatile("" : "+v"(sv), "+v"(sr)); const bool s0 = dc_update(sv, sr, curE, pE.thresh + r_th, pE);
+                  if (s0 && sv == 1.2345e30f) r_v = sv; asm volatile("" ::: "memory"); }
+#endif
                 spE = dc_update(r_v, r_r, curE, pE.thresh + r_th, pE);
                 if (spE) atomicAdd(&thc[par * CW + jj], 1);
             }
             const uint64_t mE = __ballot(spE);
+            AMARK(12);
             const int slot = t & (kCrossRing - 1);
             uint32_t pay;
             if (bad) pay = kAbortPay;
@@ -546,7 +577,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     pay = 0xC0FFFFFFu;
                 }
             }
+            WHATIF_DELAY(2);
             if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            WHATIF_DELAY(3);
             if (t + 2 <= T) DIGEST_LOAD(t + 2);
             AMARK(8);
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
@@ -573,6 +606,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         } else if (wave >= NT / 64 - NTW) {
             // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
             //      weights diagonal); it must fire exactly when that spike was there -- what everybody's inhibition assumes
+            WHATIF_DELAY(8);
             if (mine_i) {
                 const bool spA = spfin[ptile] != 0;
                 const float e3 = spA ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;
@@ -589,6 +623,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         if (wave >= NTW && do_stdp) {
+            WHATIF_DELAY(4);
             // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
             //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
             //      (the Ai waves join behind their own update: rows beyond the 256 of waves 2..5)
@@ -622,8 +657,10 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             AMARKW(3, TT);
         }
+        AMARK(13);
         lds_barrier();                                                    // ---- M
         AMARK(4);
+        WHATIF_DELAY(5);
         if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
         if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
@@ -646,6 +683,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         for (int q = 0; q < CW; ++q) cmq[q] = crossed_wg ? xq[q] : 0u;
         const int nact = !phaseB ? 0 : (full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]));
         // one element of the won branch: row i of column q
+        AMARK(14);
         auto won_elem = [&](int i, int q) __attribute__((always_inline)) {
             const bool single = __popc(xq[q]) == 1;
             const int bst = single ? __ffs(cmq[q]) - 1 : -1;
@@ -655,6 +693,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                                       : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
         };
         if (crossed_wg) {
+            WHATIF_DELAY(10);
             const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
             if (slow) {
                 if (wave == 0) {
@@ -687,6 +726,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
             lds_barrier();                                                // ---- P
         }
+        AMARK(15);
         // ---- X -> Ae currents of step t+1: four threads per (sample, column) pair; "nobody of this workgroup won step t" from wtile and,
         //      for a workgroup that crossed, the won branch of its crossing columns from wwin in the same pass
         if (crossed_wg) {
@@ -709,6 +749,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         AMARK(5);
+        WHATIF_DELAY(6);
         if (crossed_wg && wave >= NTW && !full) {
             // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
             for (int i = tid - TT; i < Nin; i += NBC) {
@@ -727,6 +768,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
                 // instead of two.  Only a sample with several crossings waits for the arbiter's draw comparison.
                 int *xc = xcnt + wave * MAXB;
+                WHATIF_DELAY(11);
                 if (lane < MAXB) xc[lane] = 0;
                 {
                     constexpr int PG = 8;                                 // granules per lane: NGS <= 512
@@ -785,8 +827,17 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             if (bad) ctl[0] = 1;
         }
         AMARK(1);
+        WHATIF_DELAY(7);
         if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+#if defined(SNN_WHATIF) && SNN_WHATIF == 20
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 2 <= T) DIGEST_STORE(t + 2);
+#endif
+        AMARK(16);
         lds_barrier();                                                    // ---- B
+#if defined(SNN_WHATIF) && SNN_WHATIF == 19
+        lds_barrier(); lds_barrier();
+#endif
         AMARK(2);
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
@@ -982,6 +1033,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             const unsigned long long *sums = c.exs + (size_t)slot * NGS;
             const unsigned long long *exr = c.ex + (size_t)slot * NG;
             bool abortseen = false;
+            WHATIF_DELAY(12);
             // ---- every crossing granule of step e: lane l takes granules l, l + 64, ... (all its loads in flight at once, the missing
             //      ones asked for again), then decodes them into bit words / per-sample count / a crossing column
             int rp = INT_MAX;                                             // raster writers' progress, read early (used at publish time)
