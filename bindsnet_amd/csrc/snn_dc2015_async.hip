@@ -212,6 +212,9 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 // e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.  The first TWO granules (six
 // winners: all of them in 97 % of the steps at cfg2) are asked for together -- a second round trip only beyond that --, and the
 // caller may have loaded them earlier (pre: valid if the tag is).
+#ifndef SNN_WPOLL_SLEEP
+#define SNN_WPOLL_SLEEP 1              // s_sleep between two polls of the winners granules (developer builds vary it: profiles/r04_async_sensitivity.txt)
+#endif
 struct WinPre { unsigned long long g0, g1; bool have; };
 __device__ __forceinline__ WinPre win_prefetch(const DcCtx &c, int e) {
     const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
@@ -226,7 +229,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
     for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
         if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SNN_WPOLL_SLEEP);
         x0 = granule_load(gr); x1 = granule_load(gr + 1);
     }
     const int nw = (int)((x0 >> 48) & 63u);
