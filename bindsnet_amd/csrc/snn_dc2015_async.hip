@@ -262,7 +262,10 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
 // vmcnt wait (the winners granules) and was measured as part of it
 #define AMARK(k) do { if constexpr (TIMING) { if (wave == 0) mk[k] = (long long)wall_clock64(); } } while (0)
 // (flushed behind the winners decode of the NEXT iteration: marks 0, 9, 10, 7 are that iteration's by then, the others the previous one's)
-#define AMARK_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 20; ++k_) { \
+// wave 2 (a PostPre wave: the won branch's rows, no resolution) keeps five marks of its own, slots 19..23, written at the top of the next iteration
+#define AMARK2(k) do { if constexpr (TIMING) { if (wave == 2) mk[k] = (long long)wall_clock64(); } } while (0)
+#define AMARK2_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 128 && t >= 1) { _Pragma("unroll") for (int k_ = 19; k_ < 24; ++k_) c.dbg[(size_t)(t - 1) * 24 + k_] = mk[k_]; } } } while (0)
+#define AMARK_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 19; ++k_) { \
         const bool early_ = k_ == 0 || k_ == 9 || k_ == 10 || k_ == 7 || k_ == 11 || k_ == 18; \
         if (k_ != 3 && k_ != 17 && (early_ || t >= 1)) c.dbg[(size_t)(early_ ? t : t - 1) * 24 + k_] = mk[k_]; } } } } while (0)
 
@@ -496,7 +499,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             c.dbg[(size_t)24 * (T + 1) + ((size_t)T * 256 + g) * 4 + 3] = (long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFFF);
         }
     }
-    long long mk[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
+    long long mk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
     (void)mk;
     for (int t = 0; t <= T; ++t) {
         const bool phaseB = t < T;
@@ -508,6 +511,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const bool do_stdp = phaseB && learn_pp;
         const bool full = t == 0;                                         // the first update of a run clamps every element
         AMARK(0);
+        AMARK2_FLUSH();
 #ifdef SNN_TIMING_SPLIT
         // (developer build) what a wave still has in flight from the previous iteration: everything older than the winners prefetch, then the prefetch itself
         if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); AMARK(11); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AMARK(18); }
@@ -687,6 +691,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const int nact = !phaseB ? 0 : (full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]));
         // one element of the won branch: row i of column q
         AMARK(14);
+        AMARK2(19);
         auto won_elem = [&](int i, int q) __attribute__((always_inline)) {
             const bool single = __popc(xq[q]) == 1;
             const int bst = single ? __ffs(cmq[q]) - 1 : -1;
@@ -727,6 +732,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
                 for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
             }
+            AMARK2(20);
             lds_barrier();                                                // ---- P
         }
         AMARK(15);
@@ -752,6 +758,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         AMARK(5);
+        AMARK2(21);
         WHATIF_DELAY(6);
         if (crossed_wg && wave >= NTW && !full) {
             // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
@@ -762,6 +769,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         AMARK(6);
+        AMARK2(22);
         // ---- tile waves: which of the own crossings of step t won -- only a wave that had one waits for the arbiter.  A winner redoes
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
         if (wave < NTW) {
@@ -837,6 +845,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         if (t + 2 <= T) DIGEST_STORE(t + 2);
 #endif
         AMARK(16);
+        AMARK2(23);
         lds_barrier();                                                    // ---- B
 #if defined(SNN_WHATIF) && SNN_WHATIF == 19
         lds_barrier(); lds_barrier();

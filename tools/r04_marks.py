@@ -29,5 +29,19 @@ for label, sel in (("plain", plain), ("crossing", ~plain)):
     for k, v in zip(order, m[:-1]):
         print(f"  {names[k]:32s} {v:6.2f}  (+{v - prev:.2f})")
         prev = v
+w2 = {19: "wave 2: crossing state read", 20: "wave 2: touched rows done (at P)", 21: "wave 2: current pass done", 22: "wave 2: untouched rows done", 23: "wave 2: digest stored (at B)"}
+rows2 = []
+for t in range(3, T - 2):
+    r = h[t]
+    if r[0] == 0 or r[23] == 0:
+        continue
+    rows2.append([(r[k] - r[0]) / 100.0 if r[k] else np.nan for k in sorted(w2)])
+if rows2:
+    a2 = np.array(rows2)
+    sel = ~(a2[:, 1] > a2[:, 0])                                 # mark 20 is written by a crossing workgroup only: older than mark 19 = plain
+    for label, ss in (("plain", sel), ("crossing", ~sel)):
+        if ss.sum():
+            m2 = np.nanmean(a2[ss], 0)
+            print(f"--- wave 2, {label} iterations ({ss.sum()}; us from wave 0's iteration start): " + ", ".join(f"{w2[k].split(': ')[1]} {v:.2f}" for k, v in zip(sorted(w2), m2)))
 st = h[3:T - 1, 17]
 print("winners prefetch at use: fresh %d, stale %d, none %d" % ((st == 0).sum(), (st == 1).sum(), (st == 2).sum()))
