@@ -35,6 +35,9 @@ for seed in range(first, first + n):
     shape = {784: (1, 28, 28), 400: (1, 20, 20), 1024: (1, 32, 32), 196: (1, 14, 14)}[Nin]
     spikes = [synth.dense_spikes(700 + 13 * seed + r, (T, B, Nin), dens) for r in range(3)]
     kw = dict(w_scale=wsc, n_inputs=3, learning=True, Nin=Nin, shape=shape, inh=inh, additive=additive, exc=exc)
+    if seed >= 1000:                                             # second family: learning off now and then, one-sided / larger learning rates
+        kw["learning"] = bool(rs.rand() < 0.85)
+        kw["nu"] = [(1e-4, 1e-2), (1e-4, 1e-2), (0.0, 1e-2), (1e-3, 0.0), (5e-4, 5e-2)][int(rs.randint(5))]
     res, plan = dc.run(0, N, B, T, spikes, **kw)
     form = _lib.lib().snn_dc2015_last_form()
     net = dc.run.last_net
@@ -49,7 +52,8 @@ for seed in range(first, first + n):
         print("MISMATCH:", str(e)[:300])
     forms[form] = forms.get(form, 0) + 1
     nsp = int(sum(r["sE"].sum() for r in res))
-    print(f"seed {seed}: N={N} B={B} T={T} Nin={Nin} dens={dens} w={wsc} inh={inh} exc={exc} additive={int(additive)} -> {plan} form {form} retries {retries} "
+    lrn, nu_ = int(kw["learning"]), kw.get("nu", (1e-4, 1e-2))
+    print(f"seed {seed}: N={N} B={B} T={T} Nin={Nin} dens={dens} w={wsc} inh={inh} exc={exc} additive={int(additive)} learning={lrn} nu={nu_} -> {plan} form {form} retries {retries} "
           f"Ae spikes {nsp} {'OK' if ok else 'DIFFERENT'}", flush=True)
 print(f"{n} cases, {bad} different, forms {forms}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
