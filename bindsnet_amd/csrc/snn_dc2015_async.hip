@@ -212,6 +212,24 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 // e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.  The first TWO granules (six
 // winners: all of them in 97 % of the steps at cfg2) are asked for together -- a second round trip only beyond that --, and the
 // caller may have loaded them earlier (pre: valid if the tag is).
+// SNN_DEFER (developer build, default off; tools/r05_defer_try.sh).  tools/r04_lateness.py: what bounds the period is the chain "a workgroup
+// that crossed at step t waits for the step's LAST publisher (all 200 crossing granules) before it can finish the iteration and publish step
+// t+1 -- and is then the last publisher of t+1 itself".  The membrane stage of step t+1 does not need the outcome of step t's arbitration
+// except through the X currents of the crossing columns, and both branches of those are prepared (curX / curXwin).  So in this build a
+// workgroup with an unresolved single-sample crossing enters iteration t+1 WITHOUT having resolved it: its tile waves update the pairs of the
+// crossing columns under both outcomes, publish step t+1 at once when both give the same crossings, THEN look at step t's granules, patch
+// trace / x_tgt*nu0 / won mask / final spike as the resolution at the end of iteration t does, and pick the state of the branch that
+// happened; waves 2..7 wait for that (barrier R) before PostPre and the Ai update of step t+1.  Columns with several crossing samples (which
+// wait for the arbiter's winners inside iteration t anyway) are resolved where they were.
+// MEASURED (round 4's last GPU minutes): bit-exact on the 41 D&C parity tests at the first run; the two outcomes gave the same crossings in
+// 665 of 665 deferred iterations -- and the run is 16 % SLOWER (1 103 vs 951 us): the workgroup still pays the wait for the step's last
+// publisher in its own time, one iteration later, and PostPre of that iteration no longer runs beside the membrane stage; the busiest
+// workgroups' own average iteration becomes the bound (profiles/r04_async_sensitivity.txt section 8).  Kept as the starting point of the
+// version that would help: carry BOTH branches of the crossing column (weights, currents, pairs) through further steps until the
+// resolution arrives, instead of waiting for it anywhere.
+#ifndef SNN_DEFER
+#define SNN_DEFER 0
+#endif
 #ifndef SNN_WPOLL_SLEEP
 #define SNN_WPOLL_SLEEP 1              // s_sleep between two polls of the winners granules (developer builds vary it: profiles/r04_async_sensitivity.txt)
 #endif
@@ -492,6 +510,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     int published = 0;                                        // steps this (tile) wave has published
     WinPre pre_w = WinPre{0ull, 0ull, false};                 // tile waves: winners granules asked for ahead of their use
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
+#if SNN_DEFER
+    bool pendwg = false;                                      // (uniform) the previous step's single-sample crossings of this workgroup are not resolved yet
+    bool pend = false;                                        // tile wave: it had one of them (it does the resolution)
+    uint32_t pendcols = 0;                                    // (uniform) the columns they are in
+#endif
 
     if constexpr (TIMING) {      // where this workgroup runs: XCC_ID, HW_ID (wave / simd / cu / sh / se) -> the row behind the last step
         if (c.dbg && tid == 0) {
@@ -524,6 +547,83 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
+#if SNN_DEFER
+        // ---- the resolution of step t-1, as the end of iteration t-1 did it (ts = t - 1; the parity it writes is this iteration's)
+        auto resolve_prev = [&]() __attribute__((always_inline)) {
+            const int ts = t - 1;
+            if (prevE == 0ull || bad) return;
+            int *xc = xcnt + wave * MAXB;
+            if (lane < MAXB) xc[lane] = 0;
+            {
+                constexpr int PG = 8;
+                const unsigned long long *sums = cold(c).exs + (size_t)(ts & (kCrossRing - 1)) * NGS;
+                unsigned long long xs[PG];
+                uint32_t need = 0;
+#pragma unroll
+                for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+                for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
+#pragma unroll
+                    for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(ts + 1)) need &= ~(1u << u);
+                    if (!__any(need != 0u)) break;
+                    if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                bool ab = false;
+#pragma unroll
+                for (int u = 0; u < PG; ++u) {
+                    const int gi = lane + 64 * u;
+                    if (bad || gi >= NGS) continue;
+                    const uint32_t pay = (uint32_t)xs[u];
+                    if (!pay) continue;
+                    if (pay == kAbortPay) { ab = true; continue; }
+                    const int w = gi % NTW;
+                    if ((pay & 0xFFu) == 0xFFu) {
+                        for (int bs = 0; bs < SPW; ++bs) if (w * SPW + bs < B) atomicAdd(&xc[w * SPW + bs], 2);
+                    } else {
+                        const int ne = (int)(pay >> 30);
+                        for (int e2 = 0; e2 < ne; ++e2) {
+                            const int bsm = w * SPW + (int)((pay >> (8 * e2)) & 0x3Fu) / CW;
+                            if (bsm < B) atomicAdd(&xc[bsm], 1);
+                        }
+                    }
+                }
+                if (__any(ab)) bad = true;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int mycnt = (crossed_prev && bl < B) ? xc[bl] : 0;
+            int jw = (crossed_prev && mycnt == 1) ? j : -1;
+            if (!bad && __any(crossed_prev && mycnt > 1)) {
+                const int ja = sample_winner(c, w0, ts, min(bl, B - 1), bad);
+                if (mycnt > 1) jw = ja;
+            }
+            const bool sp = !bad && crossed_prev && jw == j && bl < B && colv;
+            if (sp) {
+                if (pE.traces) {
+                    x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                    if (ts + 1 < T) xnu0[par * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
+                }
+                atomicOr(&colmask[par * CW + jj], 1u << bl);
+                last_s = true; sp_prev = true;
+                spfin[tid] = 1;
+            }
+            if (bad) ctl[0] = 1;
+        };
+        auto read_wonm = [&]() __attribute__((always_inline)) {
+            uint32_t m = 0;
+            if (learn_pp) {
+#pragma unroll
+                for (int q = 0; q < CW; ++q) m |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
+            }
+            return m;
+        };
+        if (pendwg && !phaseB) {                                          // the last step's crossings: resolve, then commit as usual
+            if (wave < NTW && pend) resolve_prev();
+            lds_barrier();                                                // ---- R
+            pendwg = false; pend = false;
+        }
+        if (!pendwg)
+#endif
         if (learn_pp) {
 #pragma unroll
             for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
@@ -542,6 +642,82 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             break;
         }
+#if SNN_DEFER
+        if (pendwg && wave >= NTW) {                                      // waves 2..7: PostPre and the Ai update of step t want step t-1 resolved
+            lds_barrier();                                                // ---- R
+            wonm = read_wonm();
+        }
+        if (pendwg && wave < NTW) {
+            // ---- Ae membrane update of step t with step t-1's single-sample crossings unresolved: the pairs of those columns under both outcomes
+            const bool pc = learn_pp && ((pendcols >> jj) & 1u) != 0u;
+            float cxa = 0.f, cxb = 0.f;
+            if (mine) { cxa = curX[par * TT + bl * CW + jj]; cxb = pc ? curXwin[bl * CW + jj] : cxa; }
+            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, pre_w);
+            bool spA = false, spB = false;
+            float vb = r_v, rb = r_r;
+            if (mine) {
+                const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
+                const float curEa = cxa + e2, curEb = cxb + e2;
+                if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[(par ^ 1) * CW + jj];
+                if (e_learning) r_th = r_th * theta_decay;
+                spB = dc_update(vb, rb, curEb, pE.thresh + r_th, pE);
+                spA = dc_update(r_v, r_r, curEa, pE.thresh + r_th, pE);
+            }
+            const uint64_t mEa = __ballot(spA), mEb = __ballot(spB);
+            const bool agree = mEa == mEb;
+            if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = agree ? 2 : 1; }   // (slot 3 of a deferred iteration: did the outcomes agree)
+            auto publish = [&](uint64_t mEp) __attribute__((always_inline)) {
+                const int slot = t & (kCrossRing - 1);
+                uint32_t pay;
+                if (bad) pay = kAbortPay;
+                else {
+                    const int nev = __popcll(mEp);
+                    if (nev <= 3) {
+                        pay = (uint32_t)nev << 30;
+                        int sh = 0;
+                        for (uint64_t m = mEp; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
+                    } else {
+                        const int sidx = lane / CW, b = wave * SPW + sidx;
+                        const uint32_t v = (uint32_t)((mEp >> (sidx * CW)) & 0xFFFFull);
+                        if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
+                            granule_store(cold(c).ex + (size_t)slot * (cold(c).G * cold(c).KB) + g * cold(c).KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        pay = 0xC0FFFFFFu;
+                    }
+                }
+                if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
+            };
+            if (agree) publish(mEa);                                      // both outcomes give the same crossings: the step is out before the resolution
+            if (pend) resolve_prev();
+            lds_barrier();                                                // ---- R
+            wonm = read_wonm();
+            bool spE = spA;
+            if (pc && ((wonm >> jj) & 1u)) { r_v = vb; r_r = rb; spE = spB; }   // this column won step t-1: its won branch is what happened
+            const uint64_t mE = __ballot(spE);
+            if (!agree) publish(mE);
+            if (spE) atomicAdd(&thc[par * CW + jj], 1);
+            if (t + 2 <= T) DIGEST_LOAD(t + 2);
+            if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
+            published = t + 1;
+            prevE = mE; crossed_prev = spE;
+            if (bl < B) {
+                float xn = 0.f;
+                if (colv && pE.traces) {
+                    x_before = x_cur;
+                    x_cur = trace_next(x_before, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                    xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
+                }
+                xnu0[(par ^ 1) * TT + tid] = xn * pp.nu0;
+            }
+            if (mine) last_s = false;
+            if (spE) {
+                atomicOr(&colx[par * CW + jj], 1u << bl);
+                if (pE.traces) xwinv[jj] = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
+            }
+            if (bad) ctl[0] = 1;
+            if (mine && c.rasVE) (cold(c).rasVE + (size_t)t * B * N)[kst] = r_v;
+        } else
+#endif
         if (wave < NTW) {
             WHATIF_DELAY(1);
             // ---- Ae membrane update of step t, publish its crossings
@@ -668,6 +844,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         lds_barrier();                                                    // ---- M
         AMARK(4);
         WHATIF_DELAY(5);
+#if SNN_DEFER
+        if (!pendwg)
+#endif
         if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
         if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
@@ -683,6 +862,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
+#if SNN_DEFER
+        // crossings of this step in single-sample columns only: their resolution moves into the next iteration (behind its publish)
+        const bool defer_next = phaseB && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u &&
+                                __popc(xq[0]) <= 1 && __popc(xq[1]) <= 1 && __popc(xq[2]) <= 1 && __popc(xq[3]) <= 1;
+#endif
         const float *xsrc = crossed_wg ? cold(c).xtr + (size_t)(t + 1) * B * Nin : nullptr;   // X trace after step t
         const float *xn0 = xnu0 + par * TT;
         uint32_t cmq[CW];
@@ -774,6 +958,10 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
         if (wave < NTW) {
             sp_prev = false;
+#if SNN_DEFER
+            if (defer_next) { }                                            // (resolved behind the publish of step t+1: resolve_prev)
+            else
+#endif
             if (prevE != 0ull && !bad) {
                 // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
                 // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
@@ -837,6 +1025,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             spfin[tid] = sp_prev ? 1 : 0;
             if (bad) ctl[0] = 1;
         }
+#if SNN_DEFER
+        pendwg = defer_next;
+        pend = defer_next && wave < NTW && prevE != 0ull;
+        pendcols = defer_next ? ((xq[0] ? 1u : 0u) | (xq[1] ? 2u : 0u) | (xq[2] ? 4u : 0u) | (xq[3] ? 8u : 0u)) : 0u;
+#endif
         AMARK(1);
         WHATIF_DELAY(7);
         if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
