@@ -74,9 +74,26 @@ constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_
                  OC_XWINV = OC_COLRES + 16, OC_XCNT = OC_XWINV + 16 + 16, OC_W0 = OC_XCNT + 2 * MAXB * 4, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
+// SNN_LDS_XTRACE (developer build, default off; WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON AN MI355X).  The won branch of a crossing column
+// wants the X trace of the crossing sample, one value per row, and reads it from the [T+1][B][Nin] array the pre-pass leaves in global memory:
+// first touches of HBM / MALL, ~0.6 us each, one per row a thread does, and asking for them together was SLOWER on the device
+// (profiles/r04_async_sensitivity.txt sections 4, 6, 7).  A non-additive trace (nodes.py:96-103: x <- trace_scale on a spike, x * decay
+// otherwise) that entered the run as zero is a function of "steps since the input's last spike" alone: trace_scale multiplied k times by
+// the decay, one rounding each -- a table of T + 1 floats.  So this build keeps, per compute workgroup, the step of the last spike of every
+// (sample, input) in LDS (one byte each, written by PostPre's pass over the step's active rows, which holds the row's sample mask anyway) and
+// the table; the won branch's trace values come from two LDS reads, and the untouched rows take the all-reads-first form that
+// tools/probe_won_branch.hip measured at 0.45 us against 1.1.  Applies when the X trace is not additive, every entry trace is 0 (each
+// workgroup looks at the run's entry trace itself) and T <= 254; otherwise the global array is read as before (the pre-pass still runs).
+#ifndef SNN_LDS_XTRACE
+#define SNN_LDS_XTRACE 0
+#endif
 size_t async_compute_lds(int B, int Nin, int N) {
     const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
+#if SNN_LDS_XTRACE
+    return OC_WT + (size_t)3 * Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4 + (((size_t)B * Nin + 15) & ~(size_t)15) + 256 * 4;
+#else
     return OC_WT + (size_t)3 * Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4;
+#endif
 }
 // ---- ... of the arbiter: ctl[32] | cntc[32] | colc[32] | winlist[32] | keys[32] u64 | entry winners [2][32] | crs [B*NW] | mt ring
 constexpr size_t OA_CTL = 0, OA_CNT = 128, OA_COL = 256, OA_WL = 384, OA_KEY = 512, OA_CRS = 1280;
@@ -424,6 +441,10 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
     float *wbak = (float *)(dgbuf + 2 * DGS);                // [Nin][CW] rows PostPre touched: their weights before
     float *wwin = wbak + (size_t)Nin * CW;                   // [Nin][CW] column q: the whole column with its final spikes of this step
+#if SNN_LDS_XTRACE
+    uint8_t *tlast = (uint8_t *)(wwin + (size_t)Nin * CW);   // [B][Nin] step of the (sample, input)'s last spike in this run; 255 = none yet
+    float *pw = (float *)(tlast + (((size_t)c.B * Nin + 15) & ~(size_t)15));   // [256] trace_scale times the decay, k times (one rounding per step)
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)blockIdx.x, c0 = g * CW;
@@ -459,6 +480,14 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     if (tid < 2 * MAXB) multi0 = cnt0[tid] > 1;
     if (offdiag || multi0) ctl[0] = 1;                        // (benign race: everybody writes 1)
+#if SNN_LDS_XTRACE
+    {
+        bool nz = false;                                      // an entry trace that is not zero: its decay is not in the table
+        for (int k = tid; k < c.B * Nin; k += NT) { tlast[k] = 255; nz = nz || (c.xX[1][k] != 0.f); }
+        if (nz) ctl[3] = 1;                                   // (benign race)
+        if (tid == 0) { float x = c.x_scale; pw[0] = x; for (int k = 1; k < 256; ++k) { x = x * c.x_decay; pw[k] = x; } }
+    }
+#endif
     // The digest of a step travels global memory -> registers (at the top of an iteration) -> LDS (at its end): an LDS-DMA fetch
     // (global_load_lds) makes the compiler drain vmcnt in front of EVERY later LDS read of the issuing wave -- it cannot tell which
     // LDS bytes the transfer writes --, which put the transfer's whole latency in front of the step (0.6 us per iteration measured)
@@ -495,6 +524,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
+#if SNN_LDS_XTRACE
+    const bool use_tab = ctl[3] == 0 && !c.x_additive && c.x_traces && T <= 254;    // (uniform) the X trace from LDS: last-spike steps + table
+#endif
     if (bad && tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // X -> Ae currents of step 0 (from the layer's spikes at entry, digest entry 0)
     for (int qt = tid; qt < B * CW * 4; qt += NT) {
@@ -826,6 +858,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
                 *(float4 *)(wbak + i * 4) = v;
                 *(float4 *)(wtile + i * 4) = postpre_row_nowin(pp, v, m, xn0);
+#if SNN_LDS_XTRACE
+                if (use_tab) for (uint32_t mm = m; mm; mm &= mm - 1) tlast[(__ffs(mm) - 1) * Nin + i] = (uint8_t)t;   // input i spiked at step t in these samples
+#endif
             }
             if (wonm && !full)                                            // ... and the rows this step does not touch take the won column as it is
                 for (int i = ptid; i < Nin; i += NBC) {
@@ -881,8 +916,18 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             const int bst = single ? __ffs(cmq[q]) - 1 : -1;
             const uint32_t m = rowmask[i];
             const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
+#if SNN_LDS_XTRACE
+            float xval = 0.f;
+            if (single) {
+                if (use_tab) { const int tl = (int)tlast[bst * Nin + i]; xval = tl == 255 ? 0.f : pw[t - tl]; }
+                else xval = xsrc[bst * Nin + i];
+            }
+            wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xval)
+                                      : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
+#else
             wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xsrc[bst * Nin + i])
                                       : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
+#endif
         };
         if (crossed_wg) {
             WHATIF_DELAY(10);
@@ -946,7 +991,40 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         WHATIF_DELAY(6);
         if (crossed_wg && wave >= NTW && !full) {
             // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
+#if SNN_LDS_XTRACE
+            // A row nobody's X spike touched has no pre-synaptic term, and a column with ONE crossing sample has a one-term post-synaptic
+            // cascade (= 0 + the term): postpre_elem's statements for that case, every LDS read of the thread's first three rows (all of
+            // them up to Nin = 1152) issued before the first row is worked on (tools/probe_won_branch.hip, form F)
+            int ifirst = tid - TT;
+            if (use_tab && __popc(xq[0]) <= 1 && __popc(xq[1]) <= 1 && __popc(xq[2]) <= 1 && __popc(xq[3]) <= 1) {
+                // (named scalars, not arrays: an array indexed inside the unrolled column loop went to scratch)
+                const int r0 = tid - TT, r1 = r0 + NBC, r2 = r1 + NBC;
+                const int c0r = min(r0, Nin - 1), c1r = min(r1, Nin - 1), c2r = min(r2, Nin - 1);
+                const uint32_t m0 = r0 < Nin ? rowmask[c0r] : 1u, m1 = r1 < Nin ? rowmask[c1r] : 1u, m2 = r2 < Nin ? rowmask[c2r] : 1u;
+                auto fin = [&](int i, uint32_t mr, float w, int k, int q) __attribute__((always_inline)) {
+                    if (mr != 0) return;
+                    const float xv = k == 255 ? 0.f : pw[t - k];
+                    if (pp.nu0 != 0.f) { float uu = 0.f; if (pp.use_dt) uu = uu * pp.dt; w = w - uu; }
+                    if (pp.nu1 != 0.f) { float uu = 0.0f + xv * (1.0f * pp.nu1); if (pp.use_dt) uu = uu * pp.dt; w = w + uu; }
+                    if (pp.has_min && w < pp.wmin) w = pp.wmin;
+                    if (pp.has_max && w > pp.wmax) w = pp.wmax;
+                    wwin[i * CW + q] = w;
+                };
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    if (cmq[q] && c0 + q < N) {
+                        const uint8_t *tl = tlast + (size_t)(__ffs(cmq[q]) - 1) * Nin;
+                        const float wa = wtile[c0r * CW + q], wb = wtile[c1r * CW + q], wc = wtile[c2r * CW + q];
+                        const int ka = (int)tl[c0r], kb = (int)tl[c1r], kc = (int)tl[c2r];
+                        fin(r0, m0, wa, ka, q); fin(r1, m1, wb, kb, q); fin(r2, m2, wc, kc, q);
+                    }
+                }
+                ifirst = tid - TT + 3 * NBC;
+            }
+            for (int i = ifirst; i < Nin; i += NBC) {
+#else
             for (int i = tid - TT; i < Nin; i += NBC) {
+#endif
                 if (rowmask[i] != 0) continue;
 #pragma unroll
                 for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
