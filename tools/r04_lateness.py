@@ -19,43 +19,36 @@ v = slice(5, T - 3)
 P = np.diff(pub.max(1))[v].mean()
 med = np.median(pub, axis=1)
 late = pub - med[:, None]
-longit = d > np.median(d[v]) + 1.2                             # an interval with an own crossing in it
-print(f"period {P:.2f} us;  publish-to-publish: with an own crossing {d[v][longit[v]].mean():.2f} us ({100 * longit[v].mean():.1f} % of them, "
-      f"{100 * (longit[v].sum(1) > 0).mean():.0f} % of the steps have one), without {d[v][~longit[v]].mean():.2f}")
+longit = d > np.median(d[v]) + 1.2                             # a long interval: an own crossing in it, or the whole pack late
+print(f"period {P:.2f} us;  publish-to-publish intervals: long ones {d[v][longit[v]].mean():.2f} us ({100 * longit[v].mean():.1f} % of them), the others {d[v][~longit[v]].mean():.2f}")
 print(f"the pack (median publisher) publishes step t {np.mean(med[2:][v] - out[:-2][v]):.2f} us behind the winners of t-2;  arbiter: last publish -> seen "
       f"{np.mean((seen - pub.max(1))[v]):.2f}, -> winners out +{np.mean((out - seen)[v]):.2f};  the last publisher is {late.max(1)[v].mean():.2f} us behind the pack")
 print("   => 2 x period = (pack delay) + (lateness of the last publisher) + (arbiter): "
       f"{np.mean(med[2:][v] - out[:-2][v]):.2f} + {late.max(1)[v].mean():.2f} + {np.mean((out - pub.max(1))[v]):.2f} = "
       f"{np.mean(med[2:][v] - out[:-2][v]) + late.max(1)[v].mean() + np.mean((out - pub.max(1))[v]):.2f}")
 sh = ~longit
-print("interval without an own crossing, by the workgroup's lateness at its start (a late workgroup waits for nobody: its own iteration):")
+print("ordinary interval, by the workgroup's lateness at its start (a late workgroup waits for nobody: its own iteration):")
 for lo, hi in [(-9, -0.2), (-0.2, 0.2), (0.2, 1), (1, 2), (2, 3), (3, 9)]:
     m = sh & (late[:-1] >= lo) & (late[:-1] < hi)
     m[:5] = False
     m[T - 4:] = False
     if m.sum() > 20:
         print(f"   lateness [{lo:4.1f}, {hi:4.1f}): n = {m.sum():5d}   {d[m].mean():.2f} us")
-L = pub.argmax(1)
-n = c1 = c2 = 0
-chain = []
-for t in range(6, T - 3):
-    g = L[t]
-    n += 1
-    if longit[t - 1, g]:
-        c1 += 1
-        chain.append(pub[t, g] - pub[t - 1].max())
-    elif longit[t - 2, g]:
-        c2 += 1
-print(f"the last publisher of step t had its own crossing at t-1 in {100 * c1 / n:.0f} % of the steps (at t-2: {100 * c2 / n:.0f} %)")
-chain = np.array(chain)
-print(f"   then: its publish of t comes {chain.mean():.2f} us (10 / 50 / 90 %: {np.percentile(chain, [10, 50, 90]).round(2)}) behind the LAST publish of t-1 -- "
-      "the step's granules seen, the resolution, the rest of the iteration, the next membrane stage")
-x = []
-for t in range(6, T - 3):
-    for g in np.where(longit[t])[0]:
-        x.append(pub[t].max() - pub[t, g])
-x = np.array(x)
-print(f"a workgroup that crosses at t published t {x.mean():.2f} us before the step's last publisher (10 / 50 / 90 %: {np.percentile(x, [10, 50, 90]).round(2)}): what it waits for")
+# ---- the chain, on the crossings that are KNOWN (tile wave 0 records its own; tile wave 1's are not in the dump).  (A long publish-to-publish
+#      interval alone is no proof of an own crossing: when the arbiter is late the whole pack has one.)
+cr = hw[:T, :G, 2] > 0
+tt, gg = np.where(cr[6:T - 4])
+tt = tt + 6
+if len(tt):
+    own = np.array([pub[t + 1, g] - pub[t, g] for t, g in zip(tt, gg)])
+    c1 = np.array([pub[t + 1, g] - pub[t].max() for t, g in zip(tt, gg)])
+    c2 = np.array([pub[t + 1].max() - pub[t + 1, g] for t, g in zip(tt, gg)])
+    ahead = np.array([pub[t].max() - pub[t, g] for t, g in zip(tt, gg)])
+    print(f"{len(tt)} crossings recorded by tile wave 0: the workgroup had published the step {ahead.mean():.2f} us before the step's LAST publisher "
+          f"(10 / 50 / 90 %: {np.percentile(ahead, [10, 50, 90]).round(2)}); its own publish-to-publish interval {own.mean():.2f} us")
+    print(f"   its NEXT publish comes {np.median(c1):.2f} us (10 / 90 %: {np.percentile(c1, [10, 90]).round(2)}) behind that last publish -- granules seen, resolution, rest of the "
+          f"iteration, next membrane stage -- and is itself within {np.median(c2):.2f} us (75 %: {np.percentile(c2, 75):.2f}) of being the last publish of the next step:")
+    print(f"   last publish(t+1) ~ last publish(t) + {np.median(c1):.2f}: the chain that sets the period ({P:.2f})")
 fl = hw[:T, :G, 3]
 nd = int(((fl == 1) | (fl == 2)).sum())
 if nd:
