@@ -247,6 +247,9 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 #ifndef SNN_DEFER
 #define SNN_DEFER 0
 #endif
+#ifndef SNN_DIGEST_EARLY
+#define SNN_DIGEST_EARLY 0
+#endif
 #ifndef SNN_WPOLL_SLEEP
 #define SNN_WPOLL_SLEEP 1              // s_sleep between two polls of the winners granules (developer builds vary it: profiles/r04_async_sensitivity.txt)
 #endif
@@ -500,6 +503,19 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                              if (tid + NT < nchunk) dst_[tid + NT] = dg1; if (tid + 2 * NT < nchunk) dst_[tid + 2 * NT] = dg2; } while (0)
     DIGEST_LOAD(0); DIGEST_STORE(0);
     if (T >= 1) { DIGEST_LOAD(1); DIGEST_STORE(1); }
+#if SNN_DIGEST_EARLY
+    // (developer build, default off, NOT YET RUN ON AN MI355X) The digest store sits in the tail of EVERY iteration -- the stretch that both the
+    // ordinary iteration and the crossing chain run through (0.135 us measured).  Its buffer (entry t's) is free during the whole of
+    // iteration t, so here the six non-tile waves carry the whole entry (four 16-byte pieces per thread) and store it behind their PostPre /
+    // Ai work, in front of barrier M; the tile waves neither load nor store it.  Open: whether the loads (issued at the top of the
+    // iteration, a microsecond earlier) are back by then.
+    uint4 dg3 = make_uint4(0, 0, 0, 0);
+#define DIGEST_LOAD_E(e) do { const uint4 *src_ = (const uint4 *)(c.dig + (size_t)(e) * c.DW); const int d_ = tid - TT; dg0 = src_[min(d_, nchunk - 1)]; \
+                              dg1 = src_[min(d_ + NBC, nchunk - 1)]; dg2 = src_[min(d_ + 2 * NBC, nchunk - 1)]; dg3 = src_[min(d_ + 3 * NBC, nchunk - 1)]; } while (0)
+#define DIGEST_STORE_E(e) do { uint4 *dst_ = (uint4 *)(dgbuf + ((e) & 1) * DGS); const int d_ = tid - TT; if (d_ < nchunk) dst_[d_] = dg0; \
+                               if (d_ + NBC < nchunk) dst_[d_ + NBC] = dg1; if (d_ + 2 * NBC < nchunk) dst_[d_ + 2 * NBC] = dg2; \
+                               if (d_ + 3 * NBC < nchunk) dst_[d_ + 3 * NBC] = dg3; } while (0)
+#endif
     // state of the own neuron in registers: tile thread -> Ae (v, refractory counter, theta, trace), Ai thread -> Ai (v, counter, trace)
     float r_v = 0.f, r_r = 0.f, r_th = 0.f, x_cur = 0.f, x_before = 0.f;
     bool last_s = false;                                      // last final spike of the own neuron (Ae: redone by a winner; Ai)
@@ -575,7 +591,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
+#if SNN_DIGEST_EARLY
+        if (t + 2 <= T && wave >= NTW) DIGEST_LOAD_E(t + 2);
+#else
         if (t + 2 <= T && wave >= NTW) DIGEST_LOAD(t + 2);
+#endif
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
@@ -728,7 +748,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             const uint64_t mE = __ballot(spE);
             if (!agree) publish(mE);
             if (spE) atomicAdd(&thc[par * CW + jj], 1);
+#if !SNN_DIGEST_EARLY
             if (t + 2 <= T) DIGEST_LOAD(t + 2);
+#endif
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
             published = t + 1;
             prevE = mE; crossed_prev = spE;
@@ -795,7 +817,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             WHATIF_DELAY(2);
             if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
             WHATIF_DELAY(3);
+#if !SNN_DIGEST_EARLY
             if (t + 2 <= T) DIGEST_LOAD(t + 2);
+#endif
             AMARK(8);
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
             published = t + 1;
@@ -875,6 +899,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             AMARKW(3, TT);
         }
+#if SNN_DIGEST_EARLY
+        if (t + 2 <= T && wave >= NTW) DIGEST_STORE_E(t + 2);             // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+#endif
         AMARK(13);
         lds_barrier();                                                    // ---- M
         AMARK(4);
@@ -1110,7 +1137,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #endif
         AMARK(1);
         WHATIF_DELAY(7);
+#if !SNN_DIGEST_EARLY
         if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+#endif
 #if defined(SNN_WHATIF) && SNN_WHATIF == 20
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t + 2 <= T) DIGEST_STORE(t + 2);

@@ -3,6 +3,8 @@
 # the GPU box: the D&C parity tests and a short soak against it, then its time per launch beside the product build's.
 #   built here (no GPU needed), e.g.:   WHATIF_EXTRA=-DSNN_LDS_XTRACE=1 bash tools/r04_sensitivity_build.sh 600
 #                                       WHATIF_EXTRA=-DSNN_DEFER=1      bash tools/r04_sensitivity_build.sh 500
+#                                       WHATIF_EXTRA=-DSNN_DIGEST_EARLY=1 bash tools/r04_sensitivity_build.sh 700
+#                                       WHATIF_EXTRA="-DSNN_DIGEST_EARLY=1 -DSNN_LDS_XTRACE=1" bash tools/r04_sensitivity_build.sh 800
 #   on the box:                         gpurun -- 'bash tools/r05_variant_try.sh 600 [test-timeout-s] [soak-cases]'
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
