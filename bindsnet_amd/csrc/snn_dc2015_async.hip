@@ -247,6 +247,42 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 #ifndef SNN_DEFER
 #define SNN_DEFER 0
 #endif
+// SNN_POLL2 (developer build, default off, NOT YET RUN ON AN MI355X).  A poll round that is issued when the previous one returns sees a granule
+// that became visible at time V a full round trip plus, on average, half a round trip later (detection = 1.5 RTT ~ 1.2 us of the 1.4 us between
+// the step's last publish and "all granules seen" -- the first term of the chain that sets the period, tools/r04_lateness.py).  Two rounds in
+// flight, issued half a round trip apart, make that 1.25 RTT.  poll_all4: lane l takes granules l, l + 64, l + 128, l + 192 (NGS <= 256; clamped
+// duplicates beyond NGS - 1), every round loads all four unconditionally so that the compiler can wait for the OLDER round while the newer one
+// travels; returns false when it gives up.
+#ifndef SNN_POLL2
+#define SNN_POLL2 0
+#endif
+#if SNN_POLL2
+__device__ __forceinline__ bool poll_all4(const unsigned long long *sums, int NGS, uint32_t tagv, int lane, unsigned long long (&xs)[4]) {
+    const unsigned long long *p0 = sums + min(lane, NGS - 1), *p1 = sums + min(lane + 64, NGS - 1), *p2 = sums + min(lane + 128, NGS - 1),
+                             *p3 = sums + min(lane + 192, NGS - 1);
+    // Rounds in straight-line code, two in flight, each checked when it is the OLDER one (the compiler then waits with vmcnt(4)); a loop that
+    // carries a round in flight over its back edge gets register copies there, and with them a wait for the NEWER round.  Six rounds per pass of
+    // the loop, nothing in flight at its top: one gap of a whole round trip in seven.
+#define POLL_ISSUE(x) x##0 = granule_load(p0); x##1 = granule_load(p1); x##2 = granule_load(p2); x##3 = granule_load(p3)
+#define POLL_CHECK(x) do { const bool ok_ = (uint32_t)(x##0 >> 32) == tagv && (uint32_t)(x##1 >> 32) == tagv && (uint32_t)(x##2 >> 32) == tagv && \
+                                             (uint32_t)(x##3 >> 32) == tagv; \
+                           if (!__any(!ok_)) { xs[0] = x##0; xs[1] = x##1; xs[2] = x##2; xs[3] = x##3; return true; } } while (0)
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long a0, a1, a2, a3, b0, b1, b2, b3;
+        POLL_ISSUE(a);
+        __builtin_amdgcn_s_sleep(14);                                      // ~ half a round trip
+        POLL_ISSUE(b); POLL_CHECK(a);
+        POLL_ISSUE(a); POLL_CHECK(b);
+        POLL_ISSUE(b); POLL_CHECK(a);
+        POLL_ISSUE(a); POLL_CHECK(b);
+        POLL_ISSUE(b); POLL_CHECK(a);
+        POLL_CHECK(b);
+        if (spins > kAPoll / 4) return false;
+    }
+#undef POLL_ISSUE
+#undef POLL_CHECK
+}
+#endif
 #ifndef SNN_DIGEST_EARLY
 #define SNN_DIGEST_EARLY 0
 #endif
@@ -613,6 +649,13 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 uint32_t need = 0;
 #pragma unroll
                 for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+#if SNN_POLL2
+                if (NGS <= 256) {
+                    unsigned long long x4[4];
+                    if (poll_all4(sums, NGS, (uint32_t)(ts + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
+                    else { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                } else
+#endif
                 for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                     for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
@@ -1081,6 +1124,13 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     uint32_t need = 0;
 #pragma unroll
                     for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+#if SNN_POLL2
+                    if (NGS <= 256) {
+                        unsigned long long x4[4];
+                        if (poll_all4(sums, NGS, (uint32_t)(t + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
+                        else { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    } else
+#endif
                     for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                         for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
@@ -1355,6 +1405,13 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             uint32_t need = 0;
 #pragma unroll
             for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
+#if SNN_POLL2
+            if (NGS <= 256) {
+                unsigned long long x4[4];
+                if (poll_all4(sums, NGS, (uint32_t)(e + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
+                else failed = true;
+            } else
+#endif
             for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                 for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);

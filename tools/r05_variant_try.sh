@@ -5,6 +5,7 @@
 #                                       WHATIF_EXTRA=-DSNN_DEFER=1      bash tools/r04_sensitivity_build.sh 500
 #                                       WHATIF_EXTRA=-DSNN_DIGEST_EARLY=1 bash tools/r04_sensitivity_build.sh 700
 #                                       WHATIF_EXTRA="-DSNN_DIGEST_EARLY=1 -DSNN_LDS_XTRACE=1" bash tools/r04_sensitivity_build.sh 800
+#                                       WHATIF_EXTRA=-DSNN_POLL2=1      bash tools/r04_sensitivity_build.sh 900
 #   on the box:                         gpurun -- 'bash tools/r05_variant_try.sh 600 [test-timeout-s] [soak-cases]'
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
