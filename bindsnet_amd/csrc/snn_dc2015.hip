@@ -906,7 +906,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         if (!dbg || dbg_T < R->T + 1) { if (dbg) (void)hipFree(dbg); (void)hipMalloc(&dbg, sizeof(long long) * dbg_words); dbg_T = R->T + 1; }
         (void)hipMemsetAsync(dbg, 0, sizeof(long long) * dbg_words, st);
         for (int t = 0; t <= R->T; ++t) (void)hipMemsetAsync(dbg + (size_t)t * 24 + 20, 0x7F, sizeof(long long), st);
-        c.dbg = dbg; c.dbg_wg = atoi(getenv("SNN_DC_TIMING")); if (c.dbg_wg < 0 || c.dbg_wg >= c.G) c.dbg_wg = c.G - 1;
+        c.dbg = dbg; c.dbg_wg = atoi(getenv("SNN_DC_TIMING")); if (c.dbg_wg != -1 && (c.dbg_wg < 0 || c.dbg_wg >= c.G)) c.dbg_wg = c.G - 1;   // (-1: the third generation's "lite" dump, no workgroup carries marks)
     }
     const size_t lds = lds_bytes(B, Nin, N);
     static bool lds_attr = false;

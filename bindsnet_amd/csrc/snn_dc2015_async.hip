@@ -334,10 +334,11 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
 #define AMARKW(k, th) do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == (th)) c.dbg[(size_t)t * 24 + (k)] = (long long)wall_clock64(); } } while (0)
 // wave 0's marks are kept in registers and written once per iteration, behind barrier B: a store per mark sat in front of the next
 // vmcnt wait (the winners granules) and was measured as part of it
-#define AMARK(k) do { if constexpr (TIMING) { if (wave == 0) mk[k] = (long long)wall_clock64(); } } while (0)
+// (SNN_DC_TIMING=-1, "lite": dbg_wg < 0 -- no marks at all, only every workgroup's publish time and crossing counts: the least the instance can disturb)
+#define AMARK(k) do { if constexpr (TIMING) { if (wave == 0 && c.dbg_wg >= 0) mk[k] = (long long)wall_clock64(); } } while (0)
 // (flushed behind the winners decode of the NEXT iteration: marks 0, 9, 10, 7 are that iteration's by then, the others the previous one's)
 // wave 2 (a PostPre wave: the won branch's rows, no resolution) keeps five marks of its own, slots 19..23, written at the top of the next iteration
-#define AMARK2(k) do { if constexpr (TIMING) { if (wave == 2) mk[k] = (long long)wall_clock64(); } } while (0)
+#define AMARK2(k) do { if constexpr (TIMING) { if (wave == 2 && c.dbg_wg >= 0) mk[k] = (long long)wall_clock64(); } } while (0)
 #define AMARK2_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 128 && t >= 1) { _Pragma("unroll") for (int k_ = 19; k_ < 24; ++k_) c.dbg[(size_t)(t - 1) * 24 + k_] = mk[k_]; } } } while (0)
 #define AMARK_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 19; ++k_) { \
         const bool early_ = k_ == 0 || k_ == 9 || k_ == 10 || k_ == 7 || k_ == 11 || k_ == 18; \
@@ -623,7 +624,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // (developer build) what a wave still has in flight from the previous iteration: everything older than the winners prefetch, then the prefetch itself
         if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); AMARK(11); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AMARK(18); }
 #endif
-        if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
+        if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
@@ -795,6 +796,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             if (t + 2 <= T) DIGEST_LOAD(t + 2);
 #endif
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
+            if constexpr (TIMING) { if (c.dbg && tid == 64 && c.dbg_wg < 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = 0x100 + (long long)__popcll(mE); }   // (lite: tile wave 1's crossings)
             published = t + 1;
             prevE = mE; crossed_prev = spE;
             if (bl < B) {
@@ -865,6 +867,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #endif
             AMARK(8);
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
+            if constexpr (TIMING) { if (c.dbg && tid == 64 && c.dbg_wg < 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = 0x100 + (long long)__popcll(mE); }   // (lite: tile wave 1's crossings)
             published = t + 1;
             prevE = mE; crossed_prev = spE;
             // Ae trace of step t as it is without a final spike (nodes.py:96-103), x_tgt*nu0 of step t+1 likewise (the front of the
@@ -952,7 +955,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #if SNN_DEFER
         if (!pendwg)
 #endif
-        if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
+        if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
         if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
         // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front

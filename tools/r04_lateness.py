@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What sets the period of k_dc2015_async, from the publish times of EVERY compute workgroup (SNN_DC_TIMING_DUMP of the TIMING
 instance: [T+1][256][4] per workgroup: [1] wall clock at its publish, [2] own crossings of tile wave 0; slot 255: the arbiter's
-"all granules seen" / "winners out").  python tools/r04_lateness.py dump.bin [T] [G]"""
+"all granules seen" / "winners out").  SNN_DC_TIMING=-1 writes the "lite" dump: no workgroup carries marks, the publish times are as close to the product's as the
+instance gets.  python tools/r04_lateness.py dump.bin [T] [G]"""
 import sys
 
 import numpy as np
@@ -36,7 +37,8 @@ for lo, hi in [(-9, -0.2), (-0.2, 0.2), (0.2, 1), (1, 2), (2, 3), (3, 9)]:
         print(f"   lateness [{lo:4.1f}, {hi:4.1f}): n = {m.sum():5d}   {d[m].mean():.2f} us")
 # ---- the chain, on the crossings that are KNOWN (tile wave 0 records its own; tile wave 1's are not in the dump).  (A long publish-to-publish
 #      interval alone is no proof of an own crossing: when the arbiter is late the whole pack has one.)
-cr = hw[:T, :G, 2] > 0
+s3 = hw[:T, :G, 3]
+cr = (hw[:T, :G, 2] > 0) | ((s3 > 0x100) & (s3 < 0x200))      # tile wave 0's crossings; the "lite" dump (SNN_DC_TIMING=-1) carries tile wave 1's in slot 3
 tt, gg = np.where(cr[6:T - 4])
 tt = tt + 6
 if len(tt):
