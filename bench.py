@@ -102,13 +102,37 @@ def c_port_baseline(spikes, steps=100):
             "sample": f"first {steps} timesteps of input 0, oracle/snn_oracle.c ({dt:.1f} s)"}
 
 
-def cpu_baseline(host_inputs, aff_all=None, pin=None):
-    """The reference's CPU path restated operator for operator (oracle/torch_cpu_ref.py) on this host's cores, BEFORE
-    the GPU leg.  Protocol (fixed, no best-of): 8 threads (SURVEY.md / BASELINE.md section 3's setting) = `value`,
-    median over 3 WHOLE consecutive inputs from the fixture's start state (weights and theta carry over, reset between:
-    the run tests/golden/full_cfg2_dc_n400_b32_poisson pins); 1 thread: median over the first 100 timesteps of the same
-    3 inputs; cpu_count()-1 threads (eth_mnist.py:77's setting): median over 3 samples of 3 timesteps (it runs at
-    < 1 timestep/s on a 256-thread host).  Returns (json object, records of the 8-thread run for the parity leg)."""
+def reference_leg(host_inputs, n_whole=5):
+    """The REAL reference (byte copies of /root/reference/bindsnet/{network,learning,models,encoding} + utils.py staged under oracle/_ref by
+    __graft_entry__.build(), sha256-checked against oracle/ref_manifest.json) on this host's cores: oracle/ref_cpu_leg.py in a process of its
+    own.  Returns (json object, records of the whole inputs) or (None, None) when nothing is staged on this box."""
+    import subprocess
+    import tempfile
+    from oracle import stage_ref
+    if not stage_ref.verify():
+        return None, None
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.npy"), os.path.join(td, "rec.npz")
+        np.save(fin, np.stack([h.reshape(T, BATCH, N_IN) for h in host_inputs[:n_whole]]))
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_cpu_leg.py"), "--inputs", fin, "--out", fout, "--n", str(N_EXC),
+               "--whole", str(min(n_whole, len(host_inputs)))]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            out = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as e:                               # noqa: BLE001  (the bench line must survive a failed baseline leg)
+            return {"error": f"reference leg failed: {str(e)[:300]}"}, None
+        z = np.load(fout)
+        recs = []
+        for k in range(int(z["n_inputs"])):
+            recs.append({"Ae": torch.from_numpy(np.unpackbits(z[f"r{k}_Ae"])[:T * BATCH * N_EXC].reshape(T, BATCH, N_EXC)),
+                         "Ai": torch.from_numpy(np.unpackbits(z[f"r{k}_Ai"])[:T * BATCH * N_EXC].reshape(T, BATCH, N_EXC)),
+                         "W": torch.from_numpy(z[f"r{k}_W"].copy()), "theta": torch.from_numpy(z[f"r{k}_theta"].copy())})
+    return out, recs
+
+
+def port_leg(host_inputs, full):
+    """oracle/torch_cpu_ref.py (the reference's ATen operator sequence restated) in this process: 8 threads, median of 3 whole inputs;
+    `full`: also its 1-thread and cpu_count()-1 legs (only when the real reference is not staged on this box)."""
     from oracle.torch_cpu_ref import DcTorchRef
     ncpu = os.cpu_count() or 2
     threads0 = torch.get_num_threads()
@@ -136,27 +160,49 @@ def cpu_baseline(host_inputs, aff_all=None, pin=None):
         return sorted(rates)[1], [round(x, 2) for x in rates], recs
 
     v8, all8, recs = leg(min(8, ncpu), T, 0)
-    v1, all1, _ = leg(1, 100, 0)
-    if aff_all is not None:
-        os.sched_setaffinity(0, aff_all)                   # the script's own setting is unpinned; so is everything after this leg
-    vd, alld, _ = leg(max(1, ncpu - 1), 3, 1)
+    out = {"value": round(v8, 2), "unit": "timesteps/s", "cores": min(8, ncpu), "kind": "port", "per_input_timesteps_per_s": all8,
+           "sample": f"median of 3 whole consecutive inputs through oracle/torch_cpu_ref.py (the reference's ATen operator sequence), {min(8, ncpu)} threads"}
+    if full:
+        v1, all1, _ = leg(1, 100, 0)
+        out["one_thread"] = {"value": round(v1, 2), "unit": "timesteps/s", "cores": 1, "per_sample": all1,
+                             "sample": "median over the first 100 timesteps of the same 3 inputs"}
     torch.set_num_threads(min(threads0, ncpu))
-    cpu = {"value": round(v8, 2), "unit": "timesteps/s", "cores": min(8, ncpu), "kind": "port",
-           "sample": f"median of 3 whole consecutive inputs (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors, reset between) "
-                     f"through oracle/torch_cpu_ref.py = the reference's ATen operator sequence, {min(8, ncpu)} threads; "
-                     "/root/reference itself is absent on this box",
-           "per_input_timesteps_per_s": all8,
-           "one_thread": {"value": round(v1, 2), "unit": "timesteps/s", "cores": 1, "per_sample": all1,
-                          "sample": "median over the first 100 timesteps of the same 3 inputs"},
-           "reference_default_threads": {"threads": max(1, ncpu - 1), "value": round(vd, 2), "per_sample": alld,
-                                         "note": "torch.set_num_threads(os.cpu_count() - 1), eth_mnist.py:77; median of 3 samples "
-                                                 "of 3 timesteps after 1 untimed one"},
-           "c_port": c_port_baseline(host_inputs[0]), "host_cpus": ncpu,
-           "affinity": (f"8-thread and 1-thread legs pinned to CPUs {pin}" if pin else "not pinned (sched_setaffinity unavailable)")}
-    return cpu, recs
+    return out, recs
 
 
-def parity_leg(dev, pool, recs):
+def cpu_baseline(host_inputs, aff_all=None, pin=None):
+    """The reference's CPU path on this host's cores, BEFORE the GPU leg.  `kind: "reference"` when the unmodified reference is staged on
+    this box (oracle/_ref, see reference_leg): 8 threads (SURVEY.md / BASELINE.md section 3's setting) pinned to one CCD = `value`, the MEDIAN
+    over 5 WHOLE consecutive inputs from the fixture's start state (weights and theta carry over, reset between), min / median / max
+    reported because the figure swings with the box; its 1-thread and cpu_count()-1-thread (eth_mnist.py:77) legs; and, as secondary
+    figures, the operator-for-operator port (oracle/torch_cpu_ref.py) and the scalar C port.  Without the staged reference the port is the
+    baseline (`kind: "port"`).  Returns (json object, records of the whole inputs for the parity leg)."""
+    ncpu = os.cpu_count() or 2
+    ref, recs = reference_leg(host_inputs)
+    have_ref = ref is not None and "error" not in ref and recs
+    port, precs = port_leg(host_inputs, full=not have_ref)
+    if aff_all is not None:
+        os.sched_setaffinity(0, aff_all)
+    cport = c_port_baseline(host_inputs[0])
+    pinned = f"8-thread and 1-thread legs pinned to CPUs {pin}" if pin else "not pinned (sched_setaffinity unavailable)"
+    if have_ref:
+        cpu = {"value": ref["median"], "unit": "timesteps/s", "cores": ref["threads"], "kind": "reference",
+               "sample": f"MEDIAN of {ref['inputs']} whole consecutive inputs (T={T}, batch {BATCH}, 784->{N_EXC}, PostPre on, 3 monitors, reset between) "
+                         f"through the UNMODIFIED reference (oracle/_ref/bindsnet = byte copies of BindsNET's network/learning/models/encoding packages, "
+                         f"sha256 == oracle/ref_manifest.json), Network.run() in a subprocess, {ref['threads']} threads",
+               "min": ref["min"], "median": ref["median"], "max": ref["max"], "per_input_timesteps_per_s": ref["per_input_timesteps_per_s"],
+               "one_thread": ref.get("one_thread"), "reference_default_threads": ref.get("reference_default_threads"),
+               "port": port, "c_port": cport, "host_cpus": ncpu, "affinity": pinned, "torch": ref.get("torch")}
+        return cpu, recs
+    cpu = dict(port)
+    cpu["sample"] += "; the reference itself is not staged on this box (oracle/_ref absent)"
+    if ref is not None:
+        cpu["reference_error"] = ref.get("error")
+    cpu.update({"c_port": cport, "host_cpus": ncpu, "affinity": pinned})
+    return cpu, precs
+
+
+def parity_leg(dev, host_pool, recs, against):
     """The same 3 inputs from the same seeds on the GPU (fresh network), against the 8-thread CPU run of this process."""
     net = build_network(dev)
     torch.manual_seed(2)
@@ -164,7 +210,7 @@ def parity_leg(dev, pool, recs):
     exc = inh = 0
     plans = []
     for r, rec in enumerate(recs):
-        net.run({"X": pool[r].clone()}, time=T)
+        net.run({"X": torch.from_numpy(host_pool[r]).view(T, BATCH, 1, 28, 28).to(dev)}, time=T)
         torch.cuda.synchronize()
         plans.append(net.last_plan)
         for l in ("Ae", "Ai"):
@@ -179,8 +225,7 @@ def parity_leg(dev, pool, recs):
     return {"rasters_bit_exact": ok, "inputs": len(recs), "exc_spikes": exc, "inh_spikes": inh, "max_abs_dW": dW,
             "weights_bit_exact": wexact, "max_abs_dtheta": dth, "plan": plans,
             "plan_retries(lean,resident)": [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)],
-            "against": "oracle/torch_cpu_ref.py on this host in this run, 3 consecutive inputs from identical seeds "
-                       "(weights, theta compared after each)"}
+            "against": against}
 
 
 def respawn_under_launcher(args):
@@ -231,7 +276,7 @@ def main():
         except OSError:
             aff_all = pin = None
     from bindsnet_amd import synth
-    host_pool = synth.poisson_mnist_like(BATCH, T, 4, seed=1 + 17 * rank)
+    host_pool = synth.poisson_mnist_like(BATCH, T, 5 if cpu_leg else 4, seed=1 + 17 * rank)   # (the CPU leg runs 5 inputs; 4 are cycled on the GPU)
     per = np.stack([h.reshape(T, BATCH, N_IN).sum(2) for h in host_pool])
     input_stats = {"generator": "torch.manual_seed(1 + 17*rank); per sample img = 128*U(0,1)*Bernoulli(0.19); "
                                 "bindsnet.encoding.poisson(img, time=250, dt=1.0) (BASELINE.md section 2)",
@@ -256,7 +301,7 @@ def main():
     from bindsnet_amd import _lib, parallel
     _lib.lib().snn_set_plan_mode({"auto": 0, "generic": 1, "per-step": 2}[args.plan])
     net = build_network(dev)
-    pool = [torch.from_numpy(h).view(T, BATCH, 1, 28, 28).to(dev) for h in host_pool]   # resident in HBM before the timed region
+    pool = [torch.from_numpy(h).view(T, BATCH, 1, 28, 28).to(dev) for h in host_pool[:4]]   # resident in HBM before the timed region
     # Input.s aliases the last slice of the caller's input and reset_state_variables() zeroes it in place (the
     # reference does the same: nodes.py:219 `self.s = x`, :114 `self.s.zero_()`); eth_mnist.py encodes a fresh tensor
     # per sample and never notices, a cycled pool would lose its last timestep after the first pass.  The slice is
@@ -301,7 +346,9 @@ def main():
     if rank == 0:
         plan_timed = net.last_plan
         retries = [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)]
-        par = parity_leg(dev, pool, recs) if recs else None
+        par = parity_leg(dev, host_pool, recs, (
+            f"the unmodified reference (oracle/_ref) on this host in this run, {len(recs)} consecutive inputs from identical seeds" if cpu.get("kind") == "reference"
+            else "oracle/torch_cpu_ref.py on this host in this run, 3 consecutive inputs from identical seeds") + " (weights, theta compared after each)") if recs else None
         # ---- roofline of the dominant kernel: HIP events (on the launch stream) around single launches of further
         # runs of the same input pool, LAST, so the device is busy until the process prints its line
         roof = None

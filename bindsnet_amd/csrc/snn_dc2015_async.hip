@@ -74,26 +74,9 @@ constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_
                  OC_XWINV = OC_COLRES + 16, OC_XCNT = OC_XWINV + 16 + 16, OC_W0 = OC_XCNT + 2 * MAXB * 4, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
-// SNN_LDS_XTRACE (developer build, default off; WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON AN MI355X).  The won branch of a crossing column
-// wants the X trace of the crossing sample, one value per row, and reads it from the [T+1][B][Nin] array the pre-pass leaves in global memory:
-// first touches of HBM / MALL, ~0.6 us each, one per row a thread does, and asking for them together was SLOWER on the device
-// (profiles/r04_async_sensitivity.txt sections 4, 6, 7).  A non-additive trace (nodes.py:96-103: x <- trace_scale on a spike, x * decay
-// otherwise) that entered the run as zero is a function of "steps since the input's last spike" alone: trace_scale multiplied k times by
-// the decay, one rounding each -- a table of T + 1 floats.  So this build keeps, per compute workgroup, the step of the last spike of every
-// (sample, input) in LDS (one byte each, written by PostPre's pass over the step's active rows, which holds the row's sample mask anyway) and
-// the table; the won branch's trace values come from two LDS reads, and the untouched rows take the all-reads-first form that
-// tools/probe_won_branch.hip measured at 0.45 us against 1.1.  Applies when the X trace is not additive, every entry trace is 0 (each
-// workgroup looks at the run's entry trace itself) and T <= 254; otherwise the global array is read as before (the pre-pass still runs).
-#ifndef SNN_LDS_XTRACE
-#define SNN_LDS_XTRACE 0
-#endif
 size_t async_compute_lds(int B, int Nin, int N) {
     const int DGS = (digest_lds_words(B, Nin) + 63) & ~63;
-#if SNN_LDS_XTRACE
-    return OC_WT + (size_t)3 * Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4 + (((size_t)B * Nin + 15) & ~(size_t)15) + 256 * 4;
-#else
     return OC_WT + (size_t)3 * Nin * ACW * 4 + (size_t)2 * N * ACW * 4 + (size_t)2 * DGS * 4;
-#endif
 }
 // ---- ... of the arbiter: ctl[32] | cntc[32] | colc[32] | winlist[32] | keys[32] u64 | entry winners [2][32] | crs [B*NW] | mt ring
 constexpr size_t OA_CTL = 0, OA_CNT = 128, OA_COL = 256, OA_WL = 384, OA_KEY = 512, OA_CRS = 1280;
@@ -229,66 +212,7 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
 // e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.  The first TWO granules (six
 // winners: all of them in 97 % of the steps at cfg2) are asked for together -- a second round trip only beyond that --, and the
 // caller may have loaded them earlier (pre: valid if the tag is).
-// SNN_DEFER (developer build, default off; tools/r05_defer_try.sh).  tools/r04_lateness.py: what bounds the period is the chain "a workgroup
-// that crossed at step t waits for the step's LAST publisher (all 200 crossing granules) before it can finish the iteration and publish step
-// t+1 -- and is then the last publisher of t+1 itself".  The membrane stage of step t+1 does not need the outcome of step t's arbitration
-// except through the X currents of the crossing columns, and both branches of those are prepared (curX / curXwin).  So in this build a
-// workgroup with an unresolved single-sample crossing enters iteration t+1 WITHOUT having resolved it: its tile waves update the pairs of the
-// crossing columns under both outcomes, publish step t+1 at once when both give the same crossings, THEN look at step t's granules, patch
-// trace / x_tgt*nu0 / won mask / final spike as the resolution at the end of iteration t does, and pick the state of the branch that
-// happened; waves 2..7 wait for that (barrier R) before PostPre and the Ai update of step t+1.  Columns with several crossing samples (which
-// wait for the arbiter's winners inside iteration t anyway) are resolved where they were.
-// MEASURED (round 4's last GPU minutes): bit-exact on the 41 D&C parity tests at the first run; the two outcomes gave the same crossings in
-// 665 of 665 deferred iterations -- and the run is 16 % SLOWER (1 103 vs 951 us): the workgroup still pays the wait for the step's last
-// publisher in its own time, one iteration later, and PostPre of that iteration no longer runs beside the membrane stage; the busiest
-// workgroups' own average iteration becomes the bound (profiles/r04_async_sensitivity.txt section 8).  Kept as the starting point of the
-// version that would help: carry BOTH branches of the crossing column (weights, currents, pairs) through further steps until the
-// resolution arrives, instead of waiting for it anywhere.
-#ifndef SNN_DEFER
-#define SNN_DEFER 0
-#endif
-// SNN_POLL2 (developer build, default off, NOT YET RUN ON AN MI355X).  A poll round that is issued when the previous one returns sees a granule
-// that became visible at time V a full round trip plus, on average, half a round trip later (detection = 1.5 RTT ~ 1.2 us of the 1.4 us between
-// the step's last publish and "all granules seen" -- the first term of the chain that sets the period, tools/r04_lateness.py).  Two rounds in
-// flight, issued half a round trip apart, make that 1.25 RTT.  poll_all4: lane l takes granules l, l + 64, l + 128, l + 192 (NGS <= 256; clamped
-// duplicates beyond NGS - 1), every round loads all four unconditionally so that the compiler can wait for the OLDER round while the newer one
-// travels; returns false when it gives up.
-#ifndef SNN_POLL2
-#define SNN_POLL2 0
-#endif
-#if SNN_POLL2
-__device__ __forceinline__ bool poll_all4(const unsigned long long *sums, int NGS, uint32_t tagv, int lane, unsigned long long (&xs)[4]) {
-    const unsigned long long *p0 = sums + min(lane, NGS - 1), *p1 = sums + min(lane + 64, NGS - 1), *p2 = sums + min(lane + 128, NGS - 1),
-                             *p3 = sums + min(lane + 192, NGS - 1);
-    // Rounds in straight-line code, two in flight, each checked when it is the OLDER one (the compiler then waits with vmcnt(4)); a loop that
-    // carries a round in flight over its back edge gets register copies there, and with them a wait for the NEWER round.  Six rounds per pass of
-    // the loop, nothing in flight at its top: one gap of a whole round trip in seven.
-#define POLL_ISSUE(x) x##0 = granule_load(p0); x##1 = granule_load(p1); x##2 = granule_load(p2); x##3 = granule_load(p3)
-#define POLL_CHECK(x) do { const bool ok_ = (uint32_t)(x##0 >> 32) == tagv && (uint32_t)(x##1 >> 32) == tagv && (uint32_t)(x##2 >> 32) == tagv && \
-                                             (uint32_t)(x##3 >> 32) == tagv; \
-                           if (!__any(!ok_)) { xs[0] = x##0; xs[1] = x##1; xs[2] = x##2; xs[3] = x##3; return true; } } while (0)
-    for (unsigned spins = 0;; ++spins) {
-        unsigned long long a0, a1, a2, a3, b0, b1, b2, b3;
-        POLL_ISSUE(a);
-        __builtin_amdgcn_s_sleep(14);                                      // ~ half a round trip
-        POLL_ISSUE(b); POLL_CHECK(a);
-        POLL_ISSUE(a); POLL_CHECK(b);
-        POLL_ISSUE(b); POLL_CHECK(a);
-        POLL_ISSUE(a); POLL_CHECK(b);
-        POLL_ISSUE(b); POLL_CHECK(a);
-        POLL_CHECK(b);
-        if (spins > kAPoll / 4) return false;
-    }
-#undef POLL_ISSUE
-#undef POLL_CHECK
-}
-#endif
-#ifndef SNN_DIGEST_EARLY
-#define SNN_DIGEST_EARLY 0
-#endif
-#ifndef SNN_WPOLL_SLEEP
-#define SNN_WPOLL_SLEEP 1              // s_sleep between two polls of the winners granules (developer builds vary it: profiles/r04_async_sensitivity.txt)
-#endif
+constexpr int kWinPollSleep = 1;       // s_sleep between two polls of the winners granules (other values measured: profiles/r04_async_sensitivity.txt)
 struct WinPre { unsigned long long g0, g1; bool have; };
 __device__ __forceinline__ WinPre win_prefetch(const DcCtx &c, int e) {
     const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
@@ -303,7 +227,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
     for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
         if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
-        __builtin_amdgcn_s_sleep(SNN_WPOLL_SLEEP);
+        __builtin_amdgcn_s_sleep(kWinPollSleep);
         x0 = granule_load(gr); x1 = granule_load(gr + 1);
     }
     const int nw = (int)((x0 >> 48) & 63u);
@@ -343,15 +267,6 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
 #define AMARK_FLUSH() do { if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 19; ++k_) { \
         const bool early_ = k_ == 0 || k_ == 9 || k_ == 10 || k_ == 7 || k_ == 11 || k_ == 18; \
         if (k_ != 3 && k_ != 17 && (early_ || t >= 1)) c.dbg[(size_t)(early_ ? t : t - 1) * 24 + k_] = mk[k_]; } } } } while (0)
-
-// developer aid (-DSNN_WHATIF=<k>, tools/r04_sensitivity.sh; never in the product build): a known delay (s_sleep 8 = 512 clocks) at
-// point k of the compute loop.  The change of the period per unit of delay is that point's weight on the path that bounds the period:
-// 1 = everything behind it waits for it, 0 = slack.  Results stay exact (a delay changes no value).
-#ifdef SNN_WHATIF
-#define WHATIF_DELAY(k) do { if (SNN_WHATIF == (k)) __builtin_amdgcn_s_sleep(8); } while (0)
-#else
-#define WHATIF_DELAY(k) do { } while (0)
-#endif
 
 // A loop-invariant float parameter into a VECTOR register: kernel arguments are uniform, so the compiler keeps them in scalar
 // registers -- of which the compute loop needs far more than the 102 a wave has: the first versions re-read 226 spilled scalars per
@@ -481,10 +396,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     uint32_t *dgbuf = (uint32_t *)(weiT + (size_t)N * CW);
     float *wbak = (float *)(dgbuf + 2 * DGS);                // [Nin][CW] rows PostPre touched: their weights before
     float *wwin = wbak + (size_t)Nin * CW;                   // [Nin][CW] column q: the whole column with its final spikes of this step
-#if SNN_LDS_XTRACE
-    uint8_t *tlast = (uint8_t *)(wwin + (size_t)Nin * CW);   // [B][Nin] step of the (sample, input)'s last spike in this run; 255 = none yet
-    float *pw = (float *)(tlast + (((size_t)c.B * Nin + 15) & ~(size_t)15));   // [256] trace_scale times the decay, k times (one rounding per step)
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = (int)blockIdx.x, c0 = g * CW;
@@ -520,14 +431,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     if (tid < 2 * MAXB) multi0 = cnt0[tid] > 1;
     if (offdiag || multi0) ctl[0] = 1;                        // (benign race: everybody writes 1)
-#if SNN_LDS_XTRACE
-    {
-        bool nz = false;                                      // an entry trace that is not zero: its decay is not in the table
-        for (int k = tid; k < c.B * Nin; k += NT) { tlast[k] = 255; nz = nz || (c.xX[1][k] != 0.f); }
-        if (nz) ctl[3] = 1;                                   // (benign race)
-        if (tid == 0) { float x = c.x_scale; pw[0] = x; for (int k = 1; k < 256; ++k) { x = x * c.x_decay; pw[k] = x; } }
-    }
-#endif
     // The digest of a step travels global memory -> registers (at the top of an iteration) -> LDS (at its end): an LDS-DMA fetch
     // (global_load_lds) makes the compiler drain vmcnt in front of EVERY later LDS read of the issuing wave -- it cannot tell which
     // LDS bytes the transfer writes --, which put the transfer's whole latency in front of the step (0.6 us per iteration measured)
@@ -540,19 +443,17 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                              if (tid + NT < nchunk) dst_[tid + NT] = dg1; if (tid + 2 * NT < nchunk) dst_[tid + 2 * NT] = dg2; } while (0)
     DIGEST_LOAD(0); DIGEST_STORE(0);
     if (T >= 1) { DIGEST_LOAD(1); DIGEST_STORE(1); }
-#if SNN_DIGEST_EARLY
-    // (developer build, default off, NOT YET RUN ON AN MI355X) The digest store sits in the tail of EVERY iteration -- the stretch that both the
-    // ordinary iteration and the crossing chain run through (0.135 us measured).  Its buffer (entry t's) is free during the whole of
-    // iteration t, so here the six non-tile waves carry the whole entry (four 16-byte pieces per thread) and store it behind their PostPre /
-    // Ai work, in front of barrier M; the tile waves neither load nor store it.  Open: whether the loads (issued at the top of the
-    // iteration, a microsecond earlier) are back by then.
+    // Inside the loop the digest store would sit in the tail of EVERY iteration -- the stretch that both the ordinary iteration and the
+    // crossing chain run through (0.135 us measured).  Its buffer (entry t's) is free during the whole of iteration t, so the six non-tile
+    // waves carry the whole entry (four 16-byte pieces per thread: DIGEST_LOAD_E at the top of the iteration) and store it behind their
+    // PostPre / Ai work, in front of barrier M; the tile waves neither load nor store it (round 5, first GPU call: bit-exact, 945 vs 950 us
+    // per launch on one box, twice; profiles/r05_variants_first_call.txt).
     uint4 dg3 = make_uint4(0, 0, 0, 0);
 #define DIGEST_LOAD_E(e) do { const uint4 *src_ = (const uint4 *)(c.dig + (size_t)(e) * c.DW); const int d_ = tid - TT; dg0 = src_[min(d_, nchunk - 1)]; \
                               dg1 = src_[min(d_ + NBC, nchunk - 1)]; dg2 = src_[min(d_ + 2 * NBC, nchunk - 1)]; dg3 = src_[min(d_ + 3 * NBC, nchunk - 1)]; } while (0)
 #define DIGEST_STORE_E(e) do { uint4 *dst_ = (uint4 *)(dgbuf + ((e) & 1) * DGS); const int d_ = tid - TT; if (d_ < nchunk) dst_[d_] = dg0; \
                                if (d_ + NBC < nchunk) dst_[d_ + NBC] = dg1; if (d_ + 2 * NBC < nchunk) dst_[d_ + 2 * NBC] = dg2; \
                                if (d_ + 3 * NBC < nchunk) dst_[d_ + 3 * NBC] = dg3; } while (0)
-#endif
     // state of the own neuron in registers: tile thread -> Ae (v, refractory counter, theta, trace), Ai thread -> Ai (v, counter, trace)
     float r_v = 0.f, r_r = 0.f, r_th = 0.f, x_cur = 0.f, x_before = 0.f;
     bool last_s = false;                                      // last final spike of the own neuron (Ae: redone by a winner; Ai)
@@ -577,9 +478,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
-#if SNN_LDS_XTRACE
-    const bool use_tab = ctl[3] == 0 && !c.x_additive && c.x_traces && T <= 254;    // (uniform) the X trace from LDS: last-spike steps + table
-#endif
     if (bad && tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // X -> Ae currents of step 0 (from the layer's spikes at entry, digest entry 0)
     for (int qt = tid; qt < B * CW * 4; qt += NT) {
@@ -595,11 +493,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     int published = 0;                                        // steps this (tile) wave has published
     WinPre pre_w = WinPre{0ull, 0ull, false};                 // tile waves: winners granules asked for ahead of their use
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
-#if SNN_DEFER
-    bool pendwg = false;                                      // (uniform) the previous step's single-sample crossings of this workgroup are not resolved yet
-    bool pend = false;                                        // tile wave: it had one of them (it does the resolution)
-    uint32_t pendcols = 0;                                    // (uniform) the columns they are in
-#endif
 
     if constexpr (TIMING) {      // where this workgroup runs: XCC_ID, HW_ID (wave / simd / cu / sh / se) -> the row behind the last step
         if (c.dbg && tid == 0) {
@@ -620,106 +513,14 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         const bool full = t == 0;                                         // the first update of a run clamps every element
         AMARK(0);
         AMARK2_FLUSH();
-#ifdef SNN_TIMING_SPLIT
-        // (developer build) what a wave still has in flight from the previous iteration: everything older than the winners prefetch, then the prefetch itself
-        if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); AMARK(11); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AMARK(18); }
-#endif
         if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
-#if SNN_DIGEST_EARLY
         if (t + 2 <= T && wave >= NTW) DIGEST_LOAD_E(t + 2);
-#else
-        if (t + 2 <= T && wave >= NTW) DIGEST_LOAD(t + 2);
-#endif
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
-#if SNN_DEFER
-        // ---- the resolution of step t-1, as the end of iteration t-1 did it (ts = t - 1; the parity it writes is this iteration's)
-        auto resolve_prev = [&]() __attribute__((always_inline)) {
-            const int ts = t - 1;
-            if (prevE == 0ull || bad) return;
-            int *xc = xcnt + wave * MAXB;
-            if (lane < MAXB) xc[lane] = 0;
-            {
-                constexpr int PG = 8;
-                const unsigned long long *sums = cold(c).exs + (size_t)(ts & (kCrossRing - 1)) * NGS;
-                unsigned long long xs[PG];
-                uint32_t need = 0;
-#pragma unroll
-                for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
-#if SNN_POLL2
-                if (NGS <= 256) {
-                    unsigned long long x4[4];
-                    if (poll_all4(sums, NGS, (uint32_t)(ts + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
-                    else { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                } else
-#endif
-                for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-                    for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
-#pragma unroll
-                    for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(ts + 1)) need &= ~(1u << u);
-                    if (!__any(need != 0u)) break;
-                    if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                bool ab = false;
-#pragma unroll
-                for (int u = 0; u < PG; ++u) {
-                    const int gi = lane + 64 * u;
-                    if (bad || gi >= NGS) continue;
-                    const uint32_t pay = (uint32_t)xs[u];
-                    if (!pay) continue;
-                    if (pay == kAbortPay) { ab = true; continue; }
-                    const int w = gi % NTW;
-                    if ((pay & 0xFFu) == 0xFFu) {
-                        for (int bs = 0; bs < SPW; ++bs) if (w * SPW + bs < B) atomicAdd(&xc[w * SPW + bs], 2);
-                    } else {
-                        const int ne = (int)(pay >> 30);
-                        for (int e2 = 0; e2 < ne; ++e2) {
-                            const int bsm = w * SPW + (int)((pay >> (8 * e2)) & 0x3Fu) / CW;
-                            if (bsm < B) atomicAdd(&xc[bsm], 1);
-                        }
-                    }
-                }
-                if (__any(ab)) bad = true;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int mycnt = (crossed_prev && bl < B) ? xc[bl] : 0;
-            int jw = (crossed_prev && mycnt == 1) ? j : -1;
-            if (!bad && __any(crossed_prev && mycnt > 1)) {
-                const int ja = sample_winner(c, w0, ts, min(bl, B - 1), bad);
-                if (mycnt > 1) jw = ja;
-            }
-            const bool sp = !bad && crossed_prev && jw == j && bl < B && colv;
-            if (sp) {
-                if (pE.traces) {
-                    x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                    if (ts + 1 < T) xnu0[par * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-                }
-                atomicOr(&colmask[par * CW + jj], 1u << bl);
-                last_s = true; sp_prev = true;
-                spfin[tid] = 1;
-            }
-            if (bad) ctl[0] = 1;
-        };
-        auto read_wonm = [&]() __attribute__((always_inline)) {
-            uint32_t m = 0;
-            if (learn_pp) {
-#pragma unroll
-                for (int q = 0; q < CW; ++q) m |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
-            }
-            return m;
-        };
-        if (pendwg && !phaseB) {                                          // the last step's crossings: resolve, then commit as usual
-            if (wave < NTW && pend) resolve_prev();
-            lds_barrier();                                                // ---- R
-            pendwg = false; pend = false;
-        }
-        if (!pendwg)
-#endif
         if (learn_pp) {
 #pragma unroll
             for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
@@ -738,87 +539,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             break;
         }
-#if SNN_DEFER
-        if (pendwg && wave >= NTW) {                                      // waves 2..7: PostPre and the Ai update of step t want step t-1 resolved
-            lds_barrier();                                                // ---- R
-            wonm = read_wonm();
-        }
-        if (pendwg && wave < NTW) {
-            // ---- Ae membrane update of step t with step t-1's single-sample crossings unresolved: the pairs of those columns under both outcomes
-            const bool pc = learn_pp && ((pendcols >> jj) & 1u) != 0u;
-            float cxa = 0.f, cxb = 0.f;
-            if (mine) { cxa = curX[par * TT + bl * CW + jj]; cxb = pc ? curXwin[bl * CW + jj] : cxa; }
-            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, pre_w);
-            bool spA = false, spB = false;
-            float vb = r_v, rb = r_r;
-            if (mine) {
-                const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
-                const float curEa = cxa + e2, curEb = cxb + e2;
-                if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[(par ^ 1) * CW + jj];
-                if (e_learning) r_th = r_th * theta_decay;
-                spB = dc_update(vb, rb, curEb, pE.thresh + r_th, pE);
-                spA = dc_update(r_v, r_r, curEa, pE.thresh + r_th, pE);
-            }
-            const uint64_t mEa = __ballot(spA), mEb = __ballot(spB);
-            const bool agree = mEa == mEb;
-            if constexpr (TIMING) { if (c.dbg && tid == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = agree ? 2 : 1; }   // (slot 3 of a deferred iteration: did the outcomes agree)
-            auto publish = [&](uint64_t mEp) __attribute__((always_inline)) {
-                const int slot = t & (kCrossRing - 1);
-                uint32_t pay;
-                if (bad) pay = kAbortPay;
-                else {
-                    const int nev = __popcll(mEp);
-                    if (nev <= 3) {
-                        pay = (uint32_t)nev << 30;
-                        int sh = 0;
-                        for (uint64_t m = mEp; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
-                    } else {
-                        const int sidx = lane / CW, b = wave * SPW + sidx;
-                        const uint32_t v = (uint32_t)((mEp >> (sidx * CW)) & 0xFFFFull);
-                        if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
-                            granule_store(cold(c).ex + (size_t)slot * (cold(c).G * cold(c).KB) + g * cold(c).KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        pay = 0xC0FFFFFFu;
-                    }
-                }
-                if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
-            };
-            if (agree) publish(mEa);                                      // both outcomes give the same crossings: the step is out before the resolution
-            if (pend) resolve_prev();
-            lds_barrier();                                                // ---- R
-            wonm = read_wonm();
-            bool spE = spA;
-            if (pc && ((wonm >> jj) & 1u)) { r_v = vb; r_r = rb; spE = spB; }   // this column won step t-1: its won branch is what happened
-            const uint64_t mE = __ballot(spE);
-            if (!agree) publish(mE);
-            if (spE) atomicAdd(&thc[par * CW + jj], 1);
-#if !SNN_DIGEST_EARLY
-            if (t + 2 <= T) DIGEST_LOAD(t + 2);
-#endif
-            if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
-            if constexpr (TIMING) { if (c.dbg && tid == 64 && c.dbg_wg < 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = 0x100 + (long long)__popcll(mE); }   // (lite: tile wave 1's crossings)
-            published = t + 1;
-            prevE = mE; crossed_prev = spE;
-            if (bl < B) {
-                float xn = 0.f;
-                if (colv && pE.traces) {
-                    x_before = x_cur;
-                    x_cur = trace_next(x_before, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                    xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                }
-                xnu0[(par ^ 1) * TT + tid] = xn * pp.nu0;
-            }
-            if (mine) last_s = false;
-            if (spE) {
-                atomicOr(&colx[par * CW + jj], 1u << bl);
-                if (pE.traces) xwinv[jj] = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-            }
-            if (bad) ctl[0] = 1;
-            if (mine && c.rasVE) (cold(c).rasVE + (size_t)t * B * N)[kst] = r_v;
-        } else
-#endif
         if (wave < NTW) {
-            WHATIF_DELAY(1);
+
             // ---- Ae membrane update of step t, publish its crossings
             float cx = 0.f;
             if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
@@ -832,10 +554,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 const float curE = cx + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
                 if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[(par ^ 1) * CW + jj];
                 if (e_learning) r_th = r_th * theta_decay;
-#if defined(SNN_WHATIF) && SNN_WHATIF == 22
-                { float sv = r_v, sr = r_r; asm volatile("" : "+v"(sv), "+v"(sr)); const bool s0 = dc_update(sv, sr, curE, pE.thresh + r_th, pE);
-                  if (s0 && sv == 1.2345e30f) r_v = sv; asm volatile("" ::: "memory"); }
-#endif
                 spE = dc_update(r_v, r_r, curE, pE.thresh + r_th, pE);
                 if (spE) atomicAdd(&thc[par * CW + jj], 1);
             }
@@ -859,12 +577,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     pay = 0xC0FFFFFFu;
                 }
             }
-            WHATIF_DELAY(2);
+
             if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
-            WHATIF_DELAY(3);
-#if !SNN_DIGEST_EARLY
-            if (t + 2 <= T) DIGEST_LOAD(t + 2);
-#endif
+
             AMARK(8);
             if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
             if constexpr (TIMING) { if (c.dbg && tid == 64 && c.dbg_wg < 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = 0x100 + (long long)__popcll(mE); }   // (lite: tile wave 1's crossings)
@@ -891,7 +606,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         } else if (wave >= NT / 64 - NTW) {
             // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
             //      weights diagonal); it must fire exactly when that spike was there -- what everybody's inhibition assumes
-            WHATIF_DELAY(8);
+
             if (mine_i) {
                 const bool spA = spfin[ptile] != 0;
                 const float e3 = spA ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;
@@ -908,7 +623,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
         }
         if (wave >= NTW && do_stdp) {
-            WHATIF_DELAY(4);
+
             // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
             //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
             //      (the Ai waves join behind their own update: rows beyond the 256 of waves 2..5)
@@ -928,9 +643,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
                 *(float4 *)(wbak + i * 4) = v;
                 *(float4 *)(wtile + i * 4) = postpre_row_nowin(pp, v, m, xn0);
-#if SNN_LDS_XTRACE
-                if (use_tab) for (uint32_t mm = m; mm; mm &= mm - 1) tlast[(__ffs(mm) - 1) * Nin + i] = (uint8_t)t;   // input i spiked at step t in these samples
-#endif
             }
             if (wonm && !full)                                            // ... and the rows this step does not touch take the won column as it is
                 for (int i = ptid; i < Nin; i += NBC) {
@@ -945,16 +657,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             AMARKW(3, TT);
         }
-#if SNN_DIGEST_EARLY
         if (t + 2 <= T && wave >= NTW) DIGEST_STORE_E(t + 2);             // (its buffer, entry t's, was last read before barrier B of the previous iteration)
-#endif
         AMARK(13);
         lds_barrier();                                                    // ---- M
         AMARK(4);
-        WHATIF_DELAY(5);
-#if SNN_DEFER
-        if (!pendwg)
-#endif
+
         if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
         if (tid < CW) { colmask[par * CW + tid] = 0; colx[(par ^ 1) * CW + tid] = 0; thc[(par ^ 1) * CW + tid] = 0; }
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
@@ -970,11 +677,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
-#if SNN_DEFER
-        // crossings of this step in single-sample columns only: their resolution moves into the next iteration (behind its publish)
-        const bool defer_next = phaseB && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u &&
-                                __popc(xq[0]) <= 1 && __popc(xq[1]) <= 1 && __popc(xq[2]) <= 1 && __popc(xq[3]) <= 1;
-#endif
         const float *xsrc = crossed_wg ? cold(c).xtr + (size_t)(t + 1) * B * Nin : nullptr;   // X trace after step t
         const float *xn0 = xnu0 + par * TT;
         uint32_t cmq[CW];
@@ -989,21 +691,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             const int bst = single ? __ffs(cmq[q]) - 1 : -1;
             const uint32_t m = rowmask[i];
             const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
-#if SNN_LDS_XTRACE
-            float xval = 0.f;
-            if (single) {
-                if (use_tab) { const int tl = (int)tlast[bst * Nin + i]; xval = tl == 255 ? 0.f : pw[t - tl]; }
-                else xval = xsrc[bst * Nin + i];
-            }
-            wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xval)
-                                      : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
-#else
             wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xsrc[bst * Nin + i])
                                       : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
-#endif
         };
         if (crossed_wg) {
-            WHATIF_DELAY(10);
+
             const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
             if (slow) {
                 if (wave == 0) {
@@ -1061,43 +753,10 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         }
         AMARK(5);
         AMARK2(21);
-        WHATIF_DELAY(6);
+
         if (crossed_wg && wave >= NTW && !full) {
             // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
-#if SNN_LDS_XTRACE
-            // A row nobody's X spike touched has no pre-synaptic term, and a column with ONE crossing sample has a one-term post-synaptic
-            // cascade (= 0 + the term): postpre_elem's statements for that case, every LDS read of the thread's first three rows (all of
-            // them up to Nin = 1152) issued before the first row is worked on (tools/probe_won_branch.hip, form F)
-            int ifirst = tid - TT;
-            if (use_tab && __popc(xq[0]) <= 1 && __popc(xq[1]) <= 1 && __popc(xq[2]) <= 1 && __popc(xq[3]) <= 1) {
-                // (named scalars, not arrays: an array indexed inside the unrolled column loop went to scratch)
-                const int r0 = tid - TT, r1 = r0 + NBC, r2 = r1 + NBC;
-                const int c0r = min(r0, Nin - 1), c1r = min(r1, Nin - 1), c2r = min(r2, Nin - 1);
-                const uint32_t m0 = r0 < Nin ? rowmask[c0r] : 1u, m1 = r1 < Nin ? rowmask[c1r] : 1u, m2 = r2 < Nin ? rowmask[c2r] : 1u;
-                auto fin = [&](int i, uint32_t mr, float w, int k, int q) __attribute__((always_inline)) {
-                    if (mr != 0) return;
-                    const float xv = k == 255 ? 0.f : pw[t - k];
-                    if (pp.nu0 != 0.f) { float uu = 0.f; if (pp.use_dt) uu = uu * pp.dt; w = w - uu; }
-                    if (pp.nu1 != 0.f) { float uu = 0.0f + xv * (1.0f * pp.nu1); if (pp.use_dt) uu = uu * pp.dt; w = w + uu; }
-                    if (pp.has_min && w < pp.wmin) w = pp.wmin;
-                    if (pp.has_max && w > pp.wmax) w = pp.wmax;
-                    wwin[i * CW + q] = w;
-                };
-#pragma unroll
-                for (int q = 0; q < CW; ++q) {
-                    if (cmq[q] && c0 + q < N) {
-                        const uint8_t *tl = tlast + (size_t)(__ffs(cmq[q]) - 1) * Nin;
-                        const float wa = wtile[c0r * CW + q], wb = wtile[c1r * CW + q], wc = wtile[c2r * CW + q];
-                        const int ka = (int)tl[c0r], kb = (int)tl[c1r], kc = (int)tl[c2r];
-                        fin(r0, m0, wa, ka, q); fin(r1, m1, wb, kb, q); fin(r2, m2, wc, kc, q);
-                    }
-                }
-                ifirst = tid - TT + 3 * NBC;
-            }
-            for (int i = ifirst; i < Nin; i += NBC) {
-#else
             for (int i = tid - TT; i < Nin; i += NBC) {
-#endif
                 if (rowmask[i] != 0) continue;
 #pragma unroll
                 for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
@@ -1109,16 +768,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
         if (wave < NTW) {
             sp_prev = false;
-#if SNN_DEFER
-            if (defer_next) { }                                            // (resolved behind the publish of step t+1: resolve_prev)
-            else
-#endif
             if (prevE != 0ull && !bad) {
                 // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
                 // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
                 // instead of two.  Only a sample with several crossings waits for the arbiter's draw comparison.
                 int *xc = xcnt + wave * MAXB;
-                WHATIF_DELAY(11);
+
                 if (lane < MAXB) xc[lane] = 0;
                 {
                     constexpr int PG = 8;                                 // granules per lane: NGS <= 512
@@ -1127,13 +782,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                     uint32_t need = 0;
 #pragma unroll
                     for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
-#if SNN_POLL2
-                    if (NGS <= 256) {
-                        unsigned long long x4[4];
-                        if (poll_all4(sums, NGS, (uint32_t)(t + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
-                        else { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    } else
-#endif
                     for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                         for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
@@ -1183,26 +831,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             spfin[tid] = sp_prev ? 1 : 0;
             if (bad) ctl[0] = 1;
         }
-#if SNN_DEFER
-        pendwg = defer_next;
-        pend = defer_next && wave < NTW && prevE != 0ull;
-        pendcols = defer_next ? ((xq[0] ? 1u : 0u) | (xq[1] ? 2u : 0u) | (xq[2] ? 4u : 0u) | (xq[3] ? 8u : 0u)) : 0u;
-#endif
         AMARK(1);
-        WHATIF_DELAY(7);
-#if !SNN_DIGEST_EARLY
-        if (t + 2 <= T) DIGEST_STORE(t + 2);                              // (its buffer, entry t's, was last read before barrier B of the previous iteration)
-#endif
-#if defined(SNN_WHATIF) && SNN_WHATIF == 20
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 2 <= T) DIGEST_STORE(t + 2);
-#endif
+
         AMARK(16);
         AMARK2(23);
         lds_barrier();                                                    // ---- B
-#if defined(SNN_WHATIF) && SNN_WHATIF == 19
-        lds_barrier(); lds_barrier();
-#endif
         AMARK(2);
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
@@ -1398,7 +1031,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             const unsigned long long *sums = c.exs + (size_t)slot * NGS;
             const unsigned long long *exr = c.ex + (size_t)slot * NG;
             bool abortseen = false;
-            WHATIF_DELAY(12);
+
             // ---- every crossing granule of step e: lane l takes granules l, l + 64, ... (all its loads in flight at once, the missing
             //      ones asked for again), then decodes them into bit words / per-sample count / a crossing column
             int rp = INT_MAX;                                             // raster writers' progress, read early (used at publish time)
@@ -1408,13 +1041,6 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             uint32_t need = 0;
 #pragma unroll
             for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
-#if SNN_POLL2
-            if (NGS <= 256) {
-                unsigned long long x4[4];
-                if (poll_all4(sums, NGS, (uint32_t)(e + 1), lane, x4)) { xs[0] = x4[0]; xs[1] = x4[1]; xs[2] = x4[2]; xs[3] = x4[3]; }
-                else failed = true;
-            } else
-#endif
             for (unsigned spins = 0;; ++spins) {
 #pragma unroll
                 for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
