@@ -7,7 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SNN_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libsnnhip.so")   # (developer switch: A/B of two builds)
+LIB_PATH = os.path.join(_HERE, "lib", "libsnnhip.so")
+if os.environ.get("SNN_DEVELOPER") == "1" and os.environ.get("SNN_LIB_OVERRIDE"):
+    # developer A/B of two builds (tools/): honoured only with SNN_DEVELOPER=1, and never silently
+    import warnings
+    LIB_PATH = os.environ["SNN_LIB_OVERRIDE"]
+    warnings.warn(f"bindsnet_amd: SNN_LIB_OVERRIDE is active, loading {LIB_PATH} instead of the in-tree library", RuntimeWarning)
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
 ABI_VERSION = 7

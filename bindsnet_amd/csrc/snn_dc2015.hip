@@ -131,103 +131,14 @@ __device__ __forceinline__ void stdp_cols(const DcCtx &c, uint32_t active_cols, 
     }
 }
 
-// Once per run: digest the X spikes of every step (entry 0 = the layer's `s` at entry, entry e = inputs[e-1]),
-// fully parallel over steps and off the per-timestep critical path.  One workgroup per entry.
+// Once per run: digest the X spikes of every step (entry 0 = the layer's `s` at entry, entry e = inputs[e-1]), fully parallel over steps and
+// off the per-timestep critical path.  One workgroup per entry (dc_prep_entry, snn_dc2015.hpp; the third-generation lean form runs the same
+// body on producer workgroups INSIDE its launch).
 __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int B = c.B, Nin = c.Nin, NinW = c.NinW;
-    uint32_t *sXw = (uint32_t *)smem;                               // [B][NinW]
-    uint32_t *rowmask = sXw + B * NinW;                             // [Nin]
-    int *misc = (int *)(rowmask + Nin);                             // [0] nact, [1] flags
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = blockIdx.x;
-    const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
-    uint32_t *D = c.dig + (size_t)e * c.DW;
-    uint32_t *D_xl = D, *D_meta = D_xl + B * (LX / 2), *D_rm = D_meta + 40, *D_xw = D + c.OXW;   // (bit words last)
-    uint16_t *D_ar = (uint16_t *)(D_rm + Nin), *D_rp = D_ar + 2 * ((Nin + 1) / 2);
-    for (int k = tid; k < Nin; k += NT) rowmask[k] = 0;
-    if (tid < 2) misc[tid] = 0;
-    __syncthreads();
-    {
-        const int total16 = (B * Nin) >> 4, hwps = Nin >> 4, HS = NinW * 2;
-        uint16_t *sXh = (uint16_t *)sXw;
-        uint32_t big = 0;
-        for (int k16 = tid; k16 < total16; k16 += NT) {
-            const uint4 v = ((const uint4 *)src)[k16];
-            const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps), hw = k16 - b * hwps;
-            const uint32_t any = v.x | v.y | v.z | v.w;
-            uint32_t m16 = 0;
-            if (any) {
-                if (any & 0xFEFEFEFEu) {           // some byte is not 0/1: generic non-zero test
-                    big = 1;
-                    m16 = nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12);
-                } else {                           // 0/1 bytes: byte k contributes 2^(8k) * 2^(24-7k) = 2^(24+k); the cross
-                    m16 = ((v.x * 0x01020408u) >> 24) | (((v.y * 0x01020408u) >> 24) << 4) |      // terms fall on distinct
-                          (((v.z * 0x01020408u) >> 24) << 8) | (((v.w * 0x01020408u) >> 24) << 12);   // lower bits or overflow
-                }
-            }
-            sXh[b * HS + hw] = (uint16_t)m16;
-            if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
-            while (m16) {
-                const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
-                atomicOr(&rowmask[i], 1u << b);
-            }
-        }
-        if (big) atomicOr((unsigned int *)&misc[1], 1u);
-    }
-    __syncthreads();
-    uint16_t *D_l2 = D_rp + 2 * ((Nin + 1) / 2);                     // [B][LX] events grouped by row_sum lane
-    uint32_t *D_gc = (uint32_t *)(D_l2 + B * LX);                    // [B] five GCB-bit group sizes
-    uint16_t *lscr = (uint16_t *)(misc + 4) + wave * LX;             // this wave's scratch list
-    for (int b = wave; b < B; b += NT / 64) {
-        const int nx = build_list(sXw + b * NinW, NinW, lane, lscr, LX);
-        if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > LXF) atomicOr((unsigned int *)&misc[1], 2u); if (nx > LX - 1) atomicOr((unsigned int *)&misc[1], 4u); }
-        // (LDS operations of one wave execute in program order: the list is readable right away)
-        const bool have = lane < LX && lane < nx;
-        const int i = have ? (int)lscr[lane] : 0;
-        if (lane < LX) ((uint16_t *)D_xl)[b * LX + lane] = (uint16_t)i;
-        // the same events grouped by ATen row_sum lane (index mod 4; group 4 = the n % 4 leftover sources), ascending
-        // inside a group: what a quad of threads walks for a column >= 32*floor(N/32)
-        const bool in16 = have;                     // (every listed event: the consumers walk group sizes, not 16 slots)
-        const int grp = (i >= ((Nin >> 2) << 2)) ? 4 : (i & 3);
-        int start = 0, my = 0; uint32_t gc = 0;
-        for (int k = 0; k < 5; ++k) {
-            const uint64_t mk = __ballot(in16 && grp == k);
-            const int ck = __popcll(mk);
-            if (grp == k) my = start + __popcll(mk & ((1ull << lane) - 1ull));
-            start += ck; gc |= (uint32_t)min(ck, (1 << GCB) - 1) << (GCB * k);
-        }
-        uint16_t *perm = lscr + (NT / 64) * LX;        // second per-wave scratch: permute in LDS, store each slot once
-        if (lane < LX) perm[lane] = 0;
-        if (in16) perm[my] = (uint16_t)i;
-        if (lane < LX) D_l2[b * LX + lane] = perm[lane];
-        if (lane == 0) D_gc[b] = gc;
-        // ... and how many of the (ascending) events fall into each 256-position group of the cascade order: a quad of
-        // threads of a multi_row_sum column sums one group each
-        {
-            uint32_t gq = 0;
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t mk = __ballot(in16 && min(i >> 8, 3) == k);
-                gq |= (uint32_t)min((int)__popcll(mk), (1 << GCB) - 1) << (GCB * k);
-            }
-            if (lane == 0) D_gc[B + b] = gq;
-        }
-    }
-    for (int k = tid; k < B * NinW; k += NT) D_xw[k] = sXw[k];
-    for (int base = 0; base < Nin; base += NT) {       // compact the rows with a spike in any sample
-        const int i = base + tid;
-        const bool o = i < Nin && rowmask[i] != 0;
-        const uint64_t m = __ballot(o);
-        int wbase = 0;
-        if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
-        wbase = __shfl(wbase, 0);
-        if (o) { const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull)); D_ar[cp] = (uint16_t)i; D_rp[i] = (uint16_t)cp; }
-        if (i < Nin) D_rm[i] = rowmask[i];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        D_meta[32] = (uint32_t)misc[0]; D_meta[33] = (uint32_t)misc[1];
-        if (c.tbad && (misc[1] & 5)) atomicMin(c.tbad, e);     // first entry the lean resident forms give up on (third generation: refused up front)
-    }
+    const int e = blockIdx.x;
+    const int flags = dc_prep_entry<NT>(c, smem, e, c.dig + (size_t)e * c.DW);
+    if (threadIdx.x == 0 && c.tbad && (flags & 5)) atomicMin(c.tbad, e);     // first entry the lean resident forms give up on
 }
 
 __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
@@ -725,7 +636,6 @@ size_t lds_bytes(int B, int Nin, int N) {
            (size_t)Nin * CW * 4 + 2 * MAXB * CW * 4;
 }
 
-size_t prep_lds_bytes(int B, int Nin) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4 + 2 * (NT / 64) * LX * 2; }
 
 }  // namespace
 
@@ -738,7 +648,7 @@ static size_t fused_workspace(int B, int Nin, int N) {
 
 // lean forms: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2; the third generation keeps FOUR steps of both kinds of
 // granules in flight (rings of 4), plus its winners granules [8][11], 16 progress words of the raster writers and the tbad word
-static int g_last_form = -1;          // resident form of the last D&C run: 0 general, 1 / 2 / 3 lean generations, -1 per-step
+static thread_local int g_last_form = -1;   // resident form of this thread's last D&C run (like snn_plan_name()): 0 general, 1 / 2 / 3 lean generations, -1 per-step
 constexpr int kAsyncDefault = 1;      // third-generation lean form on by default?  (SNN_DC_ASYNC overrides)
 static size_t resident_summary_bytes(int N) { return (size_t)4 * ((N + 1) / 2) * 4 * 8; }
 static size_t resident_gran_bytes(int B, int N) { return (size_t)4 * ((N + 1) / 2) * ((B + 1) / 2) * 8; }   // >= 4 * G * KB * 8 for every tile width
@@ -923,7 +833,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
             if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex), qs)))) return rc0;
             if (c.tbad && (rc0 = snn_check(hipMemsetAsync(c.tbad, 0x7F, sizeof(int), qs)))) return rc0;
-            hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
+            hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);
             if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             const bool prof = with_events && snn_prof_begin(0, qs);
             const int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs)
@@ -933,7 +843,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         }
         rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
-        hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), prep_lds_bytes(B, Nin), qs, c);
+        hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);
         for (int t = 0; t <= R->T; ++t) {
             const bool prof = with_events && snn_prof_begin(t, qs);
             hipLaunchKernelGGL(k_dc2015_step, dim3(c.G), dim3(NT), lds, qs, c, t);

@@ -271,6 +271,107 @@ __device__ __forceinline__ float quad_lane_sum(const int *ix, int cnt, const flo
 int digest_lds_words(int B, int Nin) { return (B * (LX / 2) + 40 + Nin + 2 * ((Nin + 1) / 2) + B * (LX / 2) + 2 * B + 3) & ~3; }
 int digest_words(int B, int Nin) { return (digest_lds_words(B, Nin) + B * ((Nin + 31) / 32) + 3) & ~3; }
 
+// One digest entry (entry 0 = the layer's `s` at entry, entry e = inputs[e-1]) by one workgroup of NTH threads: written to D (global memory:
+// k_dc2015_prep, one workgroup per entry; or an LDS staging copy of the entry: the producer workgroups of k_dc2015_async, which publish it with
+// write-through stores).  LDS: dc_prep_lds_bytes(B, Nin, NTH) at smem.  Returns the entry's flags (meta[33]; uniform, behind a barrier).
+template <int NTH>
+__device__ __forceinline__ int dc_prep_entry(const DcCtx &c, unsigned char *smem, int e, uint32_t *D) {
+    const int B = c.B, Nin = c.Nin, NinW = c.NinW;
+    uint32_t *sXw = (uint32_t *)smem;                               // [B][NinW]
+    uint32_t *rowmask = sXw + B * NinW;                             // [Nin]
+    int *misc = (int *)(rowmask + Nin);                             // [0] nact, [1] flags
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *src = (e == 0) ? c.sX0 : c.in + (size_t)(e - 1) * B * Nin;
+    uint32_t *D_xl = D, *D_meta = D_xl + B * (LX / 2), *D_rm = D_meta + 40, *D_xw = D + c.OXW;   // (bit words last)
+    uint16_t *D_ar = (uint16_t *)(D_rm + Nin), *D_rp = D_ar + 2 * ((Nin + 1) / 2);
+    for (int k = tid; k < Nin; k += NTH) rowmask[k] = 0;
+    if (tid < 2) misc[tid] = 0;
+    __syncthreads();
+    {
+        const int total16 = (B * Nin) >> 4, hwps = Nin >> 4, HS = NinW * 2;
+        uint16_t *sXh = (uint16_t *)sXw;
+        uint32_t big = 0;
+        for (int k16 = tid; k16 < total16; k16 += NTH) {
+            const uint4 v = ((const uint4 *)src)[k16];
+            const int b = (int)(((float)k16 + 0.5f) * c.inv_hwps), hw = k16 - b * hwps;
+            const uint32_t any = v.x | v.y | v.z | v.w;
+            uint32_t m16 = 0;
+            if (any) {
+                if (any & 0xFEFEFEFEu) {           // some byte is not 0/1: generic non-zero test
+                    big = 1;
+                    m16 = nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12);
+                } else {                           // 0/1 bytes: byte k contributes 2^(8k) * 2^(24-7k) = 2^(24+k); the cross
+                    m16 = ((v.x * 0x01020408u) >> 24) | (((v.y * 0x01020408u) >> 24) << 4) |      // terms fall on distinct
+                          (((v.z * 0x01020408u) >> 24) << 8) | (((v.w * 0x01020408u) >> 24) << 12);   // lower bits or overflow
+                }
+            }
+            sXh[b * HS + hw] = (uint16_t)m16;
+            if (hw == hwps - 1 && (hwps & 1)) sXh[b * HS + hw + 1] = 0;
+            while (m16) {
+                const int i = hw * 16 + __ffs(m16) - 1; m16 &= m16 - 1;
+                atomicOr(&rowmask[i], 1u << b);
+            }
+        }
+        if (big) atomicOr((unsigned int *)&misc[1], 1u);
+    }
+    __syncthreads();
+    uint16_t *D_l2 = D_rp + 2 * ((Nin + 1) / 2);                     // [B][LX] events grouped by row_sum lane
+    uint32_t *D_gc = (uint32_t *)(D_l2 + B * LX);                    // [B] five GCB-bit group sizes
+    uint16_t *lscr = (uint16_t *)(misc + 4) + wave * LX;             // this wave's scratch list
+    for (int b = wave; b < B; b += NTH / 64) {
+        const int nx = build_list(sXw + b * NinW, NinW, lane, lscr, LX);
+        if (lane == 0) { D_meta[b] = (uint32_t)nx; if (nx > LXF) atomicOr((unsigned int *)&misc[1], 2u); if (nx > LX - 1) atomicOr((unsigned int *)&misc[1], 4u); }
+        // (LDS operations of one wave execute in program order: the list is readable right away)
+        const bool have = lane < LX && lane < nx;
+        const int i = have ? (int)lscr[lane] : 0;
+        if (lane < LX) ((uint16_t *)D_xl)[b * LX + lane] = (uint16_t)i;
+        // the same events grouped by ATen row_sum lane (index mod 4; group 4 = the n % 4 leftover sources), ascending
+        // inside a group: what a quad of threads walks for a column >= 32*floor(N/32)
+        const bool in16 = have;                     // (every listed event: the consumers walk group sizes, not 16 slots)
+        const int grp = (i >= ((Nin >> 2) << 2)) ? 4 : (i & 3);
+        int start = 0, my = 0; uint32_t gc = 0;
+        for (int k = 0; k < 5; ++k) {
+            const uint64_t mk = __ballot(in16 && grp == k);
+            const int ck = __popcll(mk);
+            if (grp == k) my = start + __popcll(mk & ((1ull << lane) - 1ull));
+            start += ck; gc |= (uint32_t)min(ck, (1 << GCB) - 1) << (GCB * k);
+        }
+        uint16_t *perm = lscr + (NTH / 64) * LX;        // second per-wave scratch: permute in LDS, store each slot once
+        if (lane < LX) perm[lane] = 0;
+        if (in16) perm[my] = (uint16_t)i;
+        if (lane < LX) D_l2[b * LX + lane] = perm[lane];
+        if (lane == 0) D_gc[b] = gc;
+        // ... and how many of the (ascending) events fall into each 256-position group of the cascade order: a quad of
+        // threads of a multi_row_sum column sums one group each
+        {
+            uint32_t gq = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t mk = __ballot(in16 && min(i >> 8, 3) == k);
+                gq |= (uint32_t)min((int)__popcll(mk), (1 << GCB) - 1) << (GCB * k);
+            }
+            if (lane == 0) D_gc[B + b] = gq;
+        }
+    }
+    for (int k = tid; k < B * NinW; k += NTH) D_xw[k] = sXw[k];
+    for (int base = 0; base < Nin; base += NTH) {       // compact the rows with a spike in any sample
+        const int i = base + tid;
+        const bool o = i < Nin && rowmask[i] != 0;
+        const uint64_t m = __ballot(o);
+        int wbase = 0;
+        if (lane == 0 && m) wbase = atomicAdd(&misc[0], __popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (o) { const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull)); D_ar[cp] = (uint16_t)i; D_rp[i] = (uint16_t)cp; }
+        if (i < Nin) D_rm[i] = rowmask[i];
+    }
+    __syncthreads();
+    if (tid == 0) { D_meta[32] = (uint32_t)misc[0]; D_meta[33] = (uint32_t)misc[1]; }
+    const int flags = misc[1];
+    __syncthreads();                                                // (misc is rewritten by the workgroup's next entry)
+    return flags;
+}
+inline size_t dc_prep_lds_bytes(int B, int Nin, int nth) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4 + 2 * (nth / 64) * LX * 2; }
+
+
 }  // namespace
 
 // resident form (snn_dc2015_resident.hip)

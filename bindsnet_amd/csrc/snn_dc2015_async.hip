@@ -56,6 +56,12 @@ constexpr unsigned kAbortPay = 0xFFFFFFFEu;   // crossing-granule payload of a w
 
 __device__ __forceinline__ uint32_t win_tag(int e) { return (uint32_t)(e + 1) & 1023u; }
 
+// The status word keeps the FIRST error of a launch: a later SNN_ERR_TIMEOUT of somebody who waited in vain for a workgroup that had already
+// given up must not hide that workgroup's SNN_ERR_RETRY (the host picks the plan of the second attempt by it).
+__device__ __forceinline__ void report(int *status, int code) {
+    if (status) atomicCAS(status, 0, code);
+}
+
 // The kernel context for a RARELY taken path: the same struct through a pointer the compiler cannot see through, so that the fields
 // read through it are loaded where they are used (scalar loads from the kernel-argument segment) instead of being kept -- spilled --
 // in scalar registers across the whole step loop.
@@ -226,7 +232,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     unsigned long long x0, x1;
     if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
     for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
-        if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+        if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); return -1; }
         __builtin_amdgcn_s_sleep(kWinPollSleep);
         x0 = granule_load(gr); x1 = granule_load(gr + 1);
     }
@@ -244,7 +250,7 @@ __device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int 
     for (int k = 1; 3 * k < nw; ++k) {
         unsigned long long x = k == 1 ? x1 : granule_load(gr + k);
         for (unsigned spins = 0; (uint32_t)(x >> 54) != tag; ++spins) {
-            if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return -1; }
+            if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); return -1; }
             __builtin_amdgcn_s_sleep(1);
             x = granule_load(gr + k);
         }
@@ -478,7 +484,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool bad = ctl[0] != 0;                                   // this wave has seen a reason to give up (uniform per wave)
-    if (bad && tid == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad && tid == 0) report(c.status, SNN_ERR_RETRY);
     // X -> Ae currents of step 0 (from the layer's spikes at entry, digest entry 0)
     for (int qt = tid; qt < B * CW * 4; qt += NT) {
         const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
@@ -617,7 +623,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 if (pI.traces) x_cur = trace_next(x_cur, spIn, pI.trace_decay, pI.trace_scale, pI.traces_additive);
                 if (spIn != spA) {
                     ctl[0] = 1;
-                    if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    report(cold(c).status, SNN_ERR_RETRY);
                 }
                 if (c.rasVI) (cold(c).rasVI + (size_t)t * B * N)[kst] = r_v;
             }
@@ -788,7 +794,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
                         for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(t + 1)) need &= ~(1u << u);
                         if (!__any(need != 0u)) break;
-                        if (spins > kAPoll) { bad = true; if (cold(c).status) __hip_atomic_store(cold(c).status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); break; }
                     }
                     bool ab = false;
 #pragma unroll
@@ -838,9 +844,16 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         lds_barrier();                                                    // ---- B
         AMARK(2);
     }
-    // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on
-    if (bad && wave < NTW && published <= T - 1 && lane == 0)
-        granule_store(c.exs + (size_t)(published & (kCrossRing - 1)) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(published + 1) << 32) | kAbortPay);
+    // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on.  A wave that has
+    //      published all T steps sends a FINAL REPORT in the granule of "step T": nothing, or the abort mark -- a reason to give up that shows in
+    //      the LAST iteration (an Ai neuron that does not follow its partner at step T-1, a poll of that step's winners that ran out) comes
+    //      after the wave's last publish, and the arbiter must not commit over it: every other workgroup would write its state back while this
+    //      one returns, and the host would repeat the input on a half-advanced network.  (`bad` is final here: the top of iteration T read the
+    //      abort word behind the last barrier B, and nothing writes it afterwards.)
+    if (wave < NTW && lane == 0) {
+        const int pstep = (bad && published <= T - 1) ? published : T;
+        granule_store(c.exs + (size_t)(pstep & (kCrossRing - 1)) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(pstep + 1) << 32) | (bad ? kAbortPay : 0u));
+    }
     // ---- commit: the arbiter's commit granule ("step T") has arrived -> every step was published without an abort mark and the raster
     //      writers are through: nobody can give up any more
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1025,6 +1038,18 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 granule_store(c.wing + (size_t)((e0 + lane) & (kWinRing - 1)) * kWinGr,
                               ((unsigned long long)win_tag(e0 + lane) << 54) | (63ull << 48) | 0xFFFFFFFFFFFFull);
         };
+        // the raster writers must be done with the step whose ring slot step e0 (and an abort mark's two steps behind it) takes: progress >= e0 - 5
+        auto raster_wait = [&](int e0, int rp) __attribute__((always_inline)) -> bool {
+            bool late = false;
+            if (c.NRW > 0 && e0 >= kWinRing - 2 && lane < c.NRW) {
+                for (unsigned spins = 0; rp < e0 - (kWinRing - 2) + 1; ++spins) {
+                    if (spins > kAPoll) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    rp = __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return __any(late);
+        };
         int e = 0;
         for (; e < T && !failed; ++e) {
             const int slot = e & (kCrossRing - 1);
@@ -1090,9 +1115,11 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
             failed = __any(failed);
             abortseen = __any(abortseen);
             if constexpr (TIMING) { if (c.dbg && lane == 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)e * 256 + 255) * 4 + 0] = (long long)wall_clock64(); }
-            if (failed) { if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (failed) { if (lane == 0) report(c.status, SNN_ERR_TIMEOUT); }
             if (failed || abortseen) {
-                // pass the abort on: every reader of this step's (and any later) winners sees the mark
+                // pass the abort on: every reader of this step's (and any later) winners sees the mark -- once the raster writers have left
+                // the three ring slots it takes (a writer still polling one of them would wait out its bounded poll: 0.5 s)
+                (void)raster_wait(e, rp);
                 publish_abort(e);
                 failed = true;
                 break;
@@ -1115,32 +1142,23 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 if (lane == bsm) mywin = wcol;
             }
             if (failed) {
-                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) report(c.status, SNN_ERR_TIMEOUT);
                 publish_abort(e);
                 break;
             }
             // ---- pack: entry r of the list = (sample << 11) | column of the r-th crossing sample
             if (lane < B && myc > 0) winlist[__popc(anym & ((1u << lane) - 1u))] = (lane << 11) | (mywin & 0x7FF);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int ngr = arb_rows > 3 ? (arb_rows + 2) / 3 : 1;
             // the raster writers must be done with the step whose ring slot this one takes (progress read at the start of the step)
-            if (c.NRW > 0 && e >= kWinRing - 2) {
-                bool late = false;
-                if (lane < c.NRW) {
-                    for (unsigned spins = 0; rp < e - (kWinRing - 2) + 1; ++spins) {
-                        if (spins > kAPoll) { late = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        rp = __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (__any(late)) {
-                    if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    publish_abort(e);
-                    failed = true;
-                    break;
-                }
+            if (raster_wait(e, rp)) {
+                if (lane == 0) report(c.status, SNN_ERR_TIMEOUT);
+                publish_abort(e);
+                failed = true;
+                break;
             }
-            if (lane < ngr) {
+            // (all kWinGr granules of the slot, not just the ceil(arb_rows / 3) that hold winners: the tag has 10 bits, so a granule this step left alone
+            //  could still carry the tag of step e - 1024 m -- or the run's initial zero, which is win_tag(1023))
+            if (lane < kWinGr) {
                 unsigned long long pl = 0;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
@@ -1169,6 +1187,26 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
         //      compute workgroups write their state back and the arbiter the generator.  Whatever fails before that leaves an abort mark
         //      instead: nobody writes anything.
         if (!failed && e == T) {
+            // the compute workgroups' FINAL REPORTS ("step T" crossing granules): an abort mark among them -> no commit
+            {
+                const unsigned long long *sums = c.exs + (size_t)(T & (kCrossRing - 1)) * NGS;
+                bool ab = false, to = false;
+                for (int gi = lane; gi < NGS; gi += 64) {
+                    unsigned long long x = granule_load(sums + gi);
+                    for (unsigned spins = 0; (uint32_t)(x >> 32) != (uint32_t)(T + 1); ++spins) {
+                        if (spins > kAPoll) { to = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        x = granule_load(sums + gi);
+                    }
+                    if (to) break;
+                    if ((uint32_t)x == kAbortPay) ab = true;
+                }
+                if (__any(to)) { if (lane == 0) report(c.status, SNN_ERR_TIMEOUT); failed = true; }
+                else if (__any(ab)) failed = true;
+                if (failed) { (void)raster_wait(T, 0); publish_abort(T); }
+            }
+        }
+        if (!failed && e == T) {
             bool late = false;
             if (c.NRW > 0 && lane < c.NRW) {
                 for (unsigned spins = 0; __hip_atomic_load(&c.rprog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T; ++spins) {
@@ -1177,7 +1215,7 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 }
             }
             if (__any(late) || !wait_block(tb)) {
-                if (lane == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) report(c.status, SNN_ERR_TIMEOUT);
                 publish_abort(T);
             } else {
                 if (lane == 0)
@@ -1233,7 +1271,7 @@ __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
     const int blk = (int)blockIdx.x;
     if (blk == c.stall_wg) return;
     if (*c.tbad <= c.T) {             // an input the lean forms do not take: refused before anything has happened
-        if (blk == 0 && threadIdx.x == 0 && c.status) __hip_atomic_store(c.status, (int)SNN_ERR_RETRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blk == 0 && threadIdx.x == 0) report(c.status, SNN_ERR_RETRY);
         return;
     }
     if (blk < c.G) async_compute<TIMING>(c, smem);
@@ -1257,13 +1295,23 @@ static bool async_attr_once() {
 
 int snn_dc2015_async_capacity(size_t lds) {
     if (!async_attr_once()) return 0;
-    int dev = 0, cus = 0, coop = 0, per_cu = 0;
+    int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    // (asked on every run: the answer is kept per device and LDS size -- two attribute queries and an occupancy query otherwise)
+    struct Known { int dev; size_t lds; int cap; };
+    static thread_local Known known[4] = {{-1, 0, 0}, {-1, 0, 0}, {-1, 0, 0}, {-1, 0, 0}};
+    static thread_local int next = 0;
+    const char *fake = getenv("SNN_DC_FAKE_CUS");            // (test switch, read per run: never kept)
+    const int fake_cus = fake ? atoi(fake) : 0;
+    if (!fake_cus) for (const Known &k : known) if (k.dev == dev && k.lds == lds) return k.cap;
+    int cus = 0, coop = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (getenv("SNN_DC_FAKE_CUS")) cus = atoi(getenv("SNN_DC_FAKE_CUS"));
-    return coop ? cus * per_cu : 0;
+    if (fake_cus) cus = fake_cus;
+    const int cap = coop ? cus * per_cu : 0;
+    if (!fake_cus) { known[next] = Known{dev, lds, cap}; next = (next + 1) & 3; }
+    return cap;
 }
 
 // grid = G compute workgroups + the arbiter + c.NRW raster writers, all co-resident (cooperative launch)

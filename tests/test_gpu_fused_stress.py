@@ -58,6 +58,41 @@ def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, 
         _lib.lib().snn_set_plan_mode(0)
 
 
+def oracle_run(N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, inh=120.0, nu=(1e-4, 1e-2), exc=22.5, w_ei=None):
+    """The same sequence as run() through the CPU oracle (oracle/snn_oracle.c: the reference's algorithm restated, pinned to the reference
+    fixtures by tests/test_oracle_golden.py / test_oracle_fullsize.py): the THIRD party of the HIP-vs-HIP comparisons in this file, the fuzz
+    tests and tests/test_gpu_async_form.py.  Same outputs as run() (replacing traces only: the oracle's D&C run has no additive switch)."""
+    import oracle
+    P = oracle.eth_mnist_dc_params(N, B, T, Nin=Nin, learning=learning)
+    P.nu0, P.nu1 = float(nu[0]), float(nu[1])
+    W0 = np.minimum(synth.uniform_f32(3, (Nin, N), 0.0, w_scale), 1.0).astype(np.float32)
+    st = oracle.eth_mnist_dc_state(N, B, W0, Nin=Nin, exc=exc, inh=inh)
+    if w_ei is not None:
+        st["W_ei"] = np.ascontiguousarray(w_ei, np.float32)
+    out = []
+    for r in range(n_inputs):
+        Q = oracle.exp_noise(11 + r, B * N * T + 16)
+        cur = np.zeros(1, np.int64)
+        sE, sI = oracle.run_dc2015(P, st, np.ascontiguousarray(spikes[r].reshape(T, B, Nin)), Q, cur)
+        torch.manual_seed(11 + r)
+        if cur[0]:
+            torch.empty(int(cur[0])).exponential_(1)
+        probe = torch.rand(3).numpy()
+        out.append(dict(sE=sE.astype(bool), sI=sI.astype(bool), W=st["W_xe"].copy(), theta=st["theta"].copy(), vE=st["vE"].copy(), xE=st["xE"].copy(),
+                        xX=st["xX"].copy(), vI=st["vI"].copy(), probe=probe))
+        if r % 2 == 0:
+            import cases
+            cases.dc_reset(st)
+    return out
+
+
+def same_as_oracle(a, orc):
+    for r, (x, y) in enumerate(zip(a, orc)):
+        for k in y:
+            np.testing.assert_array_equal(np.ascontiguousarray(x[k]).reshape(-1).view(np.uint8), np.ascontiguousarray(y[k]).reshape(-1).view(np.uint8),
+                                          err_msg=f"input {r}: {k} (device vs CPU oracle)")
+
+
 def same(a, b):
     for r, (x, y) in enumerate(zip(a, b)):
         for k in x:
@@ -97,6 +132,8 @@ def test_fused_equals_generic_under_stress(name):
     same(fused, generic)
     same(general, generic)
     same(stepped, generic)
+    if vmax == 1 and N * B <= 4000:                      # third party: the CPU oracle (0/1 spike bytes; sizes it finishes in seconds)
+        same_as_oracle(fused, oracle_run(N, B, T, spikes, w_scale=wsc))
     assert sum(int(x["sE"].sum()) for x in fused) > 0, "no excitatory spike at all: vacuous"
     assert all(x["sE"].reshape(T, B, N).sum(axis=2).max() <= 1 for x in fused)
 
@@ -110,6 +147,7 @@ def test_learning_off_and_weak_inhibition():
     same(f, g)
     same(r3, g)
     same(h, g)
+    same_as_oracle(f, oracle_run(100, 6, 30, spikes, learning=False, inh=17.5))
 
 
 def test_plan_refuses_unsupported_shapes_and_falls_back():

@@ -119,3 +119,36 @@ def test_lean_resident_partial_last_tile(N, B):
     _same(res, gen, f"resident (auto) N={N} B={B}")
     gres, _ = dc.run(3, N, B, T, spikes, w_scale=0.5)
     _same(gres, gen, f"resident (general) N={N} B={B}")
+
+
+SOAK = int(os.environ.get("SNN_SOAK_CASES", "200"))
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_soak_resident_plan_against_the_cpu_oracle(chunk):
+    """A slice of the round-4 soak (tools/soak.py: the resident plan against the generic plan, 1 524 cases) promoted to a test with the CPU
+    ORACLE as the checker: SNN_SOAK_CASES (default 200) seeded random D&C networks at sizes the scalar oracle finishes in a fraction of a
+    second each, three consecutive inputs with learning on (weights, thresholds and the generator position carried over), input densities at
+    which the lean form stays in charge; rasters, weights, theta, membrane potentials, traces and the host generator's position bit for bit."""
+    n_lean = n_cases = 0
+    for seed in range(chunk, SOAK, 8):
+        rs = np.random.RandomState(12000 + seed)
+        N = int(rs.choice([16, 36, 64, 100, 128, 200]))
+        B = int(rs.choice([1, 4, 8, 16, 32]))
+        T = int(rs.choice([20, 40, 64]))
+        Nin = int(rs.choice([784, 784, 400, 196]))
+        dens = float(rs.choice([0.006, 0.012, 0.02, 0.03]))
+        kw = dict(w_scale=float(rs.choice([0.3, 0.6, 1.0])), n_inputs=3, learning=bool(rs.rand() < 0.9), Nin=Nin,
+                  inh=float(rs.choice([120.0, 17.5, 60.0])), exc=float(rs.choice([22.5, 22.5, 30.0])),
+                  nu=[(1e-4, 1e-2), (1e-4, 1e-2), (0.0, 1e-2), (1e-3, 0.0), (5e-4, 5e-2)][int(rs.randint(5))])
+        shape = {784: (1, 28, 28), 400: (1, 20, 20), 196: (1, 14, 14)}[Nin]
+        spikes = [synth.dense_spikes(800 + 13 * seed + r, (T, B, Nin), dens) for r in range(3)]
+        res, plan = dc.run(0, N, B, T, spikes, shape=shape, **kw)
+        assert plan.startswith("dc2015-resident"), (seed, plan)
+        n_lean += plan == "dc2015-resident-lean"
+        n_cases += 1
+        try:
+            dc.same_as_oracle(res, dc.oracle_run(N, B, T, spikes, **kw))
+        except AssertionError as e:
+            raise AssertionError(f"soak seed {seed}: N={N} B={B} T={T} Nin={Nin} dens={dens} {kw} plan {plan}: {str(e)[:400]}") from None
+    assert n_cases == 0 or n_lean >= n_cases // 2, "the lean form should be what runs in most of these cases"

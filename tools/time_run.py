@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from bindsnet_amd import _lib  # noqa: E402
 
-if os.environ.get("SNN_LIB_OVERRIDE"):          # A/B of two builds on one box (developer aid)
+if os.environ.get("SNN_LIB_OVERRIDE"):          # A/B of two builds on one box (developer aid; _lib honours it only with SNN_DEVELOPER=1)
     _lib.LIB_PATH = os.environ["SNN_LIB_OVERRIDE"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda", 0)
