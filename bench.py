@@ -202,30 +202,33 @@ def cpu_baseline(host_inputs, aff_all=None, pin=None):
     return cpu, precs
 
 
-def parity_leg(dev, host_pool, recs, against):
-    """The same 3 inputs from the same seeds on the GPU (fresh network), against the 8-thread CPU run of this process."""
+def parity_leg(dev, host_pool, recs, against, pipelined=True):
+    """The same inputs from the same seeds on the GPU (fresh network), against the CPU run of this process -- in the mode the timed region
+    ran in: inside a pipelined section the generator position of input k+1 is what input k left ON THE DEVICE."""
+    import contextlib
     net = build_network(dev)
     torch.manual_seed(2)
     ok, dW, dth, wexact = True, 0.0, 0.0, True
     exc = inh = 0
     plans = []
-    for r, rec in enumerate(recs):
-        net.run({"X": torch.from_numpy(host_pool[r]).view(T, BATCH, 1, 28, 28).to(dev)}, time=T)
-        torch.cuda.synchronize()
-        plans.append(net.last_plan)
-        for l in ("Ae", "Ai"):
-            got = net.monitors[l + "_spikes"].get("s").reshape(T, BATCH, N_EXC).cpu()
-            ok = ok and bool(torch.equal(got.bool(), rec[l].bool()))
-        W = net.connections[("X", "Ae")].pipeline[0].value.detach().cpu()
-        dW = max(dW, float((W - rec["W"]).abs().max()))
-        wexact = wexact and bool(torch.equal(W, rec["W"]))
-        dth = max(dth, float((net.layers["Ae"].theta.cpu() - rec["theta"]).abs().max()))
-        exc, inh = exc + int(rec["Ae"].sum()), inh + int(rec["Ai"].sum())
-        net.reset_state_variables()
+    with (net.pipelined() if pipelined else contextlib.nullcontext()):
+        for r, rec in enumerate(recs):
+            net.run({"X": torch.from_numpy(host_pool[r]).view(T, BATCH, 1, 28, 28).to(dev)}, time=T)
+            torch.cuda.synchronize()
+            plans.append(net.last_plan)
+            for l in ("Ae", "Ai"):
+                got = net.monitors[l + "_spikes"].get("s").reshape(T, BATCH, N_EXC).cpu()
+                ok = ok and bool(torch.equal(got.bool(), rec[l].bool()))
+            W = net.connections[("X", "Ae")].pipeline[0].value.detach().cpu()
+            dW = max(dW, float((W - rec["W"]).abs().max()))
+            wexact = wexact and bool(torch.equal(W, rec["W"]))
+            dth = max(dth, float((net.layers["Ae"].theta.cpu() - rec["theta"]).abs().max()))
+            exc, inh = exc + int(rec["Ae"].sum()), inh + int(rec["Ai"].sum())
+            net.reset_state_variables()
     return {"rasters_bit_exact": ok, "inputs": len(recs), "exc_spikes": exc, "inh_spikes": inh, "max_abs_dW": dW,
             "weights_bit_exact": wexact, "max_abs_dtheta": dth, "plan": plans,
             "plan_retries(lean,resident)": [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)],
-            "against": against}
+            "mode": "pipelined section" if pipelined else "synchronous runs", "against": against}
 
 
 def respawn_under_launcher(args):
@@ -248,10 +251,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", default="auto", choices=["auto", "generic", "per-step"])
+    ap.add_argument("--sync-runs", action="store_true", help="every network.run() waits for the device (the reference's call-by-call "
+                    "behaviour) instead of the pipelined section the timed region normally is")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="N > 1: nccl = RCCL over xGMI (one rank per GPU); gloo lets the "
+                    "whole N-rank path run with N processes on ONE GPU (tests)")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("SNN_BENCH_WATCHDOG", "240")),
+                    help="seconds a stage (rendezvous, warm-up, timed region) may take before rank 0 prints a JSON line with `error` and the process exits")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+        if not torch.cuda.is_available() or (torch.cuda.device_count() < args.gpus and args.backend == "nccl"):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
         respawn_under_launcher(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,15 +296,60 @@ def main():
     cpu = recs = None
     if cpu_leg:                                                 # N = 1 only
         cpu, recs = cpu_baseline(host_pool, aff_all, pin)
+    # ---- N > 1: a stage that hangs (a rank that died, an RCCL ring that never forms) must not cost the line: the watchdog prints one with
+    #      `error` from rank 0 and ends the process
+    stage = {"name": "start", "t0": time.time()}
+
+    def error_line(msg):
+        if rank == 0:
+            print(json.dumps({"metric": "simulated timesteps/sec (whole node), DiehlAndCook2015 784->400 batch32", "value": None, "unit": "timesteps/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                              "error": msg, "stage": stage["name"], "backend": args.backend if world > 1 else None,
+                              "env": {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")}}), flush=True)
+
+    def watchdog():
+        import threading
+
+        def bark():
+            while True:
+                time.sleep(1.0)
+                if stage["name"] == "done":
+                    return
+                if time.time() - stage["t0"] > args.watchdog:
+                    error_line(f"stage '{stage['name']}' did not finish within {args.watchdog:.0f} s (rank {rank} of {world})")
+                    sys.stdout.flush()
+                    os._exit(3)
+        threading.Thread(target=bark, daemon=True).start()
+
+    def enter(name):
+        stage["name"], stage["t0"] = name, time.time()
+
     if world > 1:
+        watchdog()
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("NCCL_DEBUG", "WARN")                      # (RCCL's own complaints end up on stderr next to the line)
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl" and local >= ndev:
+            error_line(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible (RCCL needs one GPU per rank)")
+            raise SystemExit(2)
+        local_dev = local % max(1, ndev)                                 # (gloo: several ranks may share a GPU)
+        torch.cuda.set_device(local_dev)
+        enter("init_process_group")
+        try:
+            import datetime
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=datetime.timedelta(seconds=args.watchdog))
+            else:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.watchdog))
+        except Exception as e:                                           # noqa: BLE001
+            error_line(f"init_process_group({args.backend}) failed on rank {rank}: {str(e)[:400]}")
+            raise
     else:
         dist = None
-    dev = torch.device("cuda", local if world > 1 else 0)
+        local_dev = 0
+    dev = torch.device("cuda", local_dev)
     torch.cuda.set_device(dev)
 
     from bindsnet_amd import _lib, parallel
@@ -323,32 +377,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import contextlib
+    # The timed region is ONE pipelined section (Network.pipelined(), an extension of the reference's API): run() returns without waiting
+    # for the device, so the host prepares input k+1 while input k executes; the status words of all runs and the host generator are
+    # settled by net.sync() INSIDE the timed region, before the closing fence.  --sync-runs: every run() waits, as a reference user's loop does.
+    section = contextlib.nullcontext() if args.sync_runs else net.pipelined()
     torch.manual_seed(2)                                   # host generator: feeds the one_spike arbitration (consumed on the device)
-    for k in range(args.warmup):
-        one(k)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one(args.warmup + k)
-    host_enqueue = time.perf_counter() - t0                # the host has issued every step (nothing waited for): its own cost per step
-    fence()
-    elapsed = time.perf_counter() - t0
+    enter("warmup")
+    try:
+        with section:
+            for k in range(args.warmup):
+                one(k)
+            net.sync()
+            fence()
+            enter("timed region")
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                one(args.warmup + k)
+            host_enqueue = time.perf_counter() - t0            # the host has issued every step: its own cost per step
+            net.sync()                                         # status of every run checked, host generator written back
+            fence()
+            elapsed = time.perf_counter() - t0
+    except Exception as e:                                     # noqa: BLE001
+        error_line(f"rank {rank}, stage '{stage['name']}': {type(e).__name__}: {str(e)[:400]}")
+        raise
+    enter("reduce")
     ranks_seen, devices = 1, [f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}"]
+    collective = None
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tdev = dev if args.backend == "nccl" else torch.device("cpu")
+        own = elapsed
+        tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         ranks_seen = dist.get_world_size()
         ids = [None] * ranks_seen
-        dist.all_gather_object(ids, f"rank{rank}=cuda:{dev.index}")
+        dist.all_gather_object(ids, f"rank{rank}=cuda:{dev.index} own_elapsed_s={own:.4f}")
         devices = ids
+        # the per-input collective on its own: the flat delta buffer sharded_run all-reduces (weights + thresholds), 20 times
+        st = net.__dict__.get("_shard_state")
+        if st is not None and "delta" in st:
+            buf = st["delta"].clone()
+            fence()
+            c0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            fence()
+            collective = {"op": "all_reduce(SUM) of the flat weight + threshold delta", "bytes": buf.numel() * buf.element_size(),
+                          "ms": round((time.perf_counter() - c0) / 20 * 1e3, 4), "backend": args.backend}
+    enter("post")
 
     if rank == 0:
         plan_timed = net.last_plan
         retries = [getattr(net, "lean_retries", 0), getattr(net, "resident_retries", 0)]
         par = parity_leg(dev, host_pool, recs, (
             f"the unmodified reference (oracle/_ref) on this host in this run, {len(recs)} consecutive inputs from identical seeds" if cpu.get("kind") == "reference"
-            else "oracle/torch_cpu_ref.py on this host in this run, 3 consecutive inputs from identical seeds") + " (weights, theta compared after each)") if recs else None
+            else "oracle/torch_cpu_ref.py on this host in this run, 3 consecutive inputs from identical seeds") + " (weights, theta compared after each)",
+            pipelined=not args.sync_runs) if recs else None
         # ---- roofline of the dominant kernel: HIP events (on the launch stream) around single launches of further
         # runs of the same input pool, LAST, so the device is busy until the process prints its line
         roof = None
@@ -384,14 +469,17 @@ def main():
                        "input": input_stats,
                        "timesteps_per_step": T, "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                        "sample_timesteps_per_s": round(steps_total * BATCH / elapsed, 1),
-                       "plan": plan_timed, "plan_retries(lean,resident)": retries, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+                       "plan": plan_timed, "plan_retries(lean,resident)": retries, "graph_runs(plain,captured,replayed)": list(_lib.graph_stats()), "parallelism": f"batch-shard x{world}" if world > 1 else "single",
+                       "host_sync": "per run (--sync-runs)" if args.sync_runs else "pipelined section (Network.pipelined()): status words + host generator settled by net.sync() inside the timed region",
+                       "backend": args.backend if world > 1 else None, "per_input_collective": collective},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": par,
         }
         if cpu is not None:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    stage["name"] = "done"
     if dist is not None:
         dist.destroy_process_group()
 

@@ -15,7 +15,7 @@ if os.environ.get("SNN_DEVELOPER") == "1" and os.environ.get("SNN_LIB_OVERRIDE")
     warnings.warn(f"bindsnet_amd: SNN_LIB_OVERRIDE is active, loading {LIB_PATH} instead of the in-tree library", RuntimeWarning)
 
 SNN_OK, SNN_ERR_NOISE, SNN_ERR_TIMEOUT, SNN_ERR_RETRY = 0, -4, -6, -7
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 # ---- descriptor-cache invalidation (network/network.py): every attribute assignment on a network object (layer,
@@ -75,7 +75,7 @@ class LayerDesc(C.Structure):
                 ("raster_v", C.c_void_p), ("current", C.c_void_p),
                 ("clamp", C.c_void_p), ("unclamp", C.c_void_p), ("clamp_per_step", C.c_int), ("unclamp_per_step", C.c_int),
                 ("inject_v", C.c_void_p), ("inject_per_step", C.c_int), ("inject_len", C.c_int),
-                ("ext_current", C.c_void_p)]
+                ("ext_current", C.c_void_p), ("thresh_vec", C.c_void_p)]
 
 
 class ConnDesc(C.Structure):
@@ -98,7 +98,8 @@ class RunDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("dt", C.c_float), ("learning", C.c_int),
                 ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_ulonglong),
-                ("cursor", C.c_void_p), ("status", C.c_void_p), ("one_step", C.c_int), ("plan", C.c_int)]
+                ("cursor", C.c_void_p), ("status", C.c_void_p), ("one_step", C.c_int), ("plan", C.c_int),
+                ("status2", C.c_void_p)]
 
 
 class FillSegment(C.Structure):
@@ -124,6 +125,7 @@ _SIGS = {
     "snn_prop_conv2d_f32": ([_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp], _i),
     "snn_input_step": ([_vp, _vp, _l, _f, _f, _i, _vp, _vp], _i),
     "snn_lif_step": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp], _i),
+    "snn_lif_step_vth": ([_vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(LifParams), _vp, _vp, _vp, _vp], _i),
     "snn_dc_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp, _vp], _i),
     "snn_dc_arbitrate": ([_vp, _vp, _i, _i, C.POINTER(DcParams), _vp, _ll, _vp, _vp, _vp, _vp], _i),
     "snn_stdp_postpre": ([_vp] * 5 + [_i, _i, _i, _f, _f, _i, _f, _f, _i, _f, _i, _f, _i, _vp], _i),

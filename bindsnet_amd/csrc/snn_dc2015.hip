@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_prep(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int flags = dc_prep_entry<NT>(c, smem, e, c.dig + (size_t)e * c.DW);
-    if (threadIdx.x == 0 && c.tbad && (flags & 5)) atomicMin(c.tbad, e);     // first entry the lean resident forms give up on
+    if (threadIdx.x == 0 && c.tbad && (flags & 5)) atomicOr(c.tbad, 1);      // an entry the lean resident forms give up on
 }
 
 __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) {
@@ -580,47 +580,7 @@ __global__ __launch_bounds__(NT) void k_dc2015_step(const DcCtx c, const int t) 
 }
 
 
-// X trace after every step: entry 0 = trace at run entry, entry e = trace after step e-1 (nodes.py:96-103).
-// ADD: additive traces (x = x * decay + scale * s) / replacing ones (x = s ? scale : x * decay), branch-free either way.
-template <bool ADD>
-__device__ __forceinline__ float xtrace_next(float x, uint8_t s, float decay, float scale) {
-    const float t = x * decay;
-    if (ADD) return t + scale * (float)s;
-    return s ? scale : t;
-}
-
-template <bool ADD>
-__device__ __forceinline__ void xtrace_body(const DcCtx &c, int n, int k) {
-    float x = c.xX[1][k];
-    c.xtr[k] = x;
-    int t = 0;
-    // The spike loads do not depend on x: 32 are issued together, and the NEXT 32 before the current 32 trace values are
-    // stored, so the loop body is "32 loads, 32 multiplies / selects / stores, one s_waitcnt vmcnt(32)".  (Measured: 20-21 us
-    // at cfg2 with 8 or 32 loads per batch, pipelined or not -- 25 MB written by 392 waves; not on the critical path's
-    // scale: the resident launch behind it takes 1.8 ms.)
-    if (c.T >= 32) {
-        uint8_t s[32], sn[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) s[u] = c.in[(size_t)u * n + k];
-        for (; t + 32 <= c.T; t += 32) {
-            const bool more = t + 64 <= c.T;
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < 32; ++u) sn[u] = c.in[(size_t)(t + 32 + u) * n + k];
-            }
-#pragma unroll
-            for (int u = 0; u < 32; ++u) { x = xtrace_next<ADD>(x, s[u], c.x_decay, c.x_scale); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < 32; ++u) s[u] = sn[u];
-            }
-        }
-    }
-    for (; t < c.T; ++t) { x = xtrace_next<ADD>(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale); c.xtr[(size_t)(t + 1) * n + k] = x; }
-    // (the caller's trace tensor is NOT touched here: the resident kernel copies entry T into it in its epilogue, once
-    //  the run is known to have succeeded -- a refused or timed-out run must leave every state tensor as it found it)
-}
-
+// (xtrace_next / xtrace_body: snn_dc2015.hpp -- the producer workgroups of k_dc2015_async run the same body)
 __global__ __launch_bounds__(256) void k_dc2015_xtrace(const DcCtx c) {
     const int n = c.B * c.Nin;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -656,7 +616,7 @@ constexpr size_t kAsyncCtlBytes = 8 * 11 * 8 + 16 * 4 + 64;
 
 static size_t resident_extra(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N)) + al(kAsyncCtlBytes) + al((size_t)(T + 1) * B * Nin * 4);
+    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N)) + al(kAsyncCtlBytes) + al((size_t)(T + 1 + 16) * 4) + al((size_t)(T + 1) * B * Nin * 4);
 }
 
 // The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
@@ -754,7 +714,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         c.wing = (unsigned long long *)actl;
         c.rprog = (int *)(actl + 8 * 11 * 8);
         c.tbad = nullptr;                                                                  // (set below when that form is chosen)
-        c.xtr = (float *)(actl + al2(kAsyncCtlBytes));
+        c.dready = (int *)(actl + al2(kAsyncCtlBytes));                                    // third generation with producers: [T+1] entry flags, [T+1] / [T+2] counters
+        c.xtr = (float *)((unsigned char *)c.dready + al2((size_t)(R->T + 1 + 16) * 4));
         c.status = R->status;
         c.rows4 = !(getenv("SNN_DC_ROWS4") && atoi(getenv("SNN_DC_ROWS4")) == 0);
         c.spec_flags = getenv("SNN_DC_SPECFLAGS") ? atoi(getenv("SNN_DC_SPECFLAGS")) : 0;
@@ -800,10 +761,16 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         if (lean && async_env && N <= 1024 && B <= MAXB) {
             const size_t alds = snn_dc2015_async_lds(B, Nin, N);
             const int nrw = (c.rasE || c.rasI) ? 4 : 0;
-            if (alds <= 150 * 1024 && rG + 1 + nrw <= snn_dc2015_async_capacity(alds)) {
+            const int cap3 = alds <= 150 * 1024 ? snn_dc2015_async_capacity(alds) : 0;
+            if (alds <= 150 * 1024 && rG + 1 + nrw <= cap3) {
                 lean = 3;
                 c.NRW = nrw;
                 c.tbad = (int *)((unsigned char *)c.rprog + 16 * 4);
+                // the CUs the grid leaves idle run the input-only pre-passes INSIDE the launch (producer workgroups: digest entries, then the
+                // X-trace walk; per-entry ready flags): SNN_DC_PRODUCERS=0 / a device too small for >= 16 of them -> the two launches in front
+                const char *pe = getenv("SNN_DC_PRODUCERS");
+                const int spare = cap3 - (rG + 1 + nrw), want = pe ? atoi(pe) : 128;
+                c.NP = (want > 0 && spare >= 16 && dc_prep_lds_bytes(B, Nin, 512) <= alds) ? (spare < want ? spare : want) : 0;
             }
         }
     }
@@ -831,14 +798,28 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         int rc0;
         if (resident) {
             // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
-            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex), qs)))) return rc0;
-            if (c.tbad && (rc0 = snn_check(hipMemsetAsync(c.tbad, 0x7F, sizeof(int), qs)))) return rc0;
-            hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);
-            if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
+            const size_t exbytes = (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex);      // (includes the tbad word)
+            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
+            // input-only pre-passes: launches of their own -- unless the third generation runs them on producer workgroups INSIDE its
+            // launch (c.NP > 0).  (Both in ONE launch was measured: 38 us against 10 + 22 -- the X-trace walk wants 256-thread workgroups.)
+            if (!(lean == 3 && c.NP > 0)) {
+                hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);
+                if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
+            }
             const bool prof = with_events && snn_prof_begin(0, qs);
-            const int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs)
-                                      : snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
+            int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs)
+                                : snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
             if (prof) snn_prof_end(qs);
+            if (rcl == SNN_OK && lean && R->status2) {
+                // A pipelined caller does not read the status word back between two runs, so the second attempt of an input the lean form
+                // gives up on (SNN_ERR_RETRY: nothing written) is enqueued right behind the first: the general resident kernel on the same
+                // digest and X traces, gated on the first attempt's status word, reporting into *status2.  Where the first attempt went
+                // through, its workgroups return at once.
+                DcCtx c2 = c;
+                c2.tbad = nullptr; c2.NRW = 0; c2.status = R->status2; c2.gate = R->status;
+                if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
+                rcl = snn_dc2015_resident_launch(c2, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), 0, qs);
+            }
             return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
         rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));

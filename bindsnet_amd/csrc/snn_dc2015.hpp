@@ -61,7 +61,15 @@ struct DcCtx {
     unsigned long long *wing;
     int *rprog;
     int NRW;
-    int *tbad;
+    int *tbad;                  // (zeroed with the exchange area by the run's memset; k_dc2015_prep ORs 1 into it for an entry the lean forms do not take)
+    // second attempt enqueued behind the first (pipelined callers, snn_run_desc.status2): the general resident kernel runs only if the word
+    // at `gate` holds SNN_ERR_RETRY -- otherwise every workgroup returns at once
+    const int *gate;
+    // third generation with producer workgroups (NP > 0): workgroups behind the raster writers compute the digest entries and the X traces
+    // while the compute workgroups run.  dready[e] (e <= T): 0 = not yet, 1 = entry e is there, 2 = there and one the lean forms do not take;
+    // dready[T+1]: entries finished, dready[T+2]: X-trace chunks (256 (sample, source) pairs each) finished.  Release / acquire at agent scope.
+    int *dready;
+    int NP;
 };
 
 namespace {
@@ -369,6 +377,48 @@ __device__ __forceinline__ int dc_prep_entry(const DcCtx &c, unsigned char *smem
     __syncthreads();                                                // (misc is rewritten by the workgroup's next entry)
     return flags;
 }
+// X trace after every step: entry 0 = trace at run entry, entry e = trace after step e-1 (nodes.py:96-103).
+// ADD: additive traces (x = x * decay + scale * s) / replacing ones (x = s ? scale : x * decay), branch-free either way.
+template <bool ADD>
+__device__ __forceinline__ float xtrace_next(float x, uint8_t s, float decay, float scale) {
+    const float t = x * decay;
+    if (ADD) return t + scale * (float)s;
+    return s ? scale : t;
+}
+
+template <bool ADD>
+__device__ __forceinline__ void xtrace_body(const DcCtx &c, int n, int k) {
+    float x = c.xX[1][k];
+    c.xtr[k] = x;
+    int t = 0;
+    // The spike loads do not depend on x: 32 are issued together, and the NEXT 32 before the current 32 trace values are
+    // stored, so the loop body is "32 loads, 32 multiplies / selects / stores, one s_waitcnt vmcnt(32)".  (Measured: 20-21 us
+    // at cfg2 with 8 or 32 loads per batch, pipelined or not -- 25 MB written by 392 waves; not on the critical path's
+    // scale: the resident launch behind it takes 1.8 ms.)
+    if (c.T >= 32) {
+        uint8_t s[32], sn[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s[u] = c.in[(size_t)u * n + k];
+        for (; t + 32 <= c.T; t += 32) {
+            const bool more = t + 64 <= c.T;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) sn[u] = c.in[(size_t)(t + 32 + u) * n + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { x = xtrace_next<ADD>(x, s[u], c.x_decay, c.x_scale); c.xtr[(size_t)(t + u + 1) * n + k] = x; }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) s[u] = sn[u];
+            }
+        }
+    }
+    for (; t < c.T; ++t) { x = xtrace_next<ADD>(x, c.in[(size_t)t * n + k], c.x_decay, c.x_scale); c.xtr[(size_t)(t + 1) * n + k] = x; }
+    // (the caller's trace tensor is NOT touched here: the resident kernel copies entry T into it in its epilogue, once
+    //  the run is known to have succeeded -- a refused or timed-out run must leave every state tensor as it found it)
+}
+
+
 inline size_t dc_prep_lds_bytes(int B, int Nin, int nth) { return (size_t)(B * ((Nin + 31) / 32) + Nin + 4) * 4 + 2 * (nth / 64) * LX * 2; }
 
 

@@ -364,6 +364,60 @@ __device__ __forceinline__ float postpre_elem(const PPar &c, int B, int Nin, con
     return w;
 }
 
+// ---- producer workgroups (c.NP > 0): the input-only pre-passes inside the launch ---------------------------------------------------
+// Producer p digests entries p, p + NP, ... (dc_prep_entry, snn_dc2015.hpp: k_dc2015_prep's body) and walks the X traces of chunks p,
+// p + NP, ... of 256 (sample, source) pairs (xtrace_body: k_dc2015_xtrace's body).  Hand-off to the compute workgroups -- which sit on
+// other XCDs, behind other L2s -- by RELEASE / ACQUIRE at agent scope on dready[] (the compiler's cache write-back / invalidate; the
+// tagged-granule trick of the step loop does not carry bulk data): a producer's barrier orders its threads' stores before thread 0's
+// release; a consumer acquires BEFORE its first load of an entry / of the traces, and only until it has once seen everything finished
+// (a few iterations: all producers are done after ~50 us of a ~900 us launch) -- the step loop pays one uniform branch afterwards.
+constexpr int kXChunk = 256;
+__device__ __forceinline__ int x_chunks(const DcCtx &c) { return c.x_traces ? (c.B * c.Nin + kXChunk - 1) / kXChunk : 0; }
+
+__device__ __forceinline__ void async_producer(const DcCtx &c, unsigned char *smem, int p) {
+    const int T = c.T, tid = threadIdx.x;
+    for (int e = p; e <= T; e += c.NP) {
+        const int flags = dc_prep_entry<ANT>(c, smem, e, c.dig + (size_t)e * c.DW);        // (ends with a barrier)
+        if (tid == 0) {
+            if (flags & 5) atomicOr(c.tbad, 1);
+            __hip_atomic_store(&c.dready[e], (flags & 5) ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&c.dready[T + 1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int n = c.B * c.Nin, nch = x_chunks(c);
+    for (int ch = p; ch < nch; ch += c.NP) {
+        const int k = ch * kXChunk + tid;
+        if (tid < kXChunk && k < n) { if (c.x_additive) xtrace_body<true>(c, n, k); else xtrace_body<false>(c, n, k); }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&c.dready[T + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Consumer side.  need_entry: digest entry e may be loaded (1), is one the lean forms do not take (2), or never came (-1: bounded poll).
+// `all` is set once every entry has been seen finished (the caller stops asking).  Every lane of the wave runs the same loads.
+__device__ __forceinline__ int need_entry(const DcCtx &c, int e, bool &all) {
+    const int T = c.T;
+    if (__hip_atomic_load(&c.dready[T + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == T + 1) {
+        all = true;
+        return __hip_atomic_load(c.tbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 2 : 1;
+    }
+    for (unsigned spins = 0;; ++spins) {
+        const int v = __hip_atomic_load(&c.dready[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) return v;
+        if (spins > kAPoll) return -1;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+// need_xtr: the X traces of EVERY step are there (1) or never came (-1).
+__device__ __forceinline__ int need_xtr(const DcCtx &c, bool &all) {
+    const int nch = x_chunks(c);
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(&c.dready[c.T + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == nch) { all = true; return 1; }
+        if (spins > kAPoll) return -1;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // ===================================================================================================================== compute
 // Threads: tile threads 0..127 <-> (sample tid / 4, column tid % 4): the Ae neuron of the pair, its state in registers; threads
 // 384..511 <-> the same pairs: the Ai neuron (its only input is the pair's own final Ae spike); threads 128..383 + 384..511: PostPre.
@@ -447,8 +501,23 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                             dg1 = src_[min(tid + NT, nchunk - 1)]; dg2 = src_[min(tid + 2 * NT, nchunk - 1)]; } while (0)
 #define DIGEST_STORE(e) do { uint4 *dst_ = (uint4 *)(dgbuf + ((e) & 1) * DGS); if (tid < nchunk) dst_[tid] = dg0; \
                              if (tid + NT < nchunk) dst_[tid + NT] = dg1; if (tid + 2 * NT < nchunk) dst_[tid + 2 * NT] = dg2; } while (0)
-    DIGEST_LOAD(0); DIGEST_STORE(0);
-    if (T >= 1) { DIGEST_LOAD(1); DIGEST_STORE(1); }
+    // (producer workgroups: entries 0 and 1 are waited for here, behind the weight loads; the later ones at the top of the iteration that asks for them)
+    // `pend`: bit 0 = digest entries, bit 1 = the X traces may still be on their way (wave-uniform; kept in a VECTOR register like the float
+    // parameters above -- the step loop has no scalar register to spare -- and read with v_readfirstlane where it is asked)
+    int pend = 0;
+    int dig01 = 1;
+    if (c.NP != 0) {
+        bool dig_all = false;
+        const int r0 = need_entry(c, 0, dig_all), r1 = (T >= 1 && !dig_all) ? need_entry(c, 1, dig_all) : 1;
+        dig01 = r0 != 1 ? r0 : r1;
+        if (dig01 != 1) { ctl[0] = 1; if (tid == 0) report(c.status, dig01 < 0 ? SNN_ERR_TIMEOUT : SNN_ERR_RETRY); }
+        const int p0 = (dig_all ? 0 : 1) | (c.x_traces ? 2 : 0);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(pend) : "s"(p0));
+    }
+#define PENDING(bit) (__builtin_amdgcn_readfirstlane(pend) & (bit))
+    if (dig01 >= 0) DIGEST_LOAD(0);
+    DIGEST_STORE(0);
+    if (T >= 1) { if (dig01 >= 0) DIGEST_LOAD(1); DIGEST_STORE(1); }
     // Inside the loop the digest store would sit in the tail of EVERY iteration -- the stretch that both the ordinary iteration and the
     // crossing chain run through (0.135 us measured).  Its buffer (entry t's) is free during the whole of iteration t, so the six non-tile
     // waves carry the whole entry (four 16-byte pieces per thread: DIGEST_LOAD_E at the top of the iteration) and store it behind their
@@ -523,7 +592,15 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
-        if (t + 2 <= T && wave >= NTW) DIGEST_LOAD_E(t + 2);
+        if (t + 2 <= T && wave >= NTW) {
+            if (PENDING(1)) {                                             // (producer workgroups: the first iterations only)
+                bool all = false;
+                const int r = need_entry(cold(c), t + 2, all);
+                if (r != 1) { ctl[0] = 1; report(cold(c).status, r < 0 ? SNN_ERR_TIMEOUT : SNN_ERR_RETRY); }
+                if (all) pend &= ~1;
+            }
+            DIGEST_LOAD_E(t + 2);
+        }
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
@@ -683,6 +760,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
+        if (crossed_wg && PENDING(2)) {                                   // (producer workgroups: a crossing in the launch's first ~50 us)
+            bool all = false;
+            if (need_xtr(cold(c), all) != 1) { ctl[0] = 1; report(cold(c).status, SNN_ERR_TIMEOUT); }
+            if (all) pend &= ~2;
+        }
         const float *xsrc = crossed_wg ? cold(c).xtr + (size_t)(t + 1) * B * Nin : nullptr;   // X trace after step t
         const float *xn0 = xnu0 + par * TT;
         uint32_t cmq[CW];
@@ -850,6 +932,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     //      after the wave's last publish, and the arbiter must not commit over it: every other workgroup would write its state back while this
     //      one returns, and the host would repeat the input on a half-advanced network.  (`bad` is final here: the top of iteration T read the
     //      abort word behind the last barrier B, and nothing writes it afterwards.)
+    // (producer workgroups: the epilogue copies the last X traces -- they must be there BEFORE the final report, the last point where a
+    //  wave can still give up; by now they have been for ~95 % of the launch)
+    if (PENDING(2) && !bad) {
+        bool all = false;
+        if (need_xtr(cold(c), all) != 1) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); }
+    }
     if (wave < NTW && lane == 0) {
         const int pstep = (bad && published <= T - 1) ? published : T;
         granule_store(c.exs + (size_t)(pstep & (kCrossRing - 1)) * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(pstep + 1) << 32) | (bad ? kAbortPay : 0u));
@@ -1270,20 +1358,21 @@ __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int blk = (int)blockIdx.x;
     if (blk == c.stall_wg) return;
-    if (*c.tbad <= c.T) {             // an input the lean forms do not take: refused before anything has happened
+    if (c.NP == 0 && *c.tbad != 0) {  // an input the lean forms do not take (pre-pass launches: known up front): refused before anything has happened
         if (blk == 0 && threadIdx.x == 0) report(c.status, SNN_ERR_RETRY);
         return;
     }
     if (blk < c.G) async_compute<TIMING>(c, smem);
     else if (blk == c.G) async_arbiter<TIMING>(c, smem);
-    else async_raster(c, smem, blk - c.G - 1);
+    else if (blk < c.G + 1 + c.NRW) async_raster(c, smem, blk - c.G - 1);
+    else async_producer(c, smem, blk - c.G - 1 - c.NRW);
 }
 
 }  // namespace
 
 size_t snn_dc2015_async_lds(int B, int Nin, int N) {
-    const size_t a = async_compute_lds(B, Nin, N), b = async_arbiter_lds(B, N);
-    return a > b ? a : b;
+    const size_t a = async_compute_lds(B, Nin, N), b = async_arbiter_lds(B, N), p = dc_prep_lds_bytes(B, Nin, ANT);
+    return a > b ? (a > p ? a : p) : (b > p ? b : p);
 }
 
 static bool async_attr_once() {
@@ -1314,13 +1403,13 @@ int snn_dc2015_async_capacity(size_t lds) {
     return cap;
 }
 
-// grid = G compute workgroups + the arbiter + c.NRW raster writers, all co-resident (cooperative launch)
+// grid = G compute workgroups + the arbiter + c.NRW raster writers + c.NP producers, all co-resident (cooperative launch)
 int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st) {
     if (!async_attr_once()) return SNN_ERR_LAUNCH;
     static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
-    const unsigned grid = (unsigned)(c.G + 1 + c.NRW);
+    const unsigned grid = (unsigned)(c.G + 1 + c.NRW + c.NP);
     const void *fn = c.dbg ? (const void *)k_dc2015_async<true> : (const void *)k_dc2015_async<false>;     // (the timing marks are compiled out of the ordinary instance)
     if (!coop) return snn_check(hipLaunchKernel(fn, dim3(grid), dim3(ANT), args, lds, st));
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(ANT), args, (unsigned)lds, st);

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (c.gate && __hip_atomic_load(c.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != SNN_ERR_RETRY) return;   // a second attempt nobody needs
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
     //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.

@@ -179,13 +179,16 @@ extern "C" int snn_input_step(const uint8_t *s, float *x, long n_total, float tr
 // =============================================================================================
 // a3: LIF step, fully elementwise (state streaming: v, refrac r/w, I r/w, s w, x r/w).
 // =============================================================================================
+template <bool VTH>
 __global__ __launch_bounds__(256) void k_lif(float *__restrict__ v, float *__restrict__ refrac,
                                              uint8_t *__restrict__ s, float *__restrict__ x,
                                              float *__restrict__ I, long n, snn_lif_params p,
-                                             uint8_t *__restrict__ raster_s, float *__restrict__ raster_v) {
+                                             uint8_t *__restrict__ raster_s, float *__restrict__ raster_v,
+                                             const float *__restrict__ thresh_vec, int N) {
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
         float vv = v[k], rc = refrac[k], cur = I[k];
         if (rc > 0.f) { cur = 0.f; I[k] = 0.f; }   // nodes.py:511 masks the caller's tensor in place
+        if (VTH) p.thresh = thresh_vec[k % N];     // nodes.py:519 with a tensor-valued `thresh`: broadcast over the batch
         const uint8_t sp = lif_update(vv, rc, cur, p);
         v[k] = vv; refrac[k] = rc; s[k] = sp;
         if (p.traces) x[k] = trace_next(x[k], sp, p.trace_decay, p.trace_scale, p.traces_additive);
@@ -194,15 +197,25 @@ __global__ __launch_bounds__(256) void k_lif(float *__restrict__ v, float *__res
     }
 }
 
-extern "C" int snn_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
-                            const snn_lif_params *h_p, uint8_t *raster_s, float *raster_v, snn_stream_t stream) {
+extern "C" int snn_lif_step_vth(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
+                                const snn_lif_params *h_p, const float *thresh_vec, uint8_t *raster_s, float *raster_v,
+                                snn_stream_t stream) {
     if (!v || !refrac || !s || !I || !h_p || B <= 0 || N <= 0) return SNN_ERR_INVALID;
     if (h_p->traces && !x) return SNN_ERR_INVALID;
     const long n = (long)B * N;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_lif, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, refrac, s, x, I, n, *h_p,
-                       raster_s, raster_v);
+    if (thresh_vec)
+        hipLaunchKernelGGL(k_lif<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, refrac, s, x, I, n, *h_p,
+                           raster_s, raster_v, thresh_vec, N);
+    else
+        hipLaunchKernelGGL(k_lif<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, refrac, s, x, I, n, *h_p,
+                           raster_s, raster_v, thresh_vec, N);
     return snn_check_launch();
+}
+
+extern "C" int snn_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
+                            const snn_lif_params *h_p, uint8_t *raster_s, float *raster_v, snn_stream_t stream) {
+    return snn_lif_step_vth(v, refrac, s, x, I, B, N, h_p, nullptr, raster_s, raster_v, stream);
 }
 
 // =============================================================================================

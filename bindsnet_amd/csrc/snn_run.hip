@@ -106,6 +106,7 @@ static int validate(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
                 if (d.p.one_spike && (!R->cursor || !R->status)) return SNN_ERR_INVALID;
                 if (d.p.one_spike && !R->noise_q && !(R->rng && R->qbuf)) return SNN_ERR_INVALID;
                 if (R->B > 1024) return SNN_ERR_UNSUPPORTED;
+                if (d.thresh_vec) return SNN_ERR_UNSUPPORTED;          // per-neuron thresholds: LIF layers
                 /* fallthrough */
             case SNN_LAYER_LIF:
                 if (!d.v || !d.refrac || !d.s || !d.current) return SNN_ERR_INVALID;
@@ -191,7 +192,7 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
                 hipLaunchKernelGGL(k_inject, dim3(grid_for((long)B * d.n)), dim3(256), 0, st, d.v,
                                    d.inject_v + (d.inject_per_step ? (size_t)t * len : 0), (long)B * d.n, len);
             }
-            if (d.kind == SNN_LAYER_LIF) TRY(snn_lif_step(d.v, d.refrac, d.s, d.x, d.current, B, d.n, &d.p.lif, rs, rv, st));
+            if (d.kind == SNN_LAYER_LIF) TRY(snn_lif_step_vth(d.v, d.refrac, d.s, d.x, d.current, B, d.n, &d.p.lif, d.thresh_vec, rs, rv, st));
             else if (R->rng && d.p.one_spike) {   // device generator: membrane -> draws for this step -> arbitration
                 TRY(snn_launch_dc_membrane(d.v, d.refrac, d.s, d.theta, d.current, B, d.n, d.p, R->cursor, rv, st));
                 TRY(snn_launch_rng_fill(R->rng, d.s, B, d.n, R->qbuf, R->cursor, st));
@@ -261,6 +262,7 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
     for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v || L[l].ext_current) mode = 1;   // only the generic plan implements these
     for (int c = 0; c < nC; ++c) if (C[c].mask || C[c].raster_w || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
     if (R->one_step) mode = 1;
+    for (int l = 0; l < nL; ++l) if (L[l].thresh_vec) mode = 1;      // per-neuron thresholds: generic plan
     if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));

@@ -31,6 +31,18 @@ def load(file_name: str, map_location: str = "cpu", learning: bool = None) -> "N
 _DESC_CACHE = os.environ.get("SNN_DESC_CACHE", "1") != "0"      # developer switch: rebuild the descriptors on every call
 
 
+class _Pipeline:
+    """State of a Network.pipelined() section: the runs enqueued since the last settlement."""
+
+    def __init__(self, depth: int):
+        self.depth = max(1, int(depth))
+        self.pending = []              # plan name of every unsettled run, in order
+        self.status = None             # device int32 [2 * depth]: {first attempt, second attempt} status words per run
+        self.block = self.host = None  # the generator block on the device / its page-locked host image
+        self.host0 = None              # host generator state at the start of the batch (None: no run of the batch draws)
+        self.enabled = False
+
+
 def _dptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -74,7 +86,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return torch.load(f, weights_only=False)
 
     _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown",
-                  "_run_cache", "_reset_cache", "_shard_state", "_defer_norm")
+                  "_run_cache", "_reset_cache", "_shard_state", "_defer_norm", "_pipe")
 
     def __getstate__(self):
         """save() / clone() pickle the whole object like the reference (network.py:163-209); device scratch, the
@@ -152,6 +164,109 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         self.learning = mode
         return super().train(mode)
 
+    # ------------------------------------------------------------------ pipelined runs
+    def pipelined(self, depth: int = 64):
+        """Context manager (an extension of the reference's API): inside it run() RETURNS WITHOUT WAITING for the device --
+
+            with network.pipelined():
+                for batch in inputs:                     # tensors already on the device
+                    network.run({"X": batch}, time=250)
+                    network.reset_state_variables()
+
+        The host prepares and enqueues run k+1 while run k executes (a synchronous run() costs ~0.2 ms of host time per call at
+        cfg2, during which the MI355X idles).  Results are the same bit for bit; what changes is WHEN two things happen:
+          * the host generator (the stream DiehlAndCookNodes' one_spike arbitration draws from, rng.py) lives on the device between
+            the runs of the section and is written back when the section is settled: at sync(), at the end of the `with` block,
+            every `depth` runs, and before anything in this package reads the host generator (a synchronous run, a device encoder).
+            Code of the CALLER that draws from torch's CPU generator inside the section must call network.sync() first;
+          * the device status word is read at settlement.  An input the lean kernel form gives up on (SNN_ERR_RETRY) is repeated on
+            the general form ON THE DEVICE (snn_run_desc.status2: the second attempt is enqueued behind every first one and returns
+            at once where it is not needed), so that case stays exact; a SNN_ERR_TIMEOUT (the GPU was shared and a resident grid
+            was not co-resident in time) cannot be repaired after later runs have been enqueued and raises SnnError at settlement
+            -- use synchronous runs on a shared GPU."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def section():
+            if self.__dict__.get("_pipe") is not None:
+                raise RuntimeError("Network.pipelined() sections do not nest")
+            from .. import rng
+            pipe = self.__dict__["_pipe"] = _Pipeline(depth)
+            rng._PENDING.append(self.sync)
+            try:
+                yield self
+                self.sync()
+            finally:
+                rng._PENDING.remove(self.sync)
+                self.__dict__["_pipe"] = None
+                pipe.pending.clear()
+        return section()
+
+    def sync(self) -> None:
+        """Settle the runs of an open pipelined() section: wait for them, check their status words, bring the host generator
+        up to date.  A no-op outside a section / with nothing enqueued."""
+        pipe = self.__dict__.get("_pipe")
+        if pipe is None or not pipe.pending:
+            return
+        from ..rng import RNG_STATE_BYTES, words_to_torch_state
+        n = len(pipe.pending)
+        pipe.host.copy_(pipe.block)                        # blocking: everything enqueued so far has run
+        st = pipe.status[:2 * n].cpu().numpy().reshape(n, 2)
+        pipe.pending.clear()
+        bad = None
+        for k in range(n):
+            s1, s2 = int(st[k, 0]), int(st[k, 1])
+            if s1 == _lib.SNN_ERR_RETRY and s2 == 0:       # repeated on the general form, on the device
+                self.__dict__["lean_retries"] = self.__dict__.get("lean_retries", 0) + 1
+                self.__dict__["_lean_cooldown"] = 16
+            elif (s1 != 0 or s2 != 0) and bad is None:
+                bad = (k, s1, s2)
+        if bad is not None:
+            if pipe.enabled:
+                torch.set_rng_state(pipe.host0)
+            raise _lib.SnnError(f"pipelined run {bad[0] + 1} of {n} reported status {bad[1]} (second attempt: {bad[2]}); the runs enqueued "
+                                "behind it have executed on the state it left, so the section cannot be repaired -- "
+                                "SNN_ERR_TIMEOUT (-6) means the GPU was shared: use synchronous runs there")
+        if pipe.enabled:
+            torch.set_rng_state(words_to_torch_state(pipe.host.numpy()[:RNG_STATE_BYTES // 4], pipe.host0))
+
+    def _run_pipelined(self, pipe, built, lib, stream, dev):
+        """Enqueue one run of a pipelined() section (see there)."""
+        from ..rng import RNG_STATE_BYTES, torch_state_to_words
+        L, Cn, R, names = built["L"], built["Cn"], built["R"], built["names"]
+        block, qbuf, host = built["gen_bufs"]
+        draws = built["max_draws"] > 0
+        if pipe.pending and (len(pipe.pending) >= pipe.depth or draws != pipe.enabled or pipe.block is not block):
+            self.sync()
+        if not pipe.pending:                               # first run of a batch: the host generator goes to the device
+            img = host.numpy()
+            img[:] = 0
+            pipe.enabled, pipe.host0 = draws, None
+            if draws:
+                pipe.host0 = torch.get_rng_state()
+                img[:RNG_STATE_BYTES // 4] = torch_state_to_words(pipe.host0)
+            block.copy_(host, non_blocking=True)           # (the previous settlement's blocking read-back ordered us behind it)
+            if pipe.status is None or pipe.status.device != dev:
+                pipe.status = torch.zeros(2 * pipe.depth, dtype=torch.int32, device=dev)
+            else:
+                pipe.status.zero_()
+            pipe.block, pipe.host = block, host
+        k = len(pipe.pending)
+        R.rng, R.qbuf = _dptr(block[:RNG_STATE_BYTES // 4]), _dptr(qbuf)
+        R.cursor = C.c_void_p(block.data_ptr() + 632 * 4)
+        R.status = C.c_void_p(pipe.status.data_ptr() + 8 * k)
+        R.status2 = C.c_void_p(pipe.status.data_ptr() + 8 * k + 4)
+        cool = self.__dict__.get("_lean_cooldown", 0)
+        R.plan = 3 if cool > 0 else 0
+        if cool > 0:
+            self.__dict__["_lean_cooldown"] = cool - 1
+        try:
+            _lib.check(lib.snn_net_run(L, len(names), Cn, len(self.connections), C.byref(R), stream), "snn_net_run")
+        finally:
+            R.status2 = None
+        self.__dict__["last_plan"] = lib.snn_plan_name().decode()
+        pipe.pending.append(self.last_plan)
+
     # ------------------------------------------------------------------ run
     def run(self, inputs: Dict[str, torch.Tensor], time: int, one_step=False, **kwargs) -> None:
         assert type(inputs) == dict, (
@@ -214,11 +329,14 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         # plan request of this run: automatic, unless the lean kernel form gave up on one of the last inputs (it is then
         # left alone for a while: an input it cannot finish costs a whole second run)
+        pipe = self.__dict__.get("_pipe")
+        if pipe is not None:
+            self._run_pipelined(pipe, built, lib, stream, dev)
         cool = self.__dict__.get("_lean_cooldown", 0)
         R.plan = 3 if cool > 0 else 0
-        if cool > 0:
+        if cool > 0 and pipe is None:
             self.__dict__["_lean_cooldown"] = cool - 1
-        for attempt in (0, 1, 2):
+        for attempt in (0, 1, 2) if pipe is None else ():
             with DeviceGenerator(dev, max_draws, gen_bufs) as ns:  # host generator <-> device, exact (rng.py)
                 R.rng, R.qbuf = _dptr(ns.state), _dptr(ns.qbuf)
                 R.cursor, R.status = _dptr(ns.cursor), _dptr(ns.status)
@@ -344,6 +462,11 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 elif isinstance(layer, LIFNodes):
                     d.kind = _lib.LAYER_LIF
                     d.p.lif = layer._lif_params()
+                    tv = layer._thresh_vec()               # per-neuron thresholds (nodes.py:425-498; generic plan)
+                    if tv is not None:
+                        keep.append(tv)
+                        d.thresh_vec = _dptr(tv)
+                        scalars.append((layer.thresh, layer.thresh._version))      # (an in-place change rebuilds: tv may be a converted copy)
                 else:
                     raise NotImplementedError(f"bindsnet_amd: layer type {type(layer).__name__} is outside the "
                                               "accelerated path (Input, LIFNodes, DiehlAndCookNodes)")
@@ -391,7 +514,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         # without any attribute assignment, so the kept arrays are only valid while these still are where they were
         ptrs = []
         for layer in self.layers.values():
-            for attr in ("v", "refrac_count", "x", "theta"):
+            for attr in ("v", "refrac_count", "x", "theta") + (("thresh",) if isinstance(getattr(layer, "thresh", None), torch.Tensor) and layer.thresh.numel() > 1 else ()):
                 t = getattr(layer, attr, None)
                 if isinstance(t, torch.Tensor):
                     ptrs.append((layer, attr, t.data_ptr()))

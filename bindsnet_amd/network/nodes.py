@@ -152,9 +152,27 @@ class LIFNodes(Nodes):
         self.v.fill_(_f(self.rest))
         self.refrac_count.zero_()
 
+    def _thresh_vec(self) -> Optional[torch.Tensor]:
+        """Per-neuron thresholds (nodes.py:425-498 take `thresh` as a tensor; examples/mnist/reservoir.py passes one): the [n] f32
+        device tensor the LIF kernel indexes by neuron, or None for the usual scalar."""
+        t = self.thresh
+        if not isinstance(t, torch.Tensor) or t.numel() == 1:
+            return None
+        if t.numel() != self.n:
+            raise ValueError(f"LIFNodes.thresh has {t.numel()} entries, the layer {self.n} neurons")
+        if t.device != self.v.device or t.dtype != torch.float32 or not t.is_contiguous():
+            # (a buffer: .to() moves it with the layer; anything else is brought over once and kept -- an in-place change of the
+            #  original is then not seen, which the version check below guards)
+            cached = self.__dict__.get("_thresh_dev")
+            if cached is None or cached[0] is not t or cached[1] != t._version or cached[2].device != self.v.device:
+                cached = self.__dict__["_thresh_dev"] = (t, t._version, t.detach().to(self.v.device, torch.float32).contiguous())
+            return cached[2]
+        return t
+
     def _lif_params(self) -> _lib.LifParams:
         p = _lib.LifParams()
-        p.decay, p.rest, p.reset, p.thresh = _f(self.decay), _f(self.rest), _f(self.reset), _f(self.thresh)
+        p.decay, p.rest, p.reset = _f(self.decay), _f(self.rest), _f(self.reset)
+        p.thresh = 0.0 if self._thresh_vec() is not None else _f(self.thresh)
         p.refrac, p.dt = _f(self.refrac), _f(self.dt)
         p.has_lbound = int(self.lbound is not None)
         p.lbound = _f(self.lbound) if self.lbound is not None else 0.0
@@ -168,7 +186,8 @@ class LIFNodes(Nodes):
             return host_path._step_lif(self, x)
         if self.s.dtype != torch.bool or self.s.shape != self.v.shape:
             self.s = torch.zeros_like(self.v, dtype=torch.bool)
-        ops.lif_step(self.v, self.refrac_count, self.s, self.x if self.traces else None, x, self._lif_params())
+        ops.lif_step(self.v, self.refrac_count, self.s, self.x if self.traces else None, x, self._lif_params(),
+                     thresh_vec=self._thresh_vec())
 
 
 class DiehlAndCookNodes(Nodes):

@@ -81,11 +81,14 @@ def input_step(s, x=None, trace_decay=0.0, trace_scale=1.0, additive=False, rast
                                int(additive), _ptr(raster, "spike", True), _stream()), "input_step")
 
 
-def lif_step(v, refrac, s, x, I, p: LifParams, raster_s=None, raster_v=None):
+def lif_step(v, refrac, s, x, I, p: LifParams, raster_s=None, raster_v=None, thresh_vec=None):
+    """thresh_vec: optional f32 [N] per-neuron thresholds (replace p.thresh; nodes.py:425-498 with a tensor-valued `thresh`)."""
     B = v.shape[0]
     N = v.numel() // B
-    check(lib().snn_lif_step(_ptr(v, F32), _ptr(refrac, F32), _ptr(s, "spike"), _ptr(x, F32, True), _ptr(I, F32), B, N,
-                             C.byref(p), _ptr(raster_s, "spike", True), _ptr(raster_v, F32, True), _stream()),
+    if thresh_vec is not None and thresh_vec.numel() != N:
+        raise ValueError(f"thresh_vec has {thresh_vec.numel()} entries, the layer {N} neurons")
+    check(lib().snn_lif_step_vth(_ptr(v, F32), _ptr(refrac, F32), _ptr(s, "spike"), _ptr(x, F32, True), _ptr(I, F32), B, N,
+                                 C.byref(p), _ptr(thresh_vec, F32, True), _ptr(raster_s, "spike", True), _ptr(raster_v, F32, True), _stream()),
           "lif_step")
 
 

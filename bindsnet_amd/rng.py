@@ -10,6 +10,15 @@ downstream that shares the generator (Poisson encoders, shuffling) sees the same
 """
 import torch
 
+# Pipelined networks (Network.pipelined()) keep the host generator's state ON THE DEVICE between their runs; whoever is about to read or
+# replace the host generator inside this package (a synchronous run, a device encoder, a hand-stepped layer) settles them first.
+_PENDING = []          # callables: Network.sync of every network with a pipelined section open
+
+
+def flush_pending() -> None:
+    for settle in list(_PENDING):
+        settle()
+
 
 class NoiseStream:
     """Pre-drawn Exp(1) stream + device cursor/status words.
@@ -27,6 +36,7 @@ class NoiseStream:
         self.consumed = 0
 
     def __enter__(self):
+        flush_pending()
         if self.max_draws > 0:
             self._state0 = torch.get_rng_state()
             q = torch.empty(self.max_draws).exponential_(1)      # the reference's own stream
@@ -126,6 +136,7 @@ class DeviceGenerator:
         self.always_read = False       # set by Network.run for plans that report through the status word
 
     def __enter__(self):
+        flush_pending()
         img = self._host.numpy()
         img[:] = 0                                         # status = 0, cursor = 0
         if self.enabled:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 7
+#define SNN_ABI_VERSION 8
 
 typedef void *snn_stream_t;
 
@@ -103,6 +103,12 @@ typedef struct {
 int snn_lif_step(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
                  const snn_lif_params *h_p, uint8_t *raster_s, float *raster_v,
                  snn_stream_t stream);
+/* The same step with PER-NEURON thresholds (nodes.py:425-498 take `thresh` as a tensor; examples/mnist/reservoir.py builds its
+ * LIF layer that way): thresh_vec [N] f32 on the device replaces h_p->thresh, neuron j of every sample compares against
+ * thresh_vec[j].  thresh_vec == NULL: snn_lif_step.  (ABI 8)                                                              */
+int snn_lif_step_vth(float *v, float *refrac, uint8_t *s, float *x, float *I, int B, int N,
+                     const snn_lif_params *h_p, const float *thresh_vec, uint8_t *raster_s, float *raster_v,
+                     snn_stream_t stream);
 
 typedef struct {
     snn_lif_params lif;
@@ -294,6 +300,9 @@ typedef struct {
     /* run(inputs={<non-Input layer>: current}), network.py:386-392 (nullable; generic plan): f32 [T,B,n], slice t is added
      * to the layer's summed input current after the connections' contributions, before the layer steps */
     const float *ext_current;
+    /* LIF / DC layers with per-neuron thresholds (nodes.py:425-498: `thresh` given as a tensor): nullable f32 [n] that replaces
+     * p.lif.thresh, broadcast over the batch.  Generic plan (a graph that has one is not offered to the fused plans).  (ABI 8) */
+    const float *thresh_vec;
 } snn_layer_desc;
 
 typedef struct {
@@ -343,6 +352,12 @@ typedef struct {
                                    3 = automatic, but never the lean form of a plan (what a caller re-runs with after
                                    SNN_ERR_RETRY).  A run that reports either status has left every caller-owned STATE
                                    tensor untouched. */
+    int *status2;               /* nullable device int32[1] (zeroed by the caller).  Pipelined callers -- those that do not read
+                                   *status back before they enqueue the next run -- pass it to have the SECOND attempt of a lean
+                                   plan enqueued right behind the first: the general form of the same plan, on the device gated
+                                   on *status == SNN_ERR_RETRY (its workgroups return at once otherwise), reporting into *status2.
+                                   Afterwards: the run succeeded iff *status == 0, or *status == SNN_ERR_RETRY and *status2 == 0.
+                                   (ABI 8) */
 } snn_run_desc;
 
 /* Runs T timesteps.  Asynchronous; the caller synchronises the stream before reading *status /

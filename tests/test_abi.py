@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), f"libsnnhip.so does not export {sym}"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert L.snn_abi_version() == _lib.ABI_VERSION == 7
+    assert L.snn_abi_version() == _lib.ABI_VERSION == 8
     assert L.snn_error_string(-2).decode().startswith("size or mode")
 
 

@@ -128,11 +128,12 @@ def test_off_diagonal_excitatory_weights_give_up_at_once():
     dc.same_as_oracle(res, dc.oracle_run(N, B, T, spikes, w_scale=0.8, w_ei=synth.uniform_f32(4300, (N, N), 0.0, 6.0)))
 
 
-@pytest.mark.parametrize("wg", [100, 102])
+@pytest.mark.parametrize("wg", [100, 102, 105, 140])
 def test_missing_arbiter_or_raster_writer_times_out_state_untouched(monkeypatch, wg):
     """Workgroup 100 of the cfg2 grid is the arbiter, 101..104 write the rasters: without the arbiter no winners ever arrive (every
     compute workgroup gives up after its bounded poll); without a raster writer the arbiter stops at the first ring slot it may not
-    overwrite and says so in the winners' granules."""
+    overwrite and says so in the winners' granules.  105.. are the producer workgroups (digest entries and X traces inside the launch):
+    without producer 0 the digest of step 0 never comes, without producer 35 that of entry 35 (and one chunk of the X traces)."""
     monkeypatch.setenv("SNN_DC_TEST_STALL", str(wg))
     net, plans = safety.run_cfg2_inputs(1)
     assert plans == ["dc2015-fused"] and net.resident_retries == 1

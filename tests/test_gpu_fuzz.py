@@ -136,12 +136,12 @@ def test_soak_resident_plan_against_the_cpu_oracle(chunk):
         N = int(rs.choice([16, 36, 64, 100, 128, 200]))
         B = int(rs.choice([1, 4, 8, 16, 32]))
         T = int(rs.choice([20, 40, 64]))
-        Nin = int(rs.choice([784, 784, 400, 196]))
+        Nin = int(rs.choice([784, 784, 400, 256]))      # (multiples of 16: what the fused plan takes)
         dens = float(rs.choice([0.006, 0.012, 0.02, 0.03]))
         kw = dict(w_scale=float(rs.choice([0.3, 0.6, 1.0])), n_inputs=3, learning=bool(rs.rand() < 0.9), Nin=Nin,
                   inh=float(rs.choice([120.0, 17.5, 60.0])), exc=float(rs.choice([22.5, 22.5, 30.0])),
                   nu=[(1e-4, 1e-2), (1e-4, 1e-2), (0.0, 1e-2), (1e-3, 0.0), (5e-4, 5e-2)][int(rs.randint(5))])
-        shape = {784: (1, 28, 28), 400: (1, 20, 20), 196: (1, 14, 14)}[Nin]
+        shape = {784: (1, 28, 28), 400: (1, 20, 20), 256: (1, 16, 16)}[Nin]
         spikes = [synth.dense_spikes(800 + 13 * seed + r, (T, B, Nin), dens) for r in range(3)]
         res, plan = dc.run(0, N, B, T, spikes, shape=shape, **kw)
         assert plan.startswith("dc2015-resident"), (seed, plan)
