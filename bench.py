@@ -72,16 +72,26 @@ def build_network(device):
 
 
 def pmc_traffic(plan):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (profiles/*_pmc_hbm_traffic.json; PMC cannot be read from inside the process)."""
-    names = {"dc2015-resident-lean": ["r04_lean_pmc_hbm_traffic.json", "r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc_hbm_traffic.json; PMC cannot be read from inside the process) -> (bytes, where it came from).  The profile carries
+    the sha256 of the kernel sources it was taken on (tools/pmc_summary.py): `matches_current_source` says whether that is the tree
+    this process runs in."""
+    names = {"dc2015-resident-lean": ["r05_lean_pmc_hbm_traffic.json", "r04_lean_pmc_hbm_traffic.json", "r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
              "dc2015-resident": ["r01_resident_pmc_hbm_traffic.json"], "dc2015-fused": ["r01_pmc_hbm_traffic.json"]}.get(plan, [])
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
-                return json.load(f).get("hbm_bytes_per_launch_gfx950_corrected")
-    return None
+                d = json.load(f)
+            meta = {"file": "profiles/" + name, "kernel_source_sha16": d.get("kernel_source_sha16")}
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_summary
+                meta["matches_current_source"] = d.get("kernel_source_sha16") == pmc_summary.source_sha16()
+            except Exception:                                    # noqa: BLE001
+                meta["matches_current_source"] = None
+            return d.get("hbm_bytes_per_launch_gfx950_corrected"), meta
+    return None, None
 
 
 def c_port_baseline(spikes, steps=100):
@@ -444,7 +454,7 @@ def main():
             roof = {"bound": "hbm", "kernel": prof["kernel"], "avg_launch_us": round(prof["avg_ms"] * 1e3, 3),
                     "launches_timed": prof["n"], "algorithmic_bytes_per_launch": ab, "achieved": round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic(plan_timed),
+                    "traffic": pmc_traffic(plan_timed)[0], "traffic_profile": pmc_traffic(plan_timed)[1],
                     "frac_of_measured_copy_bandwidth_6290": round(ach / 6290.0, 5)}
             if "resident_form" in prof:
                 roof["resident_form"] = prof["resident_form"]

@@ -99,7 +99,7 @@ class RunDesc(C.Structure):
                 ("noise_q", C.c_void_p), ("q_len", C.c_longlong), ("rng", C.c_void_p), ("qbuf", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_ulonglong),
                 ("cursor", C.c_void_p), ("status", C.c_void_p), ("one_step", C.c_int), ("plan", C.c_int),
-                ("status2", C.c_void_p)]
+                ("status2", C.c_void_p), ("host_state", C.c_void_p)]
 
 
 class FillSegment(C.Structure):
@@ -211,7 +211,7 @@ def profile_run(net, inputs, time, stride=4, repeats=5):
     plan = net.last_plan
     if plan.startswith("dc2015-resident"):
         form = L.snn_dc2015_last_form()
-        kname = {3: "k_dc2015_async [lean form, third generation: compute workgroups + arbiter + raster writers]", 2: "k_dc2015_spec [lean form, second generation]",
+        kname = {3: "k_dc2015_async [lean form, third generation: compute workgroups + arbiter + raster writers + producer workgroups (the digest / X-trace pre-passes run inside the launch)]", 2: "k_dc2015_spec [lean form, second generation]",
                  1: "k_dc2015_run [lean form]"}.get(form, "k_dc2015_run")
         return {"kernel": kname + " (one launch per network.run())", "resident_form": form, "avg_ms": s.value / n.value, "n": n.value,
                 "timesteps_per_launch": int(round(time / net.dt))}

@@ -614,9 +614,16 @@ static size_t resident_summary_bytes(int N) { return (size_t)4 * ((N + 1) / 2) *
 static size_t resident_gran_bytes(int B, int N) { return (size_t)4 * ((N + 1) / 2) * ((B + 1) / 2) * 8; }   // >= 4 * G * KB * 8 for every tile width
 constexpr size_t kAsyncCtlBytes = 8 * 11 * 8 + 16 * 4 + 64;
 
+// ... plus two more copies of the granule areas: where the gated second attempt of a pipelined caller exchanges (alternating, so that the
+// one it does not use can be cleared for the next run)
+static size_t resident_second_bytes(int B, int N) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N));
+}
 static size_t resident_extra(int B, int Nin, int N, int T) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N)) + al(kAsyncCtlBytes) + al((size_t)(T + 1 + 16) * 4) + al((size_t)(T + 1) * B * Nin * 4);
+    return al(resident_gran_bytes(B, N)) + al(resident_summary_bytes(N)) + al(kAsyncCtlBytes) + al((size_t)(T + 1 + 16) * 4) + al((size_t)(T + 1) * B * Nin * 4) +
+           2 * resident_second_bytes(B, N);
 }
 
 // The resident form keeps the X trace of every step ((T+1)*B*Nin floats): beyond this it is not offered and long runs
@@ -661,6 +668,8 @@ extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, i
 }
 
 void snn_set_plan_name(const char *name);
+uint8_t *snn_input_raster_request(int layer);      // snn_run.hip: a spike monitor on an Input layer, if the plan wants to serve it itself
+void snn_input_raster_done(int layer);
 unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
                                                 const snn_run_desc *R);
 int g_graph_stats[3] = {0, 0, 0};   // runs enqueued as plain launches / captured / replayed
@@ -771,6 +780,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                 const char *pe = getenv("SNN_DC_PRODUCERS");
                 const int spare = cap3 - (rG + 1 + nrw), want = pe ? atoi(pe) : 128;
                 c.NP = (want > 0 && spare >= 16 && dc_prep_lds_bytes(B, Nin, 512) <= alds) ? (spare < want ? spare : want) : 0;
+                uint8_t *rq = c.NP > 0 ? snn_input_raster_request(0) : nullptr;
+                if (rq && !(((uintptr_t)rq | (uintptr_t)c.in) & 15)) c.rasX = rq;           // the Input layer's raster: copied by the producers
             }
         }
     }
@@ -799,7 +810,19 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         if (resident) {
             // memset of the exchange granules (epochs restart at 1 every run), input-only pre-passes, ONE launch
             const size_t exbytes = (size_t)((unsigned char *)c.xtr - (unsigned char *)c.ex);      // (includes the tbad word)
-            if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
+            // A pipelined caller (status2 + host_state): the gated second attempt behind run k clears this area -- and the copy of the
+            // general form's granule areas that run k+1's second attempt will use -- for run k+1, so a section's steady state starts no run
+            // with a memset.  host_state[0]: a key of (workspace, layout) while that holds; [1]: runs enqueued that way (which copy is next).
+            const size_t secbytes = resident_second_bytes(B, N);
+            unsigned char *sec0 = (unsigned char *)c.xtr + al((size_t)(R->T + 1) * B * Nin * 4);
+            const bool chain = lean && R->status2 && R->host_state;
+            const unsigned long long key = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(uintptr_t)c.ex ^ ((unsigned long long)exbytes << 20) ^ ((unsigned long long)R->T << 44) ^ (unsigned long long)lean;
+            const bool clean = chain && R->host_state[0] == key;
+            if (R->host_state) R->host_state[0] = 0;                                               // (until this run is known to leave it clean again)
+            if (!clean) {
+                if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
+                if (chain && (rc0 = snn_check(hipMemsetAsync(sec0, 0, 2 * secbytes, qs)))) return rc0;
+            }
             // input-only pre-passes: launches of their own -- unless the third generation runs them on producer workgroups INSIDE its
             // launch (c.NP > 0).  (Both in ONE launch was measured: 38 us against 10 + 22 -- the X-trace walk wants 256-thread workgroups.)
             if (!(lean == 3 && c.NP > 0)) {
@@ -816,12 +839,23 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                 // digest and X traces, gated on the first attempt's status word, reporting into *status2.  Where the first attempt went
                 // through, its workgroups return at once.
                 DcCtx c2 = c;
-                c2.tbad = nullptr; c2.NRW = 0; c2.status = R->status2; c2.gate = R->status;
-                if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
-                rcl = snn_dc2015_resident_launch(c2, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), 0, qs);
+                c2.tbad = nullptr; c2.NRW = 0; c2.NP = 0; c2.rasX = nullptr; c2.status = R->status2; c2.gate = R->status;
+                if (chain) {
+                    const int par = (int)(R->host_state[1] & 1ull);
+                    unsigned char *mine = sec0 + (size_t)par * secbytes, *other = sec0 + (size_t)(par ^ 1) * secbytes;
+                    c2.ex = (unsigned long long *)mine;
+                    c2.exs = (unsigned long long *)(mine + al(resident_gran_bytes(B, N)));
+                    c2.zeroA = (uint4 *)c.ex; c2.zeroA_n16 = (unsigned)(exbytes >> 4);
+                    c2.zeroG = (uint4 *)other; c2.zeroG_n16 = (unsigned)(secbytes >> 4);
+                } else if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
+                static const bool gated_ordinary = getenv("SNN_DC_GATED_COOP") && atoi(getenv("SNN_DC_GATED_COOP")) == 0;   // (measurement switch)
+                rcl = snn_dc2015_resident_launch(c2, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), 0, qs, gated_ordinary);
+                if (rcl == SNN_OK && chain) { R->host_state[0] = key; R->host_state[1] += 1; }
             }
+            if (rcl == SNN_OK && lean == 3 && c.rasX) snn_input_raster_done(0);
             return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
+        if (R->host_state) R->host_state[0] = 0;          // (whatever a pipelined caller's runs knew about the workspace: no longer)
         rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
         hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);

@@ -70,6 +70,11 @@ struct DcCtx {
     // dready[T+1]: entries finished, dready[T+2]: X-trace chunks (256 (sample, source) pairs each) finished.  Release / acquire at agent scope.
     int *dready;
     int NP;
+    uint8_t *rasX;              // NP > 0, nullable: the Input layer's spike raster [T][B][Nin] -- a copy of the input, made by the producers
+    // gated second attempt (gate != nullptr): its workgroups first clear two exchange areas for the NEXT run of a pipelined caller (the
+    // third generation's, and the general form's other copy) -- the memsets a run otherwise starts with
+    uint4 *zeroA, *zeroG;
+    unsigned zeroA_n16, zeroG_n16;
 };
 
 namespace {
@@ -429,7 +434,8 @@ size_t snn_dc2015_resident_lds(int B, int Nin, int N, int cw);
 size_t snn_dc2015_spec_lds(int B, int Nin, int N);
 int snn_dc2015_resident_cw(int N);
 int snn_dc2015_resident_nt();
-int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, int lean, hipStream_t st);
+// (ordinary: a plain launch instead of a cooperative one -- co-residency then rests on snn_dc2015_resident_capacity and the in-order stream)
+int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds_bytes, int lean, hipStream_t st, bool ordinary = false);
 int snn_dc2015_resident_capacity(int cw, int nt, size_t lds_bytes);
 // third-generation lean form (snn_dc2015_async.hip)
 size_t snn_dc2015_async_lds(int B, int Nin, int N);

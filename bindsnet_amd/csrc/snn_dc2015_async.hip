@@ -391,31 +391,47 @@ __device__ __forceinline__ void async_producer(const DcCtx &c, unsigned char *sm
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(&c.dready[T + 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (c.rasX) {      // a spike monitor on the Input layer records a copy of the input (monitors.py:94-111): nobody in the launch reads it
+        const size_t n16 = ((size_t)T * c.B * c.Nin) >> 4;                  // (Nin % 16 == 0; both pointers 16-byte aligned: checked by the host)
+        const uint4 *src = (const uint4 *)c.in;
+        uint4 *dst = (uint4 *)c.rasX;
+        for (size_t k = (size_t)p * ANT + tid; k < n16; k += (size_t)c.NP * ANT) dst[k] = src[k];
+    }
 }
 
 // Consumer side.  need_entry: digest entry e may be loaded (1), is one the lean forms do not take (2), or never came (-1: bounded poll).
 // `all` is set once every entry has been seen finished (the caller stops asking).  Every lane of the wave runs the same loads.
 __device__ __forceinline__ int need_entry(const DcCtx &c, int e, bool &all) {
+    // (relaxed polls, ONE acquire fence behind the value that lets the caller go on: an acquire load per poll would invalidate the caches and
+    //  drain the wave's outstanding loads every time it is asked -- once per iteration while the producers are still at work)
     const int T = c.T;
-    if (__hip_atomic_load(&c.dready[T + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == T + 1) {
+    int r;
+    if (__hip_atomic_load(&c.dready[T + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == T + 1) {
         all = true;
-        return __hip_atomic_load(c.tbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 2 : 1;
+        r = 0;
+    } else {
+        for (unsigned spins = 0;; ++spins) {
+            r = __hip_atomic_load(&c.dready[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r) break;
+            if (spins > kAPoll) return -1;
+            __builtin_amdgcn_s_sleep(4);
+        }
     }
-    for (unsigned spins = 0;; ++spins) {
-        const int v = __hip_atomic_load(&c.dready[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (v) return v;
-        if (spins > kAPoll) return -1;
-        __builtin_amdgcn_s_sleep(8);
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (all) r = __hip_atomic_load(c.tbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 2 : 1;
+    return r;
 }
 // need_xtr: the X traces of EVERY step are there (1) or never came (-1).
 __device__ __forceinline__ int need_xtr(const DcCtx &c, bool &all) {
     const int nch = x_chunks(c);
     for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(&c.dready[c.T + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == nch) { all = true; return 1; }
+        if (__hip_atomic_load(&c.dready[c.T + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch) break;
         if (spins > kAPoll) return -1;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    all = true;
+    return 1;
 }
 
 // ===================================================================================================================== compute

@@ -123,7 +123,13 @@ __global__ __launch_bounds__(NTR) void k_dc2015_run(const DcCtx c) {
     constexpr int WPB = 8 / CW;                            //           workgroups sharing one byte of a sample's bit string
     constexpr uint32_t FM = (1u << CW) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (c.gate && __hip_atomic_load(c.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != SNN_ERR_RETRY) return;   // a second attempt nobody needs
+    if (c.gate) {
+        // (a pipelined caller's second attempt: whether it is needed or not, the exchange areas of the caller's NEXT run are cleared here)
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (unsigned k = blockIdx.x * NTR + threadIdx.x; k < c.zeroA_n16; k += gridDim.x * NTR) c.zeroA[k] = z;
+        for (unsigned k = blockIdx.x * NTR + threadIdx.x; k < c.zeroG_n16; k += gridDim.x * NTR) c.zeroG[k] = z;
+        if (__hip_atomic_load(c.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != SNN_ERR_RETRY) return;          // a second attempt nobody needs
+    }
     const int B = c.B, Nin = c.Nin, N = c.N, NW = c.NW, NinW = c.NinW, T = c.T;
     // ---- LDS carve-up.  Everything of fixed size sits at a compile-time offset (addresses fold into the
     //      instructions' immediate offsets instead of occupying registers); the four size-dependent arrays follow.
@@ -1803,9 +1809,10 @@ int snn_dc2015_resident_capacity(int cw, int nt, size_t lds) {
 
 // Cooperative launch: the runtime itself refuses (hipErrorCooperativeLaunchTooLarge) a grid it cannot make co-resident.
 // Returns SNN_ERR_UNSUPPORTED in that case so that the caller takes the one-launch-per-timestep plan instead.
-int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, int lean, hipStream_t st) {
+int snn_dc2015_resident_launch(const DcCtx &c, int cw, int nt, size_t lds, int lean, hipStream_t st, bool ordinary) {
     if (!resident_attr_once()) return SNN_ERR_LAUNCH;
-    static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    static const bool coop_env = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    const bool coop = coop_env && !ordinary;
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
     const void *fn = resident_variant(cw, nt, lean);

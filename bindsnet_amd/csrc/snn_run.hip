@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #include "../../include/snnhip.h"
 #include "snn_common.hpp"
 
@@ -252,10 +253,43 @@ static int run_generic(const snn_layer_desc *L, int nL, const snn_conn_desc *C, 
     return snn_check_launch();
 }
 
+// Spike monitors on Input layers (snn_layer_desc.raster_s of an INPUT layer): the raster of an Input layer is a copy of its input
+// (monitors.py:94-111 clone `s`, which aliases the input slice), so no plan writes it step by step -- the plans see the descriptors
+// WITHOUT it, and snn_net_run makes ONE device copy per monitored input behind the plan; a plan that has the copy made inside its own
+// launch (third-generation D&C form: its producer workgroups, snn_dc2015_async.hip) takes the request from snn_input_raster_request()
+// and says so with snn_input_raster_done().
+static thread_local uint8_t *g_in_raster_req[8];
+static thread_local unsigned g_in_raster_done;
+uint8_t *snn_input_raster_request(int layer) { return layer >= 0 && layer < 8 ? g_in_raster_req[layer] : nullptr; }
+void snn_input_raster_done(int layer) { if (layer >= 0 && layer < 8) g_in_raster_done |= 1u << layer; }
+
+static int net_run_plans(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, hipStream_t st);
+
 extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            snn_stream_t stream) {
     TRY(validate(L, nL, C, nC, R));
     hipStream_t st = (hipStream_t)stream;
+    bool any = false;
+    for (int l = 0; l < nL; ++l) any = any || (L[l].kind == SNN_LAYER_INPUT && L[l].raster_s);
+    if (!any) return net_run_plans(L, nL, C, nC, R, st);
+    std::vector<snn_layer_desc> L2(L, L + nL);
+    g_in_raster_done = 0;
+    for (int l = 0; l < nL; ++l) {
+        if (l < 8) g_in_raster_req[l] = nullptr;
+        if (L[l].kind != SNN_LAYER_INPUT || !L[l].raster_s) continue;
+        L2[l].raster_s = nullptr;
+        if (l < 8) g_in_raster_req[l] = L[l].raster_s;
+    }
+    const int rc = net_run_plans(L2.data(), nL, C, nC, R, st);
+    for (int l = 0; l < nL && l < 8; ++l) g_in_raster_req[l] = nullptr;
+    if (rc) return rc;
+    for (int l = 0; l < nL; ++l)
+        if (L[l].kind == SNN_LAYER_INPUT && L[l].raster_s && !(l < 8 && ((g_in_raster_done >> l) & 1u)))
+            TRY(snn_check(hipMemcpyAsync(L[l].raster_s, L[l].ext_spikes, (size_t)R->T * R->B * L[l].n, hipMemcpyDeviceToDevice, st)));
+    return SNN_OK;
+}
+
+static int net_run_plans(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, hipStream_t st) {
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request

@@ -86,7 +86,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         return torch.load(f, weights_only=False)
 
     _TRANSIENT = ("_workspace", "_scratch_pool", "_keep", "last_plan", "resident_retries", "lean_retries", "_lean_cooldown",
-                  "_run_cache", "_reset_cache", "_shard_state", "_defer_norm", "_pipe")
+                  "_run_cache", "_reset_cache", "_shard_state", "_defer_norm", "_pipe", "_ws_state")
 
     def __getstate__(self):
         """save() / clone() pickle the whole object like the reference (network.py:163-209); device scratch, the
@@ -536,7 +536,9 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             ws = self.__dict__.get("_workspace")
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self.__dict__["_workspace"] = torch.empty(need, dtype=torch.uint8, device=dev)
+                self.__dict__["_ws_state"] = (C.c_ulonglong * 2)()       # snn_run_desc.host_state: what the library knows about the workspace's content
             R.workspace, R.workspace_bytes = _dptr(ws), need
+            R.host_state = C.cast(self.__dict__.setdefault("_ws_state", (C.c_ulonglong * 2)()), C.c_void_p)
         pool = self.__dict__.setdefault("_scratch_pool", {})
         if "rng_host" not in pool:
             pool["rng_host"] = torch.zeros(640, dtype=torch.int32).pin_memory()
@@ -574,8 +576,13 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             keep += [x, entry]
             L[i].ext_spikes, L[i].s = _dptr(x), _dptr(entry)
             if wanted:                             # the raster of an input layer is a COPY of its input, like Monitor.record's
-                xcopy = x[:T].clone().view(T, B, *layer.shape)   # clone (monitors.py:94-111): the caller may refill its buffer in place
-                rasters += [(m, key, xcopy) for m, key in wanted]
+                # clone (monitors.py:94-111): the caller may refill its buffer in place.  The library makes the copy (snn_layer_desc.raster_s
+                # of an INPUT layer): one device copy behind the plan, or -- third-generation D&C form -- by the launch's producer workgroups
+                xcopy = torch.empty_like(x[:T])
+                L[i].raster_s = _dptr(xcopy)
+                rasters += [(m, key, xcopy.view(T, B, *layer.shape)) for m, key in wanted]
+            else:
+                L[i].raster_s = None
             inputs[name] = x
         for i, layer, requests in built["layers"]:
             # an entry of `inputs` for a non-Input layer is an external CURRENT (network.py:386-392): slice t is added to

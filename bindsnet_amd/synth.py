@@ -46,12 +46,31 @@ def uniform_f32(seed: int, shape, lo: float, hi: float) -> np.ndarray:
     return rs.uniform(lo, hi, size=shape).astype(np.float32)
 
 
+def stroke_digit(seed: int, size: int = 28) -> np.ndarray:
+    """A digit-like image f32 [size, size] in [0, 1]: three to five thick pen strokes (a random polyline through the middle 20 x 20
+    pixels, pen radius 1.1-1.7 px with a soft edge) -- the statistics of a real MNIST digit that matter to the kernels: 100-200 lit
+    pixels (MNIST: ~150 of 784), most of them SATURATED (MNIST strokes are mostly 255), in connected runs rather than scattered."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.randint(3, 6))
+    pts = rs.uniform(4.0, size - 4.0, size=(n + 1, 2))
+    rad = float(rs.uniform(1.1, 1.7))
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    d2 = np.full((size, size), 1e9)
+    for a, b in zip(pts[:-1], pts[1:]):
+        ab = b - a
+        t = np.clip(((xx - a[0]) * ab[0] + (yy - a[1]) * ab[1]) / max(float(ab @ ab), 1e-9), 0.0, 1.0)
+        d2 = np.minimum(d2, (xx - (a[0] + t * ab[0])) ** 2 + (yy - (a[1] + t * ab[1])) ** 2)
+    img = np.clip(1.0 - (np.sqrt(d2) - rad) / 0.9, 0.0, 1.0)
+    return img.astype(np.float32)
+
+
 def poisson_mnist_like(B: int, T: int = 250, n_inputs: int = 1, seed: int = 1, encoder=None, intensity: float = 128.0,
-                       active: float = 0.19, shape=(1, 28, 28), bold=()):
+                       active: float = 0.19, shape=(1, 28, 28), bold=(), strokes: bool = False):
     """`n_inputs` spike trains u8 [T, B, *shape] of BASELINE.md's cfg1 / cfg2 generator, drawn consecutively from
     torch's global CPU generator seeded with `seed`.  Inputs whose index is in `bold` use intensity 255 on 45 % of
     the pixels for their odd samples (thick, saturated digits: > 32 events per sample and timestep), the
-    worst-case input of tests/golden/full_cfg2_dc_n400_b32_bold."""
+    worst-case input of tests/golden/full_cfg2_dc_n400_b32_bold.  `strokes`: digit-like images (stroke_digit) instead of scattered pixels
+    -- tests/golden/full_cfg2_dc_n400_b32_strokes (the torch draws u, m are still made, so the generator position per sample is the same)."""
     import torch
     if encoder is None:
         from bindsnet_amd.encoding import poisson as encoder
@@ -62,7 +81,9 @@ def poisson_mnist_like(B: int, T: int = 250, n_inputs: int = 1, seed: int = 1, e
         for b in range(B):
             u = torch.rand(*shape)
             m = torch.rand(*shape)
-            if k in bold and b % 2 == 1:
+            if strokes:                         # digit-like images at eth_mnist.py's intensity (transforms.Lambda(x * 128), :117)
+                img = intensity * torch.from_numpy(stroke_digit(7919 * seed + 131 * k + b, shape[-1])).view(*shape)
+            elif k in bold and b % 2 == 1:
                 img = 255.0 * (0.5 + 0.5 * u) * (m < 0.45).float()
             else:
                 img = intensity * u * (m < active).float()

@@ -358,6 +358,10 @@ typedef struct {
                                    on *status == SNN_ERR_RETRY (its workgroups return at once otherwise), reporting into *status2.
                                    Afterwards: the run succeeded iff *status == 0, or *status == SNN_ERR_RETRY and *status2 == 0.
                                    (ABI 8) */
+    unsigned long long *host_state; /* nullable: 16 bytes of HOST memory that belong to `workspace` -- zeroed by the caller whenever the
+                                   workspace is (re)allocated or written by anybody else, otherwise left alone.  The library notes there
+                                   what it knows about the workspace's content, so that consecutive pipelined runs need not clear their
+                                   exchange area with a memset each (the gated second attempt does it for the next run).  (ABI 8) */
 } snn_run_desc;
 
 /* Runs T timesteps.  Asynchronous; the caller synchronises the stream before reading *status /

@@ -41,6 +41,50 @@ def load_reference():
     return DiehlAndCook2015, Monitor
 
 
+def config_leg(args):
+    """--config <name>: one of the OTHER BASELINE.md configs (tools/baseline_configs.py builds it from the reference's classes): `--whole`
+    consecutive inputs of T_cpu timesteps each (20 for cfg3 / cfg5) through Network.run() + reset_state_variables(),
+    8 threads pinned to one CCD; the record holds, per input, every non-input layer's raster (bit-packed) and the weights after it."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import baseline_configs as bc
+    ncpu = os.cpu_count() or 2
+    pin = None
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            pin = sorted(os.sched_getaffinity(0))[:8]
+            torch.set_num_threads(min(args.threads, len(pin)))
+            os.sched_setaffinity(0, pin)
+        except OSError:
+            pin = None
+    load_reference()
+    ns = bc.namespace("bindsnet")
+    cfg = bc.CONFIGS[args.config]
+    x = np.load(args.inputs)                                  # [n_inputs, T_cpu, B, ...]
+    Tc = x.shape[1]
+    th = min(args.threads, ncpu)
+    torch.set_num_threads(th)
+    torch.manual_seed(0)
+    net, mons = bc.build(args.config, ns, Tc)
+    torch.manual_seed(2)
+    rates, recs = [], {}
+    for k in range(min(args.whole, x.shape[0])):
+        xin = torch.from_numpy(x[k]).clone()
+        t0 = time.perf_counter()
+        net.run(inputs={"X": xin}, time=Tc, **cfg["kw"])
+        rates.append(Tc / (time.perf_counter() - t0))
+        for lname, m in mons.items():
+            if lname != "X":
+                recs[f"r{k}_s_{lname}"] = np.packbits(m.get("s").reshape(Tc, -1).numpy().astype(np.uint8))
+        for (src, dst), w in bc.learned_weights(net).items():
+            recs[f"r{k}_w_{src}_{dst}"] = w.detach().numpy().copy()
+        net.reset_state_variables()
+    out = {"kind": "reference", "config": args.config, "threads": th, "timesteps_per_input": Tc, "inputs": len(rates),
+           "per_input_timesteps_per_s": [round(v, 3) for v in rates], "min": round(min(rates), 3), "median": round(float(np.median(rates)), 3),
+           "max": round(max(rates), 3), "host_cpus": ncpu, "torch": torch.__version__, "affinity": (f"pinned to CPUs {pin}" if pin else "not pinned")}
+    np.savez(args.out, n_inputs=len(rates), **recs)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--inputs", required=True)
@@ -49,7 +93,10 @@ def main():
     ap.add_argument("--whole", type=int, default=5)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--short-legs", type=int, default=1)
+    ap.add_argument("--config", default="", help="one of tools/baseline_configs.py's names instead of the headline D&C workload")
     args = ap.parse_args()
+    if args.config:
+        return config_leg(args)
 
     ncpu = os.cpu_count() or 2
     aff_all = pin = None

@@ -50,7 +50,7 @@ def fixture_input(g, r, T, B, n=784):
 
 
 DC_FULL = ["full_cfg1_dc_n100_b1", "full_cfg2_dc_n400_b32", "full_cfg1_dc_n100_b1_poisson", "full_cfg2_dc_n400_b32_poisson",
-           "full_cfg2_dc_n400_b32_bold"]
+           "full_cfg2_dc_n400_b32_bold", "full_cfg2_dc_n400_b32_strokes"]      # (_strokes, round 5: digit-like images -- synth.stroke_digit -- at eth_mnist.py's intensity)
 
 
 def exp_noise(seed, n):

@@ -269,3 +269,45 @@ def test_two_ranks_on_one_gpu_rccl(tmp_path):
         pytest.skip("RCCL did not form a 2-rank group on one device: " + tail.replace("\n", " | ")[-600:])
     _check_two_ranks(outs)
 
+
+
+# ---------------------------------------------------------------------------------------------------- bench.py --gpus N, end to end
+def _bench(args, env_extra=None, timeout=400):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_end_to_end():
+    """`python bench.py --gpus 2 --backend gloo`: the launcher re-exec, the rendezvous on 127.0.0.1, sharded_run inside a pipelined
+    section on both ranks, the merge collective, barrier + MAX of the elapsed times and rank 0's ONE JSON line -- everything the
+    driver's N-GPU command goes through except RCCL itself, with both ranks on the one GPU of the box."""
+    res, line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line.get("error") is None, line
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["config"]["global_batch"] == 64 and line["config"]["backend"] == "gloo"
+    assert abs(line["value"] - 2 * 3 * 250 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3          # whole-job aggregate over both ranks
+    assert len(line["devices"]) == 2 and line["config"]["per_input_collective"]["bytes"] > 0
+    assert line["config"]["plan"].startswith("dc2015-resident")
+
+
+def test_bench_prints_an_error_line_when_a_stage_hangs():
+    """A rank that never shows up: rank 0's rendezvous cannot complete; the watchdog (here 20 s) prints a JSON line with `error` and
+    `stage` instead of hanging until the driver's clock runs out."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    res, line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--watchdog", "20"],
+                       env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, timeout=200)
+    assert res.returncode != 0 and line is not None, (res.stdout[-1500:], res.stderr[-2000:])
+    assert line["value"] is None and "error" in line and line["stage"] == "init_process_group" and line["n_gpus"] == 2

@@ -27,7 +27,7 @@ def go(pipelined, N, B, T, spikes, depth=64, w_scale=0.6, exc=22.5, reset=True, 
         torch.manual_seed(0)
         net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=exc, inh=120.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
         net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(synth.uniform_f32(3, (784, N), 0.0, w_scale), 1.0)))
-        mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("Ae", "Ai")}
+        mons = {l: Monitor(net.layers[l], ["s"], time=T) for l in ("X", "Ae", "Ai")}
         for l, m in mons.items():
             net.add_monitor(m, l)
         net.to(DEV)
@@ -38,13 +38,15 @@ def go(pipelined, N, B, T, spikes, depth=64, w_scale=0.6, exc=22.5, reset=True, 
             for x in xs:
                 net.run({"X": x}, time=T)
                 plans.append(net.last_plan)
-                dev_out.append(dict(sE=mons["Ae"].get("s").clone(), sI=mons["Ai"].get("s").clone(),
+                dev_out.append(dict(sX=mons["X"].get("s").clone(), sE=mons["Ae"].get("s").clone(), sI=mons["Ai"].get("s").clone(),
                                     W=net.connections[("X", "Ae")].pipeline[0].value.detach().clone(), theta=net.layers["Ae"].theta.clone(),
                                     vE=net.layers["Ae"].v.clone(), xE=net.layers["Ae"].x.clone(), vI=net.layers["Ai"].v.clone()))
                 if reset:
                     net.reset_state_variables()
         probe = torch.rand(3).numpy()                        # where the host generator stands afterwards
         out = [{k: v.cpu().numpy() for k, v in d.items()} for d in dev_out]
+        for r, d in enumerate(out):                           # the Input layer's raster is a copy of the input (made by the launch's producer workgroups
+            np.testing.assert_array_equal(d["sX"].reshape(T, B, 784).astype(np.uint8), spikes[r], err_msg=f"input {r}: X raster")   # or one device copy)
         out[-1]["probe"] = probe
         return out, plans, net
     finally:

@@ -32,21 +32,24 @@ def ref_init_weights(n_in, n, scale=0.3):
 
 # --------------------------------------------------------------------------------------------- cfg1 / cfg2
 @pytest.mark.parametrize("name,bold", [("full_cfg1_dc_n100_b1_poisson", ()), ("full_cfg2_dc_n400_b32_poisson", ()),
-                                       ("full_cfg2_dc_n400_b32_bold", (1,))])
+                                       ("full_cfg2_dc_n400_b32_bold", (1,)), ("full_cfg2_dc_n400_b32_strokes", ())])
 def test_stated_poisson_input_regenerates_through_the_package_encoder(name, bold):
     """BASELINE.md section 2's cfg1/cfg2 input (seed 1, 128*U*Bernoulli(0.19), bindsnet.encoding.poisson): the
     fixture holds the REFERENCE encoder's trains; this package's host encoder (same torch draws in the same order)
     must reproduce them bit for bit -- bench.py builds its input pool this way."""
     g = gold(name)
     B, T, runs = int(g["B"]), int(g["T"]), int(g["runs"])
-    trains = synth.poisson_mnist_like(B, T, runs, seed=1, bold=bold)
+    trains = synth.poisson_mnist_like(B, T, runs, seed=1, bold=bold, strokes=name.endswith("_strokes"))
     for r in range(runs):
         assert cases.sha(trains[r].reshape(T, B, 784)) == str(g[f"r{r}_in_sha"]), f"input {r}"
         np.testing.assert_array_equal(trains[r].reshape(T, B, 784), cases.fixture_input(g, r, T, B))
     d = np.mean([t.mean() for t in trains])
     if name == "full_cfg2_dc_n400_b32_poisson":
         assert [str(g[f"r{r}_in_sha"]) for r in range(3)] == synth.POISSON_CFG2_SHA
-    if not bold:
+    if name.endswith("_strokes"):
+        per = np.stack([t.reshape(T, B, 784).sum(2) for t in trains])
+        assert 0.018 < d < 0.023 and 30 < per.max() <= 63      # digit-like images: ~2 % density, 15 events per sample-step, inside the lean form's 63
+    elif not bold:
         assert 0.010 < d < 0.0135            # the stated generator's density (~1.17 %), not round 2's 0.62 %
 
 
@@ -54,7 +57,7 @@ def test_stated_poisson_input_regenerates_through_the_package_encoder(name, bold
 def test_oracle_dc2015_full_size(name):
     g = gold(name)
     N, B, T, runs = int(g["N"]), int(g["B"]), int(g["T"]), int(g["runs"])
-    if name == "full_cfg2_dc_n400_b32":
+    if name in ("full_cfg2_dc_n400_b32", "full_cfg2_dc_n400_b32_strokes"):
         runs = 1          # round 1/2's sparser input: one run here (a minute per three for the scalar C port); the Poisson
                           # fixtures below -- the input BASELINE.md states -- are checked over all three runs
     P = dc_params(g)

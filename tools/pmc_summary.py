@@ -21,13 +21,25 @@ def counter_mean(folder, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
+def source_sha16():
+    """sha256 (first 16 hex digits) of the sources the dominant kernel is built from: bench.py compares it with the tree it runs in, so a
+    `roofline.traffic` taken from a profile of an OLDER kernel says so (the snapshot on the GPU box has no .git to name a commit)."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("snn_dc2015_async.hip", "snn_dc2015.hpp", "snn_dc2015_tile.hpp"):
+        with open(os.path.join(root, "bindsnet_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main(out):
     for path in glob.glob(os.path.join(out, "ks", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(path, os.path.join(out, "kernel_stats.csv"))
     fetch, n = counter_mean(os.path.join(out, "fetch"), "FETCH_SIZE")
     write, _ = counter_mean(os.path.join(out, "write"), "WRITE_SIZE")
     res = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline",
-           "kernel": KERNEL, "launches": n, "timesteps_per_launch": T,
+           "kernel": KERNEL, "kernel_source_sha16": source_sha16(), "launches": n, "timesteps_per_launch": T,
            "FETCH_SIZE_KB_per_launch_mean": fetch, "WRITE_SIZE_KB_per_launch_mean": write}
     if fetch is not None and write is not None:
         raw = (fetch + write) * 1024.0

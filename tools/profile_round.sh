@@ -19,6 +19,6 @@ run() {   # name, command...
 }
 run cfg2 python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
 for cfg in cfg1 cfg3_shard cfg3_b32 cfg3 cfg4 cfg5; do
-  run $cfg python "$R/tools/bench_configs.py" --runs 5 --only $cfg
+  run $cfg python "$R/tools/bench_configs.py" --runs 5 --only $cfg --no-cpu-baseline
 done
 python "$R/tools/profile_summary.py" "$OUT"
