@@ -447,7 +447,7 @@ def main():
         # ---- roofline of the dominant kernel: HIP events (on the launch stream) around single launches of further
         # runs of the same input pool, LAST, so the device is busy until the process prints its line
         roof = None
-        prof = _lib.profile_run(net, {"X": pool[0].clone()}, T, repeats=25)
+        prof = _lib.profile_run(net, {"X": pool[0].clone()}, T, repeats=25, pipelined=not args.sync_runs)
         if prof is not None:
             ab = algorithmic_bytes_per_timestep() * prof["timesteps_per_launch"]
             ach = ab / (prof["avg_ms"] * 1e-3) / 1e9

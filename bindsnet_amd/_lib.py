@@ -188,24 +188,34 @@ def check(rc: int, what: str = ""):
         raise SnnError(f"libsnnhip {what}: {msg} (code {rc})")
 
 
-def profile_run(net, inputs, time, stride=4, repeats=5):
+def profile_run(net, inputs, time, stride=4, repeats=5, pipelined=False):
     """Extra run()s with HIP events around the plan's dominant launches (bench.py roofline): every `stride`-th
     timestep's launch for the per-step plans, the one launch of each run for the resident plan (`repeats` runs).
+    `pipelined`: the runs are those of a Network.pipelined() section (the launch mode the caller's timed region used).
+    One untimed run first: the first launch of a mode pays one-time set-up (the runtime creates the queue cooperative
+    launches go through at the first of them: several ms).
     Returns {"kernel", "avg_ms", "n", "timesteps_per_launch"} or None."""
+    import contextlib
     import torch
     L = lib()
-    L.snn_profile_enable(stride)
-    try:
-        for _ in range(max(1, repeats)):
-            net.run(dict(inputs), time=time)
-            net.reset_state_variables()
-            if not net.last_plan.startswith("dc2015-resident"):
-                break
+    with (net.pipelined() if pipelined else contextlib.nullcontext()):
+        net.run(dict(inputs), time=time)
+        net.reset_state_variables()
+        net.sync()
         torch.cuda.synchronize()
-        s, n = C.c_double(0), C.c_int(0)
-        check(L.snn_profile_collect(C.byref(s), C.byref(n)), "profile_collect")
-    finally:
-        L.snn_profile_enable(0)
+        L.snn_profile_enable(stride)
+        try:
+            for _ in range(max(1, repeats)):
+                net.run(dict(inputs), time=time)
+                net.reset_state_variables()
+                if not net.last_plan.startswith("dc2015-resident"):
+                    break
+            net.sync()
+            torch.cuda.synchronize()
+            s, n = C.c_double(0), C.c_int(0)
+            check(L.snn_profile_collect(C.byref(s), C.byref(n)), "profile_collect")
+        finally:
+            L.snn_profile_enable(0)
     if n.value == 0:
         return None
     plan = net.last_plan

@@ -830,7 +830,14 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                 if (c.x_traces) hipLaunchKernelGGL(k_dc2015_xtrace, dim3((B * Nin + 255) / 256), dim3(256), 0, qs, c);
             }
             const bool prof = with_events && snn_prof_begin(0, qs);
-            int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs)
+            // A pipelined caller's launches are ORDINARY ones: a cooperative launch costs ~20 us of dispatch latency each (it goes through a
+            // queue of its own: 0.989 -> 0.946 ms per step with both launches of a run ordinary, profiles/NOTES_r05.md).  What the cooperative
+            // launch guarantees beyond the capacity check made above -- that no kernel of ANOTHER stream of this process holds CUs meanwhile --
+            // is part of what a section asks of its caller anyway (a grid that is not co-resident in time ends with SNN_ERR_TIMEOUT, which
+            // a section reports as an error); synchronous runs keep the cooperative launch.  SNN_DC_GATED_COOP / SNN_DC_SECTION_COOP=1: measurement switches.
+            static const bool section_coop = getenv("SNN_DC_SECTION_COOP") && atoi(getenv("SNN_DC_SECTION_COOP")) != 0;
+            const bool ordinary = chain && !section_coop;
+            int rcl = lean == 3 ? snn_dc2015_async_launch(c, snn_dc2015_async_lds(B, Nin, N), qs, ordinary)
                                 : snn_dc2015_resident_launch(c, rcw, rnt, lean == 2 ? snn_dc2015_spec_lds(B, Nin, N) : snn_dc2015_resident_lds(B, Nin, N, rcw), lean, qs);
             if (prof) snn_prof_end(qs);
             if (rcl == SNN_OK && lean && R->status2) {
@@ -848,8 +855,8 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
                     c2.zeroA = (uint4 *)c.ex; c2.zeroA_n16 = (unsigned)(exbytes >> 4);
                     c2.zeroG = (uint4 *)other; c2.zeroG_n16 = (unsigned)(secbytes >> 4);
                 } else if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
-                static const bool gated_ordinary = getenv("SNN_DC_GATED_COOP") && atoi(getenv("SNN_DC_GATED_COOP")) == 0;   // (measurement switch)
-                rcl = snn_dc2015_resident_launch(c2, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), 0, qs, gated_ordinary);
+                static const bool gated_coop = getenv("SNN_DC_GATED_COOP") && atoi(getenv("SNN_DC_GATED_COOP")) != 0;
+                rcl = snn_dc2015_resident_launch(c2, rcw, rnt, snn_dc2015_resident_lds(B, Nin, N, rcw), 0, qs, !gated_coop && !section_coop);
                 if (rcl == SNN_OK && chain) { R->host_state[0] = key; R->host_state[1] += 1; }
             }
             if (rcl == SNN_OK && lean == 3 && c.rasX) snn_input_raster_done(0);

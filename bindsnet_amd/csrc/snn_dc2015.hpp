@@ -440,4 +440,4 @@ int snn_dc2015_resident_capacity(int cw, int nt, size_t lds_bytes);
 // third-generation lean form (snn_dc2015_async.hip)
 size_t snn_dc2015_async_lds(int B, int Nin, int N);
 int snn_dc2015_async_capacity(size_t lds_bytes);
-int snn_dc2015_async_launch(const DcCtx &c, size_t lds_bytes, hipStream_t st);
+int snn_dc2015_async_launch(const DcCtx &c, size_t lds_bytes, hipStream_t st, bool ordinary = false);

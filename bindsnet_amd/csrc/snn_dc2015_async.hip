@@ -1420,9 +1420,10 @@ int snn_dc2015_async_capacity(size_t lds) {
 }
 
 // grid = G compute workgroups + the arbiter + c.NRW raster writers + c.NP producers, all co-resident (cooperative launch)
-int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st) {
+int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st, bool ordinary) {
     if (!async_attr_once()) return SNN_ERR_LAUNCH;
-    static const bool coop = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    static const bool coop_env = !(getenv("SNN_DC_COOP") && atoi(getenv("SNN_DC_COOP")) == 0);
+    const bool coop = coop_env && !ordinary;
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
     const unsigned grid = (unsigned)(c.G + 1 + c.NRW + c.NP);

@@ -425,16 +425,22 @@ __device__ __forceinline__ void two_stdp(const TwoCtx &c, float *wt, const uint1
 //
 // Where a term applies to some columns only, it is multiplied by a 0/1 factor inside an fma: the product is exact
 // (x*1, x*0), so the fma rounds once -- to the same value as the plain add (or no add) it stands for.
-template <int MWT>
+// RL (round 5): the two other rules of the same outer-product skeleton take the same walk -- Hebbian  w += nu0 U1; w += nu1 U2  and
+// WeightDependentPostPre  w += 0 - (nu0 U1)(w - wmin) + (nu1 U2)(wmax - w)  with U1 = sum_b s_src x_tgt, U2 = sum_b x_src s_tgt (two_stdp's
+// statements, element for element; `xnu0` then holds the plain target trace and the post-synaptic terms are x_src * 1.0f): the batch sums
+// are the same partials in the same order, only what is done with them differs.  Hebbian visits the columns that spiked whether or not
+// nu1 is zero, like two_stdp's second pass.
+template <int MWT, int RL = SNN_RULE_POSTPRE>
 __device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, const uint32_t *am, const uint32_t *ab,
                                                   const uint16_t *ridx, const float *xnu0, const uint32_t *ul,
                                                   const float4 *fac, const float *__restrict__ xs, bool full, int c0, int tid) {
     const int B = c.B, Nin = c.Nin, N = c.N, CW = c.CW, mw = MWT == 1 ? 1 : c.MW;
     // the samples with a post-synaptic spike in this tile, ascending (bytes of ul[0..8 mw)), their number, the columns that
     // spiked at all, and per listed sample one 0/1 factor per column (fac): built by two_union_list
-    const int nun = c.nu1 != 0.f ? __builtin_amdgcn_readfirstlane(ul[8 * mw]) : 0;
-    const uint32_t postcols = c.nu1 != 0.f ? (uint32_t)__builtin_amdgcn_readfirstlane(ul[8 * mw + 1]) : 0u;
-    const float nu1c = 1.0f * c.nu1;
+    const bool want_post = c.nu1 != 0.f || RL == SNN_RULE_HEBBIAN;
+    const int nun = want_post ? __builtin_amdgcn_readfirstlane(ul[8 * mw]) : 0;
+    const uint32_t postcols = want_post ? (uint32_t)__builtin_amdgcn_readfirstlane(ul[8 * mw + 1]) : 0u;
+    const float nu1c = RL == SNN_RULE_POSTPRE ? 1.0f * c.nu1 : 1.0f;
     // x_src[b, i] = one buffer load: descriptor of the slab (scalar), row offset b*Nin*4 (scalar), lane offset i*4
     const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void *)xs, 0, B * Nin * 4, 0x00020000);
     for (int i = tid; i < Nin; i += NT) {
@@ -462,7 +468,10 @@ __device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, co
         float xA[8], xB[8];
         if (nun > 0) load_chunk(0, idA, xA);               // in flight behind the pre-synaptic part
         float a0[8], a1[8];
-        if (c.nu0 != 0.f) {                                // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
+        float u1[8];                                       // (Hebbian / WeightDependentPostPre: the pre-synaptic batch sums, used below)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u1[q] = 0.f;
+        if (c.nu0 != 0.f || RL != SNN_RULE_POSTPRE) {      // w -= dt * sum_b s_src[b,i] * (x_tgt[b,j]*nu0)
             // per lane: walk the row's samples in ascending order
 #pragma unroll
             for (int q = 0; q < 8; ++q) a0[q] = a1[q] = 0.f;
@@ -494,11 +503,12 @@ __device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, co
             for (int q = 0; q < 8; ++q) {
                 if (q >= CW) break;
                 float uu = ((a0[q] + a1[q]) + 0.f) + 0.0f;
+                if constexpr (RL != SNN_RULE_POSTPRE) { u1[q] = active ? uu : 0.f; continue; }   // (a row without a source spike: the empty sum, two_stdp's 0.0f)
                 if (c.use_dt) uu = uu * c.dt;
                 w[q] = w[q] - uu;
             }
         }
-        if (c.nu1 != 0.f) {                                // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
+        if (want_post) {                                   // w += dt * sum_b x_src[b,i] * (s_tgt[b,j]*nu1)
 #pragma unroll
             for (int q = 0; q < 8; ++q) a0[q] = a1[q] = 0.f;
             int cblk = 0;
@@ -530,8 +540,25 @@ __device__ __forceinline__ void two_stdp_rowmajor(const TwoCtx &c, float *wt, co
             for (int q = 0; q < 8; ++q) {
                 if (q >= CW) break;
                 float uu = ((postcols >> q) & 1u) ? ((a0[q] + a1[q]) + 0.f) + 0.0f : 0.f;
+                if constexpr (RL != SNN_RULE_POSTPRE) { a0[q] = uu; continue; }                  // U2 of column q (0.0f where it did not spike)
                 if (c.use_dt) uu = uu * c.dt;
                 w[q] = w[q] + uu;
+            }
+        }
+        if constexpr (RL != SNN_RULE_POSTPRE) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q >= CW) break;
+                const float u2 = want_post ? a0[q] : 0.f;
+                if constexpr (RL == SNN_RULE_HEBBIAN) {
+                    w[q] = w[q] + c.nu0 * u1[q];
+                    w[q] = w[q] + c.nu1 * u2;
+                } else {
+                    float upd = 0.f; bool have = false;
+                    if (c.nu0 != 0.f) { upd = 0.0f - (c.nu0 * u1[q]) * (w[q] - c.wmin); have = true; }
+                    if (c.nu1 != 0.f) { const float y = (c.nu1 * u2) * (c.wmax - w[q]); upd = have ? upd + y : y; have = true; }
+                    if (have) w[q] = w[q] + upd;
+                }
             }
         }
         const bool whole = CW == 8 && c0 + 8 <= N && (active || full || postcols == 0xFFu);
@@ -947,7 +974,8 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             const float *xs = c.xall + (size_t)(t - 1) * B * Nin;
             if constexpr (RULE == SNN_RULE_HEBBIAN || RULE == SNN_RULE_WDPOSTPRE) {
                 if (Etot != Emain) two_stdp<OuterSum, MWT, RULE>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
-                else two_stdp<CascT, MWT, RULE>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+                else if (sbytes || c.rowmajor == 0) two_stdp<CascT, MWT, RULE>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
+                else two_stdp_rowmajor<MWT, RULE>(c, wt, am, ab, ridx, xnu0, ul, fac, xs, full, c0, tid);
             } else {
             if (Etot != Emain) two_stdp<OuterSum, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
             else if (sbytes || c.rowmajor == 0) two_stdp<CascT, MWT>(c, wt, ar, am, ab, xnu0, cm, xs, c.use_xsl ? xsl : nullptr, sbytes, nact, full, c0, tid, cwl, Emain);
@@ -1054,7 +1082,7 @@ __global__ __launch_bounds__(NT) void k_two_run(const TwoCtx c) {
             if (c.rasVY) c.rasVY[(size_t)t * B * N + kst] = v;
         }
         lds_barrier();                                   // this step's spike masks are final
-        if (RULE == SNN_RULE_POSTPRE && do_stdp && c.rowmajor) two_union_list<MWT>(c, cmn, ul, fac, mw, c0, tid);   // (read after the next barrier)
+        if (kOuter && do_stdp && c.rowmajor) two_union_list<MWT>(c, cmn, ul, fac, mw, c0, tid);   // (read after the next barrier)
         if (c.use_xsl && do_stdp && tid < Nin) {         // source traces the next PostPre needs: in flight across the loop edge
             const float *xs = c.xall + (size_t)t * B * Nin;
 #pragma unroll
@@ -1193,7 +1221,8 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.MW = (B + 31) / 32; c.BC = 32 * c.MW;
     c.dt = R->dt; c.learning = R->learning;
     c.rule = C[0].rule;
-    c.rowmajor = c.rule == SNN_RULE_POSTPRE && c.learning && !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
+    c.rowmajor = (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && c.learning &&
+                 !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     c.mstdp_rows = !(getenv("SNN_TWO_MSTDP_ROWS") && atoi(getenv("SNN_TWO_MSTDP_ROWS")) == 0);
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);

@@ -82,6 +82,19 @@ def test_mstdpet_update_sequence_vs_reference():
     ("hebbian", 208, 48, 6, "twolayer-fused"), ("wdpp", 208, 48, 6, "twolayer-fused"),
     ("hebbian", 208, 40, 40, "twolayer-fused"), ("wdpp", 208, 40, 40, "twolayer-fused")])
 def test_network_run_with_the_rule_vs_oracle(rule, Nin, N, B, plan):
+    _run_rule_vs_oracle(rule, Nin, N, B, plan)
+
+
+@pytest.mark.parametrize("rule,N,B,nu", [("hebbian", 44, 6, (1e-4, 0.0)), ("hebbian", 44, 40, (0.0, 1e-3)), ("wdpp", 44, 6, (0.0, 1e-3)),
+                                         ("wdpp", 44, 40, (1e-4, 0.0)), ("hebbian", 48, 70, (2e-4, 5e-4)), ("wdpp", 48, 70, (2e-4, 5e-4))])
+def test_outer_rules_row_major_form_one_sided_rates_and_partial_tiles(rule, N, B, nu):
+    """Round 5: Hebbian / WeightDependentPostPre take PostPre's row-major form in the one-launch plan (two_stdp_rowmajor<., RULE>).  One-sided
+    learning rates (Hebbian visits the columns that spiked even with nu1 == 0; WeightDependentPostPre skips a side whose rate is zero), a last
+    tile of 4 columns (N = 44), three batch-mask words (B = 70: the batch sums cross four 16-sample cascade blocks)."""
+    _run_rule_vs_oracle(rule, 208, N, B, "twolayer-fused", nu=nu)
+
+
+def _run_rule_vs_oracle(rule, Nin, N, B, plan, nu=None):
     from bindsnet_amd.learning import Hebbian, MSTDPET, WeightDependentPostPre
     from bindsnet_amd.network import Network
     from bindsnet_amd.network.monitors import Monitor
@@ -93,7 +106,8 @@ def test_network_run_with_the_rule_vs_oracle(rule, Nin, N, B, plan):
     net.add_layer(Input(n=Nin, traces=True), "X")
     net.add_layer(LIFNodes(n=N, traces=True), "Y")
     cls = {"hebbian": Hebbian, "wdpp": WeightDependentPostPre, "mstdpet": MSTDPET}[rule]
-    nu = (1e-1, 1e-1) if rule == "mstdpet" else (1e-4, 1e-3)
+    if nu is None:
+        nu = (1e-1, 1e-1) if rule == "mstdpet" else (1e-4, 1e-3)
     conn = Connection(net.layers["X"], net.layers["Y"], w=torch.from_numpy(W0).clone(), wmin=0.0, wmax=1.0, update_rule=cls, nu=nu,
                       norm=0.1 * Nin, reduction=torch.sum)
     net.add_connection(conn, "X", "Y")

@@ -125,7 +125,7 @@ def baseline_config(name, runs, cpu):
             "sync_runs": r["sync"], "n_gpus": 1, "runs": runs, "dtype": "f32", "data": "synthetic (BASELINE.md section 2's generator)", "config": {"workload": name + ": " + c["what"], "plan": r["plan"],
             "monitors": "a spike monitor on every layer", "host_sync": "pipelined section"}, "roofline": roofline(name, c["T"])}
     if cpu:
-        ref, rec = reference_leg(name, xs, c["T_cpu"], 3)
+        ref, rec = reference_leg(name, xs, c["T_cpu"], c.get("n_cpu", 3))      # (cfg3 at B = 128 / cfg5: ~0.5 timesteps/s on the CPU -> one input of 20)
         if ref is not None and "error" not in ref and rec is not None:
             line["cpu_baseline"] = {"value": ref["median"], "unit": "timesteps/s", "cores": ref["threads"], "kind": "reference",
                                     "sample": f"median of {ref['inputs']} inputs of {ref['timesteps_per_input']} timesteps (batch {c['B']}) through the unmodified reference, Network.run() in a subprocess",
