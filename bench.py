@@ -401,6 +401,9 @@ def main():
             net.sync()
             fence()
             enter("timed region")
+            # HIP events (on the launch stream) around the dominant launch of every run of the timed region itself (the first 256 of them): the
+            # `roofline` of the line is the kernel as it ran inside the number it stands beside (two event records per run)
+            _lib.lib().snn_profile_enable(4)
             t0 = time.perf_counter()
             for k in range(args.steps):
                 one(args.warmup + k)
@@ -408,6 +411,10 @@ def main():
             net.sync()                                         # status of every run checked, host generator written back
             fence()
             elapsed = time.perf_counter() - t0
+            import ctypes as _C
+            ev_sum, ev_n = _C.c_double(0), _C.c_int(0)
+            _lib.check(_lib.lib().snn_profile_collect(_C.byref(ev_sum), _C.byref(ev_n)), "profile_collect")
+            _lib.lib().snn_profile_enable(0)
     except Exception as e:                                     # noqa: BLE001
         error_line(f"rank {rank}, stage '{stage['name']}': {type(e).__name__}: {str(e)[:400]}")
         raise
@@ -447,7 +454,13 @@ def main():
         # ---- roofline of the dominant kernel: HIP events (on the launch stream) around single launches of further
         # runs of the same input pool, LAST, so the device is busy until the process prints its line
         roof = None
-        prof = _lib.profile_run(net, {"X": pool[0].clone()}, T, repeats=25, pipelined=not args.sync_runs)
+        prof = None
+        if ev_n.value > 0 and plan_timed.startswith("dc2015-resident"):     # the timed region's own launches
+            form = _lib.lib().snn_dc2015_last_form()
+            prof = {"kernel": _lib.resident_kernel_name(form) + " (one launch per network.run(); HIP events around the launches of the timed region)",
+                    "resident_form": form, "avg_ms": ev_sum.value / ev_n.value, "n": ev_n.value, "timesteps_per_launch": T}
+        if prof is None:                                                    # per-step / generic plans: sampled launches of extra runs
+            prof = _lib.profile_run(net, {"X": pool[0].clone()}, T, repeats=25, pipelined=not args.sync_runs)
         if prof is not None:
             ab = algorithmic_bytes_per_timestep() * prof["timesteps_per_launch"]
             ach = ab / (prof["avg_ms"] * 1e-3) / 1e9

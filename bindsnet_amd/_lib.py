@@ -188,6 +188,12 @@ def check(rc: int, what: str = ""):
         raise SnnError(f"libsnnhip {what}: {msg} (code {rc})")
 
 
+def resident_kernel_name(form: int) -> str:
+    return {3: "k_dc2015_async [lean form, third generation: compute workgroups + arbiter + raster writers + producer workgroups (the digest / X-trace "
+               "pre-passes and the input monitor's copy run inside the launch)]", 2: "k_dc2015_spec [lean form, second generation]",
+            1: "k_dc2015_run [lean form]"}.get(form, "k_dc2015_run")
+
+
 def profile_run(net, inputs, time, stride=4, repeats=5, pipelined=False):
     """Extra run()s with HIP events around the plan's dominant launches (bench.py roofline): every `stride`-th
     timestep's launch for the per-step plans, the one launch of each run for the resident plan (`repeats` runs).
@@ -221,9 +227,7 @@ def profile_run(net, inputs, time, stride=4, repeats=5, pipelined=False):
     plan = net.last_plan
     if plan.startswith("dc2015-resident"):
         form = L.snn_dc2015_last_form()
-        kname = {3: "k_dc2015_async [lean form, third generation: compute workgroups + arbiter + raster writers + producer workgroups (the digest / X-trace pre-passes run inside the launch)]", 2: "k_dc2015_spec [lean form, second generation]",
-                 1: "k_dc2015_run [lean form]"}.get(form, "k_dc2015_run")
-        return {"kernel": kname + " (one launch per network.run())", "resident_form": form, "avg_ms": s.value / n.value, "n": n.value,
+        return {"kernel": resident_kernel_name(form) + " (one launch per network.run())", "resident_form": form, "avg_ms": s.value / n.value, "n": n.value,
                 "timesteps_per_launch": int(round(time / net.dt))}
     kernel = "k_dc2015_step (one launch per timestep)" if plan != "generic" else "generic plan: all launches of one timestep"
     return {"kernel": kernel, "avg_ms": s.value / n.value, "n": n.value, "timesteps_per_launch": 1}

@@ -17,7 +17,7 @@ static int g_plan_mode = 0;
 
 // ---- profiling samples (bench.py roofline) ------------------------------------------------------
 static int g_prof_stride = 0;
-static constexpr int kMaxSamples = 64;
+static constexpr int kMaxSamples = 256;
 static hipEvent_t g_ev0[kMaxSamples], g_ev1[kMaxSamples];
 static int g_nsamples = 0;
 static bool g_ev_ready = false;

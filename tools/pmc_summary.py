@@ -33,6 +33,24 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+def launch_durations(out, warmup=3, steps=20):
+    """Per-launch durations of the dominant kernel from the kernel trace of `bench.py --steps 20 --warmup 3`, in launch order: rocprofv3's
+    --stats average runs over EVERY launch of the process, and the first ones are slow for a reason that has nothing to do with the kernel
+    (the untrained network crosses its thresholds far more often: 1.85, 1.31, 1.25 ms ...); bench.py's `roofline.avg_launch_us` is the HIP-event
+    mean over the launches of its timed region, i.e. launches warmup .. warmup+steps-1 here."""
+    for path in glob.glob(os.path.join(out, "ks", "**", "*kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(path)) if KERNEL in r.get("Kernel_Name", "")]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        if len(d) >= warmup + steps:
+            timed = d[warmup:warmup + steps]
+            return {"launches": len(d), "all_launches_mean_us": round(sum(d) / len(d), 1), "warmup_launches_us": [round(x, 1) for x in d[:warmup]],
+                    "timed_region_launches": [warmup, warmup + steps], "timed_region_mean_us": round(sum(timed) / len(timed), 1),
+                    "timed_region_min_us": round(min(timed), 1), "timed_region_max_us": round(max(timed), 1),
+                    "later_launches_mean_us": round(sum(d[warmup + steps:]) / max(1, len(d) - warmup - steps), 1)}
+    return None
+
+
 def main(out):
     for path in glob.glob(os.path.join(out, "ks", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(path, os.path.join(out, "kernel_stats.csv"))
@@ -49,6 +67,7 @@ def main(out):
                     "note": "gfx950 rocprofv3 reports FETCH_SIZE at half the bytes of wide coalesced reads (MI355X_MICROARCH.md, "
                             "HBM section): corrected = 2*FETCH + WRITE; access widths are mixed here, so the true value lies "
                             "between raw and corrected."})
+    res["kernel_trace_durations"] = launch_durations(out)
     with open(os.path.join(out, "pmc_hbm_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))

@@ -18,7 +18,7 @@ run() {   # name, command...
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$name/write" -o p -- "$@" > "$OUT/$name.write.log" 2>&1
 }
 run cfg2 python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline
-for cfg in cfg1 cfg3_shard cfg3_b32 cfg3 cfg4 cfg5; do
+for cfg in cfg1 cfg3_shard cfg3_b32 cfg3 cfg4 cfg5 f_hebbian f_wdpp; do     # (f_*: SURVEY 8(f) rules in the one-launch plan, 784->1600, B=32)
   run $cfg python "$R/tools/bench_configs.py" --runs 5 --only $cfg --no-cpu-baseline
 done
 python "$R/tools/profile_summary.py" "$OUT"

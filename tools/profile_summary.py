@@ -17,6 +17,8 @@ CFG = {
     "cfg3": ("k_two_run", 100, 21_400_000),
     "cfg4": ("k_convlif_run", 250, 20_100_000),
     "cfg5": ("k_two_run", 100, 40_400_000),
+    "f_hebbian": ("k_two_run", 100, 4 * 3 * 784 * 1600 + 32 * (784 * 10 + 1600 * 26)),      # (the bytes of cfg3 at B = 32: same graph, another rule)
+    "f_wdpp": ("k_two_run", 100, 4 * 3 * 784 * 1600 + 32 * (784 * 10 + 1600 * 26)),
 }
 HBM_PEAK = 8000.0
 
