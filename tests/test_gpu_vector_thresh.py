@@ -16,6 +16,16 @@ from bindsnet_amd.network.topology import Connection
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def few_host_threads():
+    """The checker is the plain-PyTorch host path: on the 256-core GPU box torch's default thread count makes every small operator of it
+    take milliseconds (60 s for one test); the host path's reductions run at one thread anyway."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(4, n))
+    yield
+    torch.set_num_threads(n)
+
+
 def build(n_in, n_out, thresh, recurrent=True):
     torch.manual_seed(3)
     net = Network(dt=1.0)
