@@ -16,11 +16,15 @@ DEV = "cuda"
 
 
 def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, shape=(1, 28, 28), inh=120.0, additive=False, nu=(1e-4, 1e-2), exc=22.5,
-        tweak=None):
+        tweak=None, pipelined=False):
+    """pipelined: the same calls inside ONE Network.pipelined() section (settled before every re-seed of the host generator, as a section asks
+    of a caller that touches it): ordinary launches, per-run status pairs, the second attempt on the device, no memsets between the runs."""
+    import contextlib
     from bindsnet_amd import _lib
     from bindsnet_amd.models import DiehlAndCook2015
     from bindsnet_amd.network.monitors import Monitor
     _lib.lib().snn_set_plan_mode(int(mode))          # 0 auto (resident kernel), 1 generic, 2 one launch per timestep
+    net = None
     try:
         torch.manual_seed(0)
         net = DiehlAndCook2015(n_inpt=Nin, n_neurons=N, exc=exc, inh=inh, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=shape, nu=nu)
@@ -39,9 +43,13 @@ def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, 
                     l.trace_scale.fill_(0.5)
         net.to(DEV)
         out = []
+        section = net.pipelined() if pipelined else contextlib.nullcontext()
+        section.__enter__()
         for r in range(n_inputs):
+            net.sync()
             torch.manual_seed(11 + r)
             net.run({"X": torch.from_numpy(spikes[r]).view(T, B, *shape).to(DEV)}, time=T)
+            net.sync()
             probe = torch.rand(3).numpy()
             out.append(dict(
                 sE=mons["Ae"].get("s").cpu().numpy().copy(), sI=mons["Ai"].get("s").cpu().numpy().copy(),
@@ -53,8 +61,14 @@ def run(mode, N, B, T, spikes, w_scale=0.3, n_inputs=2, learning=True, Nin=784, 
             run.last_net = net
             if r % 2 == 0:
                 net.reset_state_variables()
+        section.__exit__(None, None, None)
         return out, plan
     finally:
+        if net is not None and net.__dict__.get("_pipe") is not None:     # (an exception inside the section: close it)
+            try:
+                section.__exit__(RuntimeError, RuntimeError("aborted"), None)
+            except Exception:                                             # noqa: BLE001
+                pass
         _lib.lib().snn_set_plan_mode(0)
 
 

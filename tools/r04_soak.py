@@ -2,7 +2,8 @@
 """Soak of the D&C resident plan (third-generation lean form where it applies) against the generic per-operator plan, bit for bit,
 on seeded random sizes at input densities where the lean form stays in charge (longer runs than the default fuzz family: three
 inputs of 40..250 timesteps with learning on, weights and thresholds carried over).  Prints one line per case with the resident form
-that ran (3 = k_dc2015_async) and the retry counters.  python tools/r04_soak.py [cases] [first_seed]"""
+that ran (3 = k_dc2015_async) and the retry counters.  python tools/r04_soak.py [cases] [first_seed] [sections]
+(`sections`, round 5: every case a third time inside a Network.pipelined() section)"""
 import os
 import sys
 import time
@@ -18,6 +19,7 @@ from bindsnet_amd import _lib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+PIPE = len(sys.argv) > 3 and sys.argv[3] == "sections"      # python tools/r04_soak.py <cases> <first_seed> sections
 bad = 0
 forms = {}
 t0 = time.time()
@@ -46,6 +48,9 @@ for seed in range(first, first + n):
     ok = True
     try:
         dc.same(res, gen)
+        if PIPE:                                                 # round 5: the same case inside a Network.pipelined() section
+            sec, _ = dc.run(0, N, B, T, spikes, pipelined=True, **kw)
+            dc.same(sec, gen)
     except AssertionError as e:
         ok = False
         bad += 1
