@@ -301,13 +301,13 @@ def test_bench_two_ranks_on_one_gpu_gloo_end_to_end():
 
 
 def test_bench_prints_an_error_line_when_a_stage_hangs():
-    """A rank that never shows up: rank 0's rendezvous cannot complete; the watchdog (here 20 s) prints a JSON line with `error` and
+    """A rank that never shows up: rank 0's rendezvous cannot complete; the watchdog (here 8 s) prints a JSON line with `error` and
     `stage` instead of hanging until the driver's clock runs out."""
     import socket
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    res, line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--watchdog", "20"],
+    res, line = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--watchdog", "8"],
                        env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, timeout=200)
     assert res.returncode != 0 and line is not None, (res.stdout[-1500:], res.stderr[-2000:])
     assert line["value"] is None and "error" in line and line["stage"] == "init_process_group" and line["n_gpus"] == 2
