@@ -196,6 +196,14 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             try:
                 yield self
                 self.sync()
+            except BaseException:
+                # the body raised: what has been enqueued still runs on the device -- settle it (so that the host generator stands where
+                # those runs left it) without letting a second error hide the first
+                try:
+                    self.sync()
+                except Exception:                          # noqa: BLE001
+                    pass
+                raise
             finally:
                 rng._PENDING.remove(self.sync)
                 self.__dict__["_pipe"] = None
