@@ -97,14 +97,17 @@ def torch_state_to_words(state: torch.Tensor) -> np.ndarray:
 
 
 def words_to_torch_state(img: np.ndarray, template: torch.Tensor) -> torch.Tensor:
-    """Inverse of torch_state_to_words: patch mt / left / next into a copy of `template`."""
+    """Inverse of torch_state_to_words: patch mt / left / next into a copy of `template` (numpy views on one 5056-byte buffer:
+    this runs once per synchronous run(), and the bytearray / struct version of it cost 32 us)."""
     img = np.ascontiguousarray(img).view(np.uint32)
-    raw = bytearray(template.numpy().tobytes())
+    raw = template.numpy().copy()
+    if raw.size != 5056:
+        raise RuntimeError(f"unexpected CPU generator state size {raw.size} (torch {torch.__version__})")
     pos = int(img[_N])
-    struct.pack_into("<i", raw, 8, _N + 1 - pos)          # left
-    struct.pack_into("<Q", raw, 16, pos)                  # next
-    raw[_STATE_OFF:_STATE_OFF + _N * 8] = img[:_N].astype(np.uint64).tobytes()
-    return torch.frombuffer(raw, dtype=torch.uint8).clone()
+    raw[8:12].view(np.int32)[0] = _N + 1 - pos             # left
+    raw[16:24].view(np.uint64)[0] = pos                    # next
+    raw[_STATE_OFF:_STATE_OFF + _N * 8].view(np.uint64)[:] = img[:_N]
+    return torch.from_numpy(raw)
 
 
 _BLOCK_WORDS = 640          # int32 words of the run's host<->device block: state[628] | status | pad[3] | cursor (i64[2]) | pad

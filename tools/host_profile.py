@@ -15,7 +15,8 @@ import bench  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     net = bench.build_network(dev)
-    pool = bench.make_inputs(1000, 2, dev)
+    from bindsnet_amd import synth
+    pool = [torch.from_numpy(h).view(bench.T, bench.BATCH, 1, 28, 28).to(dev) for h in synth.poisson_mnist_like(bench.BATCH, bench.T, 2, seed=1)]
     torch.manual_seed(2)
     for k in range(5):
         net.run({"X": pool[k % 2]}, time=bench.T)
