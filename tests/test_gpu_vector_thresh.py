@@ -83,6 +83,42 @@ def test_vector_threshold_hand_stepped_layer():
     np.testing.assert_array_equal(got["cuda"][1].view(np.uint32), got["cpu"][1].view(np.uint32))
 
 
+def _fixture_network(dev):
+    """The network of tests/golden/make_golden_r5.py (run_lif_vector_thresh), built from this package's classes."""
+    import make_golden_r5_params as P
+    from bindsnet_amd.network.topology import MulticompartmentConnection
+    from bindsnet_amd.network.topology_features import Weight
+    net = Network(dt=1.0, learning=False)
+    net.add_layer(Input(n=P.n_in), "I")
+    net.add_layer(LIFNodes(n=P.n_out, thresh=torch.from_numpy(P.thresholds()), refrac=2, tc_decay=50.0, traces=True), "O")
+    w_in, w_rec = P.weights()
+    net.add_connection(MulticompartmentConnection(net.layers["I"], net.layers["O"], device="cpu", pipeline=[Weight("weight", torch.from_numpy(w_in).clone())]), "I", "O")
+    net.add_connection(MulticompartmentConnection(net.layers["O"], net.layers["O"], device="cpu", pipeline=[Weight("weight", torch.from_numpy(w_rec).clone())]), "O", "O")
+    mon = Monitor(net.layers["O"], ["s", "v"], time=P.T)
+    net.add_monitor(mon, "O")
+    net.to(dev)
+    return net, mon, P
+
+
+def check_against_reference_fixture(dev, plan):
+    from cases import gold
+    g = gold("run_lif_vector_thresh")
+    net, mon, P = _fixture_network(dev)
+    for r in range(2):
+        sp = synth.dense_spikes(17 + r, (P.T, P.B, P.n_in), 0.08)
+        net.run({"I": torch.from_numpy(sp).to(dev)}, time=P.T)
+        assert net.last_plan == plan
+        np.testing.assert_array_equal(np.packbits(mon.get("s").cpu().numpy().astype(np.uint8)), g[f"r{r}_s"], err_msg=f"run {r}: raster")
+        np.testing.assert_array_equal(mon.get("v").cpu().numpy().view(np.uint32), g[f"r{r}_v"].view(np.uint32), err_msg=f"run {r}: voltages")
+        np.testing.assert_array_equal(net.layers["O"].x.cpu().numpy().view(np.uint32), g[f"r{r}_x"].view(np.uint32), err_msg=f"run {r}: trace")
+
+
+def test_vector_threshold_run_matches_the_reference_fixture():
+    """The REFERENCE's run of a network with per-neuron LIF thresholds (tests/golden/make_golden_r5.py; MCC + Weight connections, so its sums
+    are ATen's reproducible cascade): spike raster, voltage raster and trace of two consecutive runs, bit for bit, on the device (generic plan)."""
+    check_against_reference_fixture("cuda", "generic")
+
+
 def test_wrong_length_is_refused():
     net = build(16, 10, torch.zeros(7))
     net.to("cuda")

@@ -57,3 +57,15 @@ def test_sections_do_not_nest_and_clean_up():
             1 / 0
     assert len(rng._PENDING) == n0 and net.__dict__.get("_pipe") is None
     net.sync()
+
+
+def test_vector_thresholds_on_the_host_path_match_the_reference_fixture():
+    """(CPU tier twin of tests/test_gpu_vector_thresh.py::test_vector_threshold_run_matches_the_reference_fixture: the same fixture, the
+    package's plain-PyTorch host path.)"""
+    import test_gpu_vector_thresh as tv
+    n = torch.get_num_threads()
+    try:
+        torch.set_num_threads(min(4, n))
+        tv.check_against_reference_fixture("cpu", "host-torch")
+    finally:
+        torch.set_num_threads(n)
