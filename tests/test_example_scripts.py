@@ -51,6 +51,31 @@ REF_RESERVOIR = "/root/reference/examples/mnist/reservoir.py"
 STAGED_RESERVOIR = os.path.join(ROOT, "tests", "_staged", "reservoir.py")
 
 
+def run_reservoir(extra_argv, plan):
+    """examples/mnist/reservoir.py itself (see the host test below) with `extra_argv` added; the O raster of all twelve inputs against the
+    reference's CPU run of the same file.  With --gpu the network (per-neuron LIF thresholds, dense Connections, no learning) runs on
+    the MI355X's generic plan; the script seeds only the CUDA generator then, the harness seeds the CPU one, so weights, thresholds and
+    the encoded inputs are the fixture's."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bindsnet  # noqa: F401
+    import bindsnet_amd.network.network as netmod
+    import conv_mnist_harness as H
+    from cases import gold
+    g = gold("reservoir_literal")
+    path = REF_RESERVOIR if os.path.exists(REF_RESERVOIR) else STAGED_RESERVOIR
+    if not os.path.exists(path):
+        pytest.skip("no copy of examples/mnist/reservoir.py on this machine")
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["script_sha"])
+    np.random.seed(0)
+    r = H.run_script(path, netmod, [str(a) for a in g["argv"]] + list(extra_argv), seed=0, monitor="O_spikes",
+                     result=lambda gl: dict(thresh=gl["network"].layers["O"].thresh.detach().cpu().numpy().copy(),
+                                            accuracy=float(100 * gl["correct"] / gl["total"])))
+    assert r["plan"] == plan
+    np.testing.assert_array_equal(r["thresh"], g["thresh"])
+    return r, g
+
+
 def test_reservoir_script_itself_on_the_host():
     """examples/mnist/reservoir.py, unmodified (it runs on the CPU by default: parser.set_defaults(gpu=False)): Input -> random dense
     Connection -> LIFNodes with PER-NEURON thresholds (a numpy array handed to the constructor) and a random recurrent Connection, spike

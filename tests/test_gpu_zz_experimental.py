@@ -92,6 +92,20 @@ def test_conv_mnist_script_itself_on_the_device():
     run_and_check("generic")
 
 
+def test_reservoir_script_itself_on_the_device():
+    """The LITERAL examples/mnist/reservoir.py with --gpu: its LIF layer has PER-NEURON thresholds (a numpy array handed to the
+    constructor), which raised on the device until round 5 (snn_layer_desc.thresh_vec, ABI 8).  The reference's propagation goes through
+    MKL here (dense Connections), so the comparison is the dense family's: the O rasters of the reference's CPU run, allowing a handful of
+    threshold-edge flips."""
+    from test_example_scripts import run_reservoir
+    r, g = run_reservoir(["--gpu"], "generic")
+    ref = [int(v) for v in g["raster_sum"]]
+    assert len(r["raster_sum"]) == len(ref) and sum(ref) > 20
+    exact = sum(a == b for a, b in zip(r["raster_sha"], [str(v) for v in g["raster_sha"]]))
+    flips = sum(abs(a - b) for a, b in zip(r["raster_sum"], ref))
+    assert exact >= len(ref) - 2 and flips <= 2, (exact, flips, r["raster_sum"], ref)
+
+
 def test_index_tensor_clamps_on_the_device_match_reference():
     """supervised_mnist.py:201-207 clamps with an integer tensor of neuron INDICES (the reference's `s[:, clamp] = 1` takes masks and
     indices alike): D&C graph on the generic plan, index clamp / index unclamp / per-step index rows, against the reference fixture."""
