@@ -81,22 +81,6 @@ def test_reservoir_script_itself_on_the_host():
     Connection -> LIFNodes with PER-NEURON thresholds (a numpy array handed to the constructor) and a random recurrent Connection, spike
     / voltage monitors with a `device=` argument, no learning, then a torch read-out trained on the recorded spikes.  The O raster of
     all twelve inputs (train + test pass) equals what the same file produced on the reference's CPU path."""
-    if ROOT not in sys.path:
-        sys.path.insert(0, ROOT)
-    import bindsnet  # noqa: F401
-    import bindsnet_amd.network.network as netmod
-    import conv_mnist_harness as H
-    from cases import gold
-    g = gold("reservoir_literal")
-    path = REF_RESERVOIR if os.path.exists(REF_RESERVOIR) else STAGED_RESERVOIR
-    if not os.path.exists(path):
-        pytest.skip("no copy of examples/mnist/reservoir.py on this machine")
-    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["script_sha"])
-    np.random.seed(0)
-    r = H.run_script(path, netmod, [str(a) for a in g["argv"]], seed=0, monitor="O_spikes",
-                     result=lambda gl: dict(thresh=gl["network"].layers["O"].thresh.detach().cpu().numpy().copy(),
-                                            accuracy=float(100 * gl["correct"] / gl["total"])))
-    assert r["plan"] == "host-torch"
-    np.testing.assert_array_equal(r["thresh"], g["thresh"])
+    r, g = run_reservoir([], "host-torch")
     assert r["raster_sum"] == [int(v) for v in g["raster_sum"]] and r["raster_sha"] == [str(v) for v in g["raster_sha"]], "O rasters"
     assert r["accuracy"] == float(g["accuracy"])
