@@ -76,7 +76,7 @@ def pmc_traffic(plan):
     (profiles/*_pmc_hbm_traffic.json; PMC cannot be read from inside the process) -> (bytes, where it came from).  The profile carries
     the sha256 of the kernel sources it was taken on (tools/pmc_summary.py): `matches_current_source` says whether that is the tree
     this process runs in."""
-    names = {"dc2015-resident-lean": ["r05_lean_pmc_hbm_traffic.json", "r04_lean_pmc_hbm_traffic.json", "r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
+    names = {"dc2015-resident-lean": ["r06_lean_pmc_hbm_traffic.json", "r05_lean_pmc_hbm_traffic.json", "r04_lean_pmc_hbm_traffic.json", "r03_lean_pmc_hbm_traffic.json", "r02_lean_pmc_hbm_traffic.json"],
              "dc2015-resident": ["r01_resident_pmc_hbm_traffic.json"], "dc2015-fused": ["r01_pmc_hbm_traffic.json"]}.get(plan, [])
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
@@ -90,6 +90,13 @@ def pmc_traffic(plan):
                 meta["matches_current_source"] = d.get("kernel_source_sha16") == pmc_summary.source_sha16()
             except Exception:                                    # noqa: BLE001
                 meta["matches_current_source"] = None
+            # raw = FETCH_SIZE + WRITE_SIZE as rocprofv3 prints them; corrected = 2 * FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: gfx950
+            # tallies the 128-byte requests of 16-byte-per-lane loads at 64 bytes).  The corrected value is the one to quote: this kernel's fetches are
+            # the digest entries, the producers' input reads and the X-trace rows -- 16-byte-per-lane loads but for the X-trace walk's byte loads
+            # of the input (6.3 MB per launch, uncalibrated width) and the 8-byte granule polls (a few hundred KB).
+            meta["traffic_raw"] = d.get("hbm_bytes_per_launch_raw")
+            meta["traffic_corrected"] = d.get("hbm_bytes_per_launch_gfx950_corrected")
+            meta["quoted"] = "corrected (2 * FETCH_SIZE + WRITE_SIZE): the fetches are 16-byte-per-lane loads (digest entries, producers' input reads, X-trace rows)"
             return d.get("hbm_bytes_per_launch_gfx950_corrected"), meta
     return None, None
 
@@ -418,6 +425,22 @@ def main():
     except Exception as e:                                     # noqa: BLE001
         error_line(f"rank {rank}, stage '{stage['name']}': {type(e).__name__}: {str(e)[:400]}")
         raise
+    # ---- the same K steps as a reference user's loop runs them (examples/mnist/eth_mnist.py:243-250 reads its monitors after every
+    #      network.run()): no section, every run() waits for the device.  A secondary figure of the same line (`sync_runs`), N = 1 only.
+    sync_leg = None
+    if world == 1 and not args.sync_runs:
+        enter("sync runs")
+        try:
+            fence()
+            s0 = time.perf_counter()
+            for k in range(args.steps):
+                one(args.warmup + args.steps + k)
+            fence()
+            s_el = time.perf_counter() - s0
+            sync_leg = {"value": round(args.steps * T / s_el, 2), "unit": "timesteps/s", "ms_per_step": round(s_el / args.steps * 1e3, 4), "steps": args.steps,
+                        "what": "the same steps with every network.run() waiting for the device (no Network.pipelined() section): the reference-shaped loop"}
+        except Exception as e:                                 # noqa: BLE001  (a secondary figure must never cost the line)
+            sync_leg = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     enter("reduce")
     ranks_seen, devices = 1, [f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}"]
     collective = None
@@ -467,7 +490,8 @@ def main():
             roof = {"bound": "hbm", "kernel": prof["kernel"], "avg_launch_us": round(prof["avg_ms"] * 1e3, 3),
                     "launches_timed": prof["n"], "algorithmic_bytes_per_launch": ab, "achieved": round(ach, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic(plan_timed)[0], "traffic_profile": pmc_traffic(plan_timed)[1],
+                    "traffic": pmc_traffic(plan_timed)[0], "traffic_raw": (pmc_traffic(plan_timed)[1] or {}).get("traffic_raw"),
+                    "traffic_profile": pmc_traffic(plan_timed)[1],
                     "frac_of_measured_copy_bandwidth_6290": round(ach / 6290.0, 5)}
             if "resident_form" in prof:
                 roof["resident_form"] = prof["resident_form"]
@@ -498,6 +522,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": par,
+            "sync_runs": sync_leg,
         }
         if cpu is not None:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["value"], 1)

@@ -609,6 +609,8 @@ static size_t fused_workspace(int B, int Nin, int N) {
 // lean forms: summary granules [2][G][tile waves <= 4] with G <= (N + 1) / 2; the third generation keeps FOUR steps of both kinds of
 // granules in flight (rings of 4), plus its winners granules [8][11], 16 progress words of the raster writers and the tbad word
 static thread_local int g_last_form = -1;   // resident form of this thread's last D&C run (like snn_plan_name()): 0 general, 1 / 2 / 3 lean generations, -1 per-step
+static thread_local unsigned long long g_ws_key_in = 0;   // snn_run_desc.host_state[0] as snn_net_run found it (it zeroes the word before any plan runs)
+void snn_dc2015_ws_key_in(unsigned long long key) { g_ws_key_in = key; }
 constexpr int kAsyncDefault = 1;      // third-generation lean form on by default?  (SNN_DC_ASYNC overrides)
 static size_t resident_summary_bytes(int N) { return (size_t)4 * ((N + 1) / 2) * 4 * 8; }
 static size_t resident_gran_bytes(int B, int N) { return (size_t)4 * ((N + 1) / 2) * ((B + 1) / 2) * 8; }   // >= 4 * G * KB * 8 for every tile width
@@ -774,6 +776,7 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             if (alds <= 150 * 1024 && rG + 1 + nrw <= cap3) {
                 lean = 3;
                 c.NRW = nrw;
+                c.async_form = getenv("SNN_DC_ASYNC_FORM") ? atoi(getenv("SNN_DC_ASYNC_FORM")) : 1;
                 c.tbad = (int *)((unsigned char *)c.rprog + 16 * 4);
                 // the CUs the grid leaves idle run the input-only pre-passes INSIDE the launch (producer workgroups: digest entries, then the
                 // X-trace walk; per-entry ready flags): SNN_DC_PRODUCERS=0 / a device too small for >= 16 of them -> the two launches in front
@@ -816,9 +819,20 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             const size_t secbytes = resident_second_bytes(B, N);
             unsigned char *sec0 = (unsigned char *)c.xtr + al((size_t)(R->T + 1) * B * Nin * 4);
             const bool chain = lean && R->status2 && R->host_state;
-            const unsigned long long key = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(uintptr_t)c.ex ^ ((unsigned long long)exbytes << 20) ^ ((unsigned long long)R->T << 44) ^ (unsigned long long)lean;
-            const bool clean = chain && R->host_state[0] == key;
-            if (R->host_state) R->host_state[0] = 0;                                               // (until this run is known to leave it clean again)
+            // the key names the layout explicitly -- workspace pointer, B, Nin, N, T, kernel form, bytes -- each field mixed in through a full
+            // 64-bit finaliser (no field can cancel another: round 5 XORed shifted fields together); never 0, which means "unknown".
+            // snn_net_run has already taken the caller's word away (g_ws_key_in: what it held); it is put back below when this run leaves the area clean.
+            auto mix = [](unsigned long long h, unsigned long long v) {
+                h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+                h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+                return h;
+            };
+            unsigned long long key = 0x5EEDull;
+            for (unsigned long long v : {(unsigned long long)(uintptr_t)c.ex, (unsigned long long)B, (unsigned long long)Nin, (unsigned long long)N, (unsigned long long)R->T,
+                                         (unsigned long long)lean, (unsigned long long)exbytes, (unsigned long long)secbytes})
+                key = mix(key, v);
+            key |= 1ull;
+            const bool clean = chain && g_ws_key_in == key;
             if (!clean) {
                 if ((rc0 = snn_check(hipMemsetAsync(c.ex, 0, exbytes, qs)))) return rc0;
                 if (chain && (rc0 = snn_check(hipMemsetAsync(sec0, 0, 2 * secbytes, qs)))) return rc0;
@@ -862,7 +876,6 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             if (rcl == SNN_OK && lean == 3 && c.rasX) snn_input_raster_done(0);
             return rcl;                                     // SNN_ERR_UNSUPPORTED: the runtime refused the cooperative grid
         }
-        if (R->host_state) R->host_state[0] = 0;          // (whatever a pipelined caller's runs knew about the workspace: no longer)
         rc0 = snn_check(hipMemsetAsync(ws, 0, 4 * wb, qs));
         if (rc0) return rc0;
         hipLaunchKernelGGL(k_dc2015_prep, dim3(R->T + 1), dim3(NT), dc_prep_lds_bytes(B, Nin, NT), qs, c);
@@ -952,15 +965,21 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         if (const char *dump = getenv("SNN_DC_TIMING_DUMP")) {       // raw marks for offline analysis: [T+1][24] then [T+1][256][4] int64
             if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), 8, h.size(), f); fwrite(hw.data(), 8, hw.size(), f); fclose(f); }
         }
-        double a[9] = {0}, step = 0; int n = 0;
+        double a[24] = {0}, step = 0; int n = 0, na[24] = {0};
         for (int t = 3; t + 1 < T_; ++t, ++n) {
             const long long *r = &h[(size_t)t * 24];
-            for (int k = 1; k < 9; ++k) a[k] += (double)(r[k] - r[0]) / 100.0;
+            for (int k = 1; k < 24; ++k) if (r[k] > r[0]) { a[k] += (double)(r[k] - r[0]) / 100.0; na[k]++; }       // (a mark of the crossing path is there only in a crossing iteration)
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
         }
-        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f | other waves: PostPre done %.2f | "
-                        "barrier M %.2f | X currents %.2f | won branch %.2f | resolution of step t %.2f | barrier B %.2f || iteration %.2f us\n",
-                c.dbg_wg, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[1] / n, a[2] / n, step / n);
+        for (int k = 1; k < 24; ++k) a[k] = na[k] ? a[k] / na[k] * n : 0.0;
+        if (c.async_form == 0)
+            fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f | other waves: PostPre done %.2f | "
+                            "barrier M %.2f | X currents %.2f | won branch %.2f | resolution of step t %.2f | barrier B %.2f || iteration %.2f us\n",
+                    c.dbg_wg, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[1] / n, a[2] / n, step / n);
+        else
+            fprintf(stderr, "[dc2015 async form 1, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f, at barrier B %.2f | wave 2: PostPre done %.2f, "
+                            "counter passed %.2f, X currents %.2f | behind B %.2f | crossing iterations (%d of %d): rows done %.2f, behind P %.2f, won currents %.2f, resolution %.2f, other rows %.2f || iteration %.2f us\n",
+                    c.dbg_wg, a[7] / n, a[8] / n, a[13] / n, a[19] / n, a[20] / n, a[21] / n, a[4] / n, na[15], n, a[22] / n, a[15] / n, a[5] / n, a[1] / n, a[23] / n, step / n);
         // per step: first / last publish over the compute workgroups, arbiter: all granules seen, winners out
         double spread = 0, seen = 0, out = 0, period = 0, lastx = 0; int m = 0, nx = 0; long long prev_last = 0;
         std::vector<int> lastcnt(c.G, 0);

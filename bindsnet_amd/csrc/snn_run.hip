@@ -264,6 +264,7 @@ uint8_t *snn_input_raster_request(int layer) { return layer >= 0 && layer < 8 ? 
 void snn_input_raster_done(int layer) { if (layer >= 0 && layer < 8) g_in_raster_done |= 1u << layer; }
 
 static int net_run_plans(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, hipStream_t st);
+void snn_dc2015_ws_key_in(unsigned long long key);   // snn_dc2015.hip: the caller's host_state[0] as this run found it
 
 extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                            snn_stream_t stream) {
@@ -290,6 +291,12 @@ extern "C" int snn_net_run(const snn_layer_desc *L, int nL, const snn_conn_desc 
 }
 
 static int net_run_plans(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, hipStream_t st) {
+    // What a pipelined caller's earlier runs knew about the workspace's content (snn_run_desc.host_state[0]: "the exchange areas are clean
+    // for this layout") holds only from one chained lean D&C run to the next: EVERY run takes the word away first, and only that path puts
+    // it back (snn_dc2015.hip) -- a plan that scribbles over the workspace can never leave a stale "clean" behind.
+    const unsigned long long ws_key = R->host_state ? R->host_state[0] : 0ull;
+    if (R->host_state) R->host_state[0] = 0ull;
+    snn_dc2015_ws_key_in(ws_key);
     int handled = 0;
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request

@@ -78,6 +78,13 @@ def repeat(datum: torch.Tensor, time: int, dt: float = 1.0, **kwargs) -> torch.T
     return datum.repeat([steps, *([1] * datum.dim())])
 
 
+def _settle_sections() -> None:
+    """The host encoders draw from torch's CPU generator: a network with an open pipelined() section holds that generator's state on the
+    device meanwhile (rng.py) -- settle it first, so the draws come from where the reference's would."""
+    from .. import rng
+    rng.flush_pending()
+
+
 def bernoulli(datum: torch.Tensor, time: Optional[int] = None, dt: float = 1.0, device="cpu", **kwargs) -> torch.Tensor:
     """Bernoulli spike trains, success probability = max_prob * (datum scaled into [0, 1]) (encodings.py:51-98).
     Like the reference, a datum whose maximum exceeds 1 is divided by it IN PLACE when it is contiguous."""
@@ -94,6 +101,7 @@ def bernoulli(datum: torch.Tensor, time: Optional[int] = None, dt: float = 1.0, 
     if torch.device(device).type == "cuda":
         from ..ops import encode_bernoulli
         return encode_bernoulli(flat, 1 if steps is None else steps, max_prob, device).view(*(() if steps is None else (steps,)), *shape)
+    _settle_sections()
     with _few_threads():
         if steps is None:
             return torch.bernoulli(max_prob * flat).view(*shape).byte()
@@ -112,6 +120,7 @@ def poisson(datum: torch.Tensor, time: int, dt: float = 1.0, device="cpu", appro
 
 
 def _poisson_host(datum, time, dt, device, approx, shape, size):
+    _settle_sections()
     flat = datum.flatten().to(device)
     steps = int(time / dt)
     if approx:      # the reference's "fast, less accurate" variant: |N(0,1)| ^ ((x * 0.11 + 5) / 50) < 0.6

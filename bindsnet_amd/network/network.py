@@ -41,6 +41,7 @@ class _Pipeline:
         self.block = self.host = None  # the generator block on the device / its page-locked host image
         self.host0 = None              # host generator state at the start of the batch (None: no run of the batch draws)
         self.enabled = False
+        self.stream = None             # the stream the batch's runs were enqueued on (settlement waits for THAT stream)
 
 
 def _dptr(t: Optional[torch.Tensor]):
@@ -218,6 +219,8 @@ class Network(_lib.TouchingModule, torch.nn.Module):
             return
         from ..rng import RNG_STATE_BYTES, words_to_torch_state
         n = len(pipe.pending)
+        if pipe.stream is not None and pipe.stream != torch.cuda.current_stream(pipe.block.device):
+            pipe.stream.synchronize()                      # the caller changed streams inside the section: the read-back below is ordered behind the CURRENT one only
         pipe.host.copy_(pipe.block)                        # blocking: everything enqueued so far has run
         st = pipe.status[:2 * n].cpu().numpy().reshape(n, 2)
         pipe.pending.clear()
@@ -236,7 +239,14 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                                 "behind it have executed on the state it left, so the section cannot be repaired -- "
                                 "SNN_ERR_TIMEOUT (-6) means the GPU was shared: use synchronous runs there")
         if pipe.enabled:
+            # Between the first run of the batch and now the host generator was stale (its state lived on the device).  Whoever drew
+            # from it meanwhile -- torch.rand, a host encoder called without this package's flush -- took numbers from the wrong
+            # position, and writing the device image back would silently discard those draws: refuse instead of diverging.
+            drew = not torch.equal(torch.get_rng_state(), pipe.host0)
             torch.set_rng_state(words_to_torch_state(pipe.host.numpy()[:RNG_STATE_BYTES // 4], pipe.host0))
+            if drew:
+                raise RuntimeError("Network.pipelined(): torch's CPU generator was used inside the section while its state lived on the device "
+                                   "(draws taken from a stale position); call network.sync() before drawing from the host generator inside a section")
 
     def _run_pipelined(self, pipe, built, lib, stream, dev):
         """Enqueue one run of a pipelined() section (see there)."""
@@ -244,13 +254,20 @@ class Network(_lib.TouchingModule, torch.nn.Module):
         L, Cn, R, names = built["L"], built["Cn"], built["R"], built["names"]
         block, qbuf, host = built["gen_bufs"]
         draws = built["max_draws"] > 0
-        if pipe.pending and (len(pipe.pending) >= pipe.depth or draws != pipe.enabled or pipe.block is not block):
-            self.sync()
+        cur_stream = torch.cuda.current_stream(dev)
+        if pipe.pending and (len(pipe.pending) >= pipe.depth or draws != pipe.enabled or pipe.block is not block or cur_stream != pipe.stream):
+            self.sync()                                    # (a batch lives on ONE stream: its runs hand the generator block from one to the next in stream order)
         if not pipe.pending:                               # first run of a batch: the host generator goes to the device
             img = host.numpy()
             img[:] = 0
             pipe.enabled, pipe.host0 = draws, None
             if draws:
+                # another network's open section holds the host generator on ITS device block: settle it first, or both would
+                # consume the same mt19937 segment and the later sync() would overwrite the earlier one's position
+                from .. import rng
+                for settle in list(rng._PENDING):
+                    if settle != self.sync:
+                        settle()
                 pipe.host0 = torch.get_rng_state()
                 img[:RNG_STATE_BYTES // 4] = torch_state_to_words(pipe.host0)
             block.copy_(host, non_blocking=True)           # (the previous settlement's blocking read-back ordered us behind it)
@@ -258,7 +275,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 pipe.status = torch.zeros(2 * pipe.depth, dtype=torch.int32, device=dev)
             else:
                 pipe.status.zero_()
-            pipe.block, pipe.host = block, host
+            pipe.block, pipe.host, pipe.stream = block, host, cur_stream
         k = len(pipe.pending)
         R.rng, R.qbuf = _dptr(block[:RNG_STATE_BYTES // 4]), _dptr(qbuf)
         R.cursor = C.c_void_p(block.data_ptr() + 632 * 4)

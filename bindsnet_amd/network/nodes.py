@@ -39,6 +39,15 @@ def _f(t) -> float:
     return float(t)
 
 
+def _buf(value, dtype=None) -> torch.Tensor:
+    """torch.tensor(value, dtype=...) as the reference writes it (nodes.py:459-472) -- for a tensor-valued parameter that is a detached copy,
+    which torch.tensor() makes too but with a UserWarning into every user's log."""
+    if isinstance(value, torch.Tensor):
+        out = value.detach().clone()
+        return out if dtype is None else out.to(dtype)
+    return torch.tensor(value) if dtype is None else torch.tensor(value, dtype=dtype)
+
+
 class Nodes(_lib.TouchingModule, torch.nn.Module):
     """Base class (reference: nodes.py:9-162): spikes `s`, optional trace `x`."""
 
@@ -57,8 +66,8 @@ class Nodes(_lib.TouchingModule, torch.nn.Module):
         self.register_buffer("s", torch.ByteTensor())
         if traces:
             self.register_buffer("x", torch.Tensor())
-            self.register_buffer("tc_trace", torch.tensor(tc_trace))
-            self.register_buffer("trace_scale", torch.tensor(trace_scale))
+            self.register_buffer("tc_trace", _buf(tc_trace))
+            self.register_buffer("trace_scale", _buf(trace_scale))
             self.register_buffer("trace_decay", torch.empty_like(self.tc_trace))
         self.dt = None
         self.batch_size = None
@@ -127,11 +136,11 @@ class LIFNodes(Nodes):
                  **kwargs) -> None:
         super().__init__(n=n, shape=shape, traces=traces, traces_additive=traces_additive, tc_trace=tc_trace,
                          trace_scale=trace_scale, sum_input=sum_input)
-        self.register_buffer("rest", torch.tensor(rest, dtype=torch.float))
-        self.register_buffer("reset", torch.tensor(reset, dtype=torch.float))
-        self.register_buffer("thresh", torch.tensor(thresh, dtype=torch.float))
-        self.register_buffer("refrac", torch.tensor(refrac))
-        self.register_buffer("tc_decay", torch.tensor(tc_decay, dtype=torch.float))
+        self.register_buffer("rest", _buf(rest, torch.float))
+        self.register_buffer("reset", _buf(reset, torch.float))
+        self.register_buffer("thresh", _buf(thresh, torch.float))
+        self.register_buffer("refrac", _buf(refrac))
+        self.register_buffer("tc_decay", _buf(tc_decay, torch.float))
         self.register_buffer("decay", torch.zeros(*self.shape))
         self.register_buffer("v", torch.FloatTensor())
         self.register_buffer("refrac_count", torch.FloatTensor())
@@ -199,14 +208,14 @@ class DiehlAndCookNodes(Nodes):
                  tc_theta_decay: Scalar = 1e7, lbound: float = None, one_spike: bool = True, **kwargs) -> None:
         super().__init__(n=n, shape=shape, traces=traces, traces_additive=traces_additive, tc_trace=tc_trace,
                          trace_scale=trace_scale, sum_input=sum_input)
-        self.register_buffer("rest", torch.tensor(rest))
-        self.register_buffer("reset", torch.tensor(reset))
-        self.register_buffer("thresh", torch.tensor(thresh))
-        self.register_buffer("refrac", torch.tensor(refrac))
-        self.register_buffer("tc_decay", torch.tensor(tc_decay))
+        self.register_buffer("rest", _buf(rest))
+        self.register_buffer("reset", _buf(reset))
+        self.register_buffer("thresh", _buf(thresh))
+        self.register_buffer("refrac", _buf(refrac))
+        self.register_buffer("tc_decay", _buf(tc_decay))
         self.register_buffer("decay", torch.empty_like(self.tc_decay))
-        self.register_buffer("theta_plus", torch.tensor(theta_plus))
-        self.register_buffer("tc_theta_decay", torch.tensor(tc_theta_decay))
+        self.register_buffer("theta_plus", _buf(theta_plus))
+        self.register_buffer("tc_theta_decay", _buf(tc_theta_decay))
         self.register_buffer("theta_decay", torch.empty_like(self.tc_theta_decay))
         self.register_buffer("v", torch.FloatTensor())
         self.register_buffer("theta", torch.zeros(*self.shape))

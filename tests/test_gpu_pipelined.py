@@ -155,3 +155,85 @@ def test_timeout_inside_a_section_raises(monkeypatch):
     p, _, _ = go(True, N, B, T, spikes)                     # the process is fine afterwards
     s, _, _ = go(False, N, B, T, spikes)
     same(p, s, "after the refused section")
+
+
+def _two_nets(N, B, T):
+    from bindsnet_amd.models import DiehlAndCook2015
+    from bindsnet_amd.network.monitors import Monitor
+    nets = []
+    for k in range(2):
+        torch.manual_seed(k)
+        net = DiehlAndCook2015(n_inpt=784, n_neurons=N, exc=22.5, inh=120.0, dt=1.0, norm=78.4, theta_plus=0.05, inpt_shape=(1, 28, 28))
+        net.connections[("X", "Ae")].pipeline[0].value.data.copy_(torch.from_numpy(np.minimum(synth.uniform_f32(3 + k, (784, N), 0.0, 1.0), 1.0)))
+        net.add_monitor(Monitor(net.layers["Ae"], ["s"], time=T), "Ae")
+        net.to(DEV)
+        nets.append(net)
+    return nets
+
+
+def test_two_interleaved_sections_share_the_host_generator_like_synchronous_runs():
+    """(round-5 advisor) Two networks with open sections, both drawing for one_spike, runs interleaved: each batch start must settle the OTHER
+    network's section before it snapshots the host generator -- otherwise both consume the same mt19937 segment.  Against synchronous runs."""
+    import contextlib
+    N, B, T = 64, 4, 30
+    spikes = [synth.dense_spikes(1300 + r, (T, B, 784), 0.03) for r in range(4)]
+
+    def play(sections):
+        a, b = _two_nets(N, B, T)
+        xs = [torch.from_numpy(s).view(T, B, 1, 28, 28).to(DEV) for s in spikes]
+        torch.manual_seed(5)
+        out = []
+        with (a.pipelined() if sections else contextlib.nullcontext()), (b.pipelined() if sections else contextlib.nullcontext()):
+            for r, x in enumerate(xs):
+                net = (a, b)[r & 1]
+                net.run({"X": x}, time=T)
+                out.append(net.monitors["Ae"].get("s").clone())
+                net.reset_state_variables()
+        probe = torch.rand(3).numpy()
+        return [o.cpu().numpy() for o in out], [n.connections[("X", "Ae")].pipeline[0].value.detach().cpu().numpy() for n in (a, b)], probe
+
+    sp, wp, pp = play(True)
+    ss, ws, ps = play(False)
+    assert sum(int(o.sum()) for o in ss) > 0
+    for r in range(4):
+        np.testing.assert_array_equal(sp[r], ss[r], err_msg=f"run {r}: Ae raster, interleaved sections vs synchronous")
+    for k in range(2):
+        np.testing.assert_array_equal(wp[k].view(np.uint32), ws[k].view(np.uint32), err_msg=f"network {k}: weights")
+    np.testing.assert_array_equal(pp, ps, err_msg="host generator position after both sections")
+
+
+def test_host_draw_inside_a_section_is_refused_and_host_encoders_settle_first():
+    """(round-5 advisor) Inside a section the host generator is stale.  A caller's own torch.rand between two runs would be taken from the wrong
+    position and silently discarded at settlement: sync() raises instead.  The package's own host encoders settle the section before they draw,
+    so the canonical encode-then-run loop inside a section gives the synchronous loop's results."""
+    import contextlib
+    from bindsnet_amd.encoding import poisson
+    N, B, T = 64, 4, 30
+    spikes = [synth.dense_spikes(1500 + r, (T, B, 784), 0.03) for r in range(2)]
+    (net, _) = _two_nets(N, B, T)
+    xs = [torch.from_numpy(s).view(T, B, 1, 28, 28).to(DEV) for s in spikes]
+    torch.manual_seed(5)
+    with pytest.raises(RuntimeError, match="CPU generator was used inside the section"):
+        with net.pipelined():
+            net.run({"X": xs[0]}, time=T)
+            torch.rand(2)
+            net.run({"X": xs[1]}, time=T)
+
+    def loop(section):
+        (n2, _) = _two_nets(N, B, T)
+        torch.manual_seed(7)
+        img = 128.0 * torch.rand(B, 1, 28, 28) * (torch.rand(B, 1, 28, 28) < 0.19)
+        outs = []
+        with (n2.pipelined() if section else contextlib.nullcontext()):
+            for _ in range(3):
+                x = torch.stack([poisson(img[b], time=T, dt=1.0) for b in range(B)], 1).to(DEV)     # host encoder: draws from the CPU generator
+                n2.run({"X": x}, time=T)
+                outs.append(n2.monitors["Ae"].get("s").clone())
+                n2.reset_state_variables()
+        return [o.cpu().numpy() for o in outs], torch.rand(3).numpy()
+
+    a, pa = loop(True)
+    b, pb = loop(False)
+    for r in range(3):
+        np.testing.assert_array_equal(a[r], b[r], err_msg=f"input {r}: encode-then-run inside a section vs synchronous")
+    np.testing.assert_array_equal(pa, pb)
