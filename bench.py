@@ -261,9 +261,167 @@ def respawn_under_launcher(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def main_cfg3(args):
+    """`bench.py --config cfg3 --gpus N`: BASELINE.json configs[2] -- TwoLayerNetwork 784 -> 1600, global batch 128, 100 timesteps per
+    network.run(), PostPre (bindsnet/models/models.py:21-91, learning/learning.py:390-420) -- on N ranks, BOTH multi-GPU modes timed in
+    one line (same schema as the headline's):
+      value                 north_star's schedule: the batch shards (128 / N samples per rank), ONE flat RCCL all-reduce of the weight deltas per
+                            input, clamp, normalise (parallel.sharded_run).  Not the reference's arithmetic for a global batch.
+      exact_column_shard    the exact mode: every rank holds 32-aligned column slices and the WHOLE batch, no collective at all during the run
+                            (parallel.column_shard): bit-identical to the single-process global batch.
+    Strong scaling: the global batch is fixed at 128 as N grows."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    Tc, Bg, Nin, N = 100, 128, 784, 1600
+    if Bg % world or (Bg // world) % 16:
+        raise SystemExit(f"bench.py --config cfg3: 128 samples do not shard into 16-sample blocks over {world} ranks (SURVEY 8(e))")
+    stage = {"name": "start", "t0": time.time()}
+    metric = "simulated timesteps/sec (whole node), TwoLayerNetwork 784->1600 batch128"
+
+    def error_line(msg):
+        if rank == 0:
+            print(json.dumps({"metric": metric, "value": None, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "higher_is_better": True, "scaling": "strong", "error": msg, "stage": stage["name"], "backend": args.backend if world > 1 else None}), flush=True)
+
+    def enter(name):
+        stage["name"], stage["t0"] = name, time.time()
+
+    if world > 1:
+        import threading
+
+        def bark():
+            while stage["name"] != "done":
+                time.sleep(1.0)
+                if time.time() - stage["t0"] > args.watchdog:
+                    error_line(f"stage '{stage['name']}' did not finish within {args.watchdog:.0f} s (rank {rank} of {world})")
+                    sys.stdout.flush()
+                    os._exit(3)
+        threading.Thread(target=bark, daemon=True).start()
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl" and local >= ndev:
+            error_line(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible (RCCL needs one GPU per rank)")
+            raise SystemExit(2)
+        local_dev = local % max(1, ndev)
+        torch.cuda.set_device(local_dev)
+        enter("init_process_group")
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=datetime.timedelta(seconds=args.watchdog))
+            else:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.watchdog))
+        except Exception as e:                                           # noqa: BLE001
+            error_line(f"init_process_group({args.backend}) failed on rank {rank}: {str(e)[:400]}")
+            raise
+    else:
+        dist, local_dev = None, 0
+    dev = torch.device("cuda", local_dev)
+    torch.cuda.set_device(dev)
+    from bindsnet_amd import parallel, synth
+    from bindsnet_amd.models import TwoLayerNetwork
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step):
+        for k in range(args.warmup):
+            step(k)
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    host = [synth.dense_spikes(2 + 10 * k, (Tc, Bg, Nin), 0.012) for k in range(4)]          # tools/baseline_configs.py's cfg3 inputs
+    try:
+        # ---- north star: batch shards + one all-reduce of the deltas per input
+        enter("sharded_run")
+        Bs = Bg // world
+        torch.manual_seed(0)
+        net = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum)
+        net.to(dev)
+        shard_in = [torch.from_numpy(np.ascontiguousarray(h[:, rank * Bs:(rank + 1) * Bs])).to(dev) for h in host]
+        last = [x[Tc - 1].clone() for x in shard_in]
+
+        def step_a(k):
+            x = shard_in[k % 4]
+            parallel.sharded_run(net, {"X": x}, Tc)
+            net.reset_state_variables()
+            x[Tc - 1].copy_(last[k % 4])                    # (Input.s aliases the last slice; reset zeroes it in place)
+        el_a = timed(step_a)
+        plan_a = net.last_plan
+        st = net.__dict__.get("_shard_state")
+        coll = None
+        if dist is not None and st is not None:
+            buf = st["delta"].clone()
+            fence()
+            c0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            fence()
+            coll = {"op": "all_reduce(SUM) of the flat weight delta", "bytes": buf.numel() * buf.element_size(), "ms": round((time.perf_counter() - c0) / 20 * 1e3, 4)}
+        # ---- exact: column slices, whole batch, no collective
+        enter("column_shard")
+        torch.manual_seed(0)
+        full = TwoLayerNetwork(n_inpt=Nin, n_neurons=N, reduction=torch.sum)
+        full.batch_size = Bg
+        full.to(dev)
+        shard, lo, hi = parallel.column_shard(full, rank, world)
+        full_in = [torch.from_numpy(h).to(dev) for h in host]
+        last_f = [x[Tc - 1].clone() for x in full_in]
+
+        def step_b(k):
+            x = full_in[k % 4]
+            if shard is not None:
+                shard.run({"X": x}, time=Tc)
+                shard.reset_state_variables()
+            x[Tc - 1].copy_(last_f[k % 4])
+        el_b = timed(step_b)
+        plan_b = shard.last_plan if shard is not None else None
+    except Exception as e:                                     # noqa: BLE001
+        error_line(f"rank {rank}, stage '{stage['name']}': {type(e).__name__}: {str(e)[:400]}")
+        raise
+    enter("post")
+    if rank == 0:
+        line = {"metric": metric, "value": round(args.steps * Tc / el_a, 2), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(el_a / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[2]: TwoLayerNetwork 784->1600 exc LIF, global batch 128, 100 timesteps per network.run(), PostPre STDP, "
+                                       "reset_state_variables() per input; Bernoulli(0.012) spike trains, 4 resident batches cycled",
+                           "timesteps_per_step": Tc, "global_batch": Bg, "batch_per_gpu": Bs, "parallelism": f"batch-shard x{world} + all-reduce of the weight deltas per input (north_star)",
+                           "plan": plan_a, "backend": args.backend if world > 1 else None, "per_input_collective": coll,
+                           "sample_timesteps_per_s": round(args.steps * Tc * Bg / el_a, 1)},
+                "exact_column_shard": {"value": round(args.steps * Tc / el_b, 2), "unit": "timesteps/s", "ms_per_step": round(el_b / args.steps * 1e3, 4),
+                                       "columns_of_rank0": [lo, hi], "batch_per_gpu": Bg, "collectives_during_the_run": 0, "plan": plan_b,
+                                       "what": "parallel.column_shard: 32-aligned column slices, the whole batch on every rank: bit-identical to the single-process global batch"},
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    stage["name"] = "done"
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"], help="cfg2: the headline (BASELINE.json configs[1]); cfg3: configs[2] on N ranks, both multi-GPU modes")
     ap.add_argument("--gpus", type=int, default=1)
+
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,6 +438,8 @@ def main():
         if not torch.cuda.is_available() or (torch.cuda.device_count() < args.gpus and args.backend == "nccl"):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
         respawn_under_launcher(args)
+    if args.config == "cfg3":
+        return main_cfg3(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -776,7 +776,6 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             if (alds <= 150 * 1024 && rG + 1 + nrw <= cap3) {
                 lean = 3;
                 c.NRW = nrw;
-                c.async_form = getenv("SNN_DC_ASYNC_FORM") ? atoi(getenv("SNN_DC_ASYNC_FORM")) : 1;
                 c.tbad = (int *)((unsigned char *)c.rprog + 16 * 4);
                 // the CUs the grid leaves idle run the input-only pre-passes INSIDE the launch (producer workgroups: digest entries, then the
                 // X-trace walk; per-entry ready flags): SNN_DC_PRODUCERS=0 / a device too small for >= 16 of them -> the two launches in front
@@ -972,14 +971,9 @@ int snn_try_fused_dc2015(const snn_layer_desc *L, int nL, const snn_conn_desc *C
             step += (double)(h[(size_t)(t + 1) * 24] - r[0]) / 100.0;
         }
         for (int k = 1; k < 24; ++k) a[k] = na[k] ? a[k] / na[k] * n : 0.0;
-        if (c.async_form == 0)
-            fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f | other waves: PostPre done %.2f | "
-                            "barrier M %.2f | X currents %.2f | won branch %.2f | resolution of step t %.2f | barrier B %.2f || iteration %.2f us\n",
-                    c.dbg_wg, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[1] / n, a[2] / n, step / n);
-        else
-            fprintf(stderr, "[dc2015 async form 1, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f, at barrier B %.2f | wave 2: PostPre done %.2f, "
-                            "counter passed %.2f, X currents %.2f | behind B %.2f | crossing iterations (%d of %d): rows done %.2f, behind P %.2f, won currents %.2f, resolution %.2f, other rows %.2f || iteration %.2f us\n",
-                    c.dbg_wg, a[7] / n, a[8] / n, a[13] / n, a[19] / n, a[20] / n, a[21] / n, a[4] / n, na[15], n, a[22] / n, a[15] / n, a[5] / n, a[1] / n, a[23] / n, step / n);
+        fprintf(stderr, "[dc2015 async, us from iteration start, compute workgroup %d] tile waves: winners(t-2) read %.2f, published %.2f | other waves: PostPre done %.2f | "
+                        "barrier M %.2f | X currents %.2f | won branch %.2f | resolution of step t %.2f | barrier B %.2f || iteration %.2f us\n",
+                c.dbg_wg, a[7] / n, a[8] / n, a[3] / n, a[4] / n, a[5] / n, a[6] / n, a[1] / n, a[2] / n, step / n);
         // per step: first / last publish over the compute workgroups, arbiter: all granules seen, winners out
         double spread = 0, seen = 0, out = 0, period = 0, lastx = 0; int m = 0, nx = 0; long long prev_last = 0;
         std::vector<int> lastcnt(c.G, 0);

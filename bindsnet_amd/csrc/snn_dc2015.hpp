@@ -75,7 +75,6 @@ struct DcCtx {
     // third generation's, and the general form's other copy) -- the memsets a run otherwise starts with
     uint4 *zeroA, *zeroG;
     unsigned zeroA_n16, zeroG_n16;
-    int async_form;             // third generation: 1 = the round-6 step loop (X currents beside the membrane stage, one barrier per plain iteration), 0 = round 5's (SNN_DC_ASYNC_FORM)
 };
 
 namespace {

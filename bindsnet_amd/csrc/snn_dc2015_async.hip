@@ -76,7 +76,7 @@ __device__ __forceinline__ const DcCtx &cold(const DcCtx &) {
 // ---- LDS layout of a compute workgroup (bytes) -----------------------------------------------------------------------------------
 constexpr int AT = MAXB * ACW;         // tile threads
 constexpr size_t OC_CTL = 0, OC_XNU0 = 128, OC_XNU0S = OC_XNU0 + 2 * AT * 4, OC_CURX = OC_XNU0S + AT * 4, OC_CURXW = OC_CURX + 2 * AT * 4,
-                 OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 64, OC_COLX = OC_COLM + 32, OC_COLRES = OC_COLX + 64,
+                 OC_SPFIN = OC_CURXW + AT * 4, OC_THC = OC_SPFIN + AT * 4, OC_COLM = OC_THC + 32, OC_COLX = OC_COLM + 32, OC_COLRES = OC_COLX + 32,
                  OC_XWINV = OC_COLRES + 16, OC_XCNT = OC_XWINV + 16 + 16, OC_W0 = OC_XCNT + 2 * MAXB * 4, OC_C0 = OC_W0 + 2 * MAXB * 4, OC_WT = OC_C0 + 2 * MAXB * 4;
 static_assert(OC_WT % 16 == 0 && OC_XNU0 % 16 == 0 && OC_XNU0S % 16 == 0, "16-byte aligned float4 arrays");
 // ... then wtile [Nin][4] | wieT [N][4] | weiT [N][4] | two digests | wbak [Nin][4] | wwin [Nin][4]
@@ -199,64 +199,137 @@ __device__ __forceinline__ float x_current4(const float *ws, const float *ws2, f
     return combine(a1 + a0);
 }
 
-// The same value for a column of the multi_row_sum class by TWO lanes per (sample, column) pair (round-6 form: the X currents are computed
-// by four of the non-tile waves while the tile waves run the membrane stage): lane pL takes the cascade's 256-position groups 2 pL and
-// 2 pL + 1 -- CascadeFlat's arithmetic with its second level kept: a group that closes goes into a2 = 0 + G --, sixteen events per lane
-// asked for at once; lane 0 then has all four group sums and combines them as x_current4 does.  The value, valid in lane pL == 0.
-__device__ __forceinline__ float x_current2(const float *ws, const uint32_t *dg, int B, int Nin, int pb, int pq, int pL) {
-    constexpr int CW = ACW, NS = 16;
+// The X -> Ae currents of sample pb for ALL FOUR columns of the workgroup by lane pL of the sample's four threads (round 6): x_current4's statements with the
+// row's four weights read as one float4 and the event bookkeeping (which 16-position block, does it close) shared by the four columns --
+// per column the same additions in the same order.  The values, valid in lane pL == 0.
+// lane l of a quad reads lane l + k of the same quad (k = 1, 2, 3; meaningful in lane 0): one DPP move instead of a ds_bpermute round trip
+template <int K>
+__device__ __forceinline__ float quad_down(float v) {
+    constexpr int ctrl = K == 1 ? 0x39 : (K == 2 ? 0x0E : 0x03);          // quad_perm [1,2,3,0] / [2,3,0,0] / [3,0,0,0]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float4 x_current_f4(const float *ws, const uint32_t *dg, int B, int Nin, int pb, int pL, bool tailcol) {
     constexpr uint32_t GM = (1u << GCB) - 1u;
     const uint16_t *lstX = (const uint16_t *)dg;
     const uint32_t *rowmask = dg + B * (LX / 2) + 40;
     const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
     const uint16_t *lst2 = arows + 4 * ((Nin + 1) / 2);
-    const uint32_t *gqn = (const uint32_t *)(lst2 + B * LX) + B;
+    const uint32_t *gcnt = (const uint32_t *)(lst2 + B * LX);
+    const uint32_t *gqn = gcnt + B;
+    float r[4];
+    if (tailcol) {
+        const uint32_t gc = gcnt[pb];
+        const int st = (pL > 0 ? (int)(gc & GM) : 0) + (pL > 1 ? (int)((gc >> GCB) & GM) : 0) + (pL > 2 ? (int)((gc >> (2 * GCB)) & GM) : 0);
+        const int nL = (int)((gc >> (GCB * pL)) & GM);
+        const uint16_t *l2 = lst2 + pb * LX;
+        const int n4 = Nin >> 2, nfull = n4 >> 4;
+        int ix[8]; float4 wx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ix[u] = min((int)l2[min(st + u, LX - 1)], Nin - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wx[u] = *(const float4 *)(ws + ix[u] * 4);
+        // CascadeFlat per column (snn_order.hpp), the block / group tests shared
+        float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        int cb = -1;
+        auto add = [&](int pos, const float4 &w) __attribute__((always_inline)) {
+            int blk = pos >> 4;
+            blk = blk < nfull ? blk : nfull;
+            const bool nb = blk != cb, ng = (blk >> 4) != (cb >> 4);
+            const float t[4] = {w.x * 1.0f, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = a1[q] + a0[q];
+                a1[q] = nb ? s1 : a1[q];
+                a0[q] = nb ? 0.f : a0[q];
+                const float s2 = a2[q] + a1[q];
+                a2[q] = ng ? s2 : a2[q];
+                a1[q] = ng ? 0.f : a1[q];
+                a0[q] += t[q];
+            }
+            cb = blk;
+        };
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (u < nL) add(ix[u] >> 2, wx[u]);
+        for (int u = 8; u < nL; ++u) {
+            const int i = (int)l2[st + u];
+            add(i >> 2, *(const float4 *)(ws + i * 4));
+        }
+        const bool closeb = cb != nfull, closeg = closeb && (nfull >> 4) != (cb >> 4);
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float b0 = a0[q], b1 = a1[q], b2 = a2[q];
+            if (closeb) { b1 += b0; b0 = 0.f; if (closeg) { b2 += b1; b1 = 0.f; } }
+            v[q] = ((b0 + b1) + b2) + 0.0f;
+        }
+        if (pL == 0) {
+            const int s4 = (int)(gc & GM) + (int)((gc >> GCB) & GM) + (int)((gc >> (2 * GCB)) & GM) + (int)((gc >> (3 * GCB)) & GM);
+            const int n5 = (int)((gc >> (4 * GCB)) & GM);
+            for (int u = 0; u < n5; ++u) {
+                const int i = (int)l2[s4 + u];
+                const float4 w = *(const float4 *)(ws + i * 4);
+                v[0] += w.x * 1.0f; v[1] += w.y * 1.0f; v[2] += w.z * 1.0f; v[3] += w.w * 1.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v1 = __shfl_down(v[q], 1, 4), v2 = __shfl_down(v[q], 2, 4), v3 = __shfl_down(v[q], 3, 4);
+            r[q] = 0.0f + (((v[q] + v1) + v2) + v3);
+        }
+        return make_float4(r[0], r[1], r[2], r[3]);
+    }
     const uint32_t gq = gqn[pb];
-    const int n01 = (int)(gq & GM) + (int)((gq >> GCB) & GM), n23 = (int)((gq >> (2 * GCB)) & GM) + (int)((gq >> (3 * GCB)) & GM);
-    const int st = pL ? n01 : 0, nL = pL ? n23 : n01;
+    const int st = (pL > 0 ? (int)(gq & GM) : 0) + (pL > 1 ? (int)((gq >> GCB) & GM) : 0) + (pL > 2 ? (int)((gq >> (2 * GCB)) & GM) : 0);
+    const int nL = (int)((gq >> (GCB * pL)) & GM);
     const uint16_t *lx = lstX + pb * LX;
-    int ix[NS]; float wx[NS];
+    int ix[8]; float4 wx[8];
+    // slots behind the lane's events repeat its LAST event's position with a zero term: the same block, so nothing closes, and a0 + 0 = a0 --
+    // no lane sits out a slot, the wave runs the eight steps without a branch
+    const int last = st + max(nL, 1) - 1;
 #pragma unroll
-    for (int u = 0; u < NS; ++u) ix[u] = (int)lx[min(st + u, LX - 1)];          // (slots behind a sample's events hold 0: k_dc2015_prep fills the row)
+    for (int u = 0; u < 8; ++u) ix[u] = (int)lx[min(st + u, last)];
 #pragma unroll
-    for (int u = 0; u < NS; ++u) wx[u] = ws[ix[u] * CW + pq];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int u = 0; u < 8; ++u) wx[u] = *(const float4 *)(ws + ix[u] * 4);
+    // this lane's events lie in ONE 256-position group (x_current4): a1 + a0 per column.  A block change is applied through 0/1 factors
+    // inside fmas whose products are exact (x * 1, x * 0): a1 = a0 * diff + a1, a0 = a0 * same + term -- the single rounding of the plain adds
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
     int cb = -1;
     const int nfull = Nin >> 4;
-    auto add = [&](int pos, float term) __attribute__((always_inline)) {
+    auto add = [&](int pos, const float4 &w, float live) __attribute__((always_inline)) {
         int blk = pos >> 4;
         blk = blk < nfull ? blk : nfull;
-        const bool nb = blk != cb, ng = (blk >> 4) != (cb >> 4);
-        const float s1 = a1 + a0;
-        a1 = nb ? s1 : a1;
-        a0 = nb ? 0.f : a0;
-        const float s2 = a2 + a1;
-        a2 = ng ? s2 : a2;
-        a1 = ng ? 0.f : a1;
+        const float same = blk == cb ? 1.f : 0.f, diff = 1.f - same;
+        const float t[4] = {w.x * live, w.y * live, w.z * live, w.w * live};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a1[q] = __builtin_fmaf(a0[q], diff, a1[q]);
+            a0[q] = __builtin_fmaf(a0[q], same, t[q]);
+        }
         cb = blk;
-        a0 += term;
     };
 #pragma unroll
-    for (int u = 0; u < NS; ++u) if (u < nL) add(ix[u], wx[u] * 1.0f);
-    for (int u = NS; u < nL; ++u) {
+    for (int u = 0; u < 8; ++u) add(ix[u], wx[u], u < nL ? 1.0f : 0.0f);
+    for (int u = 8; u < nL; ++u) {
         const int i2 = (int)lx[st + u];
-        add(i2, ws[i2 * CW + pq] * 1.0f);
+        add(i2, *(const float4 *)(ws + i2 * 4), 1.0f);
     }
-    // the open group's sum; the lane's first group is the closed one (a2 = 0 + its sum) exactly when the open one is its second
-    const float Y = a1 + a0;
-    const bool second_open = cb >= 0 && ((cb >> 4) & 1) != 0;
-    const float Gf = second_open ? a2 : Y, Gs2 = second_open ? Y : 0.f;
-    const float G2 = __shfl_down(Gf, 1, 2), G3 = __shfl_down(Gs2, 1, 2);
-    const float Gs[4] = {Gf, Gs2, G2, G3};
     const int GL = (Nin >> 4) >> 4;
-    float A2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
-    float Gl = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const float G = a1[q] + a0[q];
+        const float G1 = quad_down<1>(G), G2 = quad_down<2>(G), G3 = quad_down<3>(G);
+        const float Gs[4] = {G, G1, G2, G3};
+        float A2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
-    const float res = ((0.0f + Gl) + A2) + 0.0f;
-    return 0.0f + res;
+        for (int k = 0; k < 4; ++k) if (k < GL) A2 = A2 + Gs[k];
+        float Gl = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k == GL) Gl = Gs[k];
+        const float res = ((0.0f + Gl) + A2) + 0.0f;
+        r[q] = 0.0f + res;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
 }
 
 // Entry spikes of both layers (the step before the run): per sample the column of its Ae spike -> w0[b] (the "winners of step -1":
@@ -508,7 +581,7 @@ __device__ __forceinline__ int need_xtr(const DcCtx &c, bool &all) {
 //                   a column with more than one crossing sample waits for the winners and is redone exactly;
 //                   then the tile waves: a wave that crossed at step t waits for that step's winners; a winner redoes its Ae trace
 //                   and x_tgt*nu0 and marks its column (colmask); every pair leaves its final spike of step t for its Ai thread
-template <bool TIMING, int FORM>
+template <bool TIMING>
 __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
     constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NBC = NT - TT, TI0 = NT - TT;
     const int B = c.B, Nin = c.Nin, N = c.N, T = c.T;
@@ -518,9 +591,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     float *curX = (float *)(smem + OC_CURX);                 // [2][B][CW] X -> Ae part of the Ae current, by step parity
     float *curXwin = (float *)(smem + OC_CURXW);             // [B][CW] ... of column q in its won branch
     int *spfin = (int *)(smem + OC_SPFIN);                   // [TT] final Ae spike of the pair at step t-1 (for its Ai thread)
-    int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta); FORM 1: [4][CW], by step mod 4
+    int *thc = (int *)(smem + OC_THC);                       // [2][CW] crossings per own column by step parity (theta)
     uint32_t *colmask = (uint32_t *)(smem + OC_COLM);        // [2][CW] samples with a FINAL spike per own column at step t-1, by the parity of t
-    uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity; FORM 1: [4][CW], by step mod 4
+    uint32_t *colx = (uint32_t *)(smem + OC_COLX);           // [2][CW] samples with a crossing per own column, by step parity
     uint32_t *colres = (uint32_t *)(smem + OC_COLRES);       // [CW] slow columns: their winners of this step
     float *xwinv = (float *)(smem + OC_XWINV);               // [CW] x_tgt*nu0 of the crossing pair of column q if it wins
     int *xcnt = (int *)(smem + OC_XCNT);                     // [NTW][MAXB] a crossing tile wave's own count of the step's crossings per sample
@@ -550,7 +623,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     const bool e_learning = c.pE.learning != 0;
 
     if (tid < 32) ctl[tid] = 0;
-    if (tid < 4 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid & (2 * CW - 1)] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
+    if (tid < 2 * CW) { thc[tid] = 0; colx[tid] = 0; colmask[tid] = 0; colres[tid & 3] = 0; xwinv[tid & 3] = 0.f; }
     scan_entry(c, w0, cnt0, tid);
     bool offdiag = false, multi0 = false;
     for (int k = tid; k < Nin * CW; k += NT) {
@@ -653,10 +726,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     long long mk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
     (void)mk;
-    bool had_slow = true;                                     // FORM 1: the previous iteration took the crossing path (workgroup-uniform); "true" in front of
-    (void)had_slow;                                           // step 0: the entry spikes sit in spfin as a crossing path would have left them
     for (int t = 0; t <= T; ++t) {
-      if constexpr (FORM == 0) {
         const bool phaseB = t < T;
         const int par = t & 1;
         const uint32_t *dgn = dgbuf + (par ^ 1) * DGS;                    // digest entry t+1: the X spikes of step t
@@ -899,23 +969,22 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         AMARK(15);
         // ---- X -> Ae currents of step t+1: four threads per (sample, column) pair; "nobody of this workgroup won step t" from wtile and,
         //      for a workgroup that crossed, the won branch of its crossing columns from wwin in the same pass
-        if (crossed_wg) {
-            for (int qt = tid; qt < B * CW * 4; qt += NT) {
-                const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-                float vw = 0.f;
-                const float v = x_current4<true>(wtile, wwin, vw, dgn, B, Nin, pb, pq, pL, tailcol);
-                if (pL == 0 && c0 + pq < N) {
-                    curX[(par ^ 1) * TT + pb * CW + pq] = v;
-                    const uint32_t cj = pq == 0 ? cmq[0] : (pq == 1 ? cmq[1] : (pq == 2 ? cmq[2] : cmq[3]));
-                    if (cj) curXwin[pb * CW + pq] = vw;
-                }
-            }
-        } else {
-            for (int qt = tid; qt < B * CW * 4; qt += NT) {
-                const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-                float unused = 0.f;
-                const float v = x_current4<false>(wtile, wtile, unused, dgn, B, Nin, pb, pq, pL, tailcol);
-                if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
+        //      Round 6: the float4 pass (x_current_f4: four lanes per SAMPLE, the row's four weights as one float4, the block bookkeeping shared
+        //      by the columns, DPP instead of LDS shuffles) on waves 2..3 -- and for a workgroup that crossed on waves 4..5 from wwin -- instead of
+        //      four lanes per (sample, column) pair on all eight waves: fewer instructions on two waves than the old pass had on every wave, and
+        //      the tile waves go straight to their resolution (same-box A/B, bit-exact: 947 -> 900 us per launch, profiles/NOTES_r06.md).
+        if (wave >= NTW && wave < NTW + 2) {
+            const int ptid = tid - TT, pb = ptid >> 2, pL = ptid & 3;
+            const float4 v = x_current_f4(wtile, dgn, B, Nin, min(pb, B - 1), pL, tailcol);
+            if (pL == 0 && pb < B) *(float4 *)(curX + (par ^ 1) * TT + pb * CW) = v;
+        } else if (crossed_wg && wave >= NTW + 2 && wave < NTW + 4) {
+            const int ptid = tid - TT - 128, pb = ptid >> 2, pL = ptid & 3;
+            const float4 v = x_current_f4(wwin, dgn, B, Nin, min(pb, B - 1), pL, tailcol);     // (its other columns are of no interest)
+            if (pL == 0 && pb < B) {
+                if (cmq[0] && c0 + 0 < N) curXwin[pb * CW + 0] = v.x;
+                if (cmq[1] && c0 + 1 < N) curXwin[pb * CW + 1] = v.y;
+                if (cmq[2] && c0 + 2 < N) curXwin[pb * CW + 2] = v.z;
+                if (cmq[3] && c0 + 3 < N) curXwin[pb * CW + 3] = v.w;
             }
         }
         AMARK(5);
@@ -1004,375 +1073,6 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         AMARK2(23);
         lds_barrier();                                                    // ---- B
         AMARK(2);
-      } else {
-        // ================================================================================================= FORM 1 (round 6)
-        // ONE s_barrier per iteration without an own crossing.  What changed against FORM 0: the X currents of step t+1 no longer
-        // follow the membrane stage on every wave -- four of the six non-tile waves compute them (x_current2: two lanes per pair) right
-        // behind their PostPre rows, behind a counter barrier among the non-tile waves only (LDS word ctl[2]), WHILE the tile waves
-        // are in the membrane stage of step t: nothing of "PostPre(t) under no own final spike -> currents of t+1" depends on the
-        // crossings of step t.  A workgroup that crossed finds that out behind the barrier and then prepares the won branch of its
-        // crossing columns (rows, then THEIR currents only, by the tile waves in front of their resolution poll) as before.
-        //   B(t-1) .. B(t)   tile waves: Ae trace / x_tgt*nu0 without a final spike, membrane update of step t, publish
-        //                    waves 6..7: Ai update | waves 2..7: PostPre(t), digest t+2 into LDS, counter | waves 2..5: X currents of t+1
-        //   B(t) ..          nobody crossed: next iteration.  Otherwise: won-branch rows | P | tile waves: currents of the won
-        //                    columns, resolution; waves 2..7: the untouched rows | B2
-        const bool phaseB = t < T;
-        const int par = t & 1, r4 = t & 3;
-        const uint32_t *dgn = dgbuf + (par ^ 1) * DGS;                    // digest entry t+1: the X spikes of step t
-        const int *meta = (const int *)(dgn + B * (LX / 2));
-        const uint32_t *rowmask = dgn + B * (LX / 2) + 40;
-        const uint16_t *arows = (const uint16_t *)(rowmask + Nin);
-        const bool do_stdp = phaseB && learn_pp;
-        const bool full = t == 0;                                         // the first update of a run clamps every element
-        AMARK(0);
-        AMARK2_FLUSH();
-        if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 0] = (long long)wall_clock64(); }
-        if (t + 2 <= T && wave >= NTW) {
-            if (PENDING(1)) {                                             // (producer workgroups: the first iterations only)
-                bool all = false;
-                const int r = need_entry(cold(c), t + 2, all);
-                if (r != 1) { ctl[0] = 1; report(cold(c).status, r < 0 ? SNN_ERR_TIMEOUT : SNN_ERR_RETRY); }
-                if (all) pend &= ~1;
-            }
-            DIGEST_LOAD_E(t + 2);
-        }
-        if (ctl[0]) { bad = true; break; }                                // (written in front of a barrier)
-        AMARK(9);
-        uint32_t wonm = 0;                                                // own columns that won at step t-1 (only a crossing iteration leaves any)
-        if (learn_pp && had_slow) {
-#pragma unroll
-            for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
-        }
-        AMARK(10);
-        if (!phaseB) {                                                    // behind the last step: only its winners' columns are left to commit
-            if (wonm)
-                for (int i = tid; i < Nin; i += NT) {
-                    float4 v = *(const float4 *)(wtile + i * 4);
-                    const float4 ww = *(const float4 *)(wwin + i * 4);
-                    if (wonm & 1u) v.x = ww.x;
-                    if (wonm & 2u) v.y = ww.y;
-                    if (wonm & 4u) v.z = ww.z;
-                    if (wonm & 8u) v.w = ww.w;
-                    *(float4 *)(wtile + i * 4) = v;
-                }
-            break;
-        }
-        if (wave < NTW) {
-            // ---- Ae trace of step t as it is without a final spike (nodes.py:96-103), x_tgt*nu0 of step t+1 likewise: known before the
-            //      step is simulated (a winner of step t redoes both in the crossing path)
-            if (bl < B) {
-                float xn = 0.f;
-                if (colv && pE.traces) {
-                    x_before = x_cur;
-                    x_cur = trace_next(x_before, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                    xn = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                }
-                xnu0[(par ^ 1) * TT + tid] = xn * pp.nu0;
-            }
-            // ---- Ae membrane update of step t, publish its crossings
-            float cx = 0.f;
-            if (mine) cx = ((wonm >> jj) & 1u) ? curXwin[bl * CW + jj] : curX[par * TT + bl * CW + jj];
-            if constexpr (TIMING) { if (c.dbg && g == c.dbg_wg && tid == 0) c.dbg[(size_t)t * 24 + 17] = !pre_w.have ? 2 : ((uint32_t)(pre_w.g0 >> 54) != win_tag(t - 2) ? 1 : 0); }
-            const int jI = bad ? -1 : sample_winner(c, w0, t - 2, min(bl, B - 1), bad, pre_w);   // the Ai spike of step t-1 in this sample = the Ae winner of step t-2
-            AMARK(7);
-            AMARK_FLUSH();
-            bool spE = false;
-            if (mine) {
-                const float e2 = jI >= 0 ? wieT[min(jI, N - 1) * CW + jj] * 1.0f + 0.0f : 0.0f;
-                const float curE = cx + e2;                                // (zeros + X->Ae) + Ai->Ae   (network.py:225-248)
-                if (e_learning && t >= 1) r_th = r_th + theta_plus * (float)thc[((t - 1) & 3) * CW + jj];
-                if (e_learning) r_th = r_th * theta_decay;
-                spE = dc_update(r_v, r_r, curE, pE.thresh + r_th, pE);
-                if (spE) atomicAdd(&thc[r4 * CW + jj], 1);
-            }
-            const uint64_t mE = __ballot(spE);
-            AMARK(12);
-            const int slot = t & (kCrossRing - 1);
-            uint32_t pay;
-            if (bad) pay = kAbortPay;
-            else {
-                const int nev = __popcll(mE);
-                if (nev <= 3) {
-                    pay = (uint32_t)nev << 30;
-                    int sh = 0;
-                    for (uint64_t m = mE; m; m &= m - 1) { pay |= (uint32_t)(__ffsll((unsigned long long)m) - 1) << sh; sh += 8; }
-                } else {
-                    const int sidx = lane / CW, b = wave * SPW + sidx;
-                    const uint32_t v = (uint32_t)((mE >> (sidx * CW)) & 0xFFFFull);
-                    if ((lane % CW) == 0 && (sidx % SPG) == 0 && b < B)
-                        granule_store(cold(c).ex + (size_t)slot * (cold(c).G * cold(c).KB) + g * cold(c).KB + b / SPG, ((unsigned long long)(uint32_t)(t + 1) << 32) | v);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    pay = 0xC0FFFFFFu;
-                }
-            }
-            if (lane == 0) granule_store(c.exs + (size_t)slot * NGS + g * NTW + wave, ((unsigned long long)(uint32_t)(t + 1) << 32) | pay);
-            AMARK(8);
-            if constexpr (TIMING) { if (c.dbg && tid == 0) { c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 1] = (long long)wall_clock64(); c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 2] = (long long)__popcll(mE); } }
-            if constexpr (TIMING) { if (c.dbg && tid == 64 && c.dbg_wg < 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = 0x100 + (long long)__popcll(mE); }   // (lite: tile wave 1's crossings)
-            published = t + 1;
-            prevE = mE; crossed_prev = spE;
-            if (mine) last_s = false;                                      // (a winner of step t is put back in the crossing path)
-            if (spE) {
-                atomicOr(&colx[r4 * CW + jj], 1u << bl);
-                if (pE.traces) xwinv[jj] = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-            }
-            if (bad) ctl[0] = 1;
-            if (mine && c.rasVE) (cold(c).rasVE + (size_t)t * B * N)[kst] = r_v;
-        } else {
-            if (wave >= NT / 64 - NTW) {
-                // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
-                //      weights diagonal; left by the crossing path of the previous iteration, if it took one); it must fire exactly
-                //      when that spike was there -- what everybody's inhibition assumes
-                if (mine_i) {
-                    const bool spA = had_slow && spfin[ptile] != 0;
-                    const float e3 = spA ? weiT[j * CW + jj] * 1.0f + 0.0f : 0.0f;
-                    float ci = 0.0f + e3;                                  // zeros + Ae->Ai
-                    if (r_r > 0.f) ci = 0.f;
-                    const bool spIn = lif_update(r_v, r_r, ci, pI);
-                    last_s = spIn;
-                    if (pI.traces) x_cur = trace_next(x_cur, spIn, pI.trace_decay, pI.trace_scale, pI.traces_additive);
-                    if (spIn != spA) {
-                        ctl[0] = 1;
-                        report(cold(c).status, SNN_ERR_RETRY);
-                    }
-                    if (c.rasVI) (cold(c).rasVI + (size_t)t * B * N)[kst] = r_v;
-                }
-            }
-            if (do_stdp) {
-                // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
-                //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
-                const int nact = full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
-                const int ptid = tid - TT;
-                const float *xn0 = xnu0 + par * TT;
-                for (int k = ptid; k < nact; k += NBC) {
-                    const int i = full ? k : (int)arows[k];
-                    const uint32_t m = rowmask[i];
-                    float4 v = *(const float4 *)(wtile + i * 4);
-                    if (wonm) {
-                        const float4 ww = *(const float4 *)(wwin + i * 4);
-                        if (wonm & 1u) v.x = ww.x;
-                        if (wonm & 2u) v.y = ww.y;
-                        if (wonm & 4u) v.z = ww.z;
-                        if (wonm & 8u) v.w = ww.w;
-                    }
-                    *(float4 *)(wbak + i * 4) = v;
-                    *(float4 *)(wtile + i * 4) = postpre_row_nowin(pp, v, m, xn0);
-                }
-                if (wonm && !full)                                        // ... and the rows this step does not touch take the won column as it is
-                    for (int i = ptid; i < Nin; i += NBC) {
-                        if (rowmask[i] != 0) continue;
-                        float4 v = *(const float4 *)(wtile + i * 4);
-                        const float4 ww = *(const float4 *)(wwin + i * 4);
-                        if (wonm & 1u) v.x = ww.x;
-                        if (wonm & 2u) v.y = ww.y;
-                        if (wonm & 4u) v.z = ww.z;
-                        if (wonm & 8u) v.w = ww.w;
-                        *(float4 *)(wtile + i * 4) = v;
-                    }
-            }
-            AMARK2(19);
-            if (t + 2 <= T) DIGEST_STORE_E(t + 2);                        // (its buffer, entry t's, was last read before the previous iteration's last barrier)
-            // ---- counter barrier among the six non-tile waves: every row of PostPre(t) is in LDS before the X currents read it (LDS
-            //      operations of a wave execute in order: the add stands behind the wave's row stores).  The tile waves take no part.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool xwave = tailcol || wave < NTW + 4;                 // waves 2..5 (a row_sum workgroup: all six, four lanes per pair)
-            if (xwave) {
-                const int target = (NT / 64 - NTW) * (t + 1);
-                for (unsigned spins = 0; __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spins) {
-                    if ((spins & 63u) == 63u && (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || spins > 64u * kAPoll)) {
-                        if (spins > 64u * kAPoll) { ctl[0] = 1; report(cold(c).status, SNN_ERR_TIMEOUT); }
-                        break;
-                    }
-                }
-                asm volatile("" ::: "memory");
-                AMARK2(20);
-                // ---- X -> Ae currents of step t+1 under "nobody of this workgroup won step t" (the won branch of a crossing column
-                //      follows in the crossing path)
-                const int ptid = tid - TT;
-                if (!tailcol) {
-                    const int p = ptid >> 1, pb = p / CW, pq = p % CW, pL = ptid & 1;
-                    if (pb < B) {
-                        const float v = x_current2(wtile, dgn, B, Nin, pb, pq, pL);
-                        if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
-                    }
-                } else {
-                    for (int qt = ptid; qt < B * CW * 4; qt += NBC) {
-                        const int pb = qt / (CW * 4), pq = (qt >> 2) % CW, pL = qt & 3;
-                        float unused = 0.f;
-                        const float v = x_current4<false>(wtile, wtile, unused, dgn, B, Nin, pb, pq, pL, true);
-                        if (pL == 0 && c0 + pq < N) curX[(par ^ 1) * TT + pb * CW + pq] = v;
-                    }
-                }
-                AMARK2(21);
-            }
-        }
-        AMARK(13);
-        lds_barrier();                                                    // ---- B
-        AMARK(4);
-        if constexpr (TIMING) { if (c.dbg && tid == 0 && c.dbg_wg >= 0) c.dbg[(size_t)24 * (T + 1) + ((size_t)t * 256 + g) * 4 + 3] = (long long)wall_clock64(); }
-        // (slots two steps ahead: their next writers stand behind the NEXT iteration's barrier)
-        if (tid < CW) { colmask[par * CW + tid] = 0; colx[((t + 2) & 3) * CW + tid] = 0; thc[((t + 2) & 3) * CW + tid] = 0; }
-        // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now
-        if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1); }
-        uint32_t xq[CW];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[r4 * CW + q]);
-        had_slow = (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
-        AMARK(14);
-        if (had_slow) {
-            // ---- the CROSSING PATH: a workgroup that crossed at step t prepares the WON BRANCH of its crossing columns while the arbiter
-            //      works: each such column as it is with its final spike(s) of step t, every row from the old weights.  First the rows this
-            //      step's X spikes touch -- the only rows the X currents of step t+1 read --, then (tile waves) the currents of the won
-            //      columns and (waves 2..7) the other rows.  A column with several crossing samples has no single "it won" outcome: it
-            //      waits for the winners of this step and is done exactly.
-            const bool crossed_wg = do_stdp;
-            if (crossed_wg && PENDING(2)) {                               // (producer workgroups: a crossing in the launch's first ~50 us)
-                bool all = false;
-                if (need_xtr(cold(c), all) != 1) { ctl[0] = 1; report(cold(c).status, SNN_ERR_TIMEOUT); }
-                if (all) pend &= ~2;
-            }
-            const float *xsrc = crossed_wg ? cold(c).xtr + (size_t)(t + 1) * B * Nin : nullptr;   // X trace after step t
-            const float *xn0 = xnu0 + par * TT;
-            uint32_t cmq[CW];
-#pragma unroll
-            for (int q = 0; q < CW; ++q) cmq[q] = crossed_wg ? xq[q] : 0u;
-            const int nact = full ? Nin : __builtin_amdgcn_readfirstlane(meta[32]);
-            auto won_elem = [&](int i, int q) __attribute__((always_inline)) {
-                const bool single = __popc(xq[q]) == 1;
-                const int bst = single ? __ffs(cmq[q]) - 1 : -1;
-                const uint32_t m = rowmask[i];
-                const float wold = (full || m != 0) ? wbak[i * CW + q] : wtile[i * CW + q];
-                wwin[i * CW + q] = single ? postpre_elem(pp, B, Nin, xn0, wold, i, q, m, cmq[q], bst, xwinv[q], xsrc, true, xsrc[bst * Nin + i])
-                                          : postpre_elem(pp, B, Nin, xnu0s, wold, i, q, m, cmq[q], -1, 0.f, xsrc, false, 0.f);
-            };
-            if (crossed_wg) {
-                const bool slow = __popc(xq[0]) > 1 || __popc(xq[1]) > 1 || __popc(xq[2]) > 1 || __popc(xq[3]) > 1;
-                if (slow) {
-                    if (wave == 0) {
-                        bool b2 = bad;
-                        const int jw = b2 ? -1 : sample_winner(c, w0, t, min(lane, B - 1), b2);
-#pragma unroll
-                        for (int q = 0; q < CW; ++q) {
-                            const uint64_t mm = __ballot(lane < B && jw == c0 + q && jw >= 0);
-                            if (lane == 0) colres[q] = (uint32_t)mm;
-                        }
-                        if (b2) { bad = true; ctl[0] = 1; }
-                    }
-                    lds_barrier();                                        // ---- S1
-#pragma unroll
-                    for (int q = 0; q < CW; ++q) if (__popc(xq[q]) > 1) cmq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colres[q]);
-                    if (tid < TT) {
-                        float v = xn0[tid];
-                        const uint32_t xj = jj == 0 ? xq[0] : (jj == 1 ? xq[1] : (jj == 2 ? xq[2] : xq[3]));
-                        const uint32_t cj = jj == 0 ? cmq[0] : (jj == 1 ? cmq[1] : (jj == 2 ? cmq[2] : cmq[3]));
-                        if (bl < B && colv && __popc(xj) > 1 && ((cj >> bl) & 1u) && pE.traces)
-                            v = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-                        xnu0s[tid] = v;
-                    }
-                    lds_barrier();                                        // ---- S2
-                }
-                for (int k = tid; k < nact; k += NT) {                    // the rows the X currents of step t+1 read
-                    const int i = full ? k : (int)arows[k];
-#pragma unroll
-                    for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
-                }
-                AMARK2(22);
-                lds_barrier();                                            // ---- P
-                AMARK(15);
-                if (wave < NTW) {
-                    // the X currents of step t+1 of the crossing columns in their won branch: four lanes per pair on the two tile waves
-                    const int pb = tid >> 2, pL = tid & 3;
-#pragma unroll
-                    for (int q = 0; q < CW; ++q) {
-                        if (cmq[q] == 0u || c0 + q >= N) continue;       // (uniform)
-                        float unused = 0.f;
-                        const float v = x_current4<false>(wwin, wwin, unused, dgn, B, Nin, min(pb, B - 1), q, pL, tailcol);
-                        if (pL == 0 && pb < B) curXwin[pb * CW + q] = v;
-                    }
-                    AMARK(5);
-                } else if (!full) {
-                    // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
-                    for (int i = tid - TT; i < Nin; i += NBC) {
-                        if (rowmask[i] != 0) continue;
-#pragma unroll
-                        for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
-                    }
-                    AMARK2(23);
-                }
-            }
-            // ---- tile waves: which of the own crossings of step t won -- only a wave that had one waits.  A winner redoes its Ae trace of
-            //      step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
-            if (wave < NTW) {
-                sp_prev = false;
-                if (prevE != 0ull && !bad) {
-                    // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
-                    // at the step's crossing granules itself (lane l takes granules l, l + 64, ...; per-sample counts in LDS), one hop
-                    // instead of two.  Only a sample with several crossings waits for the arbiter's draw comparison.
-                    int *xc = xcnt + wave * MAXB;
-                    if (lane < MAXB) xc[lane] = 0;
-                    {
-                        constexpr int PG = 8;                             // granules per lane: NGS <= 512
-                        const unsigned long long *sums = cold(c).exs + (size_t)(t & (kCrossRing - 1)) * NGS;
-                        unsigned long long xs[PG];
-                        uint32_t need = 0;
-#pragma unroll
-                        for (int u = 0; u < PG; ++u) { xs[u] = 0ull; if (lane + 64 * u < NGS) need |= 1u << u; }
-                        for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-                            for (int u = 0; u < PG; ++u) if ((need >> u) & 1u) xs[u] = granule_load(sums + lane + 64 * u);
-#pragma unroll
-                            for (int u = 0; u < PG; ++u) if (((need >> u) & 1u) && (uint32_t)(xs[u] >> 32) == (uint32_t)(t + 1)) need &= ~(1u << u);
-                            if (!__any(need != 0u)) break;
-                            if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); break; }
-                        }
-                        bool ab = false;
-#pragma unroll
-                        for (int u = 0; u < PG; ++u) {
-                            const int gi = lane + 64 * u;
-                            if (bad || gi >= NGS) continue;
-                            const uint32_t pay = (uint32_t)xs[u];
-                            if (!pay) continue;
-                            if (pay == kAbortPay) { ab = true; continue; }
-                            const int w = gi % NTW;
-                            if ((pay & 0xFFu) == 0xFFu) {                // that tile wave sent bit granules (> 3 crossings): any of its samples may have one
-                                for (int bs = 0; bs < SPW; ++bs) if (w * SPW + bs < B) atomicAdd(&xc[w * SPW + bs], 2);
-                            } else {
-                                const int ne = (int)(pay >> 30);
-                                for (int e2 = 0; e2 < ne; ++e2) {
-                                    const int bsm = w * SPW + (int)((pay >> (8 * e2)) & 0x3Fu) / CW;
-                                    if (bsm < B) atomicAdd(&xc[bsm], 1);
-                                }
-                            }
-                        }
-                        if (__any(ab)) bad = true;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const int mycnt = (crossed_prev && bl < B) ? xc[bl] : 0;
-                    int jw = (crossed_prev && mycnt == 1) ? j : -1;
-                    if (!bad && __any(crossed_prev && mycnt > 1)) {
-                        const int ja = sample_winner(c, w0, t, min(bl, B - 1), bad);
-                        if (mycnt > 1) jw = ja;
-                    }
-                    const bool sp = !bad && crossed_prev && jw == j && bl < B && colv;
-                    if (sp) {
-                        if (pE.traces) {
-                            x_cur = trace_next(x_before, 1, pE.trace_decay, pE.trace_scale, pE.traces_additive);
-                            if (t + 1 < T) xnu0[(par ^ 1) * TT + tid] = trace_next(x_cur, 0, pE.trace_decay, pE.trace_scale, pE.traces_additive) * pp.nu0;
-                        }
-                        atomicOr(&colmask[(par ^ 1) * CW + jj], 1u << bl);
-                        last_s = true; sp_prev = true;
-                    }
-                }
-                spfin[tid] = sp_prev ? 1 : 0;
-                if (bad) ctl[0] = 1;
-                AMARK(1);
-            }
-            AMARK(16);
-            lds_barrier();                                                // ---- B2
-        } else if (wave < NTW) sp_prev = false;
-        AMARK(2);
-      }
     }
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on.  A wave that has
     //      published all T steps sends a FINAL REPORT in the granule of "step T": nothing, or the abort mark -- a reason to give up that shows in
@@ -1406,7 +1106,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     if (mine) {
         float th = r_th;
-        if (e_learning) th = th + theta_plus * (float)thc[((T - 1) & (FORM == 0 ? 1 : 3)) * CW + jj];
+        if (e_learning) th = th + theta_plus * (float)thc[((T - 1) & 1) * CW + jj];
         c.vE[kst] = r_v; c.rE[kst] = r_r;
         if (bl == 0) c.theta[j] = th;
         if (pE.traces) c.xE[kst] = x_cur;
@@ -1801,7 +1501,7 @@ __device__ __forceinline__ void async_raster(const DcCtx &c, unsigned char *smem
     }
 }
 
-template <bool TIMING, int FORM>
+template <bool TIMING>
 __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int blk = (int)blockIdx.x;
@@ -1810,7 +1510,7 @@ __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
         if (blk == 0 && threadIdx.x == 0) report(c.status, SNN_ERR_RETRY);
         return;
     }
-    if (blk < c.G) async_compute<TIMING, FORM>(c, smem);
+    if (blk < c.G) async_compute<TIMING>(c, smem);
     else if (blk == c.G) async_arbiter<TIMING>(c, smem);
     else if (blk < c.G + 1 + c.NRW) async_raster(c, smem, blk - c.G - 1);
     else async_producer(c, smem, blk - c.G - 1 - c.NRW);
@@ -1825,10 +1525,8 @@ size_t snn_dc2015_async_lds(int B, int Nin, int N) {
 
 static bool async_attr_once() {
     static int state = 0;
-    if (!state) state = (snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
-                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
-                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
-                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) ? -1 : 1;
+    if (!state) state = (snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
+                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) ? -1 : 1;
     return state == 1;
 }
 
@@ -1846,7 +1544,7 @@ int snn_dc2015_async_capacity(size_t lds) {
     int cus = 0, coop = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false, 1>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (fake_cus) cus = fake_cus;
     const int cap = coop ? cus * per_cu : 0;
     if (!fake_cus) { known[next] = Known{dev, lds, cap}; next = (next + 1) & 3; }
@@ -1861,8 +1559,7 @@ int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st, bool ord
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
     const unsigned grid = (unsigned)(c.G + 1 + c.NRW + c.NP);
-    const void *fn = c.async_form == 0 ? (c.dbg ? (const void *)k_dc2015_async<true, 0> : (const void *)k_dc2015_async<false, 0>)
-                                       : (c.dbg ? (const void *)k_dc2015_async<true, 1> : (const void *)k_dc2015_async<false, 1>);   // (the timing marks are compiled out of the ordinary instances)
+    const void *fn = c.dbg ? (const void *)k_dc2015_async<true> : (const void *)k_dc2015_async<false>;     // (the timing marks are compiled out of the ordinary instance)
     if (!coop) return snn_check(hipLaunchKernel(fn, dim3(grid), dim3(ANT), args, lds, st));
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(ANT), args, (unsigned)lds, st);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }

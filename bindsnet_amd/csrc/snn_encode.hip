@@ -5,10 +5,8 @@
 //    order: u = (r & 0xFFFFFF) * 2^-24, spike = u < p (bernoulli_distribution<float> over uniform_real_distribution).
 //    mt19937 has no cheap jump-ahead, so one workgroup walks the stream: twist a 624-word block cooperatively, turn it
 //    into 624 spikes, next block.  The advanced state is written back for the host to re-install.
-//  * snn_encode_poisson: the construction of encodings.py:101-152 (inter-spike intervals ~ Poisson(1000 / (x dt)), zero
-//    intervals bumped to one, cumulated into spike times), one thread per input element, from a counter-based
-//    Philox-4x32-10 stream keyed by (seed, element).  Same distribution, NOT the reference's stream: ATen's Poisson
-//    sampler consumes a data-dependent number of generator outputs per element, which cannot be parallelised exactly.
+//  * snn_encode_poisson: Poisson spike trains from a counter-based stream, specified operation by operation below and restated in
+//    oracle/snn_oracle.c (bit-exact on both sides); same distribution as the reference's, not its stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/snnhip.h"
@@ -44,7 +42,17 @@ __global__ __launch_bounds__(ENT) void k_encode_bernoulli(snn_rng_state *rng, co
     if (tid == 0) rng->pos = pos;
 }
 
-// ---- Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+// ---- snn_encode_poisson.  The construction of encodings.py:101-152 -- inter-spike intervals ~ Poisson(lambda), lambda = 1 / x * (1000 / dt) in
+// f32 as the reference computes it, zero intervals bumped to one, cumulated into spike times -- one thread per input element, from a
+// counter-based stream.  Same distribution, NOT the reference's stream (ATen's Poisson sampler consumes a data-dependent number of
+// generator outputs per element: not parallelisable exactly), so the stream is SPECIFIED here, operation by operation, in terms every IEEE
+// machine computes identically -- f32 / f64 add, multiply, divide, f32 square root, integer conversions; no libm call: exp, log and
+// log-gamma are the fixed series below -- and oracle/snn_oracle.c (orc_encode_poisson) restates it in plain C: the two agree bit for bit
+// (tests/test_gpu_encoding.py).
+//   uniforms   Philox-4x32-10 (Salmon et al., SC'11), key = seed (lo, hi), counter = (block, 0, element lo, element hi), block = 0, 1, ...;
+//              the four outputs of a block are used last first; u = ((r >> 8) + 1) * 2^-24 in (0, 1]
+//   sampler    lambda < 30: multiplication method -- k = number of further uniforms until their running product (f64) drops to exp(-lambda);
+//              lambda >= 30: Hoermann's transformed rejection (PTRS, 1993), all in f64 but sqrt(lambda), which is the f32 square root
 struct Philox {
     uint32_t key[2], ctr[4], out[4];
     int have;
@@ -71,26 +79,65 @@ struct Philox {
     }
 };
 
-// Poisson(lam) sample: multiplication method below 30, Hoermann's transformed rejection (PTRS) above.
-__device__ float poisson_sample(Philox &g, float lam) {
-    if (lam <= 0.f) return 0.f;
-    if (lam < 30.f) {
-        const float limit = expf(-lam);
-        float prod = g.uniform();
-        int k = 0;
-        while (prod > limit) { prod *= g.uniform(); ++k; }
-        return (float)k;
+// floor for |x| < 2^62 (exact: the conversion truncates)
+__device__ __forceinline__ double pz_floor(double x) { double t = (double)(long long)x; if (t > x) t -= 1.0; return t; }
+// x * 2^k through the exponent field (x normal, result normal)
+__device__ __forceinline__ double pz_scale(double x, int k) { return __longlong_as_double(__double_as_longlong(x) + ((long long)k << 52)); }
+// exp(y), y in [-40, 0]: y = k ln2 + r, |r| <= ln2 / 2; Taylor to r^13 (Horner, multiply then add), scaled by 2^k
+__device__ double pz_exp(double y) {
+    const double k = pz_floor(y * 1.4426950408889634 + 0.5);
+    const double r = (y - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0; p = p * r + 1.0 / 39916800.0; p = p * r + 1.0 / 3628800.0; p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0; p = p * r + 1.0 / 5040.0; p = p * r + 1.0 / 720.0; p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0; p = p * r + 1.0 / 6.0; p = p * r + 0.5; p = p * r + 1.0; p = p * r + 1.0;
+    return pz_scale(p, (int)k);
+}
+// log(x), x > 0 normal: x = m 2^e with m in [sqrt(1/2), sqrt(2)); s = (m - 1) / (m + 1); log m = 2 (s + s^3/3 + ... + s^23/23)
+__device__ double pz_log(double x) {
+    long long bits = __double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    double m = __longlong_as_double((bits & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);      // [1, 2)
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0; p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0; p = p * z + 1.0 / 9.0; p = p * z + 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z + 1.0 / 3.0; p = p * z + 1.0;
+    return (double)e * 6.93147180559945286227e-01 + 2.0 * s * p;
+}
+// log(k!) for an integer k >= 0: the product itself up to 9!, Stirling's series in z = k + 1 beyond
+__device__ double pz_lfact(double k) {
+    if (k < 10.0) {
+        double f = 1.0;
+        for (double i = 2.0; i <= k; i += 1.0) f = f * i;
+        return pz_log(f);
     }
-    const float slam = sqrtf(lam), loglam = logf(lam);
-    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    const double z = k + 1.0, zi = 1.0 / z, z2 = zi * zi;
+    double c = -1.0 / 1680.0;
+    c = c * z2 + 1.0 / 1260.0; c = c * z2 - 1.0 / 360.0; c = c * z2 + 1.0 / 12.0;
+    return ((z - 0.5) * pz_log(z) - z) + 0.91893853320467278056 + c * zi;
+}
+
+__device__ double poisson_sample(Philox &g, float lamf) {
+    if (!(lamf > 0.f)) return 0.0;
+    const double lam = (double)lamf;
+    if (lamf < 30.f) {
+        const double limit = pz_exp(-lam);
+        double prod = (double)g.uniform();
+        double k = 0.0;
+        while (prod > limit) { prod = prod * (double)g.uniform(); k += 1.0; }
+        return k;
+    }
+    const double slam = (double)sqrtf(lamf), loglam = pz_log(lam);
+    const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
     for (;;) {
-        const float U = g.uniform() - 0.5f, V = g.uniform();
-        const float us = 0.5f - fabsf(U);
-        const float k = floorf((2.f * a / us + b) * U + lam + 0.43f);
-        if (us >= 0.07f && V <= vr) return k;
-        if (k < 0.f || (us < 0.013f && V > us)) continue;
-        if (logf(V) + logf(invalpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.f)) return k;
+        const double U = (double)g.uniform() - 0.5, V = (double)g.uniform();
+        const double us = 0.5 - (U < 0.0 ? -U : U);
+        const double k = pz_floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (pz_log(V) + pz_log(invalpha) - pz_log(a / (us * us) + b) <= (k * loglam - lam) - pz_lfact(k)) return k;
     }
 }
 
@@ -103,7 +150,7 @@ __global__ __launch_bounds__(256) void k_encode_poisson(const float *__restrict_
     Philox g; g.init(seed, (unsigned long long)i);
     // spike "times" are the running sums of the intervals; time index 0 is dropped (spikes[1:] in the reference)
     long long next = 0;
-    auto advance = [&]() { float k = poisson_sample(g, lam); if (x != 0.f && k == 0.f) k = 1.f; next += (long long)k; };
+    auto advance = [&]() { double k = poisson_sample(g, lam); if (x != 0.f && k == 0.0) k = 1.0; next += (long long)k; };
     advance();
     for (int t = 1; t <= steps; ++t) {
         uint8_t s = 0;

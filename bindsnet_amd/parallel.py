@@ -405,14 +405,95 @@ class _ExactDevice:
             self.gen.__exit__(RuntimeError, None, None)
 
 
-def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, comm=None) -> None:
+def _exact_gathered(network, inputs, T, world, rank, gather, dev):
+    """exact_run's `gathered` mode: ONE all-gather of the run's inputs and of the layers' per-sample state at entry, then every rank
+    runs the GLOBAL batch through Network.run -- on the MI355X the resident D&C kernel, one launch for the whole run -- and keeps its
+    own rows of the state and of the monitors' recordings.
+
+    Why that is the right shape for this graph and not a cop-out: the coupled operations of DiehlAndCook2015 (theta, the one_spike draws in
+    global row order, PostPre's batch sums, whose result feeds the next step's propagation: nodes.py:1093-1105,
+    MCC_learning.py:260-263,296-299) need EVERY sample's factors on every rank at every timestep, and they are all of the step's work but
+    the membrane update of the own rows (1 % of it) -- an exact mode replicates them whatever it exchanges.  Exchanging the inputs once
+    instead of the spikes 250 times gives every rank the same numbers with no per-step traffic at all: the single-GPU kernel's speed at
+    any world size (the per-step mode: 2.3 k timesteps/s at world 2), bit-identical to the single-process global batch by construction
+    (same kernel, same operands, same draws from identically seeded generators).  What it does not buy is capacity: the global batch
+    must fit one device's plan (B <= 32 for the resident kernel, 256 for the generic plan) -- beyond that `per-step` is the mode."""
+    from .network.monitors import Monitor
+    from .network.nodes import Input
+    Bs = network.batch_size
+    B, lo = Bs * world, rank * Bs
+    hi = lo + Bs
+    full_in = {}
+    for name, x in inputs.items():
+        x = x.to(dev).contiguous()
+        n = x[0].numel() // Bs
+        flat = (x.view(torch.uint8) if x.dtype == torch.bool else x)[:T].reshape(T, Bs, n)
+        if world == 1:
+            allx = flat
+        else:
+            allx = gather(flat.permute(1, 0, 2).contiguous().view(Bs, T * n)).view(B, T, n).permute(1, 0, 2).contiguous()
+        full_in[name] = allx.view(T, B, *x.shape[2:])
+    # per-sample state of every layer: the rows of all ranks side by side, in rank order
+    state_names = ("s", "x", "v", "refrac_count")
+    kept = {}
+    for name, layer in network.layers.items():                 # (identical replicas: every rank has the same tensors allocated, so the same collectives)
+        n = layer.n
+        for nm in state_names:
+            t = getattr(layer, nm, None)
+            if not isinstance(t, torch.Tensor) or t.numel() != Bs * n:
+                continue                                       # (a layer that has never run: Network.run starts it at rest)
+            own = t.reshape(Bs, n).contiguous()
+            if world > 1:
+                allt = gather(own.view(torch.uint8) if own.dtype == torch.bool else own)
+                allt = allt.view(torch.bool) if own.dtype == torch.bool else allt
+            else:
+                allt = own.clone()
+            kept[(name, nm)] = allt.reshape(B, *layer.shape)
+    stash = {}
+    for key, m in network.monitors.items():
+        if not isinstance(m, Monitor):
+            raise NotImplementedError("exact_run: Monitor objects on layers ('s', 'v') are supported")
+        stash[key] = (m.recording, m.clean)
+        m.recording, m.clean = {v: [] for v in m.state_vars}, True
+    network.batch_size = B
+    for name, layer in network.layers.items():
+        layer.set_batch_size(B)
+        for nm in state_names:
+            if (name, nm) in kept:
+                setattr(layer, nm, kept[(name, nm)])
+    try:
+        network.run(full_in, time=T * network.dt)
+    finally:
+        inner = network.__dict__.get("last_plan")
+        network.batch_size = Bs
+        for name, layer in network.layers.items():
+            cur = {nm: getattr(layer, nm, None) for nm in state_names}
+            layer.set_batch_size(Bs)
+            for nm, t in cur.items():
+                if isinstance(t, torch.Tensor) and t.numel() == B * layer.n:
+                    setattr(layer, nm, t.reshape(B, *layer.shape)[lo:hi].clone())
+        for key, m in network.monitors.items():
+            new, (old, clean) = m.recording, stash[key]
+            m.recording, m.clean = old, clean
+            for v in m.state_vars:
+                for chunk in new[v]:
+                    m._append(v, chunk[:, lo:hi].clone())
+    network.__dict__["last_plan"] = "exact-gathered:" + str(inner)
+
+
+def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, comm=None, mode: str = "auto") -> None:
     """network.run() for a batch that is sharded over the ranks of `group`, EXACTLY: `inputs` holds this rank's rows
     (rank r owns rows [r * B_shard, (r + 1) * B_shard) of the global batch), the network is this rank's replica with
     batch size B_shard, and after the call weights, theta, the state of the own rows, monitors and the host generator
     are what the single-process run of the global batch leaves (see the section comment).  Every rank must enter with the
     same weights / theta and the same state of the global generator (torch.manual_seed).  The exchange goes through
     torch.distributed (`group`; RCCL or gloo) or, with `comm` = a parallel.NativeComm, through the C ABI's own RCCL collective
-    snn_dist_allgather_step -- what a caller on the other side of the boundary would use (device tensors only)."""
+    snn_dist_allgather_step -- what a caller on the other side of the boundary would use (device tensors only).
+
+    mode: "per-step" = the schedule of the section comment (one all-gather of the spike bytes per timestep, per-operator launches: a global
+    batch beyond one device's plan); "gathered" = one all-gather of the inputs and the state per run, then the global batch through
+    Network.run on every rank (_exact_gathered: the resident kernel's speed, global batch <= what one device's plan takes); "auto" =
+    gathered where the global batch is at most 32 samples (the resident kernel's), per-step otherwise."""
     from .network.monitors import Monitor
     from .network.nodes import DiehlAndCookNodes, Input
     assert type(inputs) == dict, "'inputs' must be a dict of names of layers (str) and relevant input tensors."
@@ -452,6 +533,16 @@ def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, c
     if T <= 0:
         network._normalize_all()
         return
+    if mode not in ("auto", "gathered", "per-step"):
+        raise ValueError(f"exact_run: mode {mode!r}")
+    if mode == "gathered" or (mode == "auto" and B <= 32 and world > 1):
+
+        def gather2(own):
+            own = own.contiguous()
+            out = torch.empty(world, *own.shape, dtype=own.dtype, device=own.device)
+            exchange(out, own)
+            return out.view(B, *own.shape[1:])
+        return _exact_gathered(network, inputs, T, world, rank, gather2, dev)
     if B > 256 and learned:
         raise NotImplementedError("exact_run: the learning operators take global batches of up to 256 samples")
     u8 = torch.uint8

@@ -771,3 +771,131 @@ ORC_API void orc_mt_exponential(uint32_t *mt, int *pos, float *out, long n)
         out[k] = (float)(-1.0 * log1p(-u));
     }
 }
+
+
+/* ======================================================================================================================
+ * orc_encode_poisson -- the CPU statement of libsnnhip's snn_encode_poisson (csrc/snn_encode.hip): Poisson spike trains in the construction
+ * of bindsnet/encoding/encodings.py:101-152 (intervals ~ Poisson(lambda), lambda = 1 / x * (1000 / dt) in f32, zero intervals bumped to one,
+ * cumulated; time index 0 dropped) from a SPECIFIED counter-based stream.  The reference's own stream cannot be produced in parallel
+ * (ATen's sampler consumes a data-dependent number of generator outputs per element), so this is the one place where the oracle restates
+ * the library's specification instead of the reference's arithmetic; what ties it to the reference is the distribution
+ * (tests/test_gpu_encoding.py: rates and inter-spike intervals against bindsnet.encoding.poisson).  Every operation is an IEEE f32 / f64
+ * add, multiply, divide, f32 sqrt or an integer conversion (built with -ffp-contract=off): exp / log / log k! are the fixed series
+ * below, not libm.
+ *   uniforms: Philox-4x32-10, key = seed, counter = (block, 0, element lo, element hi); a block's four words are used last first;
+ *             u = ((r >> 8) + 1) * 2^-24.   lambda < 30: multiplication method (running f64 product against exp(-lambda));
+ *             otherwise Hoermann's PTRS in f64 with sqrt(lambda) taken in f32.
+ * ====================================================================================================================== */
+typedef struct { uint32_t key[2], ctr[4], out[4]; int have; } pz_philox;
+
+static void pz_block(pz_philox *g)
+{
+    uint32_t c0 = g->ctr[0], c1 = g->ctr[1], c2 = g->ctr[2], c3 = g->ctr[3], k0 = g->key[0], k1 = g->key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    g->out[0] = c0; g->out[1] = c1; g->out[2] = c2; g->out[3] = c3;
+}
+
+static float pz_uniform(pz_philox *g)
+{
+    if (!g->have) { pz_block(g); if (++g->ctr[0] == 0) ++g->ctr[1]; g->have = 4; }
+    const uint32_t r = g->out[--g->have];
+    return ((float)(r >> 8) + 1.0f) * 5.9604644775390625e-08f;
+}
+
+static double pz_floor(double x) { double t = (double)(long long)x; if (t > x) t -= 1.0; return t; }
+
+static double pz_scale(double x, int k)
+{
+    int64_t b; memcpy(&b, &x, 8); b += (int64_t)k << 52; memcpy(&x, &b, 8); return x;
+}
+
+static double pz_exp(double y)
+{
+    const double k = pz_floor(y * 1.4426950408889634 + 0.5);
+    const double r = (y - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0; p = p * r + 1.0 / 39916800.0; p = p * r + 1.0 / 3628800.0; p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0; p = p * r + 1.0 / 5040.0; p = p * r + 1.0 / 720.0; p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0; p = p * r + 1.0 / 6.0; p = p * r + 0.5; p = p * r + 1.0; p = p * r + 1.0;
+    return pz_scale(p, (int)k);
+}
+
+static double pz_log(double x)
+{
+    int64_t bits; memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7FF) - 1023;
+    int64_t mb = (bits & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll;
+    double m; memcpy(&m, &mb, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0; p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0; p = p * z + 1.0 / 9.0; p = p * z + 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z + 1.0 / 3.0; p = p * z + 1.0;
+    return (double)e * 6.93147180559945286227e-01 + 2.0 * s * p;
+}
+
+static double pz_lfact(double k)
+{
+    if (k < 10.0) {
+        double f = 1.0;
+        for (double i = 2.0; i <= k; i += 1.0) f = f * i;
+        return pz_log(f);
+    }
+    const double z = k + 1.0, zi = 1.0 / z, z2 = zi * zi;
+    double c = -1.0 / 1680.0;
+    c = c * z2 + 1.0 / 1260.0; c = c * z2 - 1.0 / 360.0; c = c * z2 + 1.0 / 12.0;
+    return ((z - 0.5) * pz_log(z) - z) + 0.91893853320467278056 + c * zi;
+}
+
+static double pz_sample(pz_philox *g, float lamf)
+{
+    if (!(lamf > 0.f)) return 0.0;
+    const double lam = (double)lamf;
+    if (lamf < 30.f) {
+        const double limit = pz_exp(-lam);
+        double prod = (double)pz_uniform(g), k = 0.0;
+        while (prod > limit) { prod = prod * (double)pz_uniform(g); k += 1.0; }
+        return k;
+    }
+    const double slam = (double)sqrtf(lamf), loglam = pz_log(lam);
+    const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (;;) {
+        const double U = (double)pz_uniform(g) - 0.5, V = (double)pz_uniform(g);
+        const double us = 0.5 - (U < 0.0 ? -U : U);
+        const double k = pz_floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (pz_log(V) + pz_log(invalpha) - pz_log(a / (us * us) + b) <= (k * loglam - lam) - pz_lfact(k)) return k;
+    }
+}
+
+/* out: u8 [steps][n] */
+ORC_API void orc_encode_poisson(const float *datum, long n, int steps, float dt, uint64_t seed, uint8_t *out)
+{
+    for (long i = 0; i < n; ++i) {
+        const float x = datum[i];
+        const float lam = x != 0.f ? 1.0f / x * (1000.0f / dt) : 0.f;
+        pz_philox g;
+        g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32);
+        g.ctr[0] = 0; g.ctr[1] = 0; g.ctr[2] = (uint32_t)(uint64_t)i; g.ctr[3] = (uint32_t)((uint64_t)i >> 32);
+        g.have = 0;
+        long long next = 0;
+        double k = pz_sample(&g, lam);
+        if (x != 0.f && k == 0.0) k = 1.0;
+        next += (long long)k;
+        for (int t = 1; t <= steps; ++t) {
+            uint8_t s = 0;
+            if (x != 0.f) {
+                while (next < t) { k = pz_sample(&g, lam); if (k == 0.0) k = 1.0; next += (long long)k; }
+                if (next == t) s = 1;
+            }
+            out[(size_t)(t - 1) * (size_t)n + (size_t)i] = s;
+        }
+    }
+}

@@ -18,12 +18,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def launch(world, fixture, device, tmp_path, runs=0, timeout=600, threads=2, native=False):
+def launch(world, fixture, device, tmp_path, runs=0, timeout=600, threads=2, native=False, mode="per-step"):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     outs = [str(tmp_path / f"exact_{fixture}_w{world}_r{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "exact_worker.py"), "--rank", str(r), "--world", str(world), "--port", str(port),
-                               "--device", device, "--fixture", fixture, "--runs", str(runs), "--threads", str(threads), "--out", outs[r]] + (["--native"] if native else []),
+                               "--device", device, "--fixture", fixture, "--runs", str(runs), "--threads", str(threads), "--out", outs[r], "--mode", mode] + (["--native"] if native else []),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--runs", type=int, default=0)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--native", action="store_true", help="exchange through the C ABI's own RCCL communicator (parallel.NativeComm)")
+    ap.add_argument("--mode", default="per-step", choices=["per-step", "gathered", "auto"])
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
@@ -76,11 +77,12 @@ def main():
         if a.device == "cuda":
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        parallel.exact_run(net, {"X": shard}, T, comm=comm)
+        parallel.exact_run(net, {"X": shard}, T, comm=comm, mode=a.mode)
         if a.device == "cuda":
             torch.cuda.synchronize()
         out[f"r{r}_seconds"] = time.perf_counter() - t0
-        assert net.last_plan == "exact-sharded"
+        assert net.last_plan == "exact-sharded" or (a.mode != "per-step" and net.last_plan.startswith("exact-gathered:")), net.last_plan
+        out[f"r{r}_plan"] = net.last_plan
         Ae, Ai, X = net.layers["Ae"], net.layers["Ai"], net.layers["X"]
         out[f"r{r}_sX"] = np.packbits(host(mons["X"].get("s")).astype(np.uint8))
         out[f"r{r}_sE"] = np.packbits(host(mons["Ae"].get("s")).astype(np.uint8))

@@ -311,3 +311,22 @@ def test_bench_prints_an_error_line_when_a_stage_hangs():
                        env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, timeout=200)
     assert res.returncode != 0 and line is not None, (res.stdout[-1500:], res.stderr[-2000:])
     assert line["value"] is None and "error" in line and line["stage"] == "init_process_group" and line["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_cfg3_leg_both_multi_gpu_modes(world):
+    """`python bench.py --config cfg3 --gpus N [--backend gloo]` (BASELINE.json configs[2]: TwoLayerNetwork 784 -> 1600, global batch 128): the
+    north-star schedule (batch shards + one all-reduce of the deltas per input) as `value`, the exact column-sharded mode beside it, one JSON
+    line of the headline's schema -- with N = 2 both ranks on the one GPU of the box (gloo), what an 8-GPU node runs with `--gpus 8`."""
+    args = ["--config", "cfg3", "--gpus", str(world), "--steps", "3", "--warmup", "1"] + (["--backend", "gloo"] if world > 1 else [])
+    res, line = _bench(args)
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line.get("error") is None, line
+    assert line["n_gpus"] == world and line["steps"] == 3 and line["scaling"] == "strong" and line["unit"] == "timesteps/s"
+    assert line["config"]["global_batch"] == 128 and line["config"]["batch_per_gpu"] == 128 // world and line["config"]["plan"] == "twolayer-fused"
+    assert abs(line["value"] - 3 * 100 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3
+    ex = line["exact_column_shard"]
+    assert ex["value"] > 0 and ex["collectives_during_the_run"] == 0 and ex["plan"] == "twolayer-fused" and ex["batch_per_gpu"] == 128
+    assert ex["columns_of_rank0"] == ([0, 1600] if world == 1 else [0, 800])
+    if world > 1:
+        assert line["config"]["per_input_collective"]["bytes"] == 784 * 1600 * 4

@@ -23,3 +23,19 @@ def test_exact_mode_two_ranks_on_one_gpu(tmp_path):
     name = "full_cfg2_dc_n400_b32_poisson"
     res = H.launch(2, name, "cuda", tmp_path, timeout=240)
     H.check_against_reference(res, name)
+
+
+def test_exact_gathered_mode_two_ranks_on_one_gpu_runs_the_resident_kernel(tmp_path):
+    """exact_run(mode="auto") at a global batch of 32: one all-gather of the inputs and the state per run, then BOTH ranks run the global batch
+    through the resident D&C kernel (one launch per run) and keep their 16 rows -- == the reference's single-process global batch of
+    BASELINE cfg2's stated input (three consecutive inputs: rasters, weights, theta, membrane state, traces, generator position), at the
+    single-GPU kernel's speed instead of the per-step schedule's 2.3 k timesteps/s (round 5)."""
+    import exact_harness as H
+    name = "full_cfg2_dc_n400_b32_poisson"
+    res = H.launch(2, name, "cuda", tmp_path, timeout=240, mode="auto")
+    H.check_against_reference(res, name)
+    for r in res:
+        assert str(r["r0_plan"]).startswith("exact-gathered:dc2015-resident"), str(r["r0_plan"])
+        # (two processes share the one GPU here, each running the whole batch: still >= 20x the per-step schedule)
+        rate = 250 / float(r["r2_seconds"])
+        assert rate > 20000, f"{rate:.0f} timesteps/s"

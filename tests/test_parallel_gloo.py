@@ -280,6 +280,17 @@ def test_exact_batch_sharded_mode_equals_the_reference_global_batch(world, fixtu
     H.check_against_reference(res, fixture)
 
 
+@pytest.mark.parametrize("world,fixture", [(2, "run_dc_n400_b4"), (3, "run_dc_n100_b3_busy")])
+def test_exact_gathered_mode_equals_the_reference_global_batch(world, fixture, tmp_path):
+    """exact_run(mode="gathered"): ONE all-gather of the inputs and the layer state per run, then the global batch through Network.run on
+    every rank (here the host path; on the MI355X the resident kernel) -- rows side by side == the reference's single-process global batch,
+    bit for bit, like the per-step schedule above, incl. the state carried from the first input into the second without a reset."""
+    import exact_harness as H
+    res = H.launch(world, fixture, "cpu", tmp_path, mode="gathered")
+    H.check_against_reference(res, fixture)
+    assert all(str(r["r0_plan"]).startswith("exact-gathered:") for r in res)
+
+
 def test_exact_batch_sharded_mode_full_cfg2_world4(tmp_path):
     """The same at BASELINE cfg2's full size on BASELINE.md's stated input: DiehlAndCook2015 784 -> 400, B = 32 = 4 ranks x 8,
     T = 250, three consecutive inputs, against the reference's single-process run (full_cfg2_dc_n400_b32_poisson)."""

@@ -15,9 +15,9 @@ CONFIGS = {
                        what="TwoLayerNetwork 784->1600, B=16 (one GPU's share of cfg3 over 8), T=100, PostPre"),
     "cfg3_b32": dict(T=100, T_cpu=20, B=32, algo_bytes=4 * 3 * 784 * 1600 + 32 * (784 * 10 + 1600 * 26), kw={},
                      what="TwoLayerNetwork 784->1600, B=32, T=100, PostPre"),
-    "cfg3": dict(T=100, T_cpu=20, n_cpu=1, B=128, algo_bytes=21_400_000, kw={}, what="TwoLayerNetwork 784->1600, B=128, T=100, PostPre (whole batch on one GPU)"),
+    "cfg3": dict(T=100, T_cpu=20, n_cpu=3, B=128, algo_bytes=21_400_000, kw={}, what="TwoLayerNetwork 784->1600, B=128, T=100, PostPre (whole batch on one GPU)"),
     "cfg4": dict(T=250, T_cpu=50, B=64, algo_bytes=20_100_000, kw={}, what="Conv2dConnection 28x28 -> 32 filters 5x5 -> LIF, B=64, T=250, no learning"),
-    "cfg5": dict(T=100, T_cpu=20, n_cpu=1, B=16, algo_bytes=40_400_000, kw={"reward": 1.0}, what="Input 6400 -> Connection(MSTDP) -> 500 LIF, B=16, T=100, reward 1.0"),
+    "cfg5": dict(T=100, T_cpu=20, n_cpu=3, B=16, algo_bytes=40_400_000, kw={"reward": 1.0}, what="Input 6400 -> Connection(MSTDP) -> 500 LIF, B=16, T=100, reward 1.0"),
 }
 
 
