@@ -726,6 +726,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     }
     long long mk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
     (void)mk;
+    bool prev_anyx = true;                                    // the previous iteration had a crossing in this workgroup (uniform)
     for (int t = 0; t <= T; ++t) {
         const bool phaseB = t < T;
         const int par = t & 1;
@@ -753,7 +754,8 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         if (ctl[0]) { bad = true; break; }                                // (written in front of barrier B)
         AMARK(9);
         uint32_t wonm = 0;                                                // own columns that won at step t-1: their won branch is what happened
-        if (learn_pp) {
+        if (learn_pp && prev_anyx) {                                      // (only an iteration behind a crossing can find a bit there: four LDS reads less in front of the
+                                                                          //  membrane stage otherwise -- round 6, same-box A/B: 912 -> 896 us per launch)
 #pragma unroll
             for (int q = 0; q < CW; ++q) wonm |= (__builtin_amdgcn_readfirstlane((int)colmask[par * CW + q]) != 0 ? 1u : 0u) << q;
         }
@@ -909,6 +911,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < CW; ++q) xq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colx[par * CW + q]);
         const bool crossed_wg = do_stdp && (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
+        prev_anyx = (xq[0] | xq[1] | xq[2] | xq[3]) != 0u;
         if (crossed_wg && PENDING(2)) {                                   // (producer workgroups: a crossing in the launch's first ~50 us)
             bool all = false;
             if (need_xtr(cold(c), all) != 1) { ctl[0] = 1; report(cold(c).status, SNN_ERR_TIMEOUT); }

@@ -17,6 +17,8 @@ import contextlib
 import threading
 from typing import Optional
 
+import os
+
 import torch
 
 _ENCODER_THREADS = 4
@@ -113,6 +115,12 @@ def poisson(datum: torch.Tensor, time: int, dt: float = 1.0, device="cpu", appro
     intervals bumped to one), cumulated into spike times (encodings.py:101-152)."""
     assert (datum >= 0).all(), "Inputs must be non-negative"
     shape, size = datum.shape, datum.numel()
+    if torch.device(device).type == "cpu" and os.environ.get("SNN_ENCODE_DEVICE") and not approx:
+        # A script that builds PoissonEncoder(time, dt) without a device (examples/mnist/eth_mnist.py:103-112 encodes every sample on the host
+        # inside the DataLoader) gets the device encoder without being edited: SNN_ENCODE_DEVICE=cuda.  Opt-in: the device stream is a
+        # specified one of its own (poisson_device), not the reference's CPU generator's.  The result comes back where the caller asked for it
+        # (the host: the script's DataLoader pins it and the script moves it with .cuda() -- two 196 KB copies against 3.7 ms of host encoding).
+        return poisson_device(datum, time, dt=dt, device=os.environ["SNN_ENCODE_DEVICE"], **kwargs).to(device)
     if torch.device(device).type == "cuda":
         return poisson_device(datum, time, dt=dt, device=device, **kwargs)
     with _few_threads():
@@ -145,10 +153,13 @@ def poisson_device(datum: torch.Tensor, time: int, dt: float = 1.0, device="cuda
     ~ Poisson(1000 / (x dt)), zeros bumped to one, cumulated -- one thread per input element walking its own spike
     times, from a counter-based stream keyed by (seed, element).  NOT stream-compatible with the reference's CPU
     generator: `seed` defaults to one draw from the global CPU generator (so torch.manual_seed still makes runs
-    repeatable).  Distributional agreement with the host path is tested in tests/test_gpu_encoding.py."""
+    repeatable).  The stream is specified operation by operation (csrc/snn_encode.hip) and restated on the CPU
+    (oracle/snn_oracle.c: orc_encode_poisson): tests/test_gpu_encoding.py compares the two bit for bit, and both with
+    the host path's distribution."""
     from ..ops import encode_poisson
     assert (datum >= 0).all(), "Inputs must be non-negative"
     if seed is None:
+        _settle_sections()                                    # (one draw from the host generator: an open pipelined() section holds its state)
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
     steps = int(time / dt)
     return encode_poisson(datum.flatten(), steps, dt, seed, device).view(steps, *datum.shape)

@@ -418,37 +418,62 @@ def _exact_gathered(network, inputs, T, world, rank, gather, dev):
     any world size (the per-step mode: 2.3 k timesteps/s at world 2), bit-identical to the single-process global batch by construction
     (same kernel, same operands, same draws from identically seeded generators).  What it does not buy is capacity: the global batch
     must fit one device's plan (B <= 32 for the resident kernel, 256 for the generic plan) -- beyond that `per-step` is the mode."""
+    import os
+    import time as _time
     from .network.monitors import Monitor
-    from .network.nodes import Input
     Bs = network.batch_size
     B, lo = Bs * world, rank * Bs
     hi = lo + Bs
-    full_in = {}
+    u8 = torch.uint8
+    timing = os.environ.get("SNN_EXACT_TIMING") == "1"          # developer aid: where a gathered run's wall time goes (device-synchronised marks)
+    marks = []
+
+    def mark(what):
+        if timing:
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            marks.append((what, _time.perf_counter()))
+    mark("start")
+    # ---- ONE exchange per run: [bit-packed input spike trains | per-sample state of every layer] of the own rows as one byte string
+    pieces, layout = [], []                                    # layout: (kind, key, dtype, shape of the own part)
     for name, x in inputs.items():
         x = x.to(dev).contiguous()
         n = x[0].numel() // Bs
-        flat = (x.view(torch.uint8) if x.dtype == torch.bool else x)[:T].reshape(T, Bs, n)
-        if world == 1:
-            allx = flat
-        else:
-            allx = gather(flat.permute(1, 0, 2).contiguous().view(Bs, T * n)).view(B, T, n).permute(1, 0, 2).contiguous()
-        full_in[name] = allx.view(T, B, *x.shape[2:])
-    # per-sample state of every layer: the rows of all ranks side by side, in rank order
+        flat = (x.view(u8) if x.dtype == torch.bool else x)[:T].reshape(T, Bs, n)
+        if flat.dtype != u8 or bool((flat > 1).any()):
+            raise NotImplementedError("exact_run (gathered): input spike trains must be 0/1 bytes")
+        npad = (-n) % 8
+        bits = torch.nn.functional.pad(flat, (0, npad)) if npad else flat
+        packed = (bits.view(T, Bs, -1, 8) * torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=u8, device=dev)).sum(-1, dtype=torch.int32).to(u8)
+        pieces.append(packed.permute(1, 0, 2).reshape(Bs, -1))   # rows of a sample together: [Bs, T * ceil(n / 8)]
+        layout.append(("in", name, x.shape[2:], n))
     state_names = ("s", "x", "v", "refrac_count")
-    kept = {}
-    for name, layer in network.layers.items():                 # (identical replicas: every rank has the same tensors allocated, so the same collectives)
+    for name, layer in network.layers.items():                 # (identical replicas: every rank has the same tensors allocated, so the same layout)
         n = layer.n
         for nm in state_names:
             t = getattr(layer, nm, None)
             if not isinstance(t, torch.Tensor) or t.numel() != Bs * n:
                 continue                                       # (a layer that has never run: Network.run starts it at rest)
             own = t.reshape(Bs, n).contiguous()
-            if world > 1:
-                allt = gather(own.view(torch.uint8) if own.dtype == torch.bool else own)
-                allt = allt.view(torch.bool) if own.dtype == torch.bool else allt
-            else:
-                allt = own.clone()
-            kept[(name, nm)] = allt.reshape(B, *layer.shape)
+            pieces.append((own.view(u8) if own.dtype == torch.bool else own.view(u8)).reshape(Bs, -1))
+            layout.append(("state", (name, nm), own.dtype, n))
+    own_bytes = torch.cat(pieces, dim=1).contiguous()          # [Bs, bytes per sample]
+    mark("packed")
+    allb = gather(own_bytes) if world > 1 else own_bytes        # [B, bytes per sample], rows in rank order
+    mark("exchanged")
+    full_in, kept, off = {}, {}, 0
+    for kind, key, a, n in layout:
+        if kind == "in":
+            w = T * ((n + 7) // 8)
+            pk = allb[:, off:off + w].reshape(B, T, -1)
+            off += w
+            bits = ((pk.unsqueeze(-1) >> torch.arange(8, device=dev, dtype=u8)) & 1).reshape(B, T, -1)[:, :, :n]
+            full_in[key] = bits.permute(1, 0, 2).contiguous().view(T, B, *a)
+        else:
+            name, nm = key
+            w = n * (1 if a in (torch.bool, u8) else 4)
+            kept[key] = allb[:, off:off + w].contiguous().view(a).reshape(B, *network.layers[name].shape).clone()
+            off += w
     stash = {}
     for key, m in network.monitors.items():
         if not isinstance(m, Monitor):
@@ -461,8 +486,10 @@ def _exact_gathered(network, inputs, T, world, rank, gather, dev):
         for nm in state_names:
             if (name, nm) in kept:
                 setattr(layer, nm, kept[(name, nm)])
+    mark("state set")
     try:
         network.run(full_in, time=T * network.dt)
+        mark("run")
     finally:
         inner = network.__dict__.get("last_plan")
         network.batch_size = Bs
@@ -479,6 +506,9 @@ def _exact_gathered(network, inputs, T, world, rank, gather, dev):
                 for chunk in new[v]:
                     m._append(v, chunk[:, lo:hi].clone())
     network.__dict__["last_plan"] = "exact-gathered:" + str(inner)
+    mark("restored")
+    if timing:
+        network.__dict__["_exact_timing"] = {b[0]: round((b[1] - a[1]) * 1e3, 3) for a, b in zip(marks, marks[1:])}
 
 
 def exact_run(network, inputs: Dict[str, torch.Tensor], time: int, group=None, comm=None, mode: str = "auto") -> None:

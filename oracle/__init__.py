@@ -255,6 +255,17 @@ def run_two_layer(P: TwoParams, st: dict, inputs, I_forced=None, bias=None):
     return ras
 
 
+def encode_poisson(datum: np.ndarray, steps: int, dt: float = 1.0, seed: int = 0) -> np.ndarray:
+    """orc_encode_poisson: libsnnhip's snn_encode_poisson restated (specified stream: Philox-4x32-10 + fixed-series sampler) -> u8 [steps, n]."""
+    x = np.ascontiguousarray(datum, f32).reshape(-1)
+    out = np.zeros((steps, x.size), u8)
+    fn = lib().orc_encode_poisson
+    fn.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_uint64, C.c_void_p]
+    fn.restype = None
+    fn(_p(x, f32), x.size, int(steps), float(dt), int(seed) & ((1 << 64) - 1), _p(out, u8))
+    return out
+
+
 def mt_exponential(mt_state: np.ndarray, pos: int, n: int):
     """mt_state: uint32[624] (modified in place); pos in [0,624]. Returns (float32[n], new_pos)."""
     out = np.empty(n, f32)

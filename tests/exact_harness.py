@@ -33,6 +33,8 @@ def launch(world, fixture, device, tmp_path, runs=0, timeout=600, threads=2, nat
             p.kill()
             logs.append("timeout")
     assert [p.returncode for p in procs] == [0] * world, "\n".join(logs)[-4000:]
+    if os.environ.get("SNN_EXACT_TIMING") == "1":
+        print("\n".join(l for log in logs for l in log.splitlines() if l.startswith("rank ")))
     return [np.load(o) for o in outs]
 
 

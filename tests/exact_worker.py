@@ -83,6 +83,8 @@ def main():
         out[f"r{r}_seconds"] = time.perf_counter() - t0
         assert net.last_plan == "exact-sharded" or (a.mode != "per-step" and net.last_plan.startswith("exact-gathered:")), net.last_plan
         out[f"r{r}_plan"] = net.last_plan
+        if net.__dict__.get("_exact_timing"):
+            print(f"rank {a.rank} run {r}: {out[f'r{r}_seconds'] * 1e3:.2f} ms", net.__dict__["_exact_timing"], flush=True)
         Ae, Ai, X = net.layers["Ae"], net.layers["Ai"], net.layers["X"]
         out[f"r{r}_sX"] = np.packbits(host(mons["X"].get("s")).astype(np.uint8))
         out[f"r{r}_sE"] = np.packbits(host(mons["Ae"].get("s")).astype(np.uint8))

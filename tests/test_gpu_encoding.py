@@ -87,3 +87,40 @@ def test_poisson_device_matches_host_distribution():
     b = poisson(x.clone(), time=T, device=DEV)
     torch.manual_seed(3)
     assert torch.equal(b, poisson(x.clone(), time=T, device=DEV))
+
+
+def test_poisson_device_equals_the_oracle_restatement_bit_for_bit():
+    """snn_encode_poisson's stream is specified operation by operation (csrc/snn_encode.hip); oracle/snn_oracle.c restates it in plain C
+    (orc_encode_poisson).  Same seeds, same data -> the same spike trains, bit for bit: all three sampler branches (lambda < 30 by the
+    multiplication method, lambda >= 30 by PTRS incl. its log / log k! rejection test, x = 0), several dt, several seeds, a size that is not a
+    multiple of the launch's block."""
+    import oracle
+    from bindsnet_amd.encoding import poisson_device
+    rng = np.random.default_rng(11)
+    levels = np.concatenate([np.array([0.0, 0.3, 1.0, 2.0, 5.0, 8.0, 20.0, 33.0, 33.4, 40.0, 64.0, 128.0, 255.0, 1000.0, 5000.0], np.float32),
+                             (255.0 * rng.random(986)).astype(np.float32)])          # 1001 elements
+    for dt, T, seed in ((1.0, 250, 7), (0.5, 100, 2 ** 40 + 3), (2.0, 300, 0)):
+        steps = int(T / dt)
+        dev = poisson_device(T_(levels.copy()), time=T, dt=dt, device=DEV, seed=seed).cpu().numpy()
+        ref = oracle.encode_poisson(levels, steps, dt, seed)
+        assert dev.shape == ref.shape == (steps, levels.size)
+        assert int(ref.sum()) > 1000
+        np.testing.assert_array_equal(dev, ref, err_msg=f"dt {dt}, seed {seed}")
+
+
+def test_poisson_encoder_object_and_environment_route_to_the_device(monkeypatch):
+    """PoissonEncoder(time, dt, device="cuda") -- and, for a script that builds it without a device (examples/mnist/eth_mnist.py), the
+    environment switch SNN_ENCODE_DEVICE=cuda -- encode on the MI355X: a tensor of the reference's shape (on the device asked for: the
+    switch hands a host tensor back, which the script's DataLoader may pin), repeatable under torch.manual_seed (the stream's seed is one
+    draw from the host generator)."""
+    from bindsnet_amd.encoding import PoissonEncoder
+    img = T_(synth.uniform_f32(9, (1, 28, 28), 0.0, 128.0))
+    torch.manual_seed(4)
+    a = PoissonEncoder(time=250, dt=1.0, device=DEV)(img.clone())
+    assert a.is_cuda and a.shape == (250, 1, 28, 28) and a.dtype == torch.uint8 and int(a.sum()) > 0
+    monkeypatch.setenv("SNN_ENCODE_DEVICE", DEV)
+    torch.manual_seed(4)
+    b = PoissonEncoder(time=250, dt=1.0)(img.clone())
+    assert not b.is_cuda and torch.equal(a.cpu(), b)          # (encoded on the device, handed back where the caller asked for it)
+    monkeypatch.delenv("SNN_ENCODE_DEVICE")
+    assert not PoissonEncoder(time=250, dt=1.0)(img.clone()).is_cuda

@@ -36,6 +36,7 @@ def test_exact_gathered_mode_two_ranks_on_one_gpu_runs_the_resident_kernel(tmp_p
     H.check_against_reference(res, name)
     for r in res:
         assert str(r["r0_plan"]).startswith("exact-gathered:dc2015-resident"), str(r["r0_plan"])
-        # (two processes share the one GPU here, each running the whole batch: still >= 20x the per-step schedule)
-        rate = 250 / float(r["r2_seconds"])
-        assert rate > 20000, f"{rate:.0f} timesteps/s"
+    # the rank that reaches the run's one collective LAST measures what a run costs (the other one's time contains its wait for the peer, whose
+    # worker packs and stores its outputs between the runs); two processes share the one GPU here, each running the whole batch
+    rate = 250 / min(float(r["r2_seconds"]) for r in res)
+    assert rate > 20000, f"{rate:.0f} timesteps/s"

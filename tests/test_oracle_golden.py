@@ -540,3 +540,40 @@ def test_conv2d_normalize_matches_reference():
         W = synth.uniform_f32(3300 + k, (Cout, Cin, K, K), 0.05, 1.0)
         oracle.normalize_conv2d(W, np.float32(0.4 * K * K))
         np.testing.assert_array_equal(bits(W), bits(g[f"w{k}"]), err_msg=f"case {k}")
+
+
+def test_oracle_poisson_encoder_has_the_reference_encoders_distribution():
+    """orc_encode_poisson restates libsnnhip's SPECIFIED stream (the reference's own stream cannot be produced in parallel), so what ties it
+    to the reference is the distribution: firing rates and inter-spike intervals against bindsnet.encoding.poisson's construction
+    (encodings.py:101-152: torch.poisson intervals, zeros bumped to one, cumulated) at seven intensities, and determinism per seed."""
+    import torch
+    import oracle
+    from bindsnet_amd.encoding import poisson
+    T, reps, per = 250, 40, 64
+    levels = np.array([0.0, 2.0, 8.0, 32.0, 64.0, 128.0, 255.0], np.float32)
+    x = np.repeat(levels, per)
+    torch.manual_seed(1)
+    host = np.stack([poisson(torch.from_numpy(x.copy()), time=T).numpy() for _ in range(reps)]).astype(np.float64)      # [reps, T, n]
+    orc = np.stack([oracle.encode_poisson(x, T, 1.0, seed=1000 + r) for r in range(reps)]).astype(np.float64)
+    for li, lv in enumerate(levels):
+        h, d = host[:, :, li * per:(li + 1) * per], orc[:, :, li * per:(li + 1) * per]
+        if lv == 0:
+            assert h.sum() == 0 and d.sum() == 0
+            continue
+        rh, rd = h.mean(), d.mean()
+        assert abs(rh - rd) <= 4 * np.sqrt(max(rh, 1e-6) / (reps * T * per)) + 0.01 * rh, f"intensity {lv}: host rate {rh:.5f}, oracle rate {rd:.5f}"
+
+        def isi(a):
+            out = []
+            for r in range(8):
+                for e in range(16):
+                    t = np.nonzero(a[r, :, e])[0]
+                    if len(t) > 2:
+                        out.append(np.diff(t))
+            return np.concatenate(out) if out else np.zeros(1)
+        ih, io = isi(h), isi(d)
+        if len(ih) > 200 and len(io) > 200:
+            assert abs(ih.mean() - io.mean()) <= 0.06 * ih.mean() + 0.1, f"intensity {lv}: ISI mean"
+            assert abs(ih.std() - io.std()) <= 0.12 * ih.std() + 0.15, f"intensity {lv}: ISI spread"
+    a = oracle.encode_poisson(x, T, 1.0, seed=5)
+    assert np.array_equal(a, oracle.encode_poisson(x, T, 1.0, seed=5)) and not np.array_equal(a, oracle.encode_poisson(x, T, 1.0, seed=6))

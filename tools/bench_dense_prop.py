@@ -46,7 +46,11 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only-mfma", action="store_true")
     ap.add_argument("--only-event", action="store_true")
+    ap.add_argument("--density", type=float, default=None, help="the two learning shapes (cfg3 whole batch, cfg5) at THIS input density instead of the stated ones "
+                    "(tools/r06_density_map.sh: the MFMA-vs-event map over 1 / 5 / 20 / 50 %)")
     a = ap.parse_args()
+    if a.density is not None:
+        SHAPES = [("cfg3 whole batch", 128, 784, 1600, a.density), ("cfg5", 16, 6400, 500, a.density)]
     for name, B, Nin, N, dens in SHAPES:
         W = torch.from_numpy(synth.uniform_f32(1, (Nin, N), 0.0, 0.3)).to(DEV)
         s = torch.from_numpy(synth.dense_spikes(2, (B, Nin), dens)).to(DEV)

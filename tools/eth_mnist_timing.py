@@ -43,7 +43,11 @@ def main():
     ap.add_argument("--n_neurons", type=int, default=100)
     ap.add_argument("--update_interval", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--encode-device", default=None, help="amd: SNN_ENCODE_DEVICE for the run -- PoissonEncoder(time, dt), as the script builds it, "
+                    "then encodes on that device (the specified Philox stream, not the host generator's)")
     args = ap.parse_args()
+    if args.encode_device:
+        os.environ["SNN_ENCODE_DEVICE"] = args.encode_device
 
     os.environ["MPLBACKEND"] = "Agg"
     import matplotlib
@@ -141,7 +145,7 @@ def main():
     other = total - sum(v[0] for v in acc.values())
     out = {
         "script": "examples/mnist/eth_mnist.py (literal file, sha256 " + REF_SHA[:16] + "...)", "impl": args.impl,
-        "argv": argv, "device": str(next(iter(net.layers.values())).s.device) if hasattr(net.layers["Ae"], "s") else None,
+        "argv": argv, "encode_device": os.environ.get("SNN_ENCODE_DEVICE", "cpu (the host generator's stream: the reference's)"), "device": str(next(iter(net.layers.values())).s.device) if hasattr(net.layers["Ae"], "s") else None,
         "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(),
         "samples_run": n_samples, "timesteps_per_sample": 250,
         "wall_s": round(total, 3), "samples_per_s": round(n_samples / total, 3),
