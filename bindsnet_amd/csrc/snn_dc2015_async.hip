@@ -347,49 +347,30 @@ __device__ __forceinline__ void scan_entry(const DcCtx &c, int *w0, int *cnt0, i
     __syncthreads();
 }
 
-// Winner column of sample `myb` at step e (-1: none) from the arbiter's granules; every lane of the wave polls the same words.
-// e = -1 / -2: the entry spikes (scan_entry).  bad: set on an abort mark or when the poll gives up.  The first TWO granules (six
-// winners: all of them in 97 % of the steps at cfg2) are asked for together -- a second round trip only beyond that --, and the
-// caller may have loaded them earlier (pre: valid if the tag is).
+// Winner column of sample `myb` at step e (-1: none) from the arbiter's granules.  e = -1 / -2: the entry spikes (scan_entry).  bad: set on an
+// abort mark or when the poll gives up.  Round 6: the step's kWinGr granules are indexed BY SAMPLE -- granule k holds the entries of samples
+// 3k .. 3k+2 (0xFFFF: no winner) --, so a lane loads the one granule of its sample and takes its field: a shift and a compare where the list
+// form (round 4: entries in the order of the crossing samples) walked up to six entries per lane in front of every membrane stage -- the
+// stretch every crossing chain runs through.  The caller may have loaded the granule earlier (pre: valid if the tag is).
 constexpr int kWinPollSleep = 1;       // s_sleep between two polls of the winners granules (other values measured: profiles/r04_async_sensitivity.txt)
-struct WinPre { unsigned long long g0, g1; bool have; };
-__device__ __forceinline__ WinPre win_prefetch(const DcCtx &c, int e) {
-    const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
-    WinPre p; p.g0 = granule_load(gr); p.g1 = granule_load(gr + 1); p.have = true;
+struct WinPre { unsigned long long g0; bool have; };
+__device__ __forceinline__ WinPre win_prefetch(const DcCtx &c, int e, int myb) {
+    WinPre p; p.g0 = granule_load(c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr + myb / 3); p.have = true;
     return p;
 }
-__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad, WinPre pre = WinPre{0ull, 0ull, false}) {
+__device__ __forceinline__ int sample_winner(const DcCtx &c, const int *w0, int e, int myb, bool &bad, WinPre pre = WinPre{0ull, false}) {
     if (e < 0) return w0[(e == -1 ? 0 : MAXB) + myb];
-    const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr;
+    const unsigned long long *gr = c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr + myb / 3;
     const uint32_t tag = win_tag(e);
-    unsigned long long x0, x1;
-    if (pre.have) { x0 = pre.g0; x1 = pre.g1; } else { x0 = granule_load(gr); x1 = granule_load(gr + 1); }
-    for (unsigned spins = 0; (uint32_t)(x0 >> 54) != tag; ++spins) {
+    unsigned long long x0 = pre.have ? pre.g0 : granule_load(gr);
+    for (unsigned spins = 0; __any((uint32_t)(x0 >> 54) != tag); ++spins) {
         if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); return -1; }
         __builtin_amdgcn_s_sleep(kWinPollSleep);
-        x0 = granule_load(gr); x1 = granule_load(gr + 1);
+        x0 = granule_load(gr);
     }
-    const int nw = (int)((x0 >> 48) & 63u);
-    if (nw == 63) { bad = true; return -1; }
-    int res = -1;
-    auto entries = [&](unsigned long long x) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const uint32_t w = (uint32_t)(x >> (16 * u)) & 0xFFFFu;
-            if (w != 0xFFFFu && (int)(w >> 11) == myb) res = (int)(w & 0x7FFu);
-        }
-    };
-    entries(x0);
-    for (int k = 1; 3 * k < nw; ++k) {
-        unsigned long long x = k == 1 ? x1 : granule_load(gr + k);
-        for (unsigned spins = 0; (uint32_t)(x >> 54) != tag; ++spins) {
-            if (spins > kAPoll) { bad = true; report(cold(c).status, SNN_ERR_TIMEOUT); return -1; }
-            __builtin_amdgcn_s_sleep(1);
-            x = granule_load(gr + k);
-        }
-        entries(x);
-    }
-    return res;
+    if (__any((int)((x0 >> 48) & 63u) == 63)) { bad = true; return -1; }       // (an abort mark sits in every granule of the step)
+    const uint32_t w = (uint32_t)(x0 >> (16 * (myb % 3))) & 0xFFFFu;
+    return w == 0xFFFFu ? -1 : (int)(w & 0x7FFu);
 }
 
 // developer aid (SNN_DC_TIMING=<workgroup>): 100 MHz wall-clock marks of one compute workgroup per step, [T+1][24]; behind
@@ -715,7 +696,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     bool crossed_prev = false;                                // ... and its crossing
     unsigned long long prevE = 0ull;                          // tile waves: crossing ballot of the previous step
     int published = 0;                                        // steps this (tile) wave has published
-    WinPre pre_w = WinPre{0ull, 0ull, false};                 // tile waves: winners granules asked for ahead of their use
+    WinPre pre_w = WinPre{0ull, false};                       // tile waves: the sample's winners granule asked for ahead of its use
     const bool learn_pp = c.learning && c.rule == SNN_RULE_POSTPRE;
 
     if constexpr (TIMING) {      // where this workgroup runs: XCC_ID, HW_ID (wave / simd / cu / sh / se) -> the row behind the last step
@@ -901,7 +882,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
         // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front
         // of the digest's LDS stores, which wait for every outstanding load: 0.4 us per iteration, more on some workgroups)
-        if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1); }
+        if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1, min(bl, B - 1)); }
         // ---- a workgroup that crossed at step t prepares the WON BRANCH of its crossing columns while the arbiter works: each such column
         //      as it is with its final spike(s) of step t, every row from the old weights.  First the rows this step's X spikes touch --
         //      the only rows the X currents of step t+1 read --, then the currents of both branches in ONE pass, then (waves 2..7,
@@ -1273,9 +1254,11 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
         // is waiting for (its own resolution of e+1 in front of the inhibition of e), and their ring slots are free (the raster
         // writers are done with step e-6 when step e is published)
         auto publish_abort = [&](int e0) __attribute__((always_inline)) {
-            if (lane < 3)
-                granule_store(c.wing + (size_t)((e0 + lane) & (kWinRing - 1)) * kWinGr,
-                              ((unsigned long long)win_tag(e0 + lane) << 54) | (63ull << 48) | 0xFFFFFFFFFFFFull);
+            if (lane < 3 * kWinGr) {                                      // (every granule of the three steps: a reader looks at its sample's)
+                const int de = lane / kWinGr, k = lane - de * kWinGr;
+                granule_store(c.wing + (size_t)((e0 + de) & (kWinRing - 1)) * kWinGr + k,
+                              ((unsigned long long)win_tag(e0 + de) << 54) | (63ull << 48) | 0xFFFFFFFFFFFFull);
+            }
         };
         // the raster writers must be done with the step whose ring slot step e0 (and an abort mark's two steps behind it) takes: progress >= e0 - 5
         auto raster_wait = [&](int e0, int rp) __attribute__((always_inline)) -> bool {
@@ -1385,8 +1368,8 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 publish_abort(e);
                 break;
             }
-            // ---- pack: entry r of the list = (sample << 11) | column of the r-th crossing sample
-            if (lane < B && myc > 0) winlist[__popc(anym & ((1u << lane) - 1u))] = (lane << 11) | (mywin & 0x7FF);
+            // ---- pack: the entry of sample b = (b << 11) | its winner's column, 0xFFFF without one
+            if (lane < 32) winlist[lane] = (lane < B && myc > 0) ? ((lane << 11) | (mywin & 0x7FF)) : 0xFFFF;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the raster writers must be done with the step whose ring slot this one takes (progress read at the start of the step)
             if (raster_wait(e, rp)) {
@@ -1395,14 +1378,13 @@ __device__ __forceinline__ void async_arbiter(const DcCtx &c, unsigned char *sme
                 failed = true;
                 break;
             }
-            // (all kWinGr granules of the slot, not just the ceil(arb_rows / 3) that hold winners: the tag has 10 bits, so a granule this step left alone
-            //  could still carry the tag of step e - 1024 m -- or the run's initial zero, which is win_tag(1023))
+            // (granule k <-> samples 3k .. 3k+2; every granule of the slot carries the step's tag and the number of winners)
             if (lane < kWinGr) {
                 unsigned long long pl = 0;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int idx = 3 * lane + u;
-                    const unsigned long long wv = idx < arb_rows ? (unsigned long long)(uint32_t)winlist[idx] : 0xFFFFull;
+                    const int idx = 3 * lane + u;                         // sample
+                    const unsigned long long wv = idx < 32 ? (unsigned long long)(uint32_t)winlist[idx] : 0xFFFFull;
                     pl |= wv << (16 * u);
                 }
                 granule_store(c.wing + (size_t)(e & (kWinRing - 1)) * kWinGr + lane,

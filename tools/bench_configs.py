@@ -100,7 +100,7 @@ def parity(name, xs, Tc, rec, kw):
 
 def roofline(name, T):
     """From the committed rocprofv3 summary of this same command (tools/profile_round.sh -> profiles/r05_roofline_summary_all_configs.json)."""
-    for f in ("r05_roofline_summary_all_configs.json", "r04_roofline_summary_all_configs.json"):
+    for f in ("r06_roofline_summary_all_configs.json", "r05_roofline_summary_all_configs.json", "r04_roofline_summary_all_configs.json"):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             d = json.load(open(path)).get(name)
