@@ -254,8 +254,11 @@ int snn_normalize_conv2d(float *W, int n_filters, int taps, float norm, snn_stre
  * datum.repeat([steps, 1])) draws from the HOST generator whose state is in *rng -- one 32-bit mt19937 output
  * per element, u = (r & 0xFFFFFF) * 2^-24 < p -- bit for bit; *rng is advanced by steps * n outputs.
  * bindsnet/encoding/encodings.py:101-152 (poisson): same construction (intervals ~ Poisson(1000 / (x dt)), zeros
- * bumped to one, cumulated) from a Philox stream keyed by (seed, element): same distribution, NOT the reference's
- * stream (ATen's sampler draws a data-dependent number of outputs per element).                       */
+ * bumped to one, cumulated) from a Philox-4x32-10 stream keyed by (seed, element): same distribution, NOT the reference's
+ * stream (ATen's sampler draws a data-dependent number of outputs per element).  The stream is SPECIFIED operation by
+ * operation (csrc/snn_encode.hip: IEEE f32 / f64 adds, multiplies, divides, f32 sqrt, integer conversions; exp / log /
+ * log k! are fixed series, no libm) and restated in oracle/snn_oracle.c (orc_encode_poisson), bit for bit.  out is
+ * written completely (zeroed, then the spikes).                                                        */
 int snn_encode_bernoulli(snn_rng_state *rng, const float *datum, int n, int steps, float max_prob, uint8_t *out,
                          snn_stream_t stream);
 int snn_encode_poisson(const float *datum, int n, int steps, float dt, unsigned long long seed, uint8_t *out,
