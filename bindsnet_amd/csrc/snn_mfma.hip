@@ -29,7 +29,14 @@ __global__ __launch_bounds__(256) void k_prop_dense_mfma(const float *__restrict
                                                          int N, int accumulate) {
     __shared__ uint8_t st[16][KC + 4];                         // (+4: rows land in different LDS banks)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 16, n0 = (blockIdx.x * 4 + wave) * 16;
+    // XCD-aware block -> tile map (workgroup b runs on XCD b % 8, each with an L2 of its own): the ny sample tiles of one 64-column group sit
+    // on ONE XCD, back to back, so the group's [Nin x 64] weight slice is fetched from HBM once and re-read from that L2 (the whole matrix
+    // does not fit one L2: with the (column group, sample tile) grid every XCD streamed it once per sample tile)
+    const int ny = (B + 15) >> 4, ncg = (N + 63) >> 6;
+    const int xcd = blockIdx.x & 7, w_ = blockIdx.x >> 3;
+    const int cg = xcd + 8 * (w_ / ny), ty = w_ - (w_ / ny) * ny;
+    if (cg >= ncg) return;
+    const int m0 = ty * 16, n0 = (cg * 4 + wave) * 16;
     const int r = lane & 15, kq = lane >> 4;                   // A: row r, k = kq;  B: k = kq, column r
     const int col = n0 + r;
     const bool colv = col < N;
@@ -91,7 +98,8 @@ __global__ __launch_bounds__(256) void k_prop_dense_mfma(const float *__restrict
 extern "C" int snn_prop_dense_mfma_f32(const float *W, const float *bias, const uint8_t *s, float *out, int B, int Nin, int N,
                                        int accumulate, snn_stream_t stream) {
     if (!W || !s || !out || B <= 0 || Nin <= 0 || N <= 0) return SNN_ERR_INVALID;
-    hipLaunchKernelGGL(k_prop_dense_mfma, dim3((N + 63) / 64, (B + 15) / 16), dim3(256), 0, (hipStream_t)stream, W, bias, s, out, B,
+    const int ny = (B + 15) / 16, ncg = (N + 63) / 64;
+    hipLaunchKernelGGL(k_prop_dense_mfma, dim3((unsigned)(8 * ((ncg + 7) / 8) * ny)), dim3(256), 0, (hipStream_t)stream, W, bias, s, out, B,
                        Nin, N, accumulate);
     return snn_check_launch();
 }
