@@ -92,23 +92,33 @@ extern "C" int snn_prop_dense_f32(const float *W, const float *bias, const uint8
 }
 
 // =============================================================================================
-// a7: conv2d propagation.  thread <-> (b, oy, ox); all Cout channels accumulated in registers in
-// chunks of 8 so the u8 input window is read once per chunk; weights broadcast from LDS.
+// a7: conv2d propagation.  thread <-> (b, oy, ox, chunk of 8 output channels) -- blockIdx.y = the chunk (round 6: with all channels of a
+// pixel on one thread the conv_mnist.py shapes gave 36 workgroups and 58 us per call; 8 us like this); weights broadcast from LDS.
 // Tap order (kh, kw, cin): taps row-major, input channels innermost (what oneDNN does for C_in <= 16), sequential, + bias.
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_conv2d(const float *__restrict__ W, const float *__restrict__ bias,
                                                 const uint8_t *__restrict__ s, float *__restrict__ out, int B,
                                                 int Cin, int H, int Wd, int Cout, int KH, int KW, int stride,
-                                                int pad, int OH, int OW, int accumulate) {
-    extern __shared__ float wsm[];  // [Cout][Cin*KH*KW]
+                                                int pad, int OH, int OW, int accumulate, int nstage) {
+    extern __shared__ float wsm[];  // [Cout][Cin*KH*KW] | staged input images of the block's samples (u8, when they fit: nstage > 0)
     const int taps = Cin * KH * KW;
     for (int k = threadIdx.x; k < Cout * taps; k += blockDim.x) wsm[k] = W[k];
-    __syncthreads();
     const long npix = (long)B * OH * OW;
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p0 = (long)blockIdx.x * blockDim.x;
+    const int img = Cin * H * Wd, bfirst = (int)(p0 / ((long)OW * OH));
+    uint8_t *simg = (uint8_t *)(wsm + Cout * taps);
+    if (nstage > 0) {                                    // the images of samples bfirst .. bfirst + nstage - 1: every window of the block reads them
+        const long n = (long)min(nstage, B - bfirst) * img;
+        const uint8_t *src = s + (size_t)bfirst * img;
+        for (long k = threadIdx.x; k < n; k += blockDim.x) simg[k] = src[k];
+    }
+    __syncthreads();
+    const long p = p0 + threadIdx.x;
     if (p >= npix) return;
     const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((long)OW * OH));
-    for (int c0 = 0; c0 < Cout; c0 += 8) {
+    const uint8_t *sb = nstage > 0 ? simg + (size_t)(b - bfirst) * img : s + (size_t)b * img;
+    {
+        const int c0 = (int)blockIdx.y * 8;
         float acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = 0.f;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void k_conv2d(const float *__restrict__ W, con
                     const int tap = (ci * KH + ky) * KW + kx;
                     const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
                     if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
-                    const uint8_t sv = s[(((size_t)b * Cin + ci) * H + iy) * Wd + ix];
+                    const uint8_t sv = sb[((size_t)ci * H + iy) * Wd + ix];
                     if (!sv) continue;
                     const float fs = (float)sv;
 #pragma unroll
@@ -145,11 +155,14 @@ extern "C" int snn_prop_conv2d_f32(const float *W, const float *bias, const uint
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (Wd + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
     if (Cin > 16) return SNN_ERR_UNSUPPORTED;      // the reference's accumulation order is only characterised up to 16 channels
-    const size_t lds = sizeof(float) * (size_t)Cout * Cin * KH * KW;
+    size_t lds = sizeof(float) * (size_t)Cout * Cin * KH * KW;
     if (lds > 64 * 1024) return SNN_ERR_UNSUPPORTED;
     const long npix = (long)B * OH * OW;
-    hipLaunchKernelGGL(k_conv2d, dim3((unsigned)((npix + 255) / 256)), dim3(256), lds, (hipStream_t)stream, W,
-                       bias, s, out, B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW, accumulate);
+    // a block of 256 consecutive output pixels touches at most 255 / (OH * OW) + 2 samples: their input images go to LDS when they fit 32 KB
+    int nstage = 255 / (OH * OW) + 2;
+    if ((size_t)nstage * Cin * H * Wd > 32 * 1024) nstage = 0; else lds += (size_t)nstage * Cin * H * Wd;
+    hipLaunchKernelGGL(k_conv2d, dim3((unsigned)((npix + 255) / 256), (unsigned)((Cout + 7) / 8)), dim3(256), lds, (hipStream_t)stream, W,
+                       bias, s, out, B, Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW, accumulate, nstage);
     return snn_check_launch();
 }
 
@@ -685,29 +698,49 @@ __global__ __launch_bounds__(256) void k_conv_pp_partial(const uint8_t *__restri
 __global__ __launch_bounds__(256) void k_conv_pp_partial_ev(const uint8_t *__restrict__ s_src, const float *__restrict__ x_src,
                                                             const uint8_t *__restrict__ s_tgt, const float *__restrict__ x_tgt,
                                                             float *__restrict__ part, int B, snn::ConvGeom g) {
-    extern __shared__ uint32_t ev_lds[];                 // srow[H] | trow[Cout * OH] | multi
+    // Round 6: a workgroup = (sample, input channel, chunk of CO output channels) and stages what its elements read -- the chunk's target
+    // traces, the channel's source traces, the packed spike rows -- in LDS: the walk over the events used to chase one global load per
+    // event (40 us per call at the conv_mnist.py shapes; every workgroup also packed ALL target rows of its sample).
+    constexpr int CO = 8;
+    extern __shared__ uint32_t ev_lds[];                 // srow[H] | trow[CO * OH] | multi | xt[CO * OH * OW] | xs[H * Wd]
+    const int L = g.OH * g.OW;
     uint32_t *srow = ev_lds, *trow = ev_lds + g.H;
-    int *multi = (int *)(trow + g.Cout * g.OH);
+    int *multi = (int *)(trow + CO * g.OH);
+    float *xt = (float *)(multi + 1), *xs = xt + CO * L;
     const int tid = threadIdx.x, b = blockIdx.x / g.Cin, ci = blockIdx.x - b * g.Cin;
+    const int co0 = blockIdx.y * CO, nco = min(CO, g.Cout - co0);
     if (tid == 0) *multi = 0;
     __syncthreads();
+    const size_t soff = ((size_t)b * g.Cin + ci) * g.H * g.Wd, toff0 = ((size_t)b * g.Cout + co0) * L;
     int mine = 0;
-    for (int r = tid; r < g.H; r += 256)
-        srow[r] = snn::conv_pack_row(s_src + (((size_t)b * g.Cin + ci) * g.H + r) * g.Wd, g.Wd, &mine);
-    for (int r = tid; r < g.Cout * g.OH; r += 256)
-        trow[r] = snn::conv_pack_row(s_tgt + ((size_t)b * g.Cout * g.OH + r) * g.OW, g.OW, &mine);
+    // (conv_pack_row's result from 4-byte loads where the row starts on a 4-byte boundary: a row of 24 / 28 bytes is 6 / 7 loads, not 24 / 28)
+    auto pack = [&](const uint8_t *row, int n) -> uint32_t {
+        if ((((uintptr_t)row) & 3) != 0) return snn::conv_pack_row(row, n, &mine);
+        uint32_t m = 0;
+        int x = 0;
+        for (; x + 4 <= n; x += 4) {
+            const uint32_t v = *(const uint32_t *)(row + x);
+            if (v & 0xFEFEFEFEu) mine = 1;
+            const uint32_t nz = (v | ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;      // byte k non-zero -> bit 8k+7
+            m |= (((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xFu) << x;
+        }
+        for (; x < n; ++x) { const uint8_t v = row[x]; m |= (uint32_t)(v != 0) << x; if (v > 1) mine = 1; }
+        return m;
+    };
+    for (int r = tid; r < g.H; r += 256) srow[r] = pack(s_src + soff + (size_t)r * g.Wd, g.Wd);
+    for (int r = tid; r < nco * g.OH; r += 256) trow[r] = pack(s_tgt + toff0 + (size_t)r * g.OW, g.OW);
+    for (int k = tid; k < nco * L; k += 256) xt[k] = x_tgt[toff0 + k];
+    for (int k = tid; k < g.H * g.Wd; k += 256) xs[k] = x_src[soff + k];
     if (mine) atomicOr(multi, 1);
     __syncthreads();
     const bool dense = *multi != 0;
     const int KK = g.KH * g.KW;
     const long K = (long)g.Cin * KK, E = (long)g.Cout * K;
-    const int e = blockIdx.y * 256 + tid;
-    if (e >= g.Cout * KK) return;
-    const int co = e / KK, kk = e - co * KK, ky = kk / g.KW, kx = kk - ky * g.KW;
-    const size_t soff = ((size_t)b * g.Cin + ci) * g.H * g.Wd, toff = ((size_t)b * g.Cout + co) * g.OH * g.OW;
+    if (tid >= nco * KK) return;
+    const int cl = tid / KK, kk = tid - cl * KK, ky = kk / g.KW, kx = kk - ky * g.KW, co = co0 + cl;
     float a, p;
-    if (!dense) snn::conv_pp_events(g, ky, kx, srow, trow + co * g.OH, x_src + soff, x_tgt + toff, &a, &p);
-    else snn::conv_pp_dense(g, ky, kx, s_src + soff, x_src + soff, s_tgt + toff, x_tgt + toff, &a, &p);
+    if (!dense) snn::conv_pp_events(g, ky, kx, srow, trow + cl * g.OH, xs, xt + cl * L, &a, &p);
+    else snn::conv_pp_dense(g, ky, kx, s_src + soff, xs, s_tgt + toff0 + (size_t)cl * L, xt + cl * L, &a, &p);
     const long id = (long)b * E + (long)co * K + (long)ci * KK + kk;
     part[id] = a;
     part[(size_t)B * E + id] = p;
@@ -719,16 +752,20 @@ __global__ __launch_bounds__(256) void k_conv_pp_apply(float *__restrict__ W, co
     if (e >= E) return;
     const bool tail = e >= (E / 32) * 32;
     float w = W[e];
-    if (nu0 != 0.f) {
+    // (the loads of sixteen samples' partial sums are issued together, then added in ATen's order: one round trip per sixteen terms)
+    auto ordered = [&](const float *base) {
         OuterSum acc; acc.init(tail);
-        for (int b = 0; b < B; ++b) acc.add(b, part[(size_t)b * E + e], B);
-        w = w - nu0 * acc.finish(B);
-    }
-    if (nu1 != 0.f) {
-        OuterSum acc; acc.init(tail);
-        for (int b = 0; b < B; ++b) acc.add(b, part[(size_t)(B + b) * E + e], B);
-        w = w + nu1 * acc.finish(B);
-    }
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = base[(size_t)min(b0 + u, B - 1) * E + e];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (b0 + u < B) acc.add(b0 + u, v[u], B);
+        }
+        return acc.finish(B);
+    };
+    if (nu0 != 0.f) w = w - nu0 * ordered(part);
+    if (nu1 != 0.f) w = w + nu1 * ordered(part + (size_t)B * E);
     w = w * decay;
     if (has_min && w < wmin) w = wmin;
     if (has_max && w > wmax) w = wmax;
@@ -744,10 +781,10 @@ extern "C" int snn_conv2d_postpre(float *W, const uint8_t *s_src, const float *x
     if (OH <= 0 || OW <= 0) return SNN_ERR_INVALID;
     const long E = (long)Cout * Cin * KH * KW, n = (long)B * E;
     static const bool events = [] { const char *v = getenv("SNN_CONV_PP_EVENTS"); return !(v && v[0] == '0'); }();
-    const size_t ev_lds_bytes = ((size_t)H + (size_t)Cout * OH + 1) * sizeof(uint32_t);
-    if (events && Wd <= 32 && OW <= 32 && ev_lds_bytes <= 48 * 1024) {
+    const size_t ev_lds_bytes = ((size_t)H + (size_t)8 * OH + 1) * sizeof(uint32_t) + ((size_t)8 * OH * OW + (size_t)H * Wd) * sizeof(float);
+    if (events && Wd <= 32 && OW <= 32 && ev_lds_bytes <= 60 * 1024 && 8 * KH * KW <= 256) {
         const snn::ConvGeom g{Cin, H, Wd, Cout, KH, KW, stride, pad, OH, OW};
-        hipLaunchKernelGGL(k_conv_pp_partial_ev, dim3((unsigned)(B * Cin), (unsigned)((Cout * KH * KW + 255) / 256)), dim3(256), ev_lds_bytes,
+        hipLaunchKernelGGL(k_conv_pp_partial_ev, dim3((unsigned)(B * Cin), (unsigned)((Cout + 7) / 8)), dim3(256), ev_lds_bytes,
                            (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws, B, g);
     } else {
         hipLaunchKernelGGL(k_conv_pp_partial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s_src, x_src, s_tgt, x_tgt, ws,
