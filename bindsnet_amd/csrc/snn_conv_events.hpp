@@ -52,6 +52,38 @@ __host__ __device__ inline void conv_pp_dense(const ConvGeom &g, int ky, int kx,
 __host__ __device__ inline void conv_pp_events(const ConvGeom &g, int ky, int kx, const uint32_t *srow, const uint32_t *trow,
                                                const float *x_src_c, const float *x_tgt_c, float *a_out, float *p_out) {
     float a = 0.f, p = 0.f;
+    if (g.stride == 1) {
+        // stride 1 (what conv_mnist.py builds): ox = ix + pad - kx, so the source spikes a tap can see are a contiguous bit range of the
+        // row's word -- mask it once, then every set bit is a term (no division, no per-event range tests); the same terms in the same order
+        const int sh = kx - g.pad;                         // ix = ox + sh
+        for (int oy = 0; oy < g.OH; ++oy) {
+            const int iy = oy - g.pad + ky;
+            if (iy < 0 || iy >= g.H) continue;
+            uint32_t m = srow[iy];
+            // keep ix with 0 <= ix - sh < OW
+            const int lo = sh > 0 ? sh : 0, hi = g.OW + sh < 32 ? g.OW + sh : 32;      // ix in [lo, hi)
+            m = hi <= lo ? 0u : (m >> lo << lo) & (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u));
+            const float *xt = x_tgt_c + oy * g.OW - sh;
+            while (m) {
+                const int ix = __builtin_ctz(m);
+                m &= m - 1;
+                a += xt[ix];                               // x_tgt[oy, ix - sh] * 1.0f
+            }
+            uint32_t q = trow[oy];
+            // keep ox with 0 <= ox + sh < Wd
+            const int qlo = sh < 0 ? -sh : 0, qhi = g.Wd - sh < 32 ? g.Wd - sh : 32;
+            q = qhi <= qlo ? 0u : (q >> qlo << qlo) & (qhi >= 32 ? 0xFFFFFFFFu : ((1u << qhi) - 1u));
+            const float *xs = x_src_c + iy * g.Wd + sh;
+            while (q) {
+                const int ox = __builtin_ctz(q);
+                q &= q - 1;
+                p += xs[ox];                               // 1.0f * x_src[iy, ox + sh]
+            }
+        }
+        *a_out = a;
+        *p_out = p;
+        return;
+    }
     for (int oy = 0; oy < g.OH; ++oy) {
         const int iy = oy * g.stride - g.pad + ky;
         if (iy < 0 || iy >= g.H) continue;                 // every tap of this output row lies outside the image
