@@ -273,7 +273,8 @@ def test_device_generator_matches_torch_stream(B, N, p_row, seed, warm):
 
 @pytest.mark.parametrize("B,Nin,N,dens,bias,acc", [(16, 784, 1600, 0.012, False, False), (128, 784, 1600, 0.012, False, False),
                                                     (16, 6400, 500, 0.05, False, False), (5, 37, 21, 0.5, True, True),
-                                                    (33, 130, 70, 0.3, True, False), (1, 784, 100, 0.02, False, True)])
+                                                    (33, 130, 70, 0.3, True, False), (1, 784, 100, 0.02, False, True),
+                                                    (3, 7, 16, 0.5, False, False), (20, 2053, 130, 0.1, True, True), (16, 1072, 64, 0.1, False, False)])
 def test_prop_dense_mfma_is_bit_identical_to_the_ordered_sum(B, Nin, N, dens, bias, acc):
     """snn_prop_dense_mfma_f32 (v_mfma_f32_16x16x4_f32, one k-ordered chain per tile) vs the oracle's ascending-source
     sequential sum and vs the event-driven kernel: bit for bit, for 0/1 spikes."""
