@@ -883,6 +883,15 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front
         // of the digest's LDS stores, which wait for every outstanding load: 0.4 us per iteration, more on some workgroups)
         if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1, min(bl, B - 1)); }
+        // ---- X -> Ae currents of step t+1 under "nobody of this workgroup won step t" (from wtile, final since PostPre): waves 2..3 start on
+        //      them at once -- the pass is the longest piece between the barriers M and B, and it needs nothing of what the other waves read
+        //      first (the crossing state, the row count); in a workgroup that crossed, the six other waves do the touched rows meanwhile
+        const bool f4w = wave >= NTW && wave < NTW + 2;
+        if (f4w) {
+            const int ptid = tid - TT, pb = ptid >> 2, pL = ptid & 3;
+            const float4 v = x_current_f4(wtile, dgn, B, Nin, min(pb, B - 1), pL, tailcol);
+            if (pL == 0 && pb < B) *(float4 *)(curX + (par ^ 1) * TT + pb * CW) = v;
+        }
         // ---- a workgroup that crossed at step t prepares the WON BRANCH of its crossing columns while the arbiter works: each such column
         //      as it is with its final spike(s) of step t, every row from the old weights.  First the rows this step's X spikes touch --
         //      the only rows the X currents of step t+1 read --, then the currents of both branches in ONE pass, then (waves 2..7,
@@ -942,11 +951,12 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
                 lds_barrier();                                            // ---- S2
             }
-            for (int k = tid; k < nact; k += NT) {                        // the rows the X currents of step t+1 read
-                const int i = full ? k : (int)arows[k];
+            if (!f4w)                                                     // the rows the X currents of step t+1 read (waves 2..3 are on their pass)
+                for (int k = tid < TT ? tid : tid - 128; k < nact; k += NT - 128) {
+                    const int i = full ? k : (int)arows[k];
 #pragma unroll
-                for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
-            }
+                    for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
+                }
             AMARK2(20);
             lds_barrier();                                                // ---- P
         }
@@ -957,11 +967,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      by the columns, DPP instead of LDS shuffles) on waves 2..3 -- and for a workgroup that crossed on waves 4..5 from wwin -- instead of
         //      four lanes per (sample, column) pair on all eight waves: fewer instructions on two waves than the old pass had on every wave, and
         //      the tile waves go straight to their resolution (same-box A/B, bit-exact: 947 -> 900 us per launch, profiles/NOTES_r06.md).
-        if (wave >= NTW && wave < NTW + 2) {
-            const int ptid = tid - TT, pb = ptid >> 2, pL = ptid & 3;
-            const float4 v = x_current_f4(wtile, dgn, B, Nin, min(pb, B - 1), pL, tailcol);
-            if (pL == 0 && pb < B) *(float4 *)(curX + (par ^ 1) * TT + pb * CW) = v;
-        } else if (crossed_wg && wave >= NTW + 2 && wave < NTW + 4) {
+        if (crossed_wg && wave >= NTW + 2 && wave < NTW + 4) {
             const int ptid = tid - TT - 128, pb = ptid >> 2, pL = ptid & 3;
             const float4 v = x_current_f4(wwin, dgn, B, Nin, min(pb, B - 1), pL, tailcol);     // (its other columns are of no interest)
             if (pL == 0 && pb < B) {
