@@ -661,10 +661,15 @@ static bool matches(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int
 
 extern "C" int snn_dc2015_last_form(void) { return g_last_form; }
 
+unsigned long long snn_twolayer_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R);
+unsigned long long snn_convpp_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R);
 extern "C" unsigned long long snn_net_workspace_bytes(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC,
                                           const snn_run_desc *R) {
     if (!L || !R || !C) return 0;
-    if (nL == 2 && nC == 1) return snn_twolayer_workspace_bytes(L, nL, C, nC, R);
+    if (nL == 2 && nC == 1) {
+        const unsigned long long w = snn_twolayer_workspace_bytes(L, nL, C, nC, R);
+        return w ? w : snn_convpp_workspace_bytes(L, nL, C, nC, R);          // (Input -> Conv2d PostPre -> LIF: snn_convlif.hip)
+    }
     if (nL != 3 || nC != 3) return 0;
     return fused_workspace_total(R->B, L[0].n, L[1].n, R->T);
 }

@@ -59,6 +59,7 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
                            hipStream_t st, int *handled, unsigned *normalized);
 int snn_try_fused_convlif(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R,
                           hipStream_t st, int *handled);
+int snn_try_fused_convpp(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, hipStream_t st, int *handled);
 
 int snn_launch_dc_membrane(float *v, float *refrac, uint8_t *s, float *theta, const float *I, int B, int N,
                            const snn_dc_params &p, long long *cursor, float *raster_v, hipStream_t st);
@@ -301,10 +302,17 @@ static int net_run_plans(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     unsigned normalized = 0;       // bit c: connection c was already normalised by the plan's own kernel
     int mode = g_plan_mode ? g_plan_mode : R->plan;            // the process-wide test switch wins over the per-run request
     for (int l = 0; l < nL; ++l) if (L[l].clamp || L[l].unclamp || L[l].inject_v || L[l].ext_current) mode = 1;   // only the generic plan implements these
-    for (int c = 0; c < nC; ++c) if (C[c].mask || C[c].raster_w || (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE)) mode = 1;
+    // (a Conv2dConnection with a rule: the generic plan, except PostPre on the Input -> Conv2d -> LIF graph -- snn_try_fused_convpp, whole-run form only)
+    bool conv_rule = false;
+    for (int c = 0; c < nC; ++c) if (C[c].kind == SNN_CONN_CONV2D && C[c].rule != SNN_RULE_NONE) conv_rule = true;
+    for (int c = 0; c < nC; ++c) if (C[c].mask || C[c].raster_w) mode = 1;
     if (R->one_step) mode = 1;
     for (int l = 0; l < nL; ++l) if (L[l].thresh_vec) mode = 1;      // per-neuron thresholds: generic plan
-    if (mode != 1) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
+    if (conv_rule) {
+        if (mode == 0 || mode == 3) TRY(snn_try_fused_convpp(L, nL, C, nC, R, st, &handled));
+        if (!handled) mode = 1;
+    }
+    if (mode != 1 && !handled) TRY(snn_try_fused_dc2015(L, nL, C, nC, R, st, mode == 0 || mode == 3, mode == 0, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_twolayer(L, nL, C, nC, R, st, &handled, &normalized));
     if (mode != 1 && !handled) TRY(snn_try_fused_convlif(L, nL, C, nC, R, st, &handled));
     if (!handled) {

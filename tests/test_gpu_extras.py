@@ -102,22 +102,28 @@ def test_conv2d_postpre_updates_and_run():
         np.testing.assert_array_equal(host(c.w).view(np.uint32), Wo.view(np.uint32), err_msg=f"case {k} vs oracle")
         np.testing.assert_allclose(host(c.w), g[f"cpp{k}"], rtol=0, atol=1e-5, err_msg=f"case {k} vs reference")
     B, T3 = 2, 30
-    net = Network(dt=1.0)
-    net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
-    net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
-    cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(1700, (4, 1, 3, 3), 0.0, 3.0)).clone(),
-                          update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0)
-    net.add_connection(cc, "X", "Y")
-    mon = Monitor(net.layers["Y"], ["s"], time=T3)
-    net.add_monitor(mon, "s")
-    net.to(DEV)
-    sp = synth.dense_spikes(1701, (T3, B, 1, 12, 12), 0.2)
-    net.run({"X": T_(sp).to(DEV)}, time=T3)
-    assert net.last_plan == "generic"
-    np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)))
-    # every single update is bit-exact against the oracle (above); against the REFERENCE the batch/position sums of its two
-    # torch.bmm calls run in BLAS order, and 30 updates accumulate that: the north star's 1e-5, relative to wmax = 4.0
-    np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-5 * 4.0)
+    from bindsnet_amd import _lib
+    for mode, plan in ((0, "convpp-fused"), (1, "generic")):       # the whole-run plan (round 6) and the per-operator plan, both against the reference's run
+        _lib.lib().snn_set_plan_mode(mode)
+        try:
+            net = Network(dt=1.0)
+            net.add_layer(Input(shape=(1, 12, 12), traces=True), "X")
+            net.add_layer(LIFNodes(shape=(4, 10, 10), traces=True), "Y")
+            cc = Conv2dConnection(net.layers["X"], net.layers["Y"], kernel_size=3, stride=1, w=T_(synth.uniform_f32(1700, (4, 1, 3, 3), 0.0, 3.0)).clone(),
+                                  update_rule=PostPre, nu=(1e-3, 1e-2), reduction=torch.sum, wmin=0.0, wmax=4.0)
+            net.add_connection(cc, "X", "Y")
+            mon = Monitor(net.layers["Y"], ["s"], time=T3)
+            net.add_monitor(mon, "s")
+            net.to(DEV)
+            sp = synth.dense_spikes(1701, (T3, B, 1, 12, 12), 0.2)
+            net.run({"X": T_(sp).to(DEV)}, time=T3)
+            assert net.last_plan == plan
+        finally:
+            _lib.lib().snn_set_plan_mode(0)
+        np.testing.assert_array_equal(host(mon.get("s")).reshape(T3, B, 400).astype(u8), unpack(g["crun_sY"], (T3, B, 400)), err_msg=plan)
+        # every single update is bit-exact against the oracle (above); against the REFERENCE the batch/position sums of its two
+        # torch.bmm calls run in BLAS order, and 30 updates accumulate that: the north star's 1e-5, relative to wmax = 4.0
+        np.testing.assert_allclose(host(cc.w), g["crun_W"], rtol=0, atol=1e-5 * 4.0, err_msg=plan)
 
 
 def test_mstdp_on_conv2d_connection_matches_oracle_and_reference():
