@@ -252,8 +252,8 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
     int *multi = (int *)(trow + CCP * c.OH);              // [4]: [p] the image of parity p has a byte > 1; [2] give up
     uint8_t *sbt = (uint8_t *)(multi + 4);                // [CCP][L] target spikes of this step (bytes)
     int *nev = (int *)(sbt + ((CCP * L + 3) & ~3));       // [Cin + CCP] events per list
-    uint16_t *evS = (uint16_t *)(nev + ((c.Cin + CCP + 1) & ~1));   // [Cin][H * Wd] source spikes of the step's image as (iy << 8 | ix), ascending
-    uint16_t *evT = evS + ((img + 1) & ~1);               // [CCP][L] target spikes of the step as (oy << 8 | ox), ascending
+    uint16_t *evS = (uint16_t *)(nev + ((c.Cin + CCP + 1) & ~1));   // [Cin][H * Wd + 8] source spikes of the step's image as (iy << 8 | ix), ascending, padded
+    uint16_t *evT = evS + c.Cin * (c.H * c.Wd + 8);       // [CCP][L + 8] target spikes of the step as (oy << 8 | ox), ascending, padded with 0xFFFF to a multiple of 8
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x % c.nchunk, b = blockIdx.x / c.nchunk;
     const int c0 = chunk * CCP, nco = min(CCP, c.Cout - c0), nel = nco * taps;
@@ -317,6 +317,13 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
         const uint32_t *srowc = srow + par * nrS;
         uint32_t *srown = srow + (par ^ 1) * nrS;
         const bool mcur = multi[par] != 0;
+        // (the tables the packing pass below ORs into: last read in front of the previous step's barriers)
+        const bool wordform = (c.Wd & 3) == 0 && (c.OW & 3) == 0;
+        if (wordform) {
+            for (int r = tid; r < nrS; r += NT) srown[r] = 0u;
+            for (int r = tid; r < nco * c.OH; r += NT) trow[r] = 0u;
+        }
+        if (tid == 0) multi[par ^ 1] = 0;
         // this step's input image: the convolution of the NEXT step reads it, PostPre of THIS step pairs with it
         uint32_t pre[4] = {0u, 0u, 0u, 0u};                // imgw <= 4 * NT (host check)
         {
@@ -391,13 +398,35 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
         // ---- the input trace after this step (nodes.py:96-103), the packed rows
         {
             const uint8_t *nb = (const uint8_t *)nxt;
-            for (int k = tid; k < img; k += NT) xs[k] = trace_next(xs[k], nb[k], c.x_decay, c.x_scale, c.x_additive);
             int flag = 0, flagt = 0;
-            if (tid == 0) multi[par ^ 1] = 0;              // (this parity's flag was read two steps ago; the top of this step read the other one)
-            for (int r = tid; r < nrS; r += NT) srown[r] = pack(nb + (size_t)r * c.Wd, c.Wd, flag);
-            if (a.learning) for (int r = tid; r < nco * c.OH; r += NT) { const int cl = r / c.OH, y = r - cl * c.OH; trow[r] = pack(sbt + cl * L + y * c.OW, c.OW, flagt); }
-            __syncthreads();
-            if (flag) atomicOr(&multi[par ^ 1], 1);
+            if (wordform) {
+                // a thread per 4-byte word of the image: its four traces, its four bits of the row's word (rows are whole words: Wd % 4 == 0)
+                for (int k = tid; k < (img >> 2); k += NT) {
+                    const uint32_t w = nxt[k];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[4 * k + q] = trace_next(xs[4 * k + q], (uint8_t)(w >> (8 * q)), c.x_decay, c.x_scale, c.x_additive);
+                    if (w & 0xFEFEFEFEu) flag = 1;
+                    const uint32_t nz = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+                    const uint32_t nib = ((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xFu;
+                    if (nib) { const int r = (4 * k) / c.Wd, x = 4 * k - r * c.Wd; atomicOr(&srown[r], nib << x); }
+                }
+                if (a.learning) {
+                    const uint32_t *sw = (const uint32_t *)sbt;
+                    for (int k = tid; k < ((nco * L) >> 2); k += NT) {
+                        const uint32_t w = sw[k];
+                        if (!w) continue;
+                        const uint32_t nz = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+                        const uint32_t nib = ((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xFu;
+                        const int r = (4 * k) / c.OW, x = 4 * k - r * c.OW;          // (L = OH * OW: r = cl * OH + oy)
+                        atomicOr(&trow[r], nib << x);
+                    }
+                }
+            } else {
+                for (int k = tid; k < img; k += NT) xs[k] = trace_next(xs[k], nb[k], c.x_decay, c.x_scale, c.x_additive);
+                for (int r = tid; r < nrS; r += NT) srown[r] = pack(nb + (size_t)r * c.Wd, c.Wd, flag);
+                if (a.learning) for (int r = tid; r < nco * c.OH; r += NT) { const int cl = r / c.OH, y = r - cl * c.OH; trow[r] = pack(sbt + cl * L + y * c.OW, c.OW, flagt); }
+            }
+            if (flag) atomicOr(&multi[par ^ 1], 1);        // (zeroed at the top of the step, in front of the barrier behind the convolution)
         }
         __syncthreads();
         PPMARK(1);
@@ -415,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
                 for (int li = wave; li < c.Cin + nco; li += nwaves) {
                     const bool sl = li < c.Cin;
                     const uint32_t *rows = sl ? srown + li * c.H : trow + (li - c.Cin) * c.OH;
-                    uint16_t *dst = sl ? evS + li * (c.H * c.Wd) : evT + (li - c.Cin) * L;
+                    uint16_t *dst = sl ? evS + li * (c.H * c.Wd + 8) : evT + (li - c.Cin) * (L + 8);
                     const int nr = sl ? c.H : c.OH;
                     int off = 0;
                     for (int r0 = 0; r0 < nr; r0 += 64) {
@@ -428,6 +457,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
                         while (word) { const int x = __ffs(word) - 1; word &= word - 1; dst[pos++] = (uint16_t)(((r0 + lane) << 8) | x); }
                         off += __shfl(incl, 63);
                     }
+                    if (lane < 8) dst[off + lane] = 0xFFFFu;          // (row 255: outside every window -- the sums walk whole groups of eight)
                     if (lane == 0) nev[li] = off;
                 }
             }
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
                 const int dy = ky - c.pad, sh = kx - c.pad;
                 // src: events (iy, ix) of input channel ci; the term sits at x_tgt[cl][(iy - dy) * OW + ix - sh] when (iy - dy, ix - sh) is an output position
                 // tgt: events (oy, ox) of output channel cl; the term sits at x_src[ci][(oy + dy) * Wd + ox + sh] when (oy + dy, ox + sh) is an input position
-                const uint16_t *ev = src ? evS + ci * (c.H * c.Wd) : evT + cl * L;
+                const uint16_t *ev = src ? evS + ci * (c.H * c.Wd + 8) : evT + cl * (L + 8);
                 const int n = nev[src ? ci : c.Cin + cl];
                 const float *vals = src ? xt + cl * L : xs + ci * c.H * c.Wd;
                 const int ddy = src ? -dy : dy, ddx = src ? -sh : sh, rowlen = src ? c.OW : c.Wd, nrow = src ? c.OH : c.H;
@@ -447,9 +477,9 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
                     int ad[8]; bool in[8]; float vv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int q = (int)ev[min(i0 + u, n - 1)];
+                        const int q = (int)ev[i0 + u];
                         const int y = (q >> 8) + ddy, x = (q & 0xFF) + ddx;
-                        in[u] = i0 + u < n && (unsigned)y < (unsigned)nrow && (unsigned)x < (unsigned)rowlen;
+                        in[u] = (unsigned)y < (unsigned)nrow && (unsigned)x < (unsigned)rowlen;
                         ad[u] = in[u] ? y * rowlen + x : 0;
                     }
 #pragma unroll
@@ -511,15 +541,23 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
             const bool tail = e >= (E / 32) * 32;
             float w = wl[tid];
             auto ordered = [&](const float *base) {           // (sixteen samples' values are read together, then added in ATen's order)
-                OuterSum accs; accs.init(tail);
+                if (tail) {
+                    OuterSum accs; accs.init(true);
+                    for (int bb = 0; bb < B; ++bb) accs.add(bb, base[bb * nel + tid], B);
+                    return accs.finish(B);
+                }
+                // OuterSum's cascade (snn_order.hpp Cascade) over the dense positions 0 .. B-1: the sixteen positions of a group share their
+                // block (b0 >> 4 <= B >> 4), so the block test runs once per group instead of once per term
+                Cascade cs; cs.init();
                 for (int b0 = 0; b0 < B; b0 += 16) {
                     float vv[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) vv[u] = base[min(b0 + u, B - 1) * nel + tid];
+                    if ((b0 >> 4) != cs.cb) cs.advance(b0 >> 4);
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) if (b0 + u < B) accs.add(b0 + u, vv[u], B);
+                    for (int u = 0; u < 16; ++u) if (b0 + u < B) cs.a0 += vv[u];
                 }
-                return accs.finish(B);
+                return cs.finish(B >> 4);
             };
             if (a.nu0 != 0.f) w = w - a.nu0 * ordered(red);
             if (a.nu1 != 0.f) w = w + a.nu1 * ordered(red + B * nel);
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
 size_t convpp_lds(const ConvCtx &c, int ccp) {
     const size_t taps = (size_t)c.Cin * c.KH * c.KW, img = (size_t)c.Cin * c.H * c.Wd, L = (size_t)c.OH * c.OW;
     return (ccp * taps + 2 * c.B * ccp * taps + img + ccp * L) * 4 + 2 * ((img + 3) / 4) * 4 + (2 * c.Cin * c.H + ccp * c.OH + 4) * 4 + ((ccp * L + 3) & ~(size_t)3) +
-           ((c.Cin + ccp + 1) & ~(size_t)1) * 4 + (((img + 1) & ~(size_t)1) + ccp * L) * 2 + 32;
+           ((c.Cin + ccp + 1) & ~(size_t)1) * 4 + (img + 8 * c.Cin + ccp * (L + 8)) * 2 + 32;
 }
 int convpp_threads(const ConvCtx &c, int ccp) {
     const int taps = c.Cin * c.KH * c.KW, npix = c.OH * c.OW;
@@ -572,7 +610,7 @@ bool convpp_match(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int n
     if (c.OH <= 0 || c.OW <= 0 || c.Wd > 32 || c.OW > 32) return false;          // packed rows: one 32-bit word per image row
     const int img = c.Cin * c.H * c.Wd, npix = c.OH * c.OW;
     if (L[0].n != img || L[1].n != c.Cout * npix) return false;
-    if (npix > 1024 || c.H > 255 || c.OH > 255) return false;                    // a thread per output pixel; event lists hold (row << 8 | column)
+    if (npix > 1024 || max(c.H, c.OH) + max(c.KH, c.pad) > 255) return false;    // a thread per output pixel; event lists hold (row << 8 | column), row 255 = padding
     if ((img + 3) / 4 > 4 * convpp_threads(c, 2)) return false;
     if (convpp_lds(c, 2) > 150 * 1024) return false;
     if ((double)R->T * R->B * L[1].n >= 9.0e15) return false;
