@@ -175,7 +175,7 @@ def f_postpre_ref():
 
 
 def f_conv_postpre():
-    """conv_mnist.py's training graph: Input -> Conv2dConnection(PostPre) -> LIFNodes (generic plan)."""
+    """conv_mnist.py's training graph: Input -> Conv2dConnection(PostPre) -> LIFNodes (plan convpp-fused; SNN_CONVPP_FUSED=0: the generic plan)."""
     from bindsnet_amd.learning import PostPre
     from bindsnet_amd.network import Network
     from bindsnet_amd.network.nodes import Input, LIFNodes
