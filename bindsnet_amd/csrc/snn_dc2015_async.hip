@@ -562,10 +562,14 @@ __device__ __forceinline__ int need_xtr(const DcCtx &c, bool &all) {
 //                   a column with more than one crossing sample waits for the winners and is redone exactly;
 //                   then the tile waves: a wave that crossed at step t waits for that step's winners; a winner redoes its Ae trace
 //                   and x_tgt*nu0 and marks its column (colmask); every pair leaves its final spike of step t for its Ai thread
-template <bool TIMING>
+// FT (round 6): the tile is FULL -- B == MAXB samples and every workgroup's four columns exist (N % 4 == 0), BASELINE cfg2's shape: every tile / Ai
+// thread owns a neuron and B is a constant of the instance: the per-sample loops of the resolution (840 -> 168 instructions), the `mine` tests and
+// their exec-mask bookkeeping fall away, 57 scalar registers fewer are spilled.  Same-box A/B, bit-exact on the 114 D&C tests: 894.5 -> 841 us per
+// launch at K=20, 850 -> 805 at K=200 (the source count as a constant as well -- Nin = 784 -- was 1.2 % SLOWER: longer unrolled code, 609 spilled scalars).
+template <bool TIMING, bool FT>
 __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *smem) {
     constexpr int CW = ACW, TT = AT, NT = ANT, NTW = TT / 64, SPW = 64 / CW, SPG = 16 / CW, NBC = NT - TT, TI0 = NT - TT;
-    const int B = c.B, Nin = c.Nin, N = c.N, T = c.T;
+    const int B = FT ? MAXB : c.B, Nin = c.Nin, N = c.N, T = c.T;
     int *ctl = (int *)(smem + OC_CTL);                       // [0] abort seen (any wave), [1] commit seen
     float *xnu0 = (float *)(smem + OC_XNU0);                 // [2][B][CW] x_tgt * nu0 of a step without an own final spike, by step parity
     float *xnu0s = (float *)(smem + OC_XNU0S);               // [B][CW] ... with the winners of a slow column put in
@@ -592,9 +596,9 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     const bool is_ai = tid >= TI0;                            // Ai thread of pair tid - TI0
     const int ptile = is_ai ? tid - TI0 : tid;                // pair of a tile / Ai thread
     const int jj = ptile % CW, bl = ptile / CW, j = c0 + jj;
-    const bool colv = j < N, tailcol = c0 >= (N / 32) * 32;
-    const bool mine = tid < TT && bl < B && colv;             // owns the Ae neuron of a pair
-    const bool mine_i = is_ai && bl < B && colv;              // owns the Ai neuron of a pair
+    const bool colv = FT ? true : j < N, tailcol = c0 >= (N / 32) * 32;
+    const bool mine = FT ? tid < TT : (tid < TT && bl < B && colv);             // owns the Ae neuron of a pair
+    const bool mine_i = FT ? is_ai : (is_ai && bl < B && colv);                 // owns the Ai neuron of a pair
     const unsigned kst = (unsigned)(bl * N + j);
     const int NGS = c.G * NTW;
     // loop-invariant parameters: floats in vector registers (see vgpr())
@@ -1492,7 +1496,7 @@ __device__ __forceinline__ void async_raster(const DcCtx &c, unsigned char *smem
     }
 }
 
-template <bool TIMING>
+template <bool TIMING, bool FT>
 __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int blk = (int)blockIdx.x;
@@ -1501,7 +1505,7 @@ __global__ __launch_bounds__(ANT) void k_dc2015_async(const DcCtx c) {
         if (blk == 0 && threadIdx.x == 0) report(c.status, SNN_ERR_RETRY);
         return;
     }
-    if (blk < c.G) async_compute<TIMING>(c, smem);
+    if (blk < c.G) async_compute<TIMING, FT>(c, smem);
     else if (blk == c.G) async_arbiter<TIMING>(c, smem);
     else if (blk < c.G + 1 + c.NRW) async_raster(c, smem, blk - c.G - 1);
     else async_producer(c, smem, blk - c.G - 1 - c.NRW);
@@ -1516,8 +1520,9 @@ size_t snn_dc2015_async_lds(int B, int Nin, int N) {
 
 static bool async_attr_once() {
     static int state = 0;
-    if (!state) state = (snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
-                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) ? -1 : 1;
+    if (!state) state = (snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
+                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)) ||
+                         snn_check(hipFuncSetAttribute((const void *)k_dc2015_async<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) ? -1 : 1;
     return state == 1;
 }
 
@@ -1535,7 +1540,7 @@ int snn_dc2015_async_capacity(size_t lds) {
     int cus = 0, coop = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) coop = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_dc2015_async<false, false>, ANT, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (fake_cus) cus = fake_cus;
     const int cap = coop ? cus * per_cu : 0;
     if (!fake_cus) { known[next] = Known{dev, lds, cap}; next = (next + 1) & 3; }
@@ -1550,7 +1555,10 @@ int snn_dc2015_async_launch(const DcCtx &c, size_t lds, hipStream_t st, bool ord
     DcCtx arg = c;
     void *args[1] = {(void *)&arg};
     const unsigned grid = (unsigned)(c.G + 1 + c.NRW + c.NP);
-    const void *fn = c.dbg ? (const void *)k_dc2015_async<true> : (const void *)k_dc2015_async<false>;     // (the timing marks are compiled out of the ordinary instance)
+    static const bool ft_env = !(getenv("SNN_DC_FULLTILE") && atoi(getenv("SNN_DC_FULLTILE")) == 0);      // (measurement switch: 0 = the general instance)
+    const bool ft = ft_env && c.B == MAXB && c.N % ACW == 0;
+    const void *fn = c.dbg ? (const void *)k_dc2015_async<true, false>                                     // (the timing marks are compiled out of the ordinary instances)
+                           : (ft ? (const void *)k_dc2015_async<false, true> : (const void *)k_dc2015_async<false, false>);
     if (!coop) return snn_check(hipLaunchKernel(fn, dim3(grid), dim3(ANT), args, lds, st));
     const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(ANT), args, (unsigned)lds, st);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return SNN_ERR_UNSUPPORTED; }
