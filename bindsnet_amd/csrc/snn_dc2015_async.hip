@@ -712,6 +712,14 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
     long long mk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (TIMING only)
     (void)mk;
     bool prev_anyx = true;                                    // the previous iteration had a crossing in this workgroup (uniform)
+    // The step loop is instantiated once per ROLE of a wave (round 6): 0 = tile waves 0..1, 1 = waves 2..3 (PostPre + the X-current pass), 2 = waves
+    // 4..5 (PostPre + the won branch's pass), 3 = waves 6..7 (Ai + PostPre).  A wave's role never changes, but as ONE loop with `if (wave < ...)`
+    // around the roles' pieces every wave carried every role's uniform values through the loop (350-400 spilled scalar registers, a v_readlane
+    // in front of each use) and stepped over the other roles' code.  Every copy executes the same barriers.
+    auto step_loop = [&](auto role_c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool R_TILE = ROLE == 0, R_F4 = ROLE == 1, R_W4 = ROLE == 2, R_AI = ROLE == 3, R_NT = ROLE != 0;
+    (void)R_W4; (void)R_AI; (void)R_F4;
     for (int t = 0; t <= T; ++t) {
         const bool phaseB = t < T;
         const int par = t & 1;
@@ -727,7 +735,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // (the winners granules of step t-2, which the membrane stage wants, were asked for at the end of the previous iteration: pre_w)
         // digest entry t+2 -> registers (into LDS at the end of the iteration).  The tile waves issue theirs behind the publish: loads
         // return in order, so waiting for the winners granule in the membrane stage would wait for these (first touch: HBM) as well
-        if (t + 2 <= T && wave >= NTW) {
+        if (t + 2 <= T && R_NT) {
             if (PENDING(1)) {                                             // (producer workgroups: the first iterations only)
                 bool all = false;
                 const int r = need_entry(cold(c), t + 2, all);
@@ -758,7 +766,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             break;
         }
-        if (wave < NTW) {
+        if (R_TILE) {
 
             // ---- Ae membrane update of step t, publish its crossings
             float cx = 0.f;
@@ -822,7 +830,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
             }
             if (bad) ctl[0] = 1;
             if (mine && c.rasVE) (cold(c).rasVE + (size_t)t * B * N)[kst] = r_v;
-        } else if (wave >= NT / 64 - NTW) {
+        } else if (R_AI) {
             // ---- Ai membrane update of step t: its input is the pair's own final Ae spike of step t-1 (own slice of the Ae -> Ai
             //      weights diagonal); it must fire exactly when that spike was there -- what everybody's inhibition assumes
 
@@ -841,7 +849,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 if (c.rasVI) (cold(c).rasVI + (size_t)t * B * N)[kst] = r_v;
             }
         }
-        if (wave >= NTW && do_stdp) {
+        if (R_NT && do_stdp) {
 
             // ---- PostPre of step t under "no own final spike at step t" (learning.py / MCC_learning.py:224-302), one thread per
             //      listed row, in place; a column that won at step t-1 enters with its won branch; the row as it was goes to wbak
@@ -876,7 +884,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 }
             AMARKW(3, TT);
         }
-        if (t + 2 <= T && wave >= NTW) DIGEST_STORE_E(t + 2);             // (its buffer, entry t's, was last read before barrier B of the previous iteration)
+        if (t + 2 <= T && R_NT) DIGEST_STORE_E(t + 2);             // (its buffer, entry t's, was last read before barrier B of the previous iteration)
         AMARK(13);
         lds_barrier();                                                    // ---- M
         AMARK(4);
@@ -886,11 +894,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         // the winners of step t-1, which the membrane stage of the NEXT iteration wants: asked for now (two loads in flight while the X
         // currents are computed; nothing waits for them before that stage -- asked for at the end of the iteration they sat in front
         // of the digest's LDS stores, which wait for every outstanding load: 0.4 us per iteration, more on some workgroups)
-        if (wave < NTW) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1, min(bl, B - 1)); }
+        if (R_TILE) { pre_w.have = false; if (t >= 1 && t + 1 < T) pre_w = win_prefetch(c, t - 1, min(bl, B - 1)); }
         // ---- X -> Ae currents of step t+1 under "nobody of this workgroup won step t" (from wtile, final since PostPre): waves 2..3 start on
         //      them at once -- the pass is the longest piece between the barriers M and B, and it needs nothing of what the other waves read
         //      first (the crossing state, the row count); in a workgroup that crossed, the six other waves do the touched rows meanwhile
-        const bool f4w = wave >= NTW && wave < NTW + 2;
+        constexpr bool f4w = R_F4;
         if (f4w) {
             const int ptid = tid - TT, pb = ptid >> 2, pL = ptid & 3;
             const float4 v = x_current_f4(wtile, dgn, B, Nin, min(pb, B - 1), pL, tailcol);
@@ -945,7 +953,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 lds_barrier();                                            // ---- S1
 #pragma unroll
                 for (int q = 0; q < CW; ++q) if (__popc(xq[q]) > 1) cmq[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)colres[q]);
-                if (tid < TT) {
+                if (R_TILE) {
                     float v = xn0[tid];
                     const uint32_t xj = jj == 0 ? xq[0] : (jj == 1 ? xq[1] : (jj == 2 ? xq[2] : xq[3]));
                     const uint32_t cj = jj == 0 ? cmq[0] : (jj == 1 ? cmq[1] : (jj == 2 ? cmq[2] : cmq[3]));
@@ -956,7 +964,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
                 lds_barrier();                                            // ---- S2
             }
             if (!f4w)                                                     // the rows the X currents of step t+1 read (waves 2..3 are on their pass)
-                for (int k = tid < TT ? tid : tid - 128; k < nact; k += NT - 128) {
+                for (int k = R_TILE ? tid : tid - 128; k < nact; k += NT - 128) {
                     const int i = full ? k : (int)arows[k];
 #pragma unroll
                     for (int q = 0; q < CW; ++q) if (cmq[q] && c0 + q < N) won_elem(i, q);
@@ -971,7 +979,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         //      by the columns, DPP instead of LDS shuffles) on waves 2..3 -- and for a workgroup that crossed on waves 4..5 from wwin -- instead of
         //      four lanes per (sample, column) pair on all eight waves: fewer instructions on two waves than the old pass had on every wave, and
         //      the tile waves go straight to their resolution (same-box A/B, bit-exact: 947 -> 900 us per launch, profiles/NOTES_r06.md).
-        if (crossed_wg && wave >= NTW + 2 && wave < NTW + 4) {
+        if (crossed_wg && R_W4) {
             const int ptid = tid - TT - 128, pb = ptid >> 2, pL = ptid & 3;
             const float4 v = x_current_f4(wwin, dgn, B, Nin, min(pb, B - 1), pL, tailcol);     // (its other columns are of no interest)
             if (pL == 0 && pb < B) {
@@ -984,7 +992,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         AMARK(5);
         AMARK2(21);
 
-        if (crossed_wg && wave >= NTW && !full) {
+        if (crossed_wg && R_NT && !full) {
             // the rows this step's X spikes do not touch (read again only by the next iteration's PostPre): by the non-tile waves
             for (int i = tid - TT; i < Nin; i += NBC) {
                 if (rowmask[i] != 0) continue;
@@ -996,7 +1004,7 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         AMARK2(22);
         // ---- tile waves: which of the own crossings of step t won -- only a wave that had one waits for the arbiter.  A winner redoes
         //      its Ae trace of step t and x_tgt*nu0 of step t+1 and marks its column; every pair leaves its final spike for its Ai thread
-        if (wave < NTW) {
+        if (R_TILE) {
             sp_prev = false;
             if (prevE != 0ull && !bad) {
                 // A pair that is the ONLY crossing of its sample at step t has won: that needs no draw and no arbiter -- the wave looks
@@ -1068,6 +1076,11 @@ __device__ __forceinline__ void async_compute(const DcCtx &c, unsigned char *sme
         lds_barrier();                                                    // ---- B
         AMARK(2);
     }
+    };
+    if (wave < NTW) step_loop(std::integral_constant<int, 0>{});
+    else if (wave < NTW + 2) step_loop(std::integral_constant<int, 1>{});
+    else if (wave < NTW + 4) step_loop(std::integral_constant<int, 2>{});
+    else step_loop(std::integral_constant<int, 3>{});
     // ---- a tile wave that gives up says so in the granule of the first step it has not published: the arbiter passes it on.  A wave that has
     //      published all T steps sends a FINAL REPORT in the granule of "step T": nothing, or the abort mark -- a reason to give up that shows in
     //      the LAST iteration (an Ai neuron that does not follow its partner at step T-1, a poll of that step's winners that ran out) comes
