@@ -364,7 +364,8 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
             (const void *)NS::k_two_run<true, SNN_RULE_NONE, 4>, (const void *)NS::k_two_run<true, SNN_RULE_POSTPRE, 4>, \
             (const void *)NS::k_two_run<false, SNN_RULE_NONE, 4>, (const void *)NS::k_two_run<false, SNN_RULE_POSTPRE, 4>, \
             (const void *)NS::k_two_run<false, SNN_RULE_MSTDP, 4>, (const void *)NS::k_two_run<true, SNN_RULE_MSTDP, 4>
-        const void *variants[32] = {TWO_VARIANTS(nt1024), TWO_VARIANTS(nt512)};
+        const void *variants[34] = {TWO_VARIANTS(nt1024), TWO_VARIANTS(nt512),
+                                    (const void *)nt1024::k_two_run<false, SNN_RULE_POSTPRE, 1, 16>, (const void *)nt1024::k_two_run<false, SNN_RULE_POSTPRE, 1, 32>};
 #undef TWO_VARIANTS
         for (const void *f : variants)
             if (snn_check(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))) return SNN_ERR_LAUNCH;
@@ -393,6 +394,13 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
         else if (c.rule == SNN_RULE_HEBBIAN) hipLaunchKernelGGL((NS::k_two_run<false, SNN_RULE_HEBBIAN, MWV>), grid, blk, lds, st, c); \
         else if (c.rule == SNN_RULE_WDPOSTPRE) hipLaunchKernelGGL((NS::k_two_run<false, SNN_RULE_WDPOSTPRE, MWV>), grid, blk, lds, st, c); \
         else hipLaunchKernelGGL((NS::k_two_run<false, SNN_RULE_NONE, MWV>), grid, blk, lds, st, c); } while (0)
+        // (same-box A/B, round 6: B = 16 / 32 PostPre 143.1 -> 145.8 k / 136.2 -> 137.6 k timesteps/s; B = 128 unchanged and MSTDP at B = 16 18 % SLOWER
+        //  -- 210 spilled registers against 94 -- so those two instances are not built)
+        static const bool bk_env = !(getenv("SNN_TWO_BCONST") && atoi(getenv("SNN_TWO_BCONST")) == 0);       // (measurement switch: 0 = the general instances)
+        const bool bk = bk_env && c.nt == 1024 && !c.cascade;
+        if (bk && c.rule == SNN_RULE_POSTPRE && c.MW == 1 && c.B == 16) hipLaunchKernelGGL((nt1024::k_two_run<false, SNN_RULE_POSTPRE, 1, 16>), grid, blk, lds, st, c);
+        else if (bk && c.rule == SNN_RULE_POSTPRE && c.MW == 1 && c.B == 32) hipLaunchKernelGGL((nt1024::k_two_run<false, SNN_RULE_POSTPRE, 1, 32>), grid, blk, lds, st, c);
+        else
         if (c.nt == 512) { if (c.MW == 1) TWO_LAUNCH(nt512, 1); else TWO_LAUNCH(nt512, 4); }
         else { if (c.MW == 1) TWO_LAUNCH(nt1024, 1); else TWO_LAUNCH(nt1024, 4); }
 #undef TWO_LAUNCH
