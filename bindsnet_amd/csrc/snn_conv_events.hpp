@@ -110,4 +110,42 @@ __host__ __device__ inline void conv_pp_events(const ConvGeom &g, int ky, int kx
     *p_out = p;
 }
 
+// ---- the list form (round 6, k_convpp_run in snn_convlif.hip; stride 1, 0/1 spikes).  The spikes of one image (a sample's input channel, or one
+// of its output channels) as an ASCENDING list of (row << 8 | column), padded with eight entries 0xFFFF (row 255: outside every window, so a sum
+// can walk whole groups of eight).  Every weight element's sum walks the SAME list and keeps the events inside its window: (iy, ix) ascending is
+// (oy, ox) ascending for each of them, i.e. the order of conv_pp_events / conv_pp_dense.  Serial form of the build (the kernel has a wave do it:
+// row counts, prefix over the lanes); dst holds up to rows * 32 + 8 entries.  Returns the number of events.
+__host__ __device__ inline int conv_event_list(const uint32_t *rows, int nr, uint16_t *dst) {
+    int n = 0;
+    for (int r = 0; r < nr; ++r) {
+        uint32_t m = rows[r];
+        while (m) { const int x = __builtin_ctz(m); m &= m - 1; dst[n++] = (uint16_t)((r << 8) | x); }
+    }
+    for (int u = 0; u < 8; ++u) dst[n + u] = 0xFFFFu;
+    return n;
+}
+
+// One partial sum from a padded list: event (y, x) contributes vals[(y + ddy) * rowlen + x + ddx] when (y + ddy, x + ddx) lies inside
+// [0, nrow) x [0, rowlen), in list order.  Pre-synaptic sum of element (ky, kx): the SOURCE list of the input channel, vals = x_tgt of the output
+// channel, ddy = pad - ky, ddx = pad - kx, rowlen = OW, nrow = OH.  Post-synaptic sum: the TARGET list of the output channel, vals = x_src of the
+// input channel, ddy = ky - pad, ddx = kx - pad, rowlen = Wd, nrow = H.  Eight events at a time: eight loads in flight, the additions in order.
+__host__ __device__ inline float conv_pp_list_sum(const uint16_t *ev, int n, const float *vals, int ddy, int ddx, int rowlen, int nrow) {
+    float acc = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        int ad[8]; bool in[8]; float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = (int)ev[i0 + u];
+            const int y = (q >> 8) + ddy, x = (q & 0xFF) + ddx;
+            in[u] = (unsigned)y < (unsigned)nrow && (unsigned)x < (unsigned)rowlen;
+            ad[u] = in[u] ? y * rowlen + x : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = vals[ad[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (in[u]) acc += vv[u];
+    }
+    return acc;
+}
+
 }  // namespace snn

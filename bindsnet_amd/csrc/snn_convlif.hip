@@ -472,21 +472,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
                 const int n = nev[src ? ci : c.Cin + cl];
                 const float *vals = src ? xt + cl * L : xs + ci * c.H * c.Wd;
                 const int ddy = src ? -dy : dy, ddx = src ? -sh : sh, rowlen = src ? c.OW : c.Wd, nrow = src ? c.OH : c.H;
-                float acc = 0.f;
-                for (int i0 = 0; i0 < n; i0 += 8) {
-                    int ad[8]; bool in[8]; float vv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int q = (int)ev[i0 + u];
-                        const int y = (q >> 8) + ddy, x = (q & 0xFF) + ddx;
-                        in[u] = (unsigned)y < (unsigned)nrow && (unsigned)x < (unsigned)rowlen;
-                        ad[u] = in[u] ? y * rowlen + x : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) vv[u] = vals[ad[u]];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) if (in[u]) acc += vv[u];
-                }
+                const float acc = conv_pp_list_sum(ev, n, vals, ddy, ddx, rowlen, nrow);      // (snn_conv_events.hpp: also run on the host, tests/test_conv_events_host.py)
                 granule_store((src ? ga : gp) + (size_t)b * E + (size_t)(c0 + cl) * K + kq, tag | (unsigned long long)__float_as_uint(acc));
             }
         } else {

@@ -26,6 +26,13 @@ extern "C" int hostcheck_conv_pp_partials(const uint8_t *s_src, const float *x_s
                 const uint8_t *ss = s_src + ((size_t)b * Cin + ci) * H * Wd, *st = s_tgt + ((size_t)b * Cout + co) * OH * OW;
                 const float *xs = x_src + ((size_t)b * Cin + ci) * H * Wd, *xt = x_tgt + ((size_t)b * Cout + co) * OH * OW;
                 float a, p;
+                if (use_events == 2 && !multi && stride == 1) {   // the list form of k_convpp_run: one list per image, every element walks it
+                    std::vector<uint16_t> evS((size_t)H * 32 + 8), evT((size_t)OH * 32 + 8);
+                    const int nS = snn::conv_event_list(srow.data(), H, evS.data());
+                    const int nT = snn::conv_event_list(trow.data() + (size_t)co * OH, OH, evT.data());
+                    a = snn::conv_pp_list_sum(evS.data(), nS, xt, pad - ky, pad - kx, OW, OH);
+                    p = snn::conv_pp_list_sum(evT.data(), nT, xs, ky - pad, kx - pad, Wd, H);
+                } else
                 if (use_events && !multi) snn::conv_pp_events(g, ky, kx, srow.data(), trow.data() + (size_t)co * OH, xs, xt, &a, &p);
                 else snn::conv_pp_dense(g, ky, kx, ss, xs, st, xt, &a, &p);
                 const long id = (long)b * E + (long)co * K + (long)ci * KK + kk;

@@ -97,3 +97,18 @@ def test_batch_one_update_from_the_event_partials_equals_the_oracle(host, case):
     Wo = W.copy()
     oracle.conv2d_postpre(Wo, s_src, x_src, s_tgt, x_tgt, stride=stride, pad=pad, nu0=nu0, nu1=nu1, wmin=0.0, wmax=1.0)
     np.testing.assert_array_equal(Wn.view(np.uint32), Wo.reshape(-1).view(np.uint32))
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[6] == 1] + [(3, 2, 28, 28, 4, 5, 1, 2, 0.3, 0.05), (1, 1, 32, 32, 3, 7, 1, 3, 0.9, 0.9)])
+def test_list_form_of_the_fused_plan_equals_dense_body_bit_for_bit(host, case):
+    """The list form k_convpp_run walks (round 6: one ascending event list per image, every weight element keeps the events inside its window,
+    eight at a time) against the dense body, stride 1: same partial sums, bit for bit."""
+    B, Cin, H, Wd, Cout, K, stride, pad, ps, pt = case
+    OH, OW = (H + 2 * pad - K) // stride + 1, (Wd + 2 * pad - K) // stride + 1
+    k = sum(case[:8])
+    s_src, x_src = synth.dense_spikes(8000 + k, (B, Cin, H, Wd), ps), synth.uniform_f32(8100 + k, (B, Cin, H, Wd), 0.0, 1.0)
+    s_tgt, x_tgt = synth.dense_spikes(8200 + k, (B, Cout, OH, OW), pt), synth.uniform_f32(8300 + k, (B, Cout, OH, OW), 0.0, 1.0)
+    dense, _ = partials(host, s_src, x_src, s_tgt, x_tgt, K, stride, pad, 0)
+    lists, multi = partials(host, s_src, x_src, s_tgt, x_tgt, K, stride, pad, 2)
+    assert multi == 0 and np.abs(dense).max() > 0
+    np.testing.assert_array_equal(lists.view(np.uint32), dense.view(np.uint32))
