@@ -298,7 +298,11 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.G = (N + cw - 1) / cw;
     if (c.T + 1 > 4096) return false;
     c.prodw = 0;
-    if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) { c.prodw = 4096; if (run_lds(c) > 140 * 1024) c.prodw = 0; }
+    if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) {      // (the largest staging area that fits: a chunk costs two barriers and a ramp whatever its length)
+        const int sizes[4] = {16384, 8192, 4096, 0};
+        for (int k = 0; k < 4; ++k) { c.prodw = sizes[k]; if (run_lds(c) <= 140 * 1024) break; }
+        if (getenv("SNN_TWO_PRODW")) { c.prodw = atoi(getenv("SNN_TWO_PRODW")); if (run_lds(c) > 150 * 1024) c.prodw = 0; }
+    }
     c.use_xsl = 0;
     if (Nin <= c.nt && (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
     // the per-step digest copy must fit the prefetch registers
