@@ -702,7 +702,7 @@ int snn_try_fused_convpp(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return SNN_OK; }
     // channels per workgroup: the smallest chunk whose grid of B * ceil(Cout / CCP) workgroups is resident at once (they poll each other every
     // step) -- the LIF step is vector-issue work, so more, smaller workgroups win as long as they fit.  SNN_CONVPP_CC forces one.
-    static const int force_cc = [] { const char *v = getenv("SNN_CONVPP_CC"); return v ? atoi(v) : 0; }();
+    const int force_cc = getenv("SNN_CONVPP_CC") ? atoi(getenv("SNN_CONVPP_CC")) : 0;          // (test / measurement switch, read per run)
     const int tries[3] = {2, 4, 8};
     for (int ti = 0; ti < 3; ++ti) {
         const int ccp = tries[ti];

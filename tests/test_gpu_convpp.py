@@ -89,3 +89,18 @@ def test_convpp_fused_equals_generic(name):
     if CASES[name][-1]:
         w0 = synth.uniform_f32(7, fused[0]["w"].shape, -0.1, 0.5)
         assert not np.array_equal(fused[-1]["w"], w0), "the weights never moved: vacuous"
+
+
+@pytest.mark.parametrize("cc", [2, 4, 8])
+@pytest.mark.parametrize("name", ["conv_mnist_shape_b16", "two_input_channels_odd_cout", "stride2_pad1_b3"])
+def test_every_chunk_size_of_the_fused_plan_equals_generic(name, cc, monkeypatch):
+    """The launch picks 2, 4 or 8 output channels per workgroup by what is co-resident; SNN_CONVPP_CC forces one: each instantiation against the
+    generic plan."""
+    generic, plan_g = run(1, CASES[name])
+    assert plan_g == "generic"
+    monkeypatch.setenv("SNN_CONVPP_CC", str(cc))
+    fused, plan = run(0, CASES[name])
+    assert plan == "convpp-fused"
+    for r, (a, b) in enumerate(zip(fused, generic)):
+        for k in a:
+            np.testing.assert_array_equal(a[k].view(u8), b[k].view(u8), err_msg=f"cc {cc} run {r}: {k}")
