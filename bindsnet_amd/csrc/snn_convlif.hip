@@ -227,6 +227,8 @@ struct ConvPPCtx {
     int has_min, has_max, learning;
     float *Wout;                  // the connection's weights (written back by the b == 0 workgroups)
     unsigned long long *gr;       // [2][2][B][E] granules
+    unsigned *fin;                // [2] behind the granules: workgroups through with the run, "somebody gave up"; zeroed before the launch
+    int stall_wg;                 // test hook (SNN_CONVPP_TEST_STALL): this workgroup returns at once
     int *status;                  // nullable
     long long *dbg;               // developer aid (SNN_CONVPP_TIMING=1): [8] phase totals of workgroup 0 in 10 ns ticks
 };
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
     uint16_t *evS = (uint16_t *)(nev + ((c.Cin + CCP + 1) & ~1));   // [Cin][H * Wd + 8] source spikes of the step's image as (iy << 8 | ix), ascending, padded
     uint16_t *evT = evS + c.Cin * (c.H * c.Wd + 8);       // [CCP][L + 8] target spikes of the step as (oy << 8 | ox), ascending, padded with 0xFFFF to a multiple of 8
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x == a.stall_wg) return;
     const int chunk = blockIdx.x % c.nchunk, b = blockIdx.x / c.nchunk;
     const int c0 = chunk * CCP, nco = min(CCP, c.Cout - c0), nel = nco * taps;
     const int pix = tid;
@@ -556,7 +559,22 @@ __global__ __launch_bounds__(1024) void k_convpp_run(const ConvPPCtx a) {
         PPMARK(4);
     }
     if (timing) for (int k = 0; k < 8; ++k) a.dbg[k] = ph[k];
-    if (dead) { if (tid == 0 && a.status) atomicCAS(a.status, 0, SNN_ERR_TIMEOUT); return; }
+    // ---- COMMIT: nobody writes a state tensor, the filters or the input trace back unless EVERY workgroup of the grid got through its T steps (the
+    //      chunks do not wait for each other during the run: without this a chunk that gave up would leave the others' state advanced).  One
+    //      counter hop per run; a workgroup that gave up says so and still counts, so that nobody waits for it.
+    if (tid == 0) {
+        if (dead) __hip_atomic_store(&a.fin[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.fin[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&a.fin[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x &&
+               !__hip_atomic_load(&a.fin[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (++spins > kPPPoll) { __hip_atomic_store(&a.fin[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        multi[3] = (int)__hip_atomic_load(&a.fin[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (multi[3]) { if (tid == 0 && a.status) atomicCAS(a.status, 0, SNN_ERR_TIMEOUT); return; }
 #pragma unroll
     for (int u = 0; u < CCP; ++u)
         if (valid && c0 + u < c.Cout) {
@@ -692,6 +710,8 @@ int snn_try_fused_convpp(const snn_layer_desc *L, int nL, const snn_conn_desc *C
     a.Wout = d.w;
     const size_t E = (size_t)c.Cout * taps;
     a.gr = (unsigned long long *)R->workspace;
+    a.fin = (unsigned *)((unsigned char *)R->workspace + (size_t)4 * c.B * E * sizeof(unsigned long long));
+    a.stall_wg = getenv("SNN_CONVPP_TEST_STALL") ? atoi(getenv("SNN_CONVPP_TEST_STALL")) : -1;
     a.status = R->status;
     static const bool want_timing = [] { const char *v = getenv("SNN_CONVPP_TIMING"); return v && v[0] == '1'; }();
     static long long *dbg_dev = nullptr;
@@ -717,7 +737,7 @@ int snn_try_fused_convpp(const snn_layer_desc *L, int nL, const snn_conn_desc *C
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, nt, lds) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (per_cu < 1 || grid > (long long)per_cu * prop.multiProcessorCount) continue;
-        if (a.learning && hipMemsetAsync(a.gr, 0, (size_t)4 * c.B * E * sizeof(unsigned long long), st) != hipSuccess) return SNN_ERR_LAUNCH;
+        if (hipMemsetAsync(a.learning ? (void *)a.gr : (void *)a.fin, 0, (a.learning ? (size_t)4 * c.B * E * sizeof(unsigned long long) : 0) + 16, st) != hipSuccess) return SNN_ERR_LAUNCH;
         void *args[] = {(void *)&a};
         const hipError_t e = hipLaunchCooperativeKernel((const void *)fn, dim3((unsigned)grid), dim3((unsigned)nt), args, (unsigned)lds, st);
         if (e != hipSuccess) { (void)hipGetLastError(); continue; }          // refused: a coarser chunk, then the generic plan

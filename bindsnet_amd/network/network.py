@@ -369,7 +369,7 @@ class Network(_lib.TouchingModule, torch.nn.Module):
                 self.__dict__["last_plan"] = lib.snn_plan_name().decode()
                 # plans that hand spikes between workgroups report a failed hand-off (or a step the lean form does not
                 # handle) through the status word: it is read back after EVERY such run, with or without one_spike
-                ns.always_read = self.last_plan.startswith("dc2015-resident")
+                ns.always_read = self.last_plan.startswith("dc2015-resident") or self.last_plan == "convpp-fused"
                 status = ns.finish(check_status=attempt == 2)
             if status == 0:
                 break

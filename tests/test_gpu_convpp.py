@@ -104,3 +104,16 @@ def test_every_chunk_size_of_the_fused_plan_equals_generic(name, cc, monkeypatch
     for r, (a, b) in enumerate(zip(fused, generic)):
         for k in a:
             np.testing.assert_array_equal(a[k].view(u8), b[k].view(u8), err_msg=f"cc {cc} run {r}: {k}")
+
+
+def test_a_workgroup_that_never_arrives_leaves_every_state_untouched_and_the_run_is_repeated_on_the_generic_plan(monkeypatch):
+    """SNN_CONVPP_TEST_STALL makes one workgroup of the cooperative grid return at once: its chunk's workgroups run out of their bounded polls, every
+    OTHER chunk gets through its T steps -- and must not write anything back (the commit agreement at the end of the kernel); the status word says
+    SNN_ERR_TIMEOUT, Network.run repeats the input on the per-operator plan: same bits as the generic plan from the start."""
+    case = CASES["dense_input_clamped"]
+    generic, plan_g = run(1, case, n_runs=1)
+    monkeypatch.setenv("SNN_CONVPP_TEST_STALL", "3")
+    fused, plan = run(0, case, n_runs=1)
+    assert plan == "generic", plan                      # the plan of the attempt that succeeded
+    for k in fused[0]:
+        np.testing.assert_array_equal(fused[0][k].view(u8), generic[0][k].view(u8), err_msg=k)
