@@ -52,7 +52,8 @@ struct TwoCtx {
     float *W; const float *bias;
     int cascade;                                         // 1: MCC (ATen sum order), 0: dense Connection (ascending sequential)
     int rule; float nu0, nu1; int use_dt; float wdecay; int has_min; float wmin; int has_max; float wmax;
-    uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw;   // digest: words per entry, list capacity, word offsets
+    uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw, o_ri;   // digest: words per entry, list capacity, word offsets (o_ri: u16 row -> index in the active-row list)
+    int ent2;                                            // two [meta | event list] areas in LDS (learning instances, where it fits)
     float inv_hwps;
     int prodw;                                           // floats of LDS for the staged products of the dense dot (0: off)
     int mstdp_rows;                                      // MSTDP in its row-per-thread forms (developer switch SNN_TWO_MSTDP_ROWS=0: off)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     // (MSTDP: one more entry, T+1 = the source spikes the rule remembers from its last update before this run)
     const uint8_t *src = (e == 0) ? c.sX0 : (e == c.T + 1 ? c.s_src_prev : c.in + (size_t)(e - 1) * B * Nin);
     uint32_t *D = c.dig + (size_t)e * c.DW;
-    uint16_t *D_ent = (uint16_t *)(D + c.o_ent), *D_ar = (uint16_t *)(D + c.o_ar);
+    uint16_t *D_ent = (uint16_t *)(D + c.o_ent), *D_ar = (uint16_t *)(D + c.o_ar), *D_ri = (uint16_t *)(D + c.o_ri);
     uint32_t *D_am = D + c.o_am, *D_ab = D + c.o_ab, *D_xw = D + c.o_xw;
     for (int k = tid; k < Nin * mw; k += NT) rowmask[k] = 0;
     for (int k = tid; k < NinW; k += NT) D_ab[k] = 0;    // (own entry; finished before the atomics below by the barrier)
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
         if (o) {
             const int cp = wbase + __popcll(m & ((1ull << lane) - 1ull));
             D_ar[cp] = (uint16_t)i;
+            D_ri[i] = (uint16_t)cp;                       // (rows without a spike keep whatever the workspace held: only active rows are looked up)
             for (int w = 0; w < mw; ++w) D_am[cp * mw + w] = rowmask[i * mw + w];
             atomicOr(&D_ab[i >> 5], 1u << (i & 31));
         }
@@ -240,7 +242,8 @@ int digest_layout(TwoCtx &c) {
     c.o_ar = c.o_am + c.Nin * c.MW;
     c.o_ab = c.o_ar + (c.Nin + 1) / 2;
     c.o_xw = c.o_ab + c.NinW;
-    return (c.o_xw + c.B * c.NinW + 3) & ~3;
+    c.o_ri = (c.o_xw + c.B * c.NinW + 3) & ~3;
+    return (c.o_ri + (c.Nin + 1) / 2 + 3) & ~3;
 }
 
 size_t run_lds(const TwoCtx &c) {
@@ -249,7 +252,8 @@ size_t run_lds(const TwoCtx &c) {
            (size_t)c.Nin * (c.MW - 1) * 4 +
            al((size_t)c.NinW * 4) + (c.rowmajor ? al((size_t)c.Nin * 2) : 0) + (size_t)c.BC * 8 * 4 + (size_t)16 * c.MW * 4 + (size_t)c.BC * 4 + (size_t)c.BC * 8 * 4 + (size_t)c.prodw * 4 +
            (size_t)(c.T + 2) * 8 +
-           (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0);
+           (c.use_xsl ? (size_t)c.Nin * c.CW * 4 : 0) + 16 +
+           (c.ent2 ? META * 4 + al((size_t)c.LCAP * 2) : 0);
 }
 
 bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const snn_run_desc *R, TwoCtx &c) {
@@ -311,6 +315,8 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     }
     c.use_xsl = 0;
     if (Nin <= c.nt && (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
+    c.ent2 = 0;
+    if (c.rule != SNN_RULE_NONE && c.rule != SNN_RULE_MSTDP && c.MW > 1 && !(getenv("SNN_TWO_ENT2") && atoi(getenv("SNN_TWO_ENT2")) == 0)) { c.ent2 = 1; if (run_lds(c) > 140 * 1024) c.ent2 = 0; }
     // the per-step digest copy must fit the prefetch registers
     if (META + c.LCAP / 2 + Nin * c.MW + (Nin + 1) / 2 + c.NinW > kDigestRegs) return false;
     return true;
