@@ -35,7 +35,7 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr int MAXB = 128;       // samples per run: sample masks are MW = ceil(B / 32) words wide (one word up to batch 32)
-constexpr int META = 136;       // [0] list entries, [1] active rows, [2] flags (1: spike byte > 1, 2: list overflow), [4..4+B] CSR offsets
+constexpr int META = 136;       // [0] list entries, [1] active rows, [2] flags (1: spike byte > 1, 2: list overflow), [3] longest per-sample list, [4..4+B] CSR offsets
 constexpr int kDigestRegs = 16 * 1024;   // words of a digest entry the run kernel's prefetch registers hold (PF * NT, either workgroup size)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -70,6 +70,7 @@ struct TwoCtx {
 };
 
 #define WMARK() do { if (c.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) c.dbg[(size_t)8 * 4096 + (size_t)t * 16 + (threadIdx.x >> 6)] = (long long)wall_clock64(); } while (0)
+#define SMARK(slot) do { if (c.dbg && blockIdx.x == 0 && threadIdx.x == 0) c.dbg[(size_t)8 * 4096 + (size_t)t * 16 + (slot)] = (long long)wall_clock64(); } while (0)
 #define TMARK(slot) do { if (c.dbg && blockIdx.x == 0 && threadIdx.x == 0) c.dbg[(size_t)t * 8 + (slot)] = (long long)wall_clock64(); } while (0)
 
 __device__ __forceinline__ uint32_t nz4(uint32_t w) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
         if (lane == 0) cntb[b + 1] = n;
     }
     __syncthreads();
-    if (tid == 0) { cntb[0] = 0; for (int b = 0; b < B; ++b) cntb[b + 1] += cntb[b]; }
+    if (tid == 0) { int mx = 0; cntb[0] = 0; for (int b = 0; b < B; ++b) { mx = max(mx, cntb[b + 1]); cntb[b + 1] += cntb[b]; } misc[2] = mx; }
     __syncthreads();
     const int total = cntb[B];
     // ascending event lists: wave per sample, 64 words per round, running offset
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NT) void k_two_prep(const TwoCtx c) {
     }
     __syncthreads();
     if (tid <= B) D[4 + tid] = (uint32_t)cntb[tid];
-    if (tid == 0) { D[0] = (uint32_t)total; D[1] = (uint32_t)misc[0]; D[2] = (uint32_t)(misc[1] | (total > c.LCAP ? 2 : 0)); }
+    if (tid == 0) { D[0] = (uint32_t)total; D[1] = (uint32_t)misc[0]; D[2] = (uint32_t)(misc[1] | (total > c.LCAP ? 2 : 0)); D[3] = (uint32_t)misc[2]; }
 }
 
 // ---------------------------------------------------------------------------------------------- the run
@@ -309,8 +310,9 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     if (c.T + 1 > 4096) return false;
     c.prodw = 0;
     if (C[0].kind == SNN_CONN_DENSE && B * cw <= 64) {      // (the largest staging area that fits: a chunk costs two barriers and a ramp whatever its length)
-        const int sizes[4] = {16384, 8192, 4096, 0};
-        for (int k = 0; k < 4; ++k) { c.prodw = sizes[k]; if (run_lds(c) <= 140 * 1024) break; }
+        const int sizes[9] = {16384, 12288, 8192, 6144, 5120, 4096, 3072, 2048, 0};
+        for (int k = 0; k < 9; ++k) { c.prodw = sizes[k]; if (run_lds(c) <= 140 * 1024) break; }
+        if (c.prodw / (B * cw) < 36) c.prodw = 0;           // (a chunk of at least 32 terms per pair)
         if (getenv("SNN_TWO_PRODW")) { c.prodw = atoi(getenv("SNN_TWO_PRODW")); if (run_lds(c) > 150 * 1024) c.prodw = 0; }
     }
     c.use_xsl = 0;
