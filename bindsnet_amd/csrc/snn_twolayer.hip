@@ -280,7 +280,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.rowmajor = (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && c.learning &&
                  !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     c.mstdp_rows = !(getenv("SNN_TWO_MSTDP_ROWS") && atoi(getenv("SNN_TWO_MSTDP_ROWS")) == 0);
-    c.mstdp_few = !(getenv("SNN_TWO_MSTDP_FEW") && atoi(getenv("SNN_TWO_MSTDP_FEW")) == 0);
+    c.mstdp_few = getenv("SNN_TWO_MSTDP_FEW") ? atoi(getenv("SNN_TWO_MSTDP_FEW")) : 1;
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
     // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
