@@ -57,7 +57,7 @@ struct TwoCtx {
     float inv_hwps;
     int prodw;                                           // floats of LDS for the staged products of the dense dot (0: off)
     int mstdp_rows;                                      // MSTDP in its row-per-thread forms (developer switch SNN_TWO_MSTDP_ROWS=0: off)
-    int mstdp_few;                                       // burst steps with <= 4 spiking samples: all rows' p_plus loads in flight at once (SNN_TWO_MSTDP_FEW=0: off)
+    int mstdp_burst;                                     // MSTDP burst update (developer switch SNN_TWO_MSTDP_BURST): 2 sample-major where it applies (default), 1 the row walk in its packed forms, 0 the row walk as round 5 left it
     int rowmajor;                                        // PostPre in its row-major form (developer switch SNN_TWO_ROWMAJOR=0: off)
     int use_xsl;                                         // stage the source traces of spiking columns in LDS (fits + Nin <= nt)
     int nt;                                              // threads per workgroup of the run kernel: 1024, or 512 (256 VGPRs per lane: nothing spills)
@@ -280,7 +280,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     c.rowmajor = (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && c.learning &&
                  !(getenv("SNN_TWO_ROWMAJOR") && atoi(getenv("SNN_TWO_ROWMAJOR")) == 0);
     c.mstdp_rows = !(getenv("SNN_TWO_MSTDP_ROWS") && atoi(getenv("SNN_TWO_MSTDP_ROWS")) == 0);
-    c.mstdp_few = getenv("SNN_TWO_MSTDP_FEW") ? atoi(getenv("SNN_TWO_MSTDP_FEW")) : 1;
+    c.mstdp_burst = getenv("SNN_TWO_MSTDP_BURST") ? atoi(getenv("SNN_TWO_MSTDP_BURST")) : 2;
     // list capacity: all events of a step in LDS (u16 each), up to 24 KiB
     c.LCAP = (int)((((size_t)B * Nin < 12288 ? (size_t)B * Nin : 12288) + 7) & ~(size_t)7);
     // widest column tile whose weight slice + digest fit LDS, with a tile thread per (sample, column)
@@ -450,22 +450,12 @@ int snn_try_fused_twolayer(const snn_layer_desc *L, int nL, const snn_conn_desc 
                 pub += (double)(r[7] - r[5]) / 100.0; upd += (double)(r[6] - r[7]) / 100.0;
                 if (fl[(size_t)c.T - t] != 0) { ++slow; upd_slow += (double)(r[6] - r[7]) / 100.0; }
             }
-            {
-                int hist[34] = {0}, fewn = 0; double fewt = 0, oldt = 0; int oldn = 0;
-                for (int t = 2; t < c.T; ++t) {
-                    const long long f = fl[(size_t)c.T - t];
-                    if (!f) continue;
-                    const long long *r = &h[(size_t)t * 8];
-                    ++hist[(f >> 8) > 32 ? 33 : (f >> 8)];
-                    if (f & 16) { ++fewn; fewt += (double)(r[6] - r[7]) / 100.0; } else { ++oldn; oldt += (double)(r[6] - r[7]) / 100.0; }
-                }
-                fprintf(stderr, "[twolayer timing] burst steps: few-sample path %d (%.2f us each), batch walk %d (%.2f us each); samples with a target spike:", fewn, fewn ? fewt / fewn : 0.0, oldn, oldn ? oldt / oldn : 0.0);
-                for (int k = 0; k < 34; ++k) if (hist[k]) fprintf(stderr, " %d:%d", k, hist[k]);
-                fprintf(stderr, "\n");
-            }
             fprintf(stderr, "[twolayer timing] publish = spikes/state %.2f + MSTDP update %.2f (%d steps with a target spike in workgroup 0: %.2f each, the other %d: %.2f)\n",
                     pub / n, upd / n, slow, slow ? upd_slow / slow : 0.0, n - slow, n - slow ? (upd - upd_slow) / (n - slow) : 0.0);
         }
+        if (mstdp && c.prodw)      // (the MSTDP instance has no phase A: thread 0 marks the dense current phase in slots 1 .. 8 instead)
+            fprintf(stderr, "[twolayer timing] dense current phase, us from the step's phase A mark: [1] set up | first chunk [2] staged [3] barrier [4] summed [5] barrier | last chunk [6] staged [7] barrier [8] summed:");
+        else
         fprintf(stderr, "[twolayer timing] learning phase per wave, us:");
         for (int w = 0; w < 16; ++w) {
             double sum = 0;

@@ -168,6 +168,10 @@ MSTDP_CASES = {
     "cfg5_shape_short": (6400, 500, 16, 8, 1.0, 0.05, 1),
     "b48_negative_reward": (784, 64, 48, 25, -0.5, 0.05, 1),
     "b100_reward_vector": (400, 40, 100, 20, "vec", 0.06, 1),
+    # round 6: the sample-major burst update (batch <= 16, tiles of 2 / 4 columns) and the digest through LDS-DMA
+    "wide_tile4_b12_reward_vector": (3200, 64, 12, 30, "vec", 0.05, 1),     # 4 columns per workgroup, 4 of 7 row slots, samples past the batch
+    "wide_tile2_b16_long": (6400, 24, 16, 30, -0.5, 0.05, 1),               # 2 columns per workgroup, all 7 row slots, many burst steps
+    "wide_tile4_b3": (4096, 20, 3, 40, 1.0, 0.04, 1),
 }
 
 
@@ -183,6 +187,24 @@ def test_twolayer_mstdp_fused_equals_generic(name):
             np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"{name} input {r}: {k}")
     assert sum(int(x["s"].sum()) for x in f) > 0, "silent network: vacuous"
     assert np.abs(f[-1]["pm"]).max() > 0 and not np.array_equal(f[0]["W"], f[-1]["W"])
+
+
+@pytest.mark.parametrize("name", ["b16_scalar_reward", "wide_tile4_b12_reward_vector", "wide_tile2_b16_long", "cfg5_shape_short"])
+def test_twolayer_mstdp_burst_forms_agree(name, monkeypatch):
+    """The burst update (a step in which a column of the tile spiked) exists in three forms -- sample-major (default where it applies), the row
+    walk in its packed forms, the row walk as round 5 left it (developer switch SNN_TWO_MSTDP_BURST = 2 / 1 / 0): same weights, same state."""
+    Nin, N, B, T, reward, dens, vmax = MSTDP_CASES[name]
+    outs = []
+    for form in ("2", "1", "0"):
+        monkeypatch.setenv("SNN_TWO_MSTDP_BURST", form)
+        f, plan = run_mstdp(False, Nin, N, B, T, reward, n_inputs=2, dens=dens, vmax=vmax)
+        assert plan == "twolayer-fused"
+        outs.append(f)
+    for other in outs[1:]:
+        for r, (a, b) in enumerate(zip(outs[0], other)):
+            for k in a:
+                np.testing.assert_array_equal(a[k].view(np.uint8), b[k].view(np.uint8), err_msg=f"{name} input {r}: {k}")
+    assert sum(int(x["s"].sum()) for x in outs[0]) > 0
 
 
 def test_twolayer_mstdp_learning_off():

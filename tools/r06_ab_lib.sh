@@ -1,24 +1,20 @@
 #!/bin/bash
-# Round 6: same-box A/B of the in-tree library against bindsnet_amd/lib/libsnnhip_prev.so (the previous commit's build), behind the D&C parity tests
-TAG=${1:-ablib}; O=gpurun_out/r06_$TAG; mkdir -p $O
+# GPU box: same-box A/B of the current library against another build of it (SNN_LIB_OVERRIDE), two-layer family
+#   PREV=<path to .so> CFGS=cfg5,cfg3 bash tools/r06_ab_lib.sh
+O=gpurun_out/r06_ab_lib; mkdir -p $O
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests/test_gpu_async_form.py tests/test_gpu_fullsize.py tests/test_gpu_baseline_configs.py tests/test_gpu_pipelined.py tests/test_gpu_fused_stress.py tests/test_gpu_resident_safety.py tests/test_gpu_fuzz.py -m gpu -x -q --no-header 2>&1 | tail -5) > $O/dc_tests.log; tail -2 $O/dc_tests.log
-run() {  # name, env...
-  name=$1; shift
-  for K in 20 200; do
-    W=5; [ $K = 200 ] && W=10
-    env "$@" timeout 200 python bench.py --steps $K --warmup $W --no-cpu-baseline > $O/bench_k${K}_$name.json 2> $O/bench_k${K}_$name.err
-    python - $O/bench_k${K}_$name.json k$K $name <<'P'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
-    print(sys.argv[2], sys.argv[3], d['value'], 'ms/step', d['ms_per_step'], 'kernel us', r['avg_launch_us'], 'frac', r['frac'], 'sync', (d.get('sync_runs') or {}).get('value'))
-except Exception as e:
-    print(sys.argv[2], sys.argv[3], 'FAILED', e)
-P
-  done
-}
+CFGS=${CFGS:-cfg5}
+line() { python -c "
+import sys, json
+for l in sys.stdin:
+    try: d = json.loads(l)
+    except Exception: continue
+    w = d.get('config'); w = w.get('workload', '') if isinstance(w, dict) else str(w)
+    print('$1', w[:44], d.get('value') or d.get('timesteps_per_s'))
+"; }
+(timeout 1200 python -m pytest tests/test_gpu_twolayer.py tests/test_gpu_baseline_configs.py tests/test_gpu_fused_stress.py tests/test_gpu_rules.py -m gpu -x -q --no-header 2>&1 | tail -3) > $O/tests.log; tail -2 $O/tests.log
 for rep in 1 2; do
-  run prev_$rep SNN_DEVELOPER=1 SNN_LIB_OVERRIDE=$PWD/bindsnet_amd/lib/libsnnhip_prev.so
-  run new_$rep SNN_DEVELOPER=0
-done
+    timeout 900 python tools/bench_configs.py --runs 5 --only $CFGS --no-cpu-baseline 2>/dev/null | line "new"
+    [ -f "$PREV" ] && SNN_DEVELOPER=1 SNN_LIB_OVERRIDE=$PREV timeout 900 python tools/bench_configs.py --runs 5 --only $CFGS --no-cpu-baseline 2>/dev/null | line "prev"
+done | tee $O/wall.log
+SNN_TWO_TIMING=1 timeout 300 python tools/bench_configs.py --runs 2 --only cfg5 --no-cpu-baseline 2>&1 >/dev/null | grep "twolayer timing" | tail -4 | tee $O/timing.log
