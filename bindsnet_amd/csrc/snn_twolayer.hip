@@ -53,6 +53,7 @@ struct TwoCtx {
     int cascade;                                         // 1: MCC (ATen sum order), 0: dense Connection (ascending sequential)
     int rule; float nu0, nu1; int use_dt; float wdecay; int has_min; float wmin; int has_max; float wmax;
     uint32_t *dig; int DW, LCAP, o_ent, o_am, o_ar, o_ab, o_xw, o_ri;   // digest: words per entry, list capacity, word offsets (o_ri: u16 row -> index in the active-row list)
+    int late_events;                                     // PostPre family, two event areas: the next entry's events asked for behind phase A (with the row tables) instead of at the top (SNN_TWO_LATE_EVENTS)
     int late_rows;                                       // MSTDP: the row tables asked for behind the first chunk of the dense current phase instead of at the top (SNN_TWO_LATE_ROWS)
     int ent2;                                            // two [meta | event list] areas in LDS (learning instances, where it fits)
     float inv_hwps;
@@ -318,6 +319,7 @@ bool plan(const snn_layer_desc *L, int nL, const snn_conn_desc *C, int nC, const
     }
     c.use_xsl = 0;
     if (Nin <= c.nt && (c.rule == SNN_RULE_POSTPRE || c.rule == SNN_RULE_HEBBIAN || c.rule == SNN_RULE_WDPOSTPRE) && !(c.rowmajor && ((size_t)Nin * N) % 32 == 0)) { c.use_xsl = 1; if (run_lds(c) > 140 * 1024) c.use_xsl = 0; }
+    c.late_events = getenv("SNN_TWO_LATE_EVENTS") ? atoi(getenv("SNN_TWO_LATE_EVENTS")) : 1;   // (same box, cfg3 B=128: 83.9 against 82.9 k timesteps/s)
     c.late_rows = getenv("SNN_TWO_LATE_ROWS") ? atoi(getenv("SNN_TWO_LATE_ROWS")) : 1;     // (same box, cfg5: 71.1 against 67.8 k timesteps/s)
     c.ent2 = 0;
     if (c.rule != SNN_RULE_NONE && c.rule != SNN_RULE_MSTDP && c.MW > 1 && !(getenv("SNN_TWO_ENT2") && atoi(getenv("SNN_TWO_ENT2")) == 0)) { c.ent2 = 1; if (run_lds(c) > 140 * 1024) c.ent2 = 0; }
